@@ -1,0 +1,191 @@
+/*
+ * tcmi.h — C ABI of the MI355X-native consensus hot path (libtcmi.so).
+ *
+ * The reference (RIVM-bioinformatics/TrueConsense, pure Python) has no FFI; the
+ * seam this library replaces is three Python call sites:
+ *
+ *   BuildIndex(bamfile, ref)                       TrueConsense/indexing.py:75-154
+ *   ListInserts(iDict, mincov, bam)                TrueConsense/Events.py:5-44
+ *   BuildConsensus(mincov, iDict, GFFdict, ...)    TrueConsense/Sequences.py:168-322
+ *
+ * Everything here is plain C: pointers, sizes, int status codes.  No torch or
+ * HIP types appear in a signature (streams / device buffers are `void*`).
+ * All entry points return 0 on success or a negative TCMI_E_* code; the text of
+ * the last failure is available from tcmi_last_error().  Nothing throws or
+ * aborts across this boundary.
+ *
+ * Threading: one context per device/stream; contexts are independent; a single
+ * context is not thread-safe.  Host-only entry points (tcmi_consensus_walk,
+ * tcmi_bam_*, tcmi_pack_*) are re-entrant and need no GPU.
+ */
+#ifndef TCMI_H
+#define TCMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCMI_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define TCMI_OK            0
+#define TCMI_E_NODEVICE   (-1)  /* no usable HIP device / HIP runtime error at init */
+#define TCMI_E_HIP        (-2)  /* HIP runtime call failed                         */
+#define TCMI_E_ARG        (-3)  /* bad argument (null pointer, negative size, ...) */
+#define TCMI_E_NOMEM      (-4)
+#define TCMI_E_FORMAT     (-5)  /* malformed BAM / BGZF input                      */
+#define TCMI_E_IO         (-6)
+#define TCMI_E_KEYERROR   (-7)  /* reference would raise KeyError (walk past the last position,
+                                   Sequences.py:47 via :214/:282); *err_pos = missing key */
+#define TCMI_E_ZERODIV    (-8)  /* reference would raise ZeroDivisionError (Events.py:102) */
+#define TCMI_E_UNSUPPORTED (-9)
+
+/* ---- count-matrix column order (indexing.py:134) ------------------------ */
+enum { TCMI_COV = 0, TCMI_A = 1, TCMI_T = 2, TCMI_C = 3, TCMI_G = 4, TCMI_X = 5, TCMI_I = 6,
+       TCMI_NCOL = 7 };
+
+/* ---- per-position flags produced by the call kernel --------------------- */
+#define TCMI_F_LOWCOV   0x01u  /* cov < mincov                      Sequences.py:191        */
+#define TCMI_F_PRIMX    0x02u  /* primary nucleotide is X           Sequences.py:199,277    */
+#define TCMI_F_MINDEL   0x04u  /* (X/cov)*100 >= 15, cov != 0       Events.py:85-106        */
+#define TCMI_F_INSCAND  0x08u  /* insert candidate                  Events.py:29-36         */
+#define TCMI_F_COVGT    0x10u  /* cov > mincov (strict)             Sequences.py:311, ORFs.py:142 */
+#define TCMI_F_COVZERO  0x20u  /* cov == 0                          Events.py:102 (division) */
+#define TCMI_F_AMBIG    0x40u  /* IsAmbiguous() true                Ambig.py:179-228        */
+/* a position is an "event" (needs the sequential host walk) when it carries one of: */
+#define TCMI_EVENT_MASK (TCMI_F_PRIMX | TCMI_F_MINDEL | TCMI_F_INSCAND)
+
+/* ---- reads as flat host arrays (what a BAM reader yields) --------------- */
+/* BAM field meaning per SAM spec §4.2.  Offsets are element counts.          */
+typedef struct tcmi_reads {
+    int64_t         n_reads;
+    const int32_t  *pos;        /* [n] 0-based leftmost reference position               */
+    const uint16_t *flag;       /* [n] BAM FLAG                                          */
+    const int32_t  *l_qseq;     /* [n] query length (0 when SEQ is '*')                  */
+    const uint64_t *cigar_off;  /* [n+1] offsets into cigar[]                             */
+    const uint32_t *cigar;      /* BAM encoding len<<4|op, ops MIDNSHP=X                 */
+    const uint64_t *seq_off;    /* [n+1] byte offsets into seq[]                          */
+    const uint8_t  *seq;        /* BAM 4-bit packed "=ACMGRSVTWYHKDBN", high nibble first */
+    const uint8_t  *qual;       /* optional, Σ l_qseq bytes (offsets = prefix of l_qseq) or NULL */
+    const int32_t  *tid;        /* optional [n] reference id; reads with tid<0 never pile up */
+} tcmi_reads;
+
+typedef struct tcmi_ctx tcmi_ctx;          /* one per device + stream            */
+typedef struct tcmi_readset tcmi_readset;  /* reads resident in HBM              */
+
+/* ---- library / context -------------------------------------------------- */
+int         tcmi_abi_version(void);
+const char *tcmi_last_error(const tcmi_ctx *ctx);  /* ctx may be NULL: last error of this thread */
+int         tcmi_device_count(int *out_count);     /* 0 devices is not an error                  */
+
+int  tcmi_ctx_create(int device, tcmi_ctx **out);  /* fails with TCMI_E_NODEVICE without a GPU    */
+int  tcmi_ctx_destroy(tcmi_ctx *ctx);
+int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
+void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
+
+/* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
+enum { TCMI_K_TALLY = 0, TCMI_K_CALL = 1, TCMI_K_ZERO = 2, TCMI_K_NKERNELS = 3 };
+int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
+int  tcmi_profile_reset(tcmi_ctx *ctx);
+int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+
+/* ---- stage A: pileup tally  (replaces indexing.BuildIndex, indexing.py:75-154;
+ *      inner loop parse_query_sequences, indexing.py:102-132; semantics SURVEY §8-P) */
+
+/* Reference length the tally matrix needs: max(ref_len, max end position of any
+ * piled-up read) — the reference keeps columns beyond the FASTA length (indexing.py:137-151). */
+int tcmi_reads_extent(const tcmi_reads *reads, int64_t ref_len, int64_t *out_L);
+
+/* Copy reads into HBM in the kernel's layout (SoA headers, CIGAR stream, 4-bit SEQ
+ * stream in linear nibble order padded to 4 bytes per read).                     */
+int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *reads, tcmi_readset **out);
+int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs);
+int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled,
+                      int64_t *algorithmic_bytes, int64_t *device_bytes, int64_t *max_end);
+
+/* Device-resident tally.  d_counts: device int32 [7][ld] (plane order TCMI_COV..TCMI_I,
+ * plane p at d_counts + p*ld, ld >= L).  Zeroes the planes first when `zero` != 0,
+ * otherwise accumulates (used when one BAM is split over several read sets / GPUs). */
+int tcmi_tally_dev(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld,
+                   void *d_counts, int zero);
+
+/* Host-buffer convenience: upload, tally, download.  counts: host int32 [L][7] in the
+ * reference's row layout (position p-1 at counts + 7*(p-1)).                      */
+int tcmi_tally(tcmi_ctx *ctx, const tcmi_reads *reads, int64_t L, int32_t *counts);
+
+/* planes [7][ld] on device  <->  rows [L][7] on host                              */
+int tcmi_counts_download(tcmi_ctx *ctx, const void *d_counts, int64_t L, int64_t ld, int32_t *counts);
+int tcmi_counts_upload(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int64_t ld, void *d_counts);
+
+/* ---- stage B (position-local part): base calling
+ *      replaces Sequences.GetNucleotide/GetDistribution (Sequences.py:119-165),
+ *      Ambig.IsAmbiguous (Ambig.py:179-228), Events.MinorityDel (Events.py:85-106),
+ *      the candidate test of Events.ListInserts (Events.py:29-36) and the case rule
+ *      (Sequences.py:229-235 and copies).  Outputs, one byte per position:
+ *        plain[p]  character emitted when the primary nucleotide is not X
+ *                  ('N' when cov < mincov)
+ *        alt[p]    character of the secondary nucleotide (primary == X, Sequences.py:283-290)
+ *        flags[p]  TCMI_F_* bits                                                      */
+int tcmi_call_dev(tcmi_ctx *ctx, const void *d_counts, int64_t L, int64_t ld,
+                  int32_t mincov, int include_ambig,
+                  void *d_plain, void *d_alt, void *d_flags,
+                  void *d_events /* int32[ceil(L/256)*256], may be NULL */,
+                  void *d_event_counts /* int32[ceil(L/256)], may be NULL */);
+
+/* Host-buffer convenience (counts rows [L][7] in, bytes out). event_idx (capacity L)
+ * receives the ascending 0-based indices of positions with flags & TCMI_EVENT_MASK. */
+int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, int include_ambig,
+              uint8_t *plain, uint8_t *alt, uint8_t *flags,
+              int32_t *event_idx, int64_t *n_events);
+
+/* Whole resident step: zero + tally + call + copy records to pinned host memory.
+ * Returns host pointers valid until the next step on this context.              */
+int tcmi_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig,
+              const uint8_t **plain, const uint8_t **alt, const uint8_t **flags,
+              const int32_t **counts_planes /* host [7][ld] */, int64_t *ld);
+
+/* ---- stage B (sequential part, HOST): the consensus walk
+ *      replaces the loop of Sequences.BuildConsensus (Sequences.py:179-322) with
+ *      ORFs.in_orf / SolveTripletLength / CorrectStartPositions / CorrectGFF
+ *      (ORFs.py:1-192) restated in O(L) over the call records.  No GPU needed.
+ *
+ *  orf_*      : one entry per GFF row (all rows take part in in_orf, ORFs.py:16-26;
+ *               only strand '+' rows get their end corrected, ORFs.py:154)
+ *  ins_pos    : 1-based positions of accepted inserts (ascending), ins_shift =
+ *               int(size_str) of Events.py:75-80 (last digit only), ins_seq/ins_off =
+ *               concatenated insert strings.
+ *  out_cons   : capacity cons_cap bytes (L + total insert length is enough)
+ *  new_start/new_end : corrected GFF coordinates per row
+ *  err_pos    : for TCMI_E_KEYERROR the missing key (L+1)                          */
+int tcmi_consensus_walk(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags, int64_t L,
+                        int32_t n_orf, const int64_t *orf_start, const int64_t *orf_end,
+                        const uint8_t *orf_is_plus,
+                        int32_t n_ins, const int64_t *ins_pos, const int32_t *ins_shift,
+                        const char *ins_seq, const int64_t *ins_off,
+                        int include_ins,
+                        char *out_cons, int64_t cons_cap, int64_t *out_len,
+                        int64_t *new_start, int64_t *new_end, int64_t *err_pos);
+
+/* ---- insert tokens (Events.ExtractInserts, Events.py:47-82), HOST.
+ * Scans the reads overlapping 1-based `position` under pysam's default pileup filters
+ * and returns the modal upper-cased token (first-seen tie-break).  token_cap bytes.
+ * *n_tokens = number of tokens in the column (0: empty pileup).                    */
+int tcmi_modal_token(const tcmi_reads *reads, int64_t position, int32_t min_base_quality,
+                     uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
+                     char *token, int64_t token_cap, int64_t *n_tokens);
+
+/* ---- BAM reader (pysam's role; SAM spec §4.2), HOST, zlib inflate -------- */
+typedef struct tcmi_bam tcmi_bam;
+int  tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out);
+int  tcmi_bam_free(tcmi_bam *bam);
+/* fills `reads` with pointers owned by `bam`; n_ref / first reference name and length */
+int  tcmi_bam_reads(const tcmi_bam *bam, tcmi_reads *reads);
+int  tcmi_bam_header(const tcmi_bam *bam, int32_t *n_ref, const char **ref0_name, int64_t *ref0_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCMI_H */

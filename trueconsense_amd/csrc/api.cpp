@@ -1,0 +1,498 @@
+// api.cpp — context, error text, profiling brackets, read-set upload and the host-buffer
+// conveniences of the C ABI declared in include/tcmi.h.
+#include <cstdlib>
+#include <cstring>
+
+#include "tcmi_internal.h"
+
+static thread_local std::string g_err;
+
+int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" {
+
+int tcmi_abi_version(void) { return TCMI_ABI_VERSION; }
+
+const char *tcmi_last_error(const tcmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int tcmi_device_count(int *out_count)
+{
+    if (!out_count) return tcmi_fail(nullptr, TCMI_E_ARG, "out_count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    (void)hipGetLastError();
+    *out_count = n;
+    return TCMI_OK;
+}
+
+int tcmi_ctx_create(int device, tcmi_ctx **out)
+{
+    if (!out) return tcmi_fail(nullptr, TCMI_E_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return tcmi_fail(nullptr, TCMI_E_NODEVICE,
+                         "no HIP device available (%s); libtcmi has no CPU path",
+                         e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n)
+        return tcmi_fail(nullptr, TCMI_E_ARG, "device %d out of range (%d devices)", device, n);
+    if (hipSetDevice(device) != hipSuccess)
+        return tcmi_fail(nullptr, TCMI_E_NODEVICE, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return tcmi_fail(nullptr, TCMI_E_NODEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return tcmi_fail(nullptr, TCMI_E_NODEVICE, "device %d is %s; libtcmi is built for gfx950 only",
+                         device, prop.gcnArchName);
+    tcmi_ctx *c = new tcmi_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return tcmi_fail(nullptr, TCMI_E_HIP, "hipStreamCreate failed");
+    }
+    const char *v = std::getenv("TCMI_TALLY_VARIANT");
+    if (v) c->tally_variant = std::atoi(v);
+    v = std::getenv("TCMI_ROUNDS_PER_WG");
+    if (v) c->rounds_per_wg = std::atoi(v);
+    *out = c;
+    return TCMI_OK;
+}
+
+static void free_ws(tcmi_ctx *c)
+{
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_plain) (void)hipFree(c->d_plain);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    c->d_counts = nullptr;
+    c->d_plain = c->d_alt = c->d_flags = nullptr;
+    c->h_rec = nullptr;
+    c->h_counts = nullptr;
+    c->ws_L = c->ws_ld = 0;
+}
+
+int tcmi_ctx_destroy(tcmi_ctx *c)
+{
+    if (!c) return TCMI_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    free_ws(c);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TCMI_OK;
+}
+
+int tcmi_ctx_sync(tcmi_ctx *c)
+{
+    if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
+    TCMI_HIP(c, hipStreamSynchronize(c->stream));
+    return TCMI_OK;
+}
+
+void *tcmi_ctx_stream(tcmi_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return tcmi_fail(c, TCMI_E_ARG, "null argument");
+    if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
+    else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
+    else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
+    return TCMI_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------
+int tcmi_profile_enable(tcmi_ctx *c, int on)
+{
+    if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
+    c->prof = on != 0;
+    return TCMI_OK;
+}
+
+static int drain(tcmi_ctx *c)
+{
+    for (auto &p : c->pending) {
+        TCMI_HIP(c, hipEventSynchronize(p.b));
+        float ms = 0.f;
+        TCMI_HIP(c, hipEventElapsedTime(&ms, p.a, p.b));
+        c->prof_ms[p.k] += ms;
+        c->prof_n[p.k] += 1;
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+    return TCMI_OK;
+}
+
+int tcmi_profile_reset(tcmi_ctx *c)
+{
+    if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
+    int rc = drain(c);
+    for (int k = 0; k < TCMI_K_NKERNELS; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return rc;
+}
+
+int tcmi_profile_get(tcmi_ctx *c, int k, double *total_ms, int64_t *launches)
+{
+    if (!c || k < 0 || k >= TCMI_K_NKERNELS) return tcmi_fail(c, TCMI_E_ARG, "bad kernel id");
+    int rc = drain(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return TCMI_OK;
+}
+
+} // extern "C"
+
+static hipEvent_t get_event(tcmi_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void tcmi_prof_begin(tcmi_ctx *c, int k)
+{
+    if (!c->prof) return;
+    tcmi_ctx::Pending p{k, get_event(c), get_event(c)};
+    (void)hipEventRecord(p.a, c->stream);
+    c->pending.push_back(p);
+}
+
+void tcmi_prof_end(tcmi_ctx *c, int k)
+{
+    if (!c->prof || c->pending.empty()) return;
+    (void)k;
+    (void)hipEventRecord(c->pending.back().b, c->stream);
+}
+
+// ---- read set -----------------------------------------------------------------------------
+static inline bool consumes_ref(unsigned op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+static int64_t ref_span(const uint32_t *cg, int64_t n)
+{
+    int64_t s = 0;
+    for (int64_t k = 0; k < n; ++k)
+        if (consumes_ref(cg[k] & 0xF)) s += cg[k] >> 4;
+    return s;
+}
+
+static inline bool piles_up(const tcmi_reads *r, int64_t i, int64_t *span)
+{
+    if (r->flag[i] & 0x4) return false;
+    if (r->tid && r->tid[i] < 0) return false;
+    if (r->pos[i] < 0) return false;
+    *span = ref_span(r->cigar + r->cigar_off[i], (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]));
+    return *span > 0;
+}
+
+static int check_reads(tcmi_ctx *ctx, const tcmi_reads *r)
+{
+    if (!r) return tcmi_fail(ctx, TCMI_E_ARG, "reads is NULL");
+    if (r->n_reads < 0) return tcmi_fail(ctx, TCMI_E_ARG, "n_reads < 0");
+    if (r->n_reads > 0 && (!r->pos || !r->flag || !r->l_qseq || !r->cigar_off || !r->seq_off))
+        return tcmi_fail(ctx, TCMI_E_ARG, "reads has NULL arrays");
+    return TCMI_OK;
+}
+
+extern "C" {
+
+int tcmi_reads_extent(const tcmi_reads *r, int64_t ref_len, int64_t *out_L)
+{
+    int rc = check_reads(nullptr, r);
+    if (rc) return rc;
+    if (!out_L) return tcmi_fail(nullptr, TCMI_E_ARG, "out_L is NULL");
+    int64_t L = ref_len > 0 ? ref_len : 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        int64_t span;
+        if (!piles_up(r, i, &span)) continue;
+        if (r->pos[i] + span > L) L = r->pos[i] + span;
+    }
+    *out_L = L;
+    return TCMI_OK;
+}
+
+int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
+{
+    if (!rs) return TCMI_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    void *ptrs[] = {rs->d_pos, rs->d_meta, rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete rs;
+    return TCMI_OK;
+}
+
+int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
+{
+    if (!ctx || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    *out = nullptr;
+    int rc = check_reads(ctx, r);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+
+    // pass 1: select reads, size the streams
+    std::vector<int64_t> keep;
+    keep.reserve((size_t)r->n_reads);
+    int64_t n_cig = 0, n_seqw = 0, alg = 0, max_end = 0, max_span = 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        int64_t span;
+        if (!piles_up(r, i, &span)) continue;
+        int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+        if (nc > 65535)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)", (long long)i, (long long)nc);
+        int64_t lq = r->l_qseq[i];
+        if (lq < 0) return tcmi_fail(ctx, TCMI_E_ARG, "read %lld has negative l_qseq", (long long)i);
+        int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
+        if (nbytes < (lq + 1) / 2)
+            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)", (long long)i, (long long)nbytes);
+        if (span > INT32_MAX || r->pos[i] + span > INT32_MAX)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31", (long long)i);
+        keep.push_back(i);
+        n_cig += nc;
+        n_seqw += (lq + 7) / 8;
+        alg += 12 + 4 * nc + (lq + 1) / 2;
+        if (r->pos[i] + span > max_end) max_end = r->pos[i] + span;
+        if (span > max_span) max_span = span;
+    }
+    const int64_t n = (int64_t)keep.size();
+    const int64_t n_rounds = (n + TCMI_ROUND - 1) / TCMI_ROUND;
+
+    // pass 2: pack
+    std::vector<int32_t> h_pos((size_t)n), h_lseq((size_t)n);
+    std::vector<uint32_t> h_meta((size_t)n), h_cig((size_t)n_cig + 1), h_seq((size_t)n_seqw + 1);
+    std::vector<int64_t> h_rc((size_t)n_rounds + 1), h_rs((size_t)n_rounds + 1);
+    int64_t co = 0, so = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t i = keep[(size_t)j];
+        if (j % TCMI_ROUND == 0) { h_rc[(size_t)(j / TCMI_ROUND)] = co; h_rs[(size_t)(j / TCMI_ROUND)] = so; }
+        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+        const int64_t lq = r->l_qseq[i];
+        h_pos[(size_t)j] = r->pos[i];
+        h_lseq[(size_t)j] = (int32_t)lq;
+        h_meta[(size_t)j] = ((uint32_t)r->flag[i] << 16) | (uint32_t)nc;
+        std::memcpy(&h_cig[(size_t)co], r->cigar + r->cigar_off[i], (size_t)nc * 4);
+        co += nc;
+        const uint8_t *s = r->seq + r->seq_off[i];
+        const int64_t nw = (lq + 7) / 8, nb = (lq + 1) / 2;
+        uint8_t *dst = reinterpret_cast<uint8_t *>(&h_seq[(size_t)so]);
+        for (int64_t b = 0; b < nb; ++b) dst[b] = (uint8_t)((s[b] << 4) | (s[b] >> 4));   // linear nibble order
+        if (lq & 1) dst[nb - 1] &= 0x0F;                                                   // pad nibble = 0
+        for (int64_t b = nb; b < nw * 4; ++b) dst[b] = 0;
+        so += nw;
+    }
+    h_rc[(size_t)n_rounds] = co;
+    h_rs[(size_t)n_rounds] = so;
+
+    tcmi_readset *rs = new tcmi_readset();
+    rs->n_reads = r->n_reads; rs->n_piled = n; rs->n_rounds = n_rounds; rs->n_cigar = n_cig; rs->n_seqw = n_seqw;
+    rs->alg_bytes = alg; rs->max_end = max_end; rs->max_span = (int32_t)max_span; rs->device = ctx->device;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        // +256 B slack so 16-byte vector loads of the last elements stay in bounds
+        hipError_t e = hipMalloc(d, bytes + 256);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        e = hipMemsetAsync((char *)*d + bytes, 0, 256, ctx->stream);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "upload failed: %s", hipGetErrorString(e));
+        rs->dev_bytes += (int64_t)bytes;
+        return TCMI_OK;
+    };
+    rc = up((void **)&rs->d_pos, h_pos.data(), (size_t)n * 4);
+    if (!rc) rc = up((void **)&rs->d_meta, h_meta.data(), (size_t)n * 4);
+    if (!rc) rc = up((void **)&rs->d_lseq, h_lseq.data(), (size_t)n * 4);
+    if (!rc) rc = up((void **)&rs->d_cigar, h_cig.data(), (size_t)n_cig * 4);
+    if (!rc) rc = up((void **)&rs->d_seq, h_seq.data(), (size_t)n_seqw * 4);
+    if (!rc) rc = up((void **)&rs->d_round_cig, h_rc.data(), (size_t)(n_rounds + 1) * 8);
+    if (!rc) rc = up((void **)&rs->d_round_seq, h_rs.data(), (size_t)(n_rounds + 1) * 8);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "sync after upload failed");
+    if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    *out = rs;
+    return TCMI_OK;
+}
+
+int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled, int64_t *alg, int64_t *dev,
+                      int64_t *max_end)
+{
+    if (!rs) return tcmi_fail(nullptr, TCMI_E_ARG, "readset is NULL");
+    if (n_reads) *n_reads = rs->n_reads;
+    if (n_piled) *n_piled = rs->n_piled;
+    if (alg) *alg = rs->alg_bytes;
+    if (dev) *dev = rs->dev_bytes;
+    if (max_end) *max_end = rs->max_end;
+    return TCMI_OK;
+}
+
+// ---- tally -----------------------------------------------------------------------------------
+int tcmi_tally_dev(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, void *d_counts, int zero)
+{
+    if (!ctx || !rs || !d_counts) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 < L <= ld (L=%lld ld=%lld)", (long long)L, (long long)ld);
+    if (L > INT32_MAX - 1024) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "L too large");
+    if (rs->device != ctx->device) return tcmi_fail(ctx, TCMI_E_ARG, "read set lives on device %d, context on %d", rs->device, ctx->device);
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (zero) {
+        tcmi_prof_begin(ctx, TCMI_K_ZERO);
+        TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
+        tcmi_prof_end(ctx, TCMI_K_ZERO);
+    }
+    if (rs->n_piled == 0) return TCMI_OK;
+    return tcmi_launch_tally(ctx, rs, L, ld, (int32_t *)d_counts);
+}
+
+static int ensure_ws(tcmi_ctx *ctx, int64_t L)
+{
+    if (ctx->ws_L >= L && ctx->d_counts) return TCMI_OK;
+    free_ws(ctx);
+    int64_t ld = tcmi_round_up(L, 256);
+    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4));
+    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_plain, (size_t)ld * 3));
+    ctx->d_alt = ctx->d_plain + ld;
+    ctx->d_flags = ctx->d_plain + 2 * ld;
+    TCMI_HIP(ctx, hipHostMalloc((void **)&ctx->h_rec, (size_t)ld * 3, hipHostMallocDefault));
+    TCMI_HIP(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)ld * TCMI_NCOL * 4, hipHostMallocDefault));
+    ctx->ws_L = L;
+    ctx->ws_ld = ld;
+    return TCMI_OK;
+}
+
+int tcmi_counts_download(tcmi_ctx *ctx, const void *d_counts, int64_t L, int64_t ld, int32_t *counts)
+{
+    if (!ctx || !d_counts || !counts || L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "bad argument");
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> planes((size_t)ld * TCMI_NCOL);
+    TCMI_HIP(ctx, hipMemcpyAsync(planes.data(), d_counts, planes.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < TCMI_NCOL; ++c) {
+        const int32_t *src = planes.data() + (size_t)c * ld;
+        for (int64_t p = 0; p < L; ++p) counts[p * TCMI_NCOL + c] = src[p];
+    }
+    return TCMI_OK;
+}
+
+int tcmi_counts_upload(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int64_t ld, void *d_counts)
+{
+    if (!ctx || !d_counts || !counts || L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "bad argument");
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> planes((size_t)ld * TCMI_NCOL, 0);
+    for (int c = 0; c < TCMI_NCOL; ++c)
+        for (int64_t p = 0; p < L; ++p) planes[(size_t)c * ld + p] = counts[p * TCMI_NCOL + c];
+    TCMI_HIP(ctx, hipMemcpyAsync(d_counts, planes.data(), planes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TCMI_OK;
+}
+
+int tcmi_tally(tcmi_ctx *ctx, const tcmi_reads *reads, int64_t L, int32_t *counts)
+{
+    if (!ctx || !counts) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0) return tcmi_fail(ctx, TCMI_E_ARG, "L must be positive");
+    tcmi_readset *rs = nullptr;
+    int rc = tcmi_readset_upload(ctx, reads, &rs);
+    if (rc) return rc;
+    if (rs->max_end > L) {
+        tcmi_readset_free(ctx, rs);
+        return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the read extent %lld (use tcmi_reads_extent)",
+                         (long long)L, (long long)rs->max_end);
+    }
+    rc = ensure_ws(ctx, L);
+    if (!rc) rc = tcmi_tally_dev(ctx, rs, L, ctx->ws_ld, ctx->d_counts, 1);
+    if (!rc) rc = tcmi_counts_download(ctx, ctx->d_counts, L, ctx->ws_ld, counts);
+    tcmi_readset_free(ctx, rs);
+    return rc;
+}
+
+// ---- call ------------------------------------------------------------------------------------
+int tcmi_call_dev(tcmi_ctx *ctx, const void *d_counts, int64_t L, int64_t ld, int32_t mincov, int include_ambig,
+                  void *d_plain, void *d_alt, void *d_flags, void *d_events, void *d_event_counts)
+{
+    if (!ctx || !d_counts || !d_plain || !d_alt || !d_flags) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 < L <= ld");
+    if ((d_events == nullptr) != (d_event_counts == nullptr))
+        return tcmi_fail(ctx, TCMI_E_ARG, "d_events and d_event_counts must both be given or both NULL");
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    return tcmi_launch_call(ctx, (const int32_t *)d_counts, L, ld, mincov, include_ambig, (uint8_t *)d_plain,
+                            (uint8_t *)d_alt, (uint8_t *)d_flags, (int32_t *)d_events, (int32_t *)d_event_counts);
+}
+
+int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, int include_ambig, uint8_t *plain,
+              uint8_t *alt, uint8_t *flags, int32_t *event_idx, int64_t *n_events)
+{
+    if (!ctx || !counts || !plain || !alt || !flags) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0) return tcmi_fail(ctx, TCMI_E_ARG, "L must be positive");
+    int rc = ensure_ws(ctx, L);
+    if (rc) return rc;
+    const int64_t ld = ctx->ws_ld;
+    rc = tcmi_counts_upload(ctx, counts, L, ld, ctx->d_counts);
+    if (rc) return rc;
+    int32_t *d_ev = nullptr, *d_evc = nullptr;
+    const int64_t nblk = (L + 255) / 256;
+    if (event_idx) {
+        TCMI_HIP(ctx, hipMalloc((void **)&d_ev, (size_t)nblk * 256 * 4));
+        TCMI_HIP(ctx, hipMalloc((void **)&d_evc, (size_t)nblk * 4));
+    }
+    rc = tcmi_call_dev(ctx, ctx->d_counts, L, ld, mincov, include_ambig, ctx->d_plain, ctx->d_alt, ctx->d_flags, d_ev, d_evc);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "record download failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        std::memcpy(plain, ctx->h_rec, (size_t)L);
+        std::memcpy(alt, ctx->h_rec + ld, (size_t)L);
+        std::memcpy(flags, ctx->h_rec + 2 * ld, (size_t)L);
+    }
+    if (!rc && event_idx) {
+        std::vector<int32_t> ev((size_t)nblk * 256), evc((size_t)nblk);
+        hipError_t e = hipMemcpy(ev.data(), d_ev, ev.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(evc.data(), d_evc, evc.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "event download failed: %s", hipGetErrorString(e));
+        int64_t n = 0;
+        for (int64_t b = 0; !rc && b < nblk; ++b)
+            for (int32_t k = 0; k < evc[(size_t)b]; ++k) event_idx[n++] = ev[(size_t)b * 256 + k];
+        if (n_events) *n_events = n;
+    }
+    if (d_ev) (void)hipFree(d_ev);
+    if (d_evc) (void)hipFree(d_evc);
+    return rc;
+}
+
+int tcmi_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig,
+              const uint8_t **plain, const uint8_t **alt, const uint8_t **flags, const int32_t **counts_planes,
+              int64_t *ld_out)
+{
+    if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || rs->max_end > L) return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld does not cover the reads (extent %lld)", (long long)L, (long long)rs->max_end);
+    int rc = ensure_ws(ctx, L);
+    if (rc) return rc;
+    const int64_t ld = ctx->ws_ld;
+    rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 1);
+    if (rc) return rc;
+    rc = tcmi_call_dev(ctx, ctx->d_counts, L, ld, mincov, include_ambig, ctx->d_plain, ctx->d_alt, ctx->d_flags, nullptr, nullptr);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts_planes)
+        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (plain) *plain = ctx->h_rec;
+    if (alt) *alt = ctx->h_rec + ld;
+    if (flags) *flags = ctx->h_rec + 2 * ld;
+    if (counts_planes) *counts_planes = ctx->h_counts;
+    if (ld_out) *ld_out = ld;
+    return TCMI_OK;
+}
+
+} // extern "C"

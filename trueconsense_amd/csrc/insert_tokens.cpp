@@ -1,0 +1,157 @@
+// insert_tokens.cpp — HOST: the token multiset behind Events.ExtractInserts
+// (TrueConsense/Events.py:47-82), for all candidate positions in one sweep over the reads.
+//
+// The reference opens a fresh region pileup per candidate with pysam's DEFAULT arguments
+// (Events.py:66): stepper "samtools" (drop UNMAP|SECONDARY|QCFAIL|DUP and orphans),
+// min_base_quality 13, no reference attached; it upper-cases every token and takes the modal
+// one with first-seen tie-break (collections.Counter.most_common, Events.py:71-74).
+// Token text follows pysam's PileupColumn.get_query_sequences(add_indels=True).
+// Not modelled (documented in DESIGN.md): mate-overlap quality tweaking (ignore_overlaps) and
+// the max_depth=8000 read cap — `*depth_exceeded` reports when the latter could matter.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "tcmi_internal.h"
+
+namespace {
+
+const char NT16[] = "=ACMGRSVTWYHKDBN";
+
+inline bool consumes_ref(unsigned op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+inline bool is_match(unsigned op) { return op == 0 || op == 7 || op == 8; }
+inline bool consumes_query(unsigned op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+
+// p->indel of htslib's resolve_cigar2 at the last base of op k
+int64_t indel_after(const uint32_t *cg, int64_t n, int64_t k)
+{
+    if (k + 1 >= n) return 0;
+    const unsigned op = cg[k] & 0xF, op2 = cg[k + 1] & 0xF;
+    int64_t tot = 0;
+    if (op2 == 2 && op != 2) {
+        tot = -(int64_t)(cg[k + 1] >> 4);
+        for (int64_t j = k + 2; j < n && (cg[j] & 0xF) == 2; ++j) tot -= cg[j] >> 4;
+    } else if (op2 == 1) {
+        tot = cg[k + 1] >> 4;
+        for (int64_t j = k + 2; j < n; ++j) {
+            const unsigned o = cg[j] & 0xF;
+            if (o == 1) tot += cg[j] >> 4;
+            else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        for (int64_t j = k + 2; j < n; ++j) {
+            const unsigned o = cg[j] & 0xF;
+            if (o == 1) tot += cg[j] >> 4;
+            else if (consumes_ref(o)) break;
+        }
+    }
+    return tot;
+}
+
+struct Column {
+    std::unordered_map<std::string, std::pair<int64_t, int64_t>> seen;   // token -> (count, first order)
+    int64_t n = 0;
+    int64_t depth = 0;     // reads overlapping the column before base-quality filtering
+};
+
+} // namespace
+
+extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64_t *positions /* 1-based, ascending */,
+                                 int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
+                                 char *tokens, int64_t tokens_cap, int64_t *token_off /* [n_pos+1] */,
+                                 int64_t *n_tokens /* [n_pos] */, int32_t *depth_exceeded)
+{
+    if (!r || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
+        return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    for (int32_t k = 1; k < n_pos; ++k)
+        if (positions[k] <= positions[k - 1]) return tcmi_fail(nullptr, TCMI_E_ARG, "positions must ascend");
+    if (depth_exceeded) *depth_exceeded = 0;
+    std::vector<Column> cols((size_t)n_pos);
+    int64_t qoff = 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        const int64_t lq = r->l_qseq[i];
+        const int64_t my_qoff = qoff;
+        qoff += lq;
+        const unsigned fl = r->flag[i];
+        if ((fl & 0x4) || (r->tid && r->tid[i] < 0) || r->pos[i] < 0) continue;
+        if (fl & flag_filter) continue;
+        if (ignore_orphans && (fl & 0x1) && !(fl & 0x2)) continue;
+        const uint32_t *cg = r->cigar + r->cigar_off[i];
+        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+        int64_t span = 0;
+        for (int64_t k = 0; k < nc; ++k)
+            if (consumes_ref(cg[k] & 0xF)) span += cg[k] >> 4;
+        if (span == 0) continue;
+        const int64_t beg = r->pos[i], end = beg + span;      // 0-based half-open
+        // candidate columns c = position-1 in [beg, end)
+        const int64_t *lo = std::lower_bound(positions, positions + n_pos, beg + 1);
+        for (const int64_t *pp = lo; pp < positions + n_pos && *pp - 1 < end; ++pp) {
+            const int64_t col = *pp - 1;
+            Column &C = cols[(size_t)(pp - positions)];
+            ++C.depth;
+            // locate the op covering col
+            int64_t x = beg, y = 0;
+            for (int64_t k = 0; k < nc; ++k) {
+                const unsigned op = cg[k] & 0xF;
+                const int64_t len = cg[k] >> 4;
+                if (consumes_ref(op)) {
+                    if (col < x + len) {
+                        const bool rev = fl & 0x10;
+                        const uint8_t *s = r->seq + r->seq_off[i];
+                        auto base = [&](int64_t q) -> char {
+                            if (q >= lq) return 'N';
+                            const unsigned nib = (q & 1) ? (s[q >> 1] & 0xF) : (s[q >> 1] >> 4);
+                            const char ch = NT16[nib];
+                            return ch == '=' ? (rev ? ',' : '.') : ch;       // upper-cased text
+                        };
+                        const int64_t qpos = is_match(op) ? y + (col - x) : y;
+                        int q = 255;
+                        if (r->qual) q = qpos < lq ? r->qual[my_qoff + qpos] : 0;
+                        if (q < min_base_quality) break;                     // pileup_base_qual_skip
+                        std::string tok;
+                        if (is_match(op)) tok.push_back(base(qpos));
+                        else tok.push_back(op == 3 ? (rev ? '<' : '>') : '*');
+                        if (col == x + len - 1) {
+                            const int64_t indel = indel_after(cg, nc, k);
+                            if (indel > 0) {
+                                tok += "+" + std::to_string(indel);
+                                for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
+                            } else if (indel < 0) {
+                                tok += "-" + std::to_string(-indel);
+                                tok.append((size_t)(-indel), 'N');
+                            }
+                        }
+                        auto it = C.seen.find(tok);
+                        if (it == C.seen.end()) C.seen.emplace(std::move(tok), std::make_pair((int64_t)1, C.n));
+                        else ++it->second.first;
+                        ++C.n;
+                        break;
+                    }
+                    x += len;
+                }
+                if (consumes_query(op)) y += len;
+            }
+        }
+    }
+    int64_t off = 0;
+    for (int32_t k = 0; k < n_pos; ++k) {
+        token_off[k] = off;
+        n_tokens[k] = cols[(size_t)k].n;
+        if (max_depth > 0 && cols[(size_t)k].depth > max_depth && depth_exceeded) *depth_exceeded = 1;
+        const std::string *best = nullptr;
+        int64_t bc = 0, bo = 0;
+        for (auto &kv : cols[(size_t)k].seen)
+            if (!best || kv.second.first > bc || (kv.second.first == bc && kv.second.second < bo)) {
+                best = &kv.first; bc = kv.second.first; bo = kv.second.second;
+            }
+        if (best) {
+            if (off + (int64_t)best->size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");
+            std::memcpy(tokens + off, best->data(), best->size());
+            off += (int64_t)best->size();
+        }
+    }
+    token_off[n_pos] = off;
+    return TCMI_OK;
+}

@@ -85,6 +85,8 @@ int  tcmi_ctx_create(int device, tcmi_ctx **out);  /* fails with TCMI_E_NODEVICE
 int  tcmi_ctx_destroy(tcmi_ctx *ctx);
 int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
 void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
+/* tuning knobs: "tally_variant" (0 = default kernel), "rounds_per_wg" (0 = auto)               */
+int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
 enum { TCMI_K_TALLY = 0, TCMI_K_CALL = 1, TCMI_K_ZERO = 2, TCMI_K_NKERNELS = 3 };
@@ -170,12 +172,18 @@ int tcmi_consensus_walk(const uint8_t *plain, const uint8_t *alt, const uint8_t 
                         int64_t *new_start, int64_t *new_end, int64_t *err_pos);
 
 /* ---- insert tokens (Events.ExtractInserts, Events.py:47-82), HOST.
- * Scans the reads overlapping 1-based `position` under pysam's default pileup filters
- * and returns the modal upper-cased token (first-seen tie-break).  token_cap bytes.
- * *n_tokens = number of tokens in the column (0: empty pileup).                    */
-int tcmi_modal_token(const tcmi_reads *reads, int64_t position, int32_t min_base_quality,
-                     uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
-                     char *token, int64_t token_cap, int64_t *n_tokens);
+ * For each 1-based candidate position (ascending) scans the reads overlapping it under the
+ * filters of pysam's default-argument region pileup (Events.py:66) and returns the modal
+ * upper-cased token (Counter.most_common, first-seen tie-break, Events.py:71-74).
+ *   tokens / token_off : concatenated modal tokens, token k = tokens[token_off[k] .. token_off[k+1])
+ *                        (empty when the column has no token)
+ *   n_tokens[k]        : tokens in column k after filtering (0: empty pileup -> position dropped)
+ *   depth_exceeded     : set to 1 when some column holds more than max_depth reads (pysam's
+ *                        max_depth=8000 cap is not modelled)                    */
+int tcmi_modal_tokens(const tcmi_reads *reads, int32_t n_pos, const int64_t *positions,
+                      int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans,
+                      int64_t max_depth, char *tokens, int64_t tokens_cap, int64_t *token_off,
+                      int64_t *n_tokens, int32_t *depth_exceeded);
 
 /* ---- BAM reader (pysam's role; SAM spec §4.2), HOST, zlib inflate -------- */
 typedef struct tcmi_bam tcmi_bam;
@@ -184,6 +192,10 @@ int  tcmi_bam_free(tcmi_bam *bam);
 /* fills `reads` with pointers owned by `bam`; n_ref / first reference name and length */
 int  tcmi_bam_reads(const tcmi_bam *bam, tcmi_reads *reads);
 int  tcmi_bam_header(const tcmi_bam *bam, int32_t *n_ref, const char **ref0_name, int64_t *ref0_len);
+/* any out pointer may be NULL; sorted = 1 when mapped reads ascend by (tid, pos)               */
+int  tcmi_bam_info(const tcmi_bam *bam, int64_t *n_reads, int32_t *sorted, int64_t *file_bytes,
+                   int64_t *inflated_bytes, int64_t *n_blocks, int64_t *n_cigar, int64_t *n_qual);
+const char *tcmi_bam_text(const tcmi_bam *bam);    /* SAM header text, owned by bam                */
 
 #ifdef __cplusplus
 }

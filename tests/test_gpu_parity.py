@@ -1,0 +1,251 @@
+"""GPU parity (run with -m gpu on an MI355X): the HIP tally / call kernels and the whole
+BAM -> FASTA/VCF/GFF/TSV path, through the C ABI, against the golden vectors from the real
+reference and against the oracle on seeded inputs.  Integer / byte results: bit-exact."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import tc_oracle as orc
+from tests import synth_small as ss
+from trueconsense_amd import Events, Sequences, _ffi, _state, engine, indexing
+from trueconsense_amd import synthetic as sy
+from trueconsense_amd.io import bamwriter
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name + ".json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _state.default_context()          # raises loudly without a GPU / without libtcmi.so
+    yield c
+
+
+def gffdict(orfs):
+    return {k: {"seqid": "S", "source": "x", "type": "CDS", "start": o["start"], "end": o["end"], "score": ".",
+                "strand": o["strand"], "phase": "0", "attributes": "ID=o%d;Name=orf%d" % (k, k)}
+            for k, o in enumerate(orfs)}
+
+
+# ------------------------------------------------------------------ stage A
+def test_tally_matches_reference_counts(ctx):
+    for case in load("outputs"):
+        reads = ss.reads_from_spec(case["spec"])
+        got = ctx.tally(reads, ref_len=len(case["spec"]["ref"]))
+        assert got.tolist() == case["counts"], case["name"]
+
+
+def _check_tally(ctx, reads, L):
+    want = c_oracle.tally(reads, L)
+    got = ctx.tally(reads, L=L)
+    assert np.array_equal(got, want)
+    return got
+
+
+def test_tally_seeded_mid_size_with_indels(ctx):
+    ref, orfs = sy.make_reference()
+    reads = sy.make_reads(ref, 200_000, seed=11, indel_sites=sy.default_indel_sites(orfs))
+    got = _check_tally(ctx, reads, len(ref))
+    assert got[:, 5].sum() > 1000 and got[:, 6].sum() > 1000
+
+
+def test_tally_edge_cases(ctx):
+    ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
+    base = sy.make_reads(ref, 3000, seed=3)
+    # sparse reads: every workgroup window misses most of its reads
+    sparse = sy.make_reads(ref, 40, seed=4)
+    _check_tally(ctx, sparse, len(ref))
+    # unsorted input: still correct (window misses fall back to global atomics)
+    perm = np.random.default_rng(0).permutation(base["n_reads"])
+    shuf = dict(base)
+    shuf["pos"], shuf["flag"] = base["pos"][perm], base["flag"][perm]
+    shuf["seq"] = base["seq"].reshape(base["n_reads"], -1)[perm].reshape(-1)
+    _check_tally(ctx, shuf, len(ref))
+    # long reads (span > LDS window) and reads running past the reference end
+    spec = {"reads": [{"pos": 10, "flag": 0, "cigar": "900M", "seq": "ACGT" * 225},
+                      {"pos": 12, "flag": 16, "cigar": "5M700N5M", "seq": "ACGTACGTAC"},
+                      {"pos": 4990, "flag": 0, "cigar": "30M", "seq": "ACGTAC" * 5},
+                      {"pos": 100, "flag": 0, "cigar": "4M2D3M1I2M", "seq": "ACGTACGTAC"},
+                      {"pos": 100, "flag": 4, "cigar": "10M", "seq": "ACGTACGTAC"},
+                      {"pos": 200, "flag": 0, "cigar": "10M", "seq": "*"},
+                      {"pos": 300, "flag": 0, "cigar": "3M", "seq": "NRA"}]}
+    reads = ss.reads_from_spec(spec)
+    L = engine.reads_extent(reads, len(ref))
+    assert L == 5020
+    got = _check_tally(ctx, reads, L)
+    assert got[205, 0] == 1 and got[205, 1:].sum() == 0            # SEQ '*' -> N tokens: coverage only
+    # nothing piles up / no reads at all
+    none = ss.reads_from_spec({"reads": [{"pos": 5, "flag": 4, "cigar": "10M", "seq": "ACGTACGTAC"}]})
+    assert ctx.tally(none, L=50).sum() == 0
+    empty = ss.reads_from_spec({"reads": []})
+    assert ctx.tally(empty, L=50).sum() == 0
+    with pytest.raises(_ffi.TcmiError):
+        ctx.tally(base, L=100)                                       # L smaller than the read extent
+
+
+def test_tally_accumulate_split_readsets(ctx):
+    """cfg 5 shape: one BAM split into contiguous read ranges, partial matrices summed."""
+    ref, _ = sy.make_reference(L=8000, cds=[(10, 900)])
+    reads = sy.make_reads(ref, 30_000, seed=9)
+    L, ld = len(ref), 8192
+    whole = c_oracle.tally(reads, L)
+    import torch
+    d_counts = torch.zeros(7 * ld, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                    # torch's stream is not the context's stream
+    n = reads["n_reads"]
+    nb = len(reads["seq"]) // n
+    for part, (a, b) in enumerate(((0, n // 3), (n // 3, n))):
+        sub = {"n_reads": b - a, "pos": reads["pos"][a:b], "flag": reads["flag"][a:b], "l_qseq": reads["l_qseq"][a:b],
+               "cigar_off": reads["cigar_off"][a:b + 1] - reads["cigar_off"][a], "cigar": reads["cigar"][a:b],
+               "seq_off": reads["seq_off"][a:b + 1] - reads["seq_off"][a], "seq": reads["seq"][a * nb:b * nb]}
+        rs = ctx.upload(sub)
+        _ffi.check(_ffi.lib().tcmi_tally_dev(ctx.handle, rs.handle, L, ld, C.c_void_p(d_counts.data_ptr()), int(part == 0)),
+                   ctx.handle)
+        ctx.sync()
+        rs.free()
+    got = d_counts.cpu().numpy().reshape(7, ld)[:, :L].T
+    assert np.array_equal(got, whole)
+
+
+def test_full_size_1m_reads_exact_and_deterministic(ctx):
+    """BASELINE config 2: 29 903 bp x 1M reads; compared with the C oracle and run twice."""
+    ref, _ = sy.make_reference()
+    reads = sy.make_reads(ref, 1_000_000, seed=2)
+    L = len(ref)
+    rs = ctx.upload(reads)
+    assert rs.n_piled == 1_000_000 and rs.algorithmic_bytes == 91 * 1_000_000
+    p1, a1, f1, c1 = ctx.step(rs, L, 30, True)
+    p2, a2, f2, c2 = ctx.step(rs, L, 30, True)
+    assert np.array_equal(c1, c2) and np.array_equal(p1, p2) and np.array_equal(f1, f2)
+    assert int(c1[:, 0].sum()) == 150_000_000                       # every base is one token
+    assert np.array_equal(c1[:, 1:6].sum(1), c1[:, 0])              # ACGT-only reads: classes partition coverage
+    want = c_oracle.tally(reads, L)
+    assert np.array_equal(c1, want)
+    wp, wa, wf = c_oracle.call(want, 30, True)
+    assert np.array_equal(p1, wp) and np.array_equal(a1, wa) and np.array_equal(f1, wf)
+    rs.free()
+
+
+# ------------------------------------------------------------------ stage B
+def test_call_matches_reference_rows(ctx):
+    rows = load("rows")
+    m = np.array([c["row"] for c in rows], np.int32)
+    for mincov in (1, 30):
+        for amb in (True, False):
+            plain, alt, flags, ev = ctx.call(m, mincov, amb, want_events=True)
+            wp, wa, wf = c_oracle.call(m, mincov, amb)
+            assert np.array_equal(plain, wp) and np.array_equal(alt, wa) and np.array_equal(flags, wf)
+            assert ev.tolist() == np.nonzero(flags & 14)[0].tolist()
+            for i, case in enumerate(rows):
+                rk = case["rank"]
+                assert bool(flags[i] & _ffi.F_PRIMX) == (rk[0][0] == "X")
+                assert bool(flags[i] & _ffi.F_AMBIG) == case["ambig"][0]
+                if case["mindel"] != "ZeroDivisionError":
+                    assert bool(flags[i] & _ffi.F_MINDEL) == case["mindel"]
+                else:
+                    assert flags[i] & _ffi.F_COVZERO
+                assert bool(flags[i] & _ffi.F_INSCAND) == case["inscand"][str(mincov)]
+                if amb and case["ambig"][0] and not (flags[i] & _ffi.F_LOWCOV):
+                    assert chr(plain[i]) == case["ambig"][1]
+
+
+def test_call_random_matrix_against_oracle(ctx):
+    rng = np.random.default_rng(5)
+    L = 70_001
+    cov = rng.integers(0, 400, L)
+    m = np.zeros((L, 7), np.int32)
+    frac = rng.dirichlet([0.6] * 6, L)
+    m[:, 1:6] = np.floor(frac[:, :5] * cov[:, None]).astype(np.int32)
+    m[:, 0] = cov
+    m[:, 6] = (rng.random(L) < 0.3) * rng.integers(0, 400, L)
+    m[:, 6] = np.minimum(m[:, 6], m[:, 0])
+    for mincov, amb in ((30, True), (0, False), (100, True)):
+        got = ctx.call(m, mincov, amb)
+        want = c_oracle.call(m, mincov, amb)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+
+
+def test_build_consensus_matches_reference(ctx):
+    class Bam:
+        def __init__(self, region):
+            self.region = region
+
+        def modal_token(self, p):
+            from collections import Counter
+            toks = self.region.get(p)
+            return Counter(t.upper() for t in toks).most_common(1)[0][0] if toks else None
+
+    n_ok = n_raise = 0
+    for case in load("consensus"):
+        counts = np.array(case["counts"], np.int32)
+        idict = {i + 1: dict(zip(orc.COLS, (int(v) for v in counts[i]))) for i in range(len(counts))}
+        bam = Bam({int(k): v for k, v in case["region"].items()})
+        has, ins = Events.ListInserts(idict, case["mincov"], bam)
+        assert ins == (None if not case["inserts"] else {int(k): v for k, v in case["inserts"].items()})
+        for key, exp in case["expected"].items():
+            amb, inc = key[3] == "1", key[-1] == "1"
+            if "raises" in exp:
+                n_raise += 1
+                with pytest.raises((KeyError, ZeroDivisionError)) as ei:
+                    Sequences.BuildConsensus(case["mincov"], idict, gffdict(case["orfs"]), amb, bam, inc)
+                assert type(ei.value).__name__ in (exp["raises"], "WalkKeyError")
+                continue
+            cons, gff = Sequences.BuildConsensus(case["mincov"], idict, gffdict(case["orfs"]), amb, bam, inc)
+            assert cons == exp["consensus"], (case["name"], key)
+            assert [[gff[k]["start"], gff[k]["end"]] for k in sorted(gff)] == exp["orfs"]
+            n_ok += 1
+    assert n_ok > 600 and n_raise > 5
+
+
+# ------------------------------------------------------------------ whole path through files
+def test_cli_bam_to_outputs_matches_reference(ctx, tmp_path, monkeypatch):
+    from trueconsense_amd import TrueConsense as cli
+    monkeypatch.chdir(tmp_path)
+    n_done = 0
+    for case in load("outputs"):
+        spec = case["spec"]
+        reads = ss.reads_from_spec(spec)
+        bamwriter.write_bam("in.bam", reads, "refid", len(spec["ref"]))
+        with open("ref.fa", "w") as fh:
+            fh.write(">refid some description\n")
+            for o in range(0, len(spec["ref"]), 60):
+                fh.write(spec["ref"][o:o + 60] + "\n")
+        with open("f.gff", "w") as fh:
+            fh.write("##gff-version 3\n")
+            for k, o in enumerate(spec["orfs"]):
+                fh.write("S\tx\tCDS\t%d\t%d\t.\t%s\t0\tID=o%d;Name=orf%d\n" % (o["start"], o["end"], o["strand"], k, k))
+        df = indexing.BuildIndex("in.bam", "ref.fa")
+        assert df.values.tolist() == case["counts"] and list(df.columns) == list(orc.COLS)
+        assert list(df.index) == list(range(1, len(case["counts"]) + 1))
+        for key, run in case["runs"].items():
+            argv = ["-i", "in.bam", "-ref", "ref.fa", "-gff", "f.gff", "-cov", str(spec["mincov"]), "-name", "SAMPLE",
+                    "-o", "out.fa", "-vcf", "out.vcf", "-ogff", "out.gff", "-doc", "out.tsv"]
+            if key == "amb0":
+                argv.append("-noambig")
+            monkeypatch.setattr(sys, "argv", ["TrueConsense", "ARGS"])
+            if "raises" in run:
+                with pytest.raises((KeyError, ZeroDivisionError, IndexError)):
+                    cli.main(argv)
+                continue
+            cli.main(argv)
+            assert open("out.fa").read() == run["fa"], case["name"]
+            assert open("out.tsv").read() == run["tsv"]
+            lines = open("out.vcf").read().split("\n")
+            lines[1] = "##fileDate=DATE"
+            assert "\n".join(lines) == run["vcf"], case["name"]
+            got = [l.split("\t")[3:5] for l in open("out.gff").read().split("\n")[1:] if l]
+            want = [l.split("\t")[3:5] for l in run["gff"].split("\n")[1:] if l]
+            assert got == want
+            n_done += 1
+    assert n_done >= 20

@@ -1,0 +1,136 @@
+"""ctypes binding of libtcmi.so (C ABI: include/tcmi.h).
+
+There is no Python or CPU fallback anywhere in this package: if the library is missing or
+no gfx950 device is usable, the call raises.  Build it with `python __graft_entry__.py` or
+`make -C trueconsense_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtcmi.so")
+
+TCMI_OK = 0
+E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_FORMAT, E_IO, E_KEYERROR, E_ZERODIV, E_UNSUPPORTED = range(-1, -10, -1)
+COLS = ("coverage", "A", "T", "C", "G", "X", "I")        # indexing.py:134
+F_LOWCOV, F_PRIMX, F_MINDEL, F_INSCAND, F_COVGT, F_COVZERO, F_AMBIG = 1, 2, 4, 8, 16, 32, 64
+K_TALLY, K_CALL, K_ZERO = 0, 1, 2
+
+
+class TcmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtcmi error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Reads(C.Structure):
+    """struct tcmi_reads"""
+    _fields_ = [("n_reads", C.c_int64),
+                ("pos", C.POINTER(C.c_int32)), ("flag", C.POINTER(C.c_uint16)),
+                ("l_qseq", C.POINTER(C.c_int32)),
+                ("cigar_off", C.POINTER(C.c_uint64)), ("cigar", C.POINTER(C.c_uint32)),
+                ("seq_off", C.POINTER(C.c_uint64)), ("seq", C.POINTER(C.c_uint8)),
+                ("qual", C.POINTER(C.c_uint8)), ("tid", C.POINTER(C.c_int32))]
+
+
+_P = C.POINTER
+_vp, _i32, _i64, _int, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_uint32
+_SIGS = {
+    "tcmi_abi_version": (_int, []),
+    "tcmi_last_error": (C.c_char_p, [_vp]),
+    "tcmi_device_count": (_int, [_P(_int)]),
+    "tcmi_ctx_create": (_int, [_int, _P(_vp)]),
+    "tcmi_ctx_destroy": (_int, [_vp]),
+    "tcmi_ctx_sync": (_int, [_vp]),
+    "tcmi_ctx_stream": (_vp, [_vp]),
+    "tcmi_ctx_set_option": (_int, [_vp, C.c_char_p, _int]),
+    "tcmi_profile_enable": (_int, [_vp, _int]),
+    "tcmi_profile_reset": (_int, [_vp]),
+    "tcmi_profile_get": (_int, [_vp, _int, _P(C.c_double), _P(_i64)]),
+    "tcmi_reads_extent": (_int, [_P(Reads), _i64, _P(_i64)]),
+    "tcmi_readset_upload": (_int, [_vp, _P(Reads), _P(_vp)]),
+    "tcmi_readset_free": (_int, [_vp, _vp]),
+    "tcmi_readset_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
+    "tcmi_tally_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _int]),
+    "tcmi_tally": (_int, [_vp, _P(Reads), _i64, _vp]),
+    "tcmi_counts_download": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "tcmi_counts_upload": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "tcmi_call_dev": (_int, [_vp, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp, _vp, _vp]),
+    "tcmi_call": (_int, [_vp, _vp, _i64, _i32, _int, _vp, _vp, _vp, _vp, _P(_i64)]),
+    "tcmi_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
+    "tcmi_consensus_walk": (_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, C.c_char_p, _vp,
+                                   _int, _vp, _i64, _P(_i64), _vp, _vp, _P(_i64)]),
+    "tcmi_modal_tokens": (_int, [_P(Reads), _i32, _vp, _i32, _u32, _int, _i64, _vp, _i64, _vp, _vp, _P(_i32)]),
+    "tcmi_bam_load": (_int, [C.c_char_p, _int, _P(_vp)]),
+    "tcmi_bam_free": (_int, [_vp]),
+    "tcmi_bam_reads": (_int, [_vp, _P(Reads)]),
+    "tcmi_bam_header": (_int, [_vp, _P(_i32), _P(C.c_char_p), _P(_i64)]),
+    "tcmi_bam_info": (_int, [_vp, _P(_i64), _P(_i32), _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
+    "tcmi_bam_text": (C.c_char_p, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C trueconsense_amd/csrc` (needs hipcc). "
+                "trueconsense_amd has no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.tcmi_abi_version() != 1:
+            raise ImportError("libtcmi ABI version %d, expected 1" % handle.tcmi_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc != TCMI_OK:
+        msg = lib().tcmi_last_error(ctx)
+        raise TcmiError(rc, (msg or b"").decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def as_reads(d):
+    """dict of flat numpy arrays (tcmi_reads layout) -> (Reads struct, keep-alive list)."""
+    keep = {}
+
+    def arr(key, dt, required=True):
+        v = d.get(key)
+        if v is None:
+            if required:
+                raise KeyError(key)
+            return None
+        v = np.ascontiguousarray(v, dtype=dt)
+        keep[key] = v
+        return v
+
+    r = Reads()
+    r.n_reads = int(d["n_reads"])
+    for key, dt, ct, req in (("pos", np.int32, C.c_int32, True), ("flag", np.uint16, C.c_uint16, True),
+                             ("l_qseq", np.int32, C.c_int32, True), ("cigar_off", np.uint64, C.c_uint64, True),
+                             ("cigar", np.uint32, C.c_uint32, True), ("seq_off", np.uint64, C.c_uint64, True),
+                             ("seq", np.uint8, C.c_uint8, True), ("qual", np.uint8, C.c_uint8, False),
+                             ("tid", np.int32, C.c_int32, False)):
+        a = arr(key, dt, req)
+        setattr(r, key, a.ctypes.data_as(C.POINTER(ct)) if a is not None else None)
+    return r, keep
+
+
+def device_count():
+    n = _int(0)
+    check(lib().tcmi_device_count(C.byref(n)))
+    return n.value

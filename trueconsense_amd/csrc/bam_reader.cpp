@@ -1,0 +1,278 @@
+// bam_reader.cpp — HOST: BGZF / BAM decoding into the flat read arrays of tcmi_reads.
+//
+// Plays the part pysam.AlignmentFile plays for the reference (TrueConsense/indexing.py:19, 96;
+// the wire format is SAM spec §4.1 BGZF and §4.2 BAM).  No index (.bai) is
+// needed: the whole file is inflated (BGZF blocks are independent gzip members, so they are
+// inflated by `n_threads` workers straight into their final place in one buffer) and every
+// record is decoded once into struct-of-arrays form, the layout tcmi_readset_upload consumes.
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tcmi_internal.h"
+
+struct tcmi_bam {
+    std::string text;                          // SAM header text
+    std::vector<std::string> ref_name;
+    std::vector<int64_t> ref_len;
+    int64_t n = 0;
+    std::vector<int32_t> pos, l_qseq, tid;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint64_t> cigar_off, seq_off;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq, qual;
+    int sorted = 1;                            // coordinate-sorted (tid, pos) among mapped reads
+    int64_t file_bytes = 0, inflated_bytes = 0, n_blocks = 0;
+};
+
+namespace {
+
+struct Block { size_t cin, clen, uout, ulen; uint32_t crc; };
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// Walk the gzip member headers (RFC 1952 + the BC extra subfield of SAM spec §4.1).
+int scan_blocks(const std::vector<uint8_t> &f, std::vector<Block> &blocks, size_t *total)
+{
+    size_t off = 0, out = 0;
+    while (off < f.size()) {
+        if (f.size() - off < 18) return tcmi_fail(nullptr, TCMI_E_FORMAT, "truncated BGZF block header at byte %zu", off);
+        const uint8_t *h = f.data() + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
+            return tcmi_fail(nullptr, TCMI_E_FORMAT, "not a BGZF block at byte %zu (is the file a BAM?)", off);
+        const size_t xlen = rd16(h + 10);
+        if (f.size() - off < 12 + xlen) return tcmi_fail(nullptr, TCMI_E_FORMAT, "truncated BGZF extra field at byte %zu", off);
+        size_t bsize = 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *s = h + 12 + x;
+            const size_t slen = rd16(s + 2);
+            if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (size_t)rd16(s + 4) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || f.size() - off < bsize)
+            return tcmi_fail(nullptr, TCMI_E_FORMAT, "bad BGZF block size at byte %zu", off);
+        Block b;
+        b.cin = off + 12 + xlen;
+        b.clen = bsize - 12 - xlen - 8;
+        b.crc = rd32(h + bsize - 8);
+        b.ulen = rd32(h + bsize - 4);
+        b.uout = out;
+        if (b.ulen > 65536) return tcmi_fail(nullptr, TCMI_E_FORMAT, "BGZF block at byte %zu inflates to %zu bytes (> 64 KiB)", off, b.ulen);
+        out += b.ulen;
+        off += bsize;
+        blocks.push_back(b);
+    }
+    *total = out;
+    return TCMI_OK;
+}
+
+bool inflate_block(const uint8_t *in, const Block &b, uint8_t *out)
+{
+    if (b.ulen == 0) return true;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(in + b.cin);
+    zs.avail_in = (uInt)b.clen;
+    zs.next_out = out + b.uout;
+    zs.avail_out = (uInt)b.ulen;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == b.ulen;
+    inflateEnd(&zs);
+    if (!ok) return false;
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + b.uout, (uInt)b.ulen) == b.crc;
+}
+
+} // namespace
+
+extern "C" {
+
+int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
+{
+    if (!path || !out) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    *out = nullptr;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return tcmi_fail(nullptr, TCMI_E_IO, "cannot open %s", path);
+    std::vector<uint8_t> file;
+    {
+        std::fseek(fp, 0, SEEK_END);
+        const long sz = std::ftell(fp);
+        std::fseek(fp, 0, SEEK_SET);
+        if (sz < 0) { std::fclose(fp); return tcmi_fail(nullptr, TCMI_E_IO, "cannot size %s", path); }
+        file.resize((size_t)sz);
+        const size_t got = sz ? std::fread(file.data(), 1, (size_t)sz, fp) : 0;
+        std::fclose(fp);
+        if (got != (size_t)sz) return tcmi_fail(nullptr, TCMI_E_IO, "short read on %s", path);
+    }
+    std::vector<Block> blocks;
+    size_t total = 0;
+    int rc = scan_blocks(file, blocks, &total);
+    if (rc) return rc;
+    std::vector<uint8_t> raw(total + 8);
+
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    if ((size_t)n_threads > blocks.size()) n_threads = blocks.empty() ? 1 : (int)blocks.size();
+    std::atomic<size_t> next{0};
+    std::atomic<long long> bad{-1};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t b0 = next.fetch_add(64);
+            if (b0 >= blocks.size() || bad.load() >= 0) return;
+            const size_t b1 = b0 + 64 < blocks.size() ? b0 + 64 : blocks.size();
+            for (size_t b = b0; b < b1; ++b)
+                if (!inflate_block(file.data(), blocks[b], raw.data())) { bad.store((long long)b); return; }
+        }
+    };
+    if (n_threads == 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    if (bad.load() >= 0)
+        return tcmi_fail(nullptr, TCMI_E_FORMAT, "BGZF block %lld failed to inflate or its CRC32 does not match", bad.load());
+
+    // ---- BAM header (SAM spec §4.2) ----
+    const uint8_t *p = raw.data();
+    const size_t N = total;
+    size_t o = 0;
+    auto need = [&](size_t k) { return N - o >= k; };
+    if (!need(12) || std::memcmp(p, "BAM\1", 4) != 0) return tcmi_fail(nullptr, TCMI_E_FORMAT, "%s: BAM magic missing", path);
+    tcmi_bam *bam = new tcmi_bam();
+    bam->file_bytes = (int64_t)file.size();
+    bam->inflated_bytes = (int64_t)total;
+    bam->n_blocks = (int64_t)blocks.size();
+    auto fail = [&](const char *what) {
+        delete bam;
+        return tcmi_fail(nullptr, TCMI_E_FORMAT, "%s: %s at inflated byte %zu", path, what, o);
+    };
+    const size_t l_text = rd32(p + 4);
+    o = 8;
+    if (!need(l_text + 4)) return fail("truncated header text");
+    bam->text.assign((const char *)p + o, l_text);
+    o += l_text;
+    const size_t n_ref = rd32(p + o);
+    o += 4;
+    for (size_t r = 0; r < n_ref; ++r) {
+        if (!need(4)) return fail("truncated reference list");
+        const size_t l_name = rd32(p + o);
+        o += 4;
+        if (!need(l_name + 4)) return fail("truncated reference name");
+        bam->ref_name.emplace_back((const char *)p + o, l_name ? l_name - 1 : 0);
+        o += l_name;
+        bam->ref_len.push_back((int64_t)rd32(p + o));
+        o += 4;
+    }
+
+    // ---- records: pass 1 sizes, pass 2 fill ----
+    const size_t rec0 = o;
+    int64_t n = 0, n_cig = 0, n_seqb = 0, n_qual = 0;
+    while (o < N) {
+        if (!need(4)) return fail("truncated record length");
+        const size_t bs = rd32(p + o);
+        if (bs < 32 || !need(4 + bs)) return fail("truncated alignment record");
+        const uint8_t *r = p + o + 4;
+        const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
+        if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) return fail("alignment record fields overrun block_size");
+        ++n; n_cig += (int64_t)n_c; n_seqb += (int64_t)((l_seq + 1) / 2); n_qual += (int64_t)l_seq;
+        o += 4 + bs;
+    }
+    bam->n = n;
+    bam->pos.resize((size_t)n); bam->l_qseq.resize((size_t)n); bam->tid.resize((size_t)n);
+    bam->flag.resize((size_t)n); bam->mapq.resize((size_t)n);
+    bam->cigar_off.resize((size_t)n + 1); bam->seq_off.resize((size_t)n + 1);
+    bam->cigar.resize((size_t)n_cig + 1); bam->seq.resize((size_t)n_seqb + 1); bam->qual.resize((size_t)n_qual + 1);
+    o = rec0;
+    uint64_t co = 0, so = 0, qo = 0;
+    int32_t last_tid = 0, last_pos = -1;
+    bool seen_unplaced = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const size_t bs = rd32(p + o);
+        const uint8_t *r = p + o + 4;
+        const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+        const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
+        bam->tid[(size_t)i] = tid;
+        bam->pos[(size_t)i] = pos;
+        bam->mapq[(size_t)i] = r[9];
+        bam->flag[(size_t)i] = rd16(r + 14);
+        bam->l_qseq[(size_t)i] = (int32_t)l_seq;
+        bam->cigar_off[(size_t)i] = co;
+        bam->seq_off[(size_t)i] = so;
+        const uint8_t *c = r + 32 + l_name;
+        std::memcpy(bam->cigar.data() + co, c, 4 * n_c);           // little-endian host
+        co += n_c;
+        const uint8_t *s = c + 4 * n_c;
+        std::memcpy(bam->seq.data() + so, s, (l_seq + 1) / 2);
+        so += (l_seq + 1) / 2;
+        std::memcpy(bam->qual.data() + qo, s + (l_seq + 1) / 2, l_seq);
+        qo += l_seq;
+        if (tid < 0) seen_unplaced = true;
+        else {
+            if (seen_unplaced || tid < last_tid || (tid == last_tid && pos < last_pos)) bam->sorted = 0;
+            last_tid = tid;
+            last_pos = pos;
+        }
+        o += 4 + bs;
+    }
+    bam->cigar_off[(size_t)n] = co;
+    bam->seq_off[(size_t)n] = so;
+    *out = bam;
+    return TCMI_OK;
+}
+
+int tcmi_bam_free(tcmi_bam *bam)
+{
+    delete bam;
+    return TCMI_OK;
+}
+
+int tcmi_bam_reads(const tcmi_bam *bam, tcmi_reads *reads)
+{
+    if (!bam || !reads) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    reads->n_reads = bam->n;
+    reads->pos = bam->pos.data();
+    reads->flag = bam->flag.data();
+    reads->l_qseq = bam->l_qseq.data();
+    reads->cigar_off = bam->cigar_off.data();
+    reads->cigar = bam->cigar.data();
+    reads->seq_off = bam->seq_off.data();
+    reads->seq = bam->seq.data();
+    reads->qual = bam->qual.data();
+    reads->tid = bam->tid.data();
+    return TCMI_OK;
+}
+
+int tcmi_bam_header(const tcmi_bam *bam, int32_t *n_ref, const char **ref0_name, int64_t *ref0_len)
+{
+    if (!bam) return tcmi_fail(nullptr, TCMI_E_ARG, "bam is NULL");
+    if (n_ref) *n_ref = (int32_t)bam->ref_name.size();
+    if (ref0_name) *ref0_name = bam->ref_name.empty() ? "" : bam->ref_name[0].c_str();
+    if (ref0_len) *ref0_len = bam->ref_len.empty() ? 0 : bam->ref_len[0];
+    return TCMI_OK;
+}
+
+int tcmi_bam_info(const tcmi_bam *bam, int64_t *n_reads, int32_t *sorted, int64_t *file_bytes, int64_t *inflated_bytes,
+                  int64_t *n_blocks, int64_t *n_cigar, int64_t *n_qual)
+{
+    if (!bam) return tcmi_fail(nullptr, TCMI_E_ARG, "bam is NULL");
+    if (n_reads) *n_reads = bam->n;
+    if (sorted) *sorted = bam->sorted;
+    if (file_bytes) *file_bytes = bam->file_bytes;
+    if (inflated_bytes) *inflated_bytes = bam->inflated_bytes;
+    if (n_blocks) *n_blocks = bam->n_blocks;
+    if (n_cigar) *n_cigar = (int64_t)bam->cigar_off[(size_t)bam->n];
+    if (n_qual) *n_qual = (int64_t)bam->qual.size() - 1;
+    return TCMI_OK;
+}
+
+const char *tcmi_bam_text(const tcmi_bam *bam) { return bam ? bam->text.c_str() : ""; }
+
+} // extern "C"

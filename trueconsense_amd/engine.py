@@ -1,0 +1,265 @@
+"""Device context and the host-side calls of libtcmi, as thin Python objects.
+
+    Context      one HIP stream on one MI355X (tcmi_ctx)
+    ReadSet      reads resident in HBM (tcmi_readset)
+    BamFile      a decoded BAM (tcmi_bam): flat read arrays + header
+    consensus_walk / modal_tokens   the HOST entry points (no GPU involved)
+
+Everything that computes goes through the C ABI (include/tcmi.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib, ptr
+
+
+class ReadSet:
+    def __init__(self, ctx, handle, keep):
+        self.ctx, self.handle, self._keep = ctx, handle, keep
+        v = [C.c_int64(0) for _ in range(5)]
+        check(lib().tcmi_readset_info(handle, *[C.byref(x) for x in v]))
+        self.n_reads, self.n_piled, self.algorithmic_bytes, self.device_bytes, self.max_end = (x.value for x in v)
+
+    def free(self):
+        if self.handle:
+            lib().tcmi_readset_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + stream.  Raises TcmiError(E_NODEVICE) when no gfx950 GPU is usable."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(lib().tcmi_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib().tcmi_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def sync(self):
+        check(lib().tcmi_ctx_sync(self.handle), self.handle)
+
+    @property
+    def stream(self):
+        return lib().tcmi_ctx_stream(self.handle)
+
+    def set_option(self, key, value):
+        check(lib().tcmi_ctx_set_option(self.handle, key.encode(), int(value)), self.handle)
+
+    def profile(self, on=True):
+        check(lib().tcmi_profile_enable(self.handle, int(on)), self.handle)
+        check(lib().tcmi_profile_reset(self.handle), self.handle)
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(lib().tcmi_profile_get(self.handle, kernel, C.byref(ms), C.byref(n)), self.handle)
+        return ms.value, n.value
+
+    # ---- stage A
+    def upload(self, reads):
+        """reads: dict of flat arrays (tcmi_reads layout) or BamFile -> ReadSet in HBM."""
+        r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
+        h = C.c_void_p()
+        check(lib().tcmi_readset_upload(self.handle, C.byref(r), C.byref(h)), self.handle)
+        return ReadSet(self, h, keep)
+
+    def tally(self, reads, L=None, ref_len=0):
+        """reads -> int32 [L,7] (coverage,A,T,C,G,X,I); L defaults to max(ref_len, read extent)."""
+        r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
+        if L is None:
+            L = reads_extent(reads, ref_len)
+        counts = np.zeros((int(L), 7), np.int32)
+        check(lib().tcmi_tally(self.handle, C.byref(r), int(L), ptr(counts)), self.handle)
+        del keep
+        return counts
+
+    # ---- stage B, position-local
+    def call(self, counts, mincov, include_ambig, want_events=False):
+        """counts [L,7] -> (plain, alt, flags) uint8 [L] (+ ascending 0-based event indices)."""
+        counts = np.ascontiguousarray(counts, np.int32)
+        L = len(counts)
+        plain, alt, flags = (np.empty(L, np.uint8) for _ in range(3))
+        ev = np.empty(L, np.int32) if want_events else None
+        n_ev = C.c_int64(0)
+        check(lib().tcmi_call(self.handle, ptr(counts), L, int(mincov), int(bool(include_ambig)), ptr(plain),
+                              ptr(alt), ptr(flags), ptr(ev), C.byref(n_ev)), self.handle)
+        if want_events:
+            return plain, alt, flags, ev[:n_ev.value].copy()
+        return plain, alt, flags
+
+    # ---- whole resident step: zero + tally + call + records to pinned host memory
+    def step(self, readset, L, mincov, include_ambig, want_counts=True):
+        p, a, f, c = (C.c_void_p() for _ in range(4))
+        ld = C.c_int64(0)
+        check(lib().tcmi_step(self.handle, readset.handle, int(L), int(mincov), int(bool(include_ambig)),
+                              C.byref(p), C.byref(a), C.byref(f), C.byref(c) if want_counts else None,
+                              C.byref(ld)), self.handle)
+
+        def view(vp, dt, n):
+            return np.ctypeslib.as_array(C.cast(vp, C.POINTER(dt)), shape=(n,))
+        L = int(L)
+        plain = view(p, C.c_uint8, L).copy()
+        alt = view(a, C.c_uint8, L).copy()
+        flags = view(f, C.c_uint8, L).copy()
+        counts = None
+        if want_counts:
+            planes = view(c, C.c_int32, 7 * ld.value).reshape(7, ld.value)
+            counts = np.ascontiguousarray(planes[:, :L].T)
+        return plain, alt, flags, counts
+
+
+# --------------------------------------------------------------------------- host-only entry points
+def reads_extent(reads, ref_len=0):
+    r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
+    out = C.c_int64(0)
+    check(lib().tcmi_reads_extent(C.byref(r), int(ref_len), C.byref(out)))
+    del keep
+    return out.value
+
+
+class WalkKeyError(KeyError):
+    """The reference raises KeyError here (Sequences.py:47): a deletion walk ran past the last position."""
+
+
+def consensus_walk(plain, alt, flags, orf_start, orf_end, orf_is_plus, ins_pos, ins_shift, ins_seqs,
+                   include_ins):
+    """Sequential part of BuildConsensus (Sequences.py:179-322 + ORFs.py) over call records.
+    -> (consensus str, new_start int64[n_orf], new_end int64[n_orf])."""
+    plain, alt, flags = (np.ascontiguousarray(x, np.uint8) for x in (plain, alt, flags))
+    L = len(plain)
+    os_, oe = np.ascontiguousarray(orf_start, np.int64), np.ascontiguousarray(orf_end, np.int64)
+    op = np.ascontiguousarray(orf_is_plus, np.uint8)
+    ip = np.ascontiguousarray(ins_pos, np.int64)
+    ish = np.ascontiguousarray(ins_shift, np.int32)
+    blob = "".join(ins_seqs).encode("ascii")
+    off = np.zeros(len(ins_seqs) + 1, np.int64)
+    if len(ins_seqs):
+        off[1:] = np.cumsum([len(s) for s in ins_seqs])
+    cap = L + len(blob) + 1
+    out = C.create_string_buffer(cap)
+    n_out, err = C.c_int64(0), C.c_int64(0)
+    ns, ne = np.zeros(len(os_), np.int64), np.zeros(len(os_), np.int64)
+    rc = lib().tcmi_consensus_walk(ptr(plain), ptr(alt), ptr(flags), L, len(os_), ptr(os_), ptr(oe), ptr(op),
+                                   len(ip), ptr(ip), ptr(ish), blob, ptr(off), int(bool(include_ins)),
+                                   C.cast(out, C.c_void_p), cap, C.byref(n_out), ptr(ns), ptr(ne), C.byref(err))
+    if rc == _ffi.E_KEYERROR:
+        raise WalkKeyError(err.value)
+    if rc == _ffi.E_ZERODIV:
+        raise ZeroDivisionError("division by zero")
+    check(rc)
+    return out.raw[:n_out.value].decode("ascii"), ns, ne
+
+
+# pysam's defaults for AlignmentFile.pileup() (Events.py:66 passes none): SURVEY §8-Q8
+DEFAULT_MIN_BASE_QUALITY = 13
+DEFAULT_FLAG_FILTER = 0x4 | 0x100 | 0x200 | 0x400
+DEFAULT_MAX_DEPTH = 8000
+
+
+def modal_tokens(reads, positions, min_base_quality=DEFAULT_MIN_BASE_QUALITY, flag_filter=DEFAULT_FLAG_FILTER,
+                 ignore_orphans=True, max_depth=DEFAULT_MAX_DEPTH):
+    """For each 1-based position: (modal upper-cased token or None, n_tokens)."""
+    positions = np.ascontiguousarray(sorted(int(p) for p in positions), np.int64)
+    n = len(positions)
+    if n == 0:
+        return {}
+    r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        off = np.zeros(n + 1, np.int64)
+        cnt = np.zeros(n, np.int64)
+        deep = C.c_int32(0)
+        rc = lib().tcmi_modal_tokens(C.byref(r), n, ptr(positions), int(min_base_quality), int(flag_filter),
+                                     int(bool(ignore_orphans)), int(max_depth), C.cast(buf, C.c_void_p), cap,
+                                     ptr(off), ptr(cnt), C.byref(deep))
+        if rc == _ffi.E_ARG and b"token buffer too small" in (lib().tcmi_last_error(None) or b"") and cap < (1 << 30):
+            cap *= 16
+            continue
+        check(rc)
+        break
+    del keep
+    out = {}
+    for k in range(n):
+        tok = buf.raw[off[k]:off[k + 1]].decode("ascii") if cnt[k] else None
+        out[int(positions[k])] = (tok, int(cnt[k]))
+    return out
+
+
+class BamFile:
+    """A BAM decoded by libtcmi (tcmi_bam_load): pysam.AlignmentFile's role for this path."""
+
+    def __init__(self, path, threads=0):
+        h = C.c_void_p()
+        check(lib().tcmi_bam_load(str(path).encode(), int(threads), C.byref(h)))
+        self.handle = h
+        self.filename = str(path)
+        n_ref, name, ln = C.c_int32(0), C.c_char_p(), C.c_int64(0)
+        check(lib().tcmi_bam_header(h, C.byref(n_ref), C.byref(name), C.byref(ln)))
+        self.nreferences = n_ref.value
+        self.references = ((name.value or b"").decode(),) if n_ref.value else ()
+        self.lengths = (ln.value,) if n_ref.value else ()
+        v = [C.c_int64(0), C.c_int32(0)] + [C.c_int64(0) for _ in range(5)]
+        check(lib().tcmi_bam_info(h, *[C.byref(x) for x in v]))
+        (self.n_reads, self.sorted, self.file_bytes, self.inflated_bytes, self.n_blocks, self.n_cigar,
+         self.n_qual) = (x.value for x in v)
+        self.text = (lib().tcmi_bam_text(h) or b"").decode("utf-8", "replace")
+
+    def as_struct(self):
+        r = _ffi.Reads()
+        check(lib().tcmi_bam_reads(self.handle, C.byref(r)))
+        return r, self
+
+    def arrays(self):
+        """numpy views (owned by this object) in the tcmi_reads layout."""
+        r, _ = self.as_struct()
+        n = self.n_reads
+
+        def view(p, cnt):
+            if cnt == 0:
+                return np.zeros(0, np.ctypeslib.as_array(p, shape=(1,)).dtype)
+            return np.ctypeslib.as_array(p, shape=(cnt,))
+        cig_off = view(r.cigar_off, n + 1)
+        seq_off = view(r.seq_off, n + 1)
+        return {"n_reads": n, "pos": view(r.pos, n), "flag": view(r.flag, n), "l_qseq": view(r.l_qseq, n),
+                "tid": view(r.tid, n), "cigar_off": cig_off, "cigar": view(r.cigar, max(1, self.n_cigar)),
+                "seq_off": seq_off, "seq": view(r.seq, max(1, int(seq_off[n]) if n else 1)),
+                "qual": view(r.qual, max(1, self.n_qual)), "_owner": self}
+
+    def close(self):
+        if self.handle:
+            lib().tcmi_bam_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the pileup-tally + base-calling hot path on MI355X.
+
+A "step" = one pass of the hot path over one synthetic 1M-read x 29 903-bp BAM whose reads
+are already resident in HBM: zero the count matrix, HIP tally kernel, HIP call kernel, copy
+the call records (3 bytes / position) to pinned host memory, native host consensus walk to the
+FASTA sequence.  Metric: reference positions per second (BASELINE.json), whole job.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline]
+
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank
+processes its own independent BAMs (BASELINE config 4: many-BAM shard, no data-path
+collective; weak scaling) and the only collective is the timing barrier / max-reduce.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+
+
+def cpu_baseline(reads, L, mincov, orfs):
+    """The oracle timed on this box's host cores (1 thread): the scalar C restatement on the
+    full workload, and the Python-loop restatement (the reference's own structure: per-token
+    Python loop + O(L^2) ORF pass) on a small sample."""
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import tc_oracle as orc
+    c_oracle.tally(reads, L)                                  # warm (page-in)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 8.0:
+        counts = c_oracle.tally(reads, L)
+        c_oracle.call(counts, mincov, True)
+        reps += 1
+        if reps >= 40:
+            break
+    c_s = (time.perf_counter() - t0) / reps
+    # Python-loop port on the first 3 000 reads (about 450 k pileup tokens)
+    n_s = min(3000, int(reads["n_reads"]))
+    nb = len(reads["seq"]) // int(reads["n_reads"])
+    sub = {"n_reads": n_s, "pos": reads["pos"][:n_s], "flag": reads["flag"][:n_s], "l_qseq": reads["l_qseq"][:n_s],
+           "cigar_off": reads["cigar_off"][:n_s + 1], "cigar": reads["cigar"], "seq_off": reads["seq_off"][:n_s + 1],
+           "seq": reads["seq"][:n_s * nb]}
+    t0 = time.perf_counter()
+    cols = orc.pileup_columns(sub)
+    for toks in cols.values():
+        orc.tally_tokens(toks)
+    py_tok_s = (time.perf_counter() - t0) / max(1, sum(len(v) for v in cols.values()))
+    t0 = time.perf_counter()
+    Ls = 3000
+    orc.build_consensus(mincov, counts[:Ls].astype(np.int64), [{"start": 266, "end": 2900, "strand": "+"}], True, None, True)
+    py_walk_s = time.perf_counter() - t0
+    tokens = float(np.sum(reads["l_qseq"]))
+    return {"value": L / c_s, "unit": "positions/s", "cores": 1, "kind": "port",
+            "sample": "oracle/tally_oracle.c (scalar C, -O2) tally+call over the full %d-read workload, %d repetitions"
+                      % (int(reads["n_reads"]), reps),
+            "seconds_per_bam": c_s,
+            "python_port": {"tally_seconds_per_bam_extrapolated": py_tok_s * tokens,
+                            "ns_per_token": py_tok_s * 1e9,
+                            "walk_seconds_first_3000_positions": py_walk_s,
+                            "sample": "oracle/tc_oracle.py per-token loop on the first %d reads; literal O(L^2) "
+                                      "BuildConsensus restatement on 3 000 positions" % n_s}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--bams", type=int, default=4, help="distinct resident BAMs cycled through per rank")
+    ap.add_argument("--mincov", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-only", action="store_true", help="leave the host consensus walk out of the step")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from trueconsense_amd import _ffi
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.engine import Context, consensus_walk
+
+    ref, orfs = sy.make_reference()
+    L = len(ref)
+    ctx = Context(local_rank)
+    readsets, host_reads0 = [], None
+    for b in range(a.bams):
+        reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1)
+        if b == 0:
+            host_reads0 = reads
+        readsets.append(ctx.upload(reads))
+        if b:
+            del reads
+    alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
+    alg_tally = alg_reads + 28 * L                              # + one write of the [L,7] int32 matrix
+    o_start = [o["start"] for o in orfs]
+    o_end = [o["end"] for o in orfs]
+    o_plus = [1] * len(orfs)
+
+    def step(i):
+        plain, alt, flags, _ = ctx.step(readsets[i % len(readsets)], L, a.mincov, True, want_counts=False)
+        if a.gpu_only:
+            return None
+        return consensus_walk(plain, alt, flags, o_start, o_end, o_plus, [], [], [], True)[0]
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    ctx.profile(True)                                           # HIP events around every kernel, on ctx's stream
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        cons = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tally_ms, tally_n = ctx.profile_get(_ffi.K_TALLY)
+    call_ms, call_n = ctx.profile_get(_ffi.K_CALL)
+    zero_ms, _ = ctx.profile_get(_ffi.K_ZERO)
+    ctx.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        tally_us = 1e3 * tally_ms / max(1, tally_n)
+        achieved = alg_tally / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")      # PMC passes are separate runs (see profiles/README)
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "reference positions/sec (1M reads x 29 903 bp per BAM, reads resident in HBM, BAM -> consensus)",
+            "value": L * a.steps * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32 tallies, f64 thresholds", "data": "synthetic",
+            "bams_per_min": 60.0 * a.steps * world / dt,
+            "config": {"workload": "BASELINE configs[1]: 29 903-bp reference, %d synthetic 150-bp reads per BAM "
+                                   "(~%dx coverage), %d distinct BAMs resident per GPU, one BAM per step%s"
+                                   % (a.reads, a.reads * 150 // L, a.bams,
+                                      "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
+                       "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
+                       "step": "memset + tally kernel + call kernel + D2H records" + ("" if a.gpu_only else " + host consensus walk")},
+            "kernels_us": {"tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
+            "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_tally, "avg_launch_us": tally_us},
+        }
+        if not a.gpu_only:
+            out["consensus_len"] = len(cons)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_reads0, L, a.mincov, orfs)
+            out["cpu_baseline"]["cores_on_box"] = os.cpu_count()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,13 +77,13 @@ def test_tally_edge_cases(ctx):
                       {"pos": 4990, "flag": 0, "cigar": "30M", "seq": "ACGTAC" * 5},
                       {"pos": 100, "flag": 0, "cigar": "4M2D3M1I2M", "seq": "ACGTACGTAC"},
                       {"pos": 100, "flag": 4, "cigar": "10M", "seq": "ACGTACGTAC"},
-                      {"pos": 200, "flag": 0, "cigar": "10M", "seq": "*"},
+                      {"pos": 2000, "flag": 0, "cigar": "10M", "seq": "*"},
                       {"pos": 300, "flag": 0, "cigar": "3M", "seq": "NRA"}]}
     reads = ss.reads_from_spec(spec)
     L = engine.reads_extent(reads, len(ref))
     assert L == 5020
     got = _check_tally(ctx, reads, L)
-    assert got[205, 0] == 1 and got[205, 1:].sum() == 0            # SEQ '*' -> N tokens: coverage only
+    assert got[2005, 0] == 1 and got[2005, 1:].sum() == 0           # SEQ '*' -> N tokens: coverage only
     # nothing piles up / no reads at all
     none = ss.reads_from_spec({"reads": [{"pos": 5, "flag": 4, "cigar": "10M", "seq": "ACGTACGTAC"}]})
     assert ctx.tally(none, L=50).sum() == 0

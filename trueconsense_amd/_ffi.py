@@ -76,6 +76,26 @@ _SIGS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP/HSA runtime.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so (soname libamdhip64.so.7, same as /opt/rocm's): if libtcmi pulled in
+    /opt/rocm's copy first, a later `import torch` would bring up a second runtime that sees no
+    GPU.  So when torch is installed its copy is loaded first (without importing torch) and
+    libtcmi's NEEDED libamdhip64.so.7 binds to it; without torch, /opt/rocm's is used."""
+    if os.environ.get("TCMI_HIP_RUNTIME") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises (never falls back) when it has not been built."""
     global _lib
@@ -84,6 +104,7 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `make -C trueconsense_amd/csrc` (needs hipcc). "
                 "trueconsense_amd has no CPU fallback." % LIB_PATH)
+        _preload_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)

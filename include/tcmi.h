@@ -89,7 +89,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
-enum { TCMI_K_TALLY = 0, TCMI_K_CALL = 1, TCMI_K_ZERO = 2, TCMI_K_NKERNELS = 3 };
+enum { TCMI_K_TALLY = 0 /* aligned-read (fast) tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZERO = 2,
+       TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */, TCMI_K_NKERNELS = 4 };
 int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
 int  tcmi_profile_reset(tcmi_ctx *ctx);
 int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
@@ -107,6 +108,9 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *reads, tcmi_readset **o
 int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs);
 int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled,
                       int64_t *algorithmic_bytes, int64_t *device_bytes, int64_t *max_end);
+/* how the reads were split: aligned (single match op -> fast kernel) vs general (CIGAR walk) */
+int tcmi_readset_sets(const tcmi_readset *rs, int64_t *aligned_reads, int64_t *aligned_chunks,
+                      int64_t *general_reads);
 
 /* Device-resident tally.  d_counts: device int32 [7][ld] (plane order TCMI_COV..TCMI_I,
  * plane p at d_counts + p*ld, ld >= L).  Zeroes the planes first when `zero` != 0,

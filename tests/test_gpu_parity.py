@@ -93,6 +93,42 @@ def test_tally_edge_cases(ctx):
         ctx.tally(base, L=100)                                       # L smaller than the read extent
 
 
+def test_both_tally_kernels_agree(ctx):
+    """aligned reads take the fast kernel by default; option tally_variant=1 forces every read
+    through the CIGAR-walk kernel: both must give the oracle's matrix."""
+    import ctypes as C2
+    ref, orfs = sy.make_reference(L=9000, cds=[(50, 4000), (4200, 8800)])
+    reads = sy.make_reads(ref, 60_000, seed=21, indel_sites=sy.default_indel_sites(orfs))
+    # soft / hard clips and =/X runs are still "aligned"; odd clip lengths exercise the odd-offset packer
+    extra = ss.reads_from_spec({"reads": [
+        {"pos": 1000, "flag": 0, "cigar": "3S20M2S", "seq": "NNNACGTACGTACGTACGTACGTAA"},
+        {"pos": 1001, "flag": 16, "cigar": "2H4S10=1X9M", "seq": "ACGTACGTACGTACGTACGTACGT"},
+        {"pos": 1002, "flag": 0, "cigar": "20M", "seq": "ACGTNACGTRACGTACG=ACG"[:20]},
+        {"pos": 1003, "flag": 0, "cigar": "30M", "seq": "ACGTACGTAC"},              # SEQ shorter than the CIGAR
+        {"pos": 1004, "flag": 0, "cigar": "700M", "seq": "ACGT" * 175}]})             # too long for the fast kernel
+    L = len(ref)
+    want = c_oracle.tally(reads, L)
+    want_x = c_oracle.tally(extra, L)
+    for variant in (0, 1):
+        ctx.set_option("tally_variant", variant)
+        rs = ctx.upload(reads)
+        a, c, g = (C2.c_int64(0) for _ in range(3))
+        _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
+        if variant == 0:
+            assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 1024
+        else:
+            assert a.value == 0 and g.value == rs.n_piled
+        rs.free()
+        assert np.array_equal(ctx.tally(reads, L=L), want), variant
+        assert np.array_equal(ctx.tally(extra, L=L), want_x), variant
+    ctx.set_option("tally_variant", 0)
+    rs = ctx.upload(extra)
+    a, c, g = (C2.c_int64(0) for _ in range(3))
+    _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
+    assert (a.value, g.value) == (4, 1)
+    rs.free()
+
+
 def test_tally_accumulate_split_readsets(ctx):
     """cfg 5 shape: one BAM split into contiguous read ranges, partial matrices summed."""
     ref, _ = sy.make_reference(L=8000, cds=[(10, 900)])

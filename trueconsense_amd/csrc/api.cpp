@@ -1,4 +1,4 @@
-// api.cpp — context, error text, profiling brackets, read-set upload and the host-buffer
+// api.cpp — context, error text, profiling brackets and the host-buffer
 // conveniences of the C ABI declared in include/tcmi.h.
 #include <cstdlib>
 #include <cstring>
@@ -181,161 +181,7 @@ void tcmi_prof_end(tcmi_ctx *c, int k)
     (void)hipEventRecord(c->pending.back().b, c->stream);
 }
 
-// ---- read set -----------------------------------------------------------------------------
-static inline bool consumes_ref(unsigned op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
-
-static int64_t ref_span(const uint32_t *cg, int64_t n)
-{
-    int64_t s = 0;
-    for (int64_t k = 0; k < n; ++k)
-        if (consumes_ref(cg[k] & 0xF)) s += cg[k] >> 4;
-    return s;
-}
-
-static inline bool piles_up(const tcmi_reads *r, int64_t i, int64_t *span)
-{
-    if (r->flag[i] & 0x4) return false;
-    if (r->tid && r->tid[i] < 0) return false;
-    if (r->pos[i] < 0) return false;
-    *span = ref_span(r->cigar + r->cigar_off[i], (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]));
-    return *span > 0;
-}
-
-static int check_reads(tcmi_ctx *ctx, const tcmi_reads *r)
-{
-    if (!r) return tcmi_fail(ctx, TCMI_E_ARG, "reads is NULL");
-    if (r->n_reads < 0) return tcmi_fail(ctx, TCMI_E_ARG, "n_reads < 0");
-    if (r->n_reads > 0 && (!r->pos || !r->flag || !r->l_qseq || !r->cigar_off || !r->seq_off))
-        return tcmi_fail(ctx, TCMI_E_ARG, "reads has NULL arrays");
-    return TCMI_OK;
-}
-
 extern "C" {
-
-int tcmi_reads_extent(const tcmi_reads *r, int64_t ref_len, int64_t *out_L)
-{
-    int rc = check_reads(nullptr, r);
-    if (rc) return rc;
-    if (!out_L) return tcmi_fail(nullptr, TCMI_E_ARG, "out_L is NULL");
-    int64_t L = ref_len > 0 ? ref_len : 0;
-    for (int64_t i = 0; i < r->n_reads; ++i) {
-        int64_t span;
-        if (!piles_up(r, i, &span)) continue;
-        if (r->pos[i] + span > L) L = r->pos[i] + span;
-    }
-    *out_L = L;
-    return TCMI_OK;
-}
-
-int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
-{
-    if (!rs) return TCMI_OK;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_pos, rs->d_meta, rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    delete rs;
-    return TCMI_OK;
-}
-
-int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
-{
-    if (!ctx || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
-    *out = nullptr;
-    int rc = check_reads(ctx, r);
-    if (rc) return rc;
-    TCMI_HIP(ctx, hipSetDevice(ctx->device));
-
-    // pass 1: select reads, size the streams
-    std::vector<int64_t> keep;
-    keep.reserve((size_t)r->n_reads);
-    int64_t n_cig = 0, n_seqw = 0, alg = 0, max_end = 0, max_span = 0;
-    for (int64_t i = 0; i < r->n_reads; ++i) {
-        int64_t span;
-        if (!piles_up(r, i, &span)) continue;
-        int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
-        if (nc > 65535)
-            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)", (long long)i, (long long)nc);
-        int64_t lq = r->l_qseq[i];
-        if (lq < 0) return tcmi_fail(ctx, TCMI_E_ARG, "read %lld has negative l_qseq", (long long)i);
-        int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
-        if (nbytes < (lq + 1) / 2)
-            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)", (long long)i, (long long)nbytes);
-        if (span > INT32_MAX || r->pos[i] + span > INT32_MAX)
-            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31", (long long)i);
-        keep.push_back(i);
-        n_cig += nc;
-        n_seqw += (lq + 7) / 8;
-        alg += 12 + 4 * nc + (lq + 1) / 2;
-        if (r->pos[i] + span > max_end) max_end = r->pos[i] + span;
-        if (span > max_span) max_span = span;
-    }
-    const int64_t n = (int64_t)keep.size();
-    const int64_t n_rounds = (n + TCMI_ROUND - 1) / TCMI_ROUND;
-
-    // pass 2: pack
-    std::vector<int32_t> h_pos((size_t)n), h_lseq((size_t)n);
-    std::vector<uint32_t> h_meta((size_t)n), h_cig((size_t)n_cig + 1), h_seq((size_t)n_seqw + 1);
-    std::vector<int64_t> h_rc((size_t)n_rounds + 1), h_rs((size_t)n_rounds + 1);
-    int64_t co = 0, so = 0;
-    for (int64_t j = 0; j < n; ++j) {
-        const int64_t i = keep[(size_t)j];
-        if (j % TCMI_ROUND == 0) { h_rc[(size_t)(j / TCMI_ROUND)] = co; h_rs[(size_t)(j / TCMI_ROUND)] = so; }
-        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
-        const int64_t lq = r->l_qseq[i];
-        h_pos[(size_t)j] = r->pos[i];
-        h_lseq[(size_t)j] = (int32_t)lq;
-        h_meta[(size_t)j] = ((uint32_t)r->flag[i] << 16) | (uint32_t)nc;
-        std::memcpy(&h_cig[(size_t)co], r->cigar + r->cigar_off[i], (size_t)nc * 4);
-        co += nc;
-        const uint8_t *s = r->seq + r->seq_off[i];
-        const int64_t nw = (lq + 7) / 8, nb = (lq + 1) / 2;
-        uint8_t *dst = reinterpret_cast<uint8_t *>(&h_seq[(size_t)so]);
-        for (int64_t b = 0; b < nb; ++b) dst[b] = (uint8_t)((s[b] << 4) | (s[b] >> 4));   // linear nibble order
-        if (lq & 1) dst[nb - 1] &= 0x0F;                                                   // pad nibble = 0
-        for (int64_t b = nb; b < nw * 4; ++b) dst[b] = 0;
-        so += nw;
-    }
-    h_rc[(size_t)n_rounds] = co;
-    h_rs[(size_t)n_rounds] = so;
-
-    tcmi_readset *rs = new tcmi_readset();
-    rs->n_reads = r->n_reads; rs->n_piled = n; rs->n_rounds = n_rounds; rs->n_cigar = n_cig; rs->n_seqw = n_seqw;
-    rs->alg_bytes = alg; rs->max_end = max_end; rs->max_span = (int32_t)max_span; rs->device = ctx->device;
-    auto up = [&](void **d, const void *h, size_t bytes) -> int {
-        // +256 B slack so 16-byte vector loads of the last elements stay in bounds
-        hipError_t e = hipMalloc(d, bytes + 256);
-        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        e = hipMemsetAsync((char *)*d + bytes, 0, 256, ctx->stream);
-        if (e == hipSuccess && bytes) e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "upload failed: %s", hipGetErrorString(e));
-        rs->dev_bytes += (int64_t)bytes;
-        return TCMI_OK;
-    };
-    rc = up((void **)&rs->d_pos, h_pos.data(), (size_t)n * 4);
-    if (!rc) rc = up((void **)&rs->d_meta, h_meta.data(), (size_t)n * 4);
-    if (!rc) rc = up((void **)&rs->d_lseq, h_lseq.data(), (size_t)n * 4);
-    if (!rc) rc = up((void **)&rs->d_cigar, h_cig.data(), (size_t)n_cig * 4);
-    if (!rc) rc = up((void **)&rs->d_seq, h_seq.data(), (size_t)n_seqw * 4);
-    if (!rc) rc = up((void **)&rs->d_round_cig, h_rc.data(), (size_t)(n_rounds + 1) * 8);
-    if (!rc) rc = up((void **)&rs->d_round_seq, h_rs.data(), (size_t)(n_rounds + 1) * 8);
-    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "sync after upload failed");
-    if (rc) { tcmi_readset_free(ctx, rs); return rc; }
-    *out = rs;
-    return TCMI_OK;
-}
-
-int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled, int64_t *alg, int64_t *dev,
-                      int64_t *max_end)
-{
-    if (!rs) return tcmi_fail(nullptr, TCMI_E_ARG, "readset is NULL");
-    if (n_reads) *n_reads = rs->n_reads;
-    if (n_piled) *n_piled = rs->n_piled;
-    if (alg) *alg = rs->alg_bytes;
-    if (dev) *dev = rs->dev_bytes;
-    if (max_end) *max_end = rs->max_end;
-    return TCMI_OK;
-}
 
 // ---- tally -----------------------------------------------------------------------------------
 int tcmi_tally_dev(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, void *d_counts, int zero)
@@ -344,6 +190,9 @@ int tcmi_tally_dev(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld,
     if (L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 < L <= ld (L=%lld ld=%lld)", (long long)L, (long long)ld);
     if (L > INT32_MAX - 1024) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "L too large");
     if (rs->device != ctx->device) return tcmi_fail(ctx, TCMI_E_ARG, "read set lives on device %d, context on %d", rs->device, ctx->device);
+    if (rs->max_end > L)
+        return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the read extent %lld (use tcmi_reads_extent)",
+                         (long long)L, (long long)rs->max_end);
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     if (zero) {
         tcmi_prof_begin(ctx, TCMI_K_ZERO);

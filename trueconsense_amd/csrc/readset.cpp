@@ -1,0 +1,291 @@
+// readset.cpp — HOST: selects the reads that pile up, splits them into the
+// ALIGNED and GENERAL device sets (layout: tcmi_internal.h) and copies them into HBM.
+#include <algorithm>
+#include <cstring>
+
+#include "tcmi_internal.h"
+
+namespace {
+
+inline bool consumes_ref(unsigned op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+inline bool is_match(unsigned op) { return op == 0 || op == 7 || op == 8; }
+
+int64_t ref_span(const uint32_t *cg, int64_t n)
+{
+    int64_t s = 0;
+    for (int64_t k = 0; k < n; ++k)
+        if (consumes_ref(cg[k] & 0xF)) s += cg[k] >> 4;
+    return s;
+}
+
+inline bool piles_up(const tcmi_reads *r, int64_t i, int64_t *span)
+{
+    if (r->flag[i] & 0x4) return false;
+    if (r->tid && r->tid[i] < 0) return false;
+    if (r->pos[i] < 0) return false;
+    *span = ref_span(r->cigar + r->cigar_off[i], (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]));
+    return *span > 0;
+}
+
+int check_reads(tcmi_ctx *ctx, const tcmi_reads *r)
+{
+    if (!r) return tcmi_fail(ctx, TCMI_E_ARG, "reads is NULL");
+    if (r->n_reads < 0) return tcmi_fail(ctx, TCMI_E_ARG, "n_reads < 0");
+    if (r->n_reads > 0 && (!r->pos || !r->flag || !r->l_qseq || !r->cigar_off || !r->seq_off))
+        return tcmi_fail(ctx, TCMI_E_ARG, "reads has NULL arrays");
+    return TCMI_OK;
+}
+
+// [H]*[S]* (M|=|X)+ [S]*[H]*  ->  query offset of the first aligned base, aligned length
+bool aligned_shape(const uint32_t *cg, int64_t n, int64_t *y0, int64_t *len)
+{
+    int64_t k = 0, clip = 0, m = 0;
+    while (k < n && (cg[k] & 0xF) == 5) ++k;
+    while (k < n && (cg[k] & 0xF) == 4) { clip += cg[k] >> 4; ++k; }
+    if (k == n || !is_match(cg[k] & 0xF)) return false;
+    while (k < n && is_match(cg[k] & 0xF)) { m += cg[k] >> 4; ++k; }
+    while (k < n && (cg[k] & 0xF) == 4) ++k;
+    while (k < n && (cg[k] & 0xF) == 5) ++k;
+    if (k != n || m <= 0 || m > TCMI_F_MAXSPAN) return false;
+    *y0 = clip;
+    *len = m;
+    return true;
+}
+
+// BAM byte (two 4-bit codes, first base in the high nibble) -> two one-hot class nibbles in
+// linear order (first base in the low nibble); codes other than A/C/G/T become 0.
+struct SwapLut {
+    uint8_t t[256];
+    SwapLut()
+    {
+        auto oh = [](unsigned c) -> unsigned { return (c == 1 || c == 2 || c == 4 || c == 8) ? c : 0; };
+        for (unsigned b = 0; b < 256; ++b) t[b] = (uint8_t)(oh(b >> 4) | (oh(b & 15) << 4));
+    }
+};
+const SwapLut kSwap;
+
+struct Up {
+    tcmi_ctx *ctx;
+    tcmi_readset *rs;
+    int operator()(void **d, const void *h, size_t bytes)
+    {
+        // +256 B slack so 16-byte vector loads around the last elements stay inside the allocation
+        hipError_t e = hipMalloc(d, bytes + 256);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        e = hipMemsetAsync((char *)*d + bytes, 0, 256, ctx->stream);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "upload failed: %s", hipGetErrorString(e));
+        rs->dev_bytes += (int64_t)bytes;
+        return TCMI_OK;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int tcmi_reads_extent(const tcmi_reads *r, int64_t ref_len, int64_t *out_L)
+{
+    int rc = check_reads(nullptr, r);
+    if (rc) return rc;
+    if (!out_L) return tcmi_fail(nullptr, TCMI_E_ARG, "out_L is NULL");
+    int64_t L = ref_len > 0 ? ref_len : 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        int64_t span;
+        if (!piles_up(r, i, &span)) continue;
+        if (r->pos[i] + span > L) L = r->pos[i] + span;
+    }
+    *out_L = L;
+    return TCMI_OK;
+}
+
+int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
+{
+    if (!rs) return TCMI_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    void *ptrs[] = {rs->d_fpos, rs->d_flen, rs->d_fseq, rs->d_fchunk, rs->d_pos, rs->d_meta,
+                    rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete rs;
+    return TCMI_OK;
+}
+
+int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
+{
+    if (!ctx || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    *out = nullptr;
+    int rc = check_reads(ctx, r);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    const bool use_fast = ctx->tally_variant != 1;
+
+    // pass 1: select, classify, size
+    struct Sel { int64_t i, y0, len; };
+    std::vector<Sel> fsel;                  // aligned set (len > 0)
+    std::vector<int64_t> gsel;              // general set
+    int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        int64_t span;
+        if (!piles_up(r, i, &span)) continue;
+        const uint32_t *cg = r->cigar + r->cigar_off[i];
+        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+        if (nc > 65535)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)", (long long)i, (long long)nc);
+        const int64_t lq = r->l_qseq[i];
+        if (lq < 0) return tcmi_fail(ctx, TCMI_E_ARG, "read %lld has negative l_qseq", (long long)i);
+        const int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
+        if (nbytes < (lq + 1) / 2)
+            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)", (long long)i, (long long)nbytes);
+        if (span > INT32_MAX || r->pos[i] + span > INT32_MAX - 4096)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31", (long long)i);
+        alg += 12 + 4 * nc + (lq + 1) / 2;
+        if (r->pos[i] + span > max_end) max_end = r->pos[i] + span;
+        int64_t y0, len;
+        if (use_fast && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({i, y0, len});
+        else { gsel.push_back(i); g_cig += nc; g_seqw += (lq + 7) / 8; }
+    }
+
+    // ---- aligned set: chunks + sanitized bases -------------------------------------------
+    const int64_t nf = (int64_t)fsel.size();
+    std::vector<int32_t> f_pos((size_t)nf), f_len((size_t)nf);
+    std::vector<tcmi_fast_chunk> chunks;
+    std::vector<uint32_t> f_seq;
+    f_seq.reserve((size_t)(nf * 20 + 16));
+    {
+        int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
+        auto close = [&](int64_t next_read) {
+            if (c_n == 0) return;
+            tcmi_fast_chunk c;
+            c.read0 = c_read0;
+            c.word0 = 0;                        // filled below, when the bases are packed
+            c.n_reads = (int32_t)c_n;
+            c.P0 = (int32_t)c_lo;
+            c.Wn = (int32_t)((c_hi - c_lo + 7) / 8);
+            int64_t sub = (TCMI_F_SEQCAP - 8) / c_maxnw / 64 * 64;
+            c.sub_reads = (int32_t)std::min<int64_t>(TCMI_F_SUB, sub);
+            chunks.push_back(c);
+            c_read0 = next_read;
+            c_n = 0;
+        };
+        for (int64_t j = 0; j < nf; ++j) {
+            const int64_t p = r->pos[fsel[(size_t)j].i], e = p + fsel[(size_t)j].len;
+            const int64_t lo = p & ~(int64_t)7, nw = (fsel[(size_t)j].len + 7) / 8;
+            if (c_n > 0) {
+                const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e);
+                if (c_n == TCMI_F_CHUNK || (nhi - nlo + 7) / 8 > TCMI_F_MAXW) close(j);
+                else { c_lo = nlo; c_hi = nhi; c_maxnw = std::max(c_maxnw, nw); }
+            }
+            if (c_n == 0) { c_read0 = j; c_lo = lo; c_hi = e; c_maxnw = nw; }
+            ++c_n;
+            f_pos[(size_t)j] = (int32_t)p;
+            f_len[(size_t)j] = (int32_t)fsel[(size_t)j].len;
+        }
+        close(nf);
+        // pack the aligned bases chunk by chunk, each chunk starting on a 16-byte boundary
+        for (auto &c : chunks) {
+            while (f_seq.size() & 3) f_seq.push_back(0);
+            c.word0 = (int64_t)f_seq.size();
+            for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
+                const Sel &s = fsel[(size_t)j];
+                const uint8_t *src = r->seq + r->seq_off[s.i];
+                const int64_t lq = r->l_qseq[s.i];
+                const int64_t nw = (s.len + 7) / 8;
+                const size_t base = f_seq.size();
+                f_seq.resize(base + (size_t)nw, 0);
+                uint8_t *dst = reinterpret_cast<uint8_t *>(&f_seq[base]);
+                const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
+                if ((s.y0 & 1) == 0) {
+                    const uint8_t *b = src + (s.y0 >> 1);
+                    const int64_t full = have >> 1;
+                    for (int64_t k = 0; k < full; ++k) dst[k] = kSwap.t[b[k]];
+                    if (have & 1) dst[full] = (uint8_t)(kSwap.t[b[full]] & 0x0F);
+                } else {
+                    for (int64_t k = 0; k < have; ++k) {
+                        const int64_t q = s.y0 + k;
+                        const unsigned code = (q & 1) ? (src[q >> 1] & 15u) : (src[q >> 1] >> 4);
+                        const unsigned oh = (code == 1 || code == 2 || code == 4 || code == 8) ? code : 0;
+                        dst[k >> 1] |= (uint8_t)(oh << ((k & 1) * 4));
+                    }
+                }
+            }
+        }
+        while (f_seq.size() & 3) f_seq.push_back(0);
+    }
+
+    // ---- general set: rounds, raw codes --------------------------------------------------
+    const int64_t ng = (int64_t)gsel.size();
+    const int64_t n_rounds = (ng + TCMI_ROUND - 1) / TCMI_ROUND;
+    std::vector<int32_t> h_pos((size_t)ng), h_lseq((size_t)ng);
+    std::vector<uint32_t> h_meta((size_t)ng), h_cig((size_t)g_cig + 1), h_seq((size_t)g_seqw + 1);
+    std::vector<int64_t> h_rc((size_t)n_rounds + 1), h_rs((size_t)n_rounds + 1);
+    int64_t co = 0, so = 0;
+    for (int64_t j = 0; j < ng; ++j) {
+        const int64_t i = gsel[(size_t)j];
+        if (j % TCMI_ROUND == 0) { h_rc[(size_t)(j / TCMI_ROUND)] = co; h_rs[(size_t)(j / TCMI_ROUND)] = so; }
+        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+        const int64_t lq = r->l_qseq[i];
+        h_pos[(size_t)j] = r->pos[i];
+        h_lseq[(size_t)j] = (int32_t)lq;
+        h_meta[(size_t)j] = ((uint32_t)r->flag[i] << 16) | (uint32_t)nc;
+        std::memcpy(&h_cig[(size_t)co], r->cigar + r->cigar_off[i], (size_t)nc * 4);
+        co += nc;
+        const uint8_t *s = r->seq + r->seq_off[i];
+        const int64_t nw = (lq + 7) / 8, nb = (lq + 1) / 2;
+        uint8_t *dst = reinterpret_cast<uint8_t *>(&h_seq[(size_t)so]);
+        for (int64_t b = 0; b < nb; ++b) dst[b] = (uint8_t)((s[b] << 4) | (s[b] >> 4));   // linear nibble order
+        if (lq & 1) dst[nb - 1] &= 0x0F;                                                   // pad nibble = 0
+        for (int64_t b = nb; b < nw * 4; ++b) dst[b] = 0;
+        so += nw;
+    }
+    h_rc[(size_t)n_rounds] = co;
+    h_rs[(size_t)n_rounds] = so;
+
+    tcmi_readset *rs = new tcmi_readset();
+    rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
+    rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
+    rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
+    Up up{ctx, rs};
+    if (nf) {
+        rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
+        if (!rc) rc = up((void **)&rs->d_flen, f_len.data(), (size_t)nf * 4);
+        if (!rc) rc = up((void **)&rs->d_fseq, f_seq.data(), f_seq.size() * 4);
+        if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
+    }
+    if (!rc && ng) {
+        rc = up((void **)&rs->d_pos, h_pos.data(), (size_t)ng * 4);
+        if (!rc) rc = up((void **)&rs->d_meta, h_meta.data(), (size_t)ng * 4);
+        if (!rc) rc = up((void **)&rs->d_lseq, h_lseq.data(), (size_t)ng * 4);
+        if (!rc) rc = up((void **)&rs->d_cigar, h_cig.data(), (size_t)g_cig * 4);
+        if (!rc) rc = up((void **)&rs->d_seq, h_seq.data(), (size_t)g_seqw * 4);
+        if (!rc) rc = up((void **)&rs->d_round_cig, h_rc.data(), (size_t)(n_rounds + 1) * 8);
+        if (!rc) rc = up((void **)&rs->d_round_seq, h_rs.data(), (size_t)(n_rounds + 1) * 8);
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "sync after upload failed");
+    if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    *out = rs;
+    return TCMI_OK;
+}
+
+int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled, int64_t *alg, int64_t *dev,
+                      int64_t *max_end)
+{
+    if (!rs) return tcmi_fail(nullptr, TCMI_E_ARG, "readset is NULL");
+    if (n_reads) *n_reads = rs->n_reads;
+    if (n_piled) *n_piled = rs->n_piled;
+    if (alg) *alg = rs->alg_bytes;
+    if (dev) *dev = rs->dev_bytes;
+    if (max_end) *max_end = rs->max_end;
+    return TCMI_OK;
+}
+
+int tcmi_readset_sets(const tcmi_readset *rs, int64_t *aligned_reads, int64_t *aligned_chunks, int64_t *general_reads)
+{
+    if (!rs) return tcmi_fail(nullptr, TCMI_E_ARG, "readset is NULL");
+    if (aligned_reads) *aligned_reads = rs->f_reads;
+    if (aligned_chunks) *aligned_chunks = rs->f_chunks;
+    if (general_reads) *general_reads = rs->g_reads;
+    return TCMI_OK;
+}
+
+} // extern "C"

@@ -3,7 +3,12 @@
 // Replaces indexing.BuildIndex (TrueConsense/indexing.py:75-154): htslib's pileup plus the
 // per-token Python loop parse_query_sequences (indexing.py:102-132).  Semantics: SURVEY §8-P.
 //
-// Decomposition (read-major; the count matrix is a commutative integer sum):
+// Two kernels, one per device read set (tcmi_internal.h):
+//   tally_fast_kernel    ALIGNED reads (one match op): bit-sliced register accumulation,
+//                        no atomics in the inner loop — see the comment above it.
+//   tally_atomic_kernel  GENERAL reads (any CIGAR): token-by-token walk, LDS atomics.
+//
+// tally_atomic_kernel decomposition (read-major; the count matrix is a commutative integer sum):
 //   workgroup  = `rounds_per_wg` consecutive ROUNDS of 256 coordinate-sorted reads
 //   LDS window = counters for WIN positions starting at the first read's position:
 //                planes A,C,G,T,X,I (u32) + a coverage difference array
@@ -207,18 +212,23 @@ __global__ __launch_bounds__(BLOCK) void tally_atomic_kernel(TallyArgs a)
 
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
+    if (rs->f_chunks > 0) {
+        const int rc = tcmi_launch_tally_fast(ctx, rs, L, ld, d_counts);
+        if (rc) return rc;
+    }
+    if (rs->g_reads == 0) return TCMI_OK;
     TallyArgs a;
     a.pos = rs->d_pos; a.meta = rs->d_meta; a.lseq = rs->d_lseq; a.cigar = rs->d_cigar; a.seq = rs->d_seq;
     a.round_cig = rs->d_round_cig; a.round_seq = rs->d_round_seq;
-    a.n_piled = rs->n_piled; a.n_rounds = rs->n_rounds; a.ld = ld; a.counts = d_counts; a.L = (int32_t)L;
+    a.n_piled = rs->g_reads; a.n_rounds = rs->n_rounds; a.ld = ld; a.counts = d_counts; a.L = (int32_t)L;
     int rpw = ctx->rounds_per_wg;
     if (rpw <= 0) rpw = rs->n_rounds >= 4096 ? 4 : rs->n_rounds >= 1024 ? 2 : 1;
     a.rounds_per_wg = rpw;
     const int64_t grid = (rs->n_rounds + rpw - 1) / rpw;
     if (grid <= 0 || grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_ARG, "bad grid %lld", (long long)grid);
-    tcmi_prof_begin(ctx, TCMI_K_TALLY);
+    tcmi_prof_begin(ctx, TCMI_K_TALLY_GENERAL);
     hipLaunchKernelGGL(tally_atomic_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream, a);
-    tcmi_prof_end(ctx, TCMI_K_TALLY);
+    tcmi_prof_end(ctx, TCMI_K_TALLY_GENERAL);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;
 }

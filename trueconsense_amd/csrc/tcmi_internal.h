@@ -12,28 +12,57 @@
 
 // ---- device read layout -------------------------------------------------------------
 // Only reads that pile up (mapped, tid >= 0, pos >= 0, reference span > 0)
-// are kept.  They are grouped in ROUNDS of TCMI_ROUND consecutive reads; the per-round
-// offset tables replace per-read offsets (the kernel rebuilds those with a block scan),
-// so HBM traffic is the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes per read plus
-// 16 bytes per round and <= 3 bytes of word padding per read.
+// are kept, split in two sets at upload time:
+//
+//  * ALIGNED set (fast kernel): reads whose CIGAR is one match op (M / = / X), optionally
+//    flanked by S / H clips, no longer than TCMI_F_MAXSPAN positions.  Kept as
+//    (pos, len) + the aligned bases only, 8 bases per 32-bit word in linear nibble order,
+//    each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for anything else (N, IUPAC, '=',
+//    base beyond SEQ): exactly what indexing.py:115-132 distinguishes.  Consecutive reads are
+//    grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW grid words of 8
+//    positions); one workgroup tallies one chunk.
+//  * GENERAL set (CIGAR-walk kernel): every other read (indels, ref-skips, pads, long reads),
+//    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
+//    offsets with a block scan), raw 4-bit codes.
+//
+// HBM traffic per read stays the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes or less
+// (aligned reads carry 8 bytes of header and no CIGAR) plus <= 3 bytes of word padding.
 #define TCMI_ROUND 256
+#define TCMI_F_CHUNK 1024          // max reads per chunk
+#define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
+#define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes
+#define TCMI_F_SUB 256             // max reads staged in LDS at a time
+#define TCMI_F_SEQCAP 6144         // LDS words for staged bases
+
+struct tcmi_fast_chunk {           // 32 bytes
+    int64_t read0;                 // first read (index into f_pos / f_len)
+    int64_t word0;                 // first base word (multiple of 4)
+    int32_t n_reads;
+    int32_t P0;                    // window start, multiple of 8
+    int32_t Wn;                    // window length in grid words
+    int32_t sub_reads;             // reads per LDS stage (multiple of 64, <= TCMI_F_SUB)
+};
 
 struct tcmi_readset {
     int64_t n_reads = 0;        // as handed in
-    int64_t n_piled = 0;        // kept on device
-    int64_t n_rounds = 0;
-    int64_t n_cigar = 0;        // total ops of kept reads
-    int64_t n_seqw = 0;         // total 32-bit SEQ words of kept reads
+    int64_t n_piled = 0;        // kept on device (aligned + general)
     int64_t alg_bytes = 0;      // sum over kept reads of 12 + 4*n_cigar + ceil(l_qseq/2)
     int64_t dev_bytes = 0;
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
-    int32_t max_span = 0;       // max reference span of a kept read
     int device = -1;
-    int32_t *d_pos = nullptr;   // [n_piled]
-    uint32_t *d_meta = nullptr; // [n_piled] flag<<16 | n_cigar
-    int32_t *d_lseq = nullptr;  // [n_piled]
+    // aligned set
+    int64_t f_reads = 0, f_chunks = 0, f_words = 0;
+    int32_t *d_fpos = nullptr;  // [f_reads]
+    int32_t *d_flen = nullptr;  // [f_reads]
+    uint32_t *d_fseq = nullptr; // [f_words]
+    tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]
+    // general set
+    int64_t g_reads = 0, n_rounds = 0, n_cigar = 0, n_seqw = 0;
+    int32_t *d_pos = nullptr;   // [g_reads]
+    uint32_t *d_meta = nullptr; // [g_reads] flag<<16 | n_cigar
+    int32_t *d_lseq = nullptr;  // [g_reads]
     uint32_t *d_cigar = nullptr;// [n_cigar]
-    uint32_t *d_seq = nullptr;  // [n_seqw] 8 bases per word, base i at bits [4(i%8), +4)
+    uint32_t *d_seq = nullptr;  // [n_seqw] 8 bases per word, base i at bits [4(i%8), +4), raw BAM codes
     int64_t *d_round_cig = nullptr; // [n_rounds+1]
     int64_t *d_round_seq = nullptr; // [n_rounds+1]
 };
@@ -48,15 +77,15 @@ struct tcmi_ctx {
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
-    double prof_ms[TCMI_K_NKERNELS] = {0, 0, 0};
-    int64_t prof_n[TCMI_K_NKERNELS] = {0, 0, 0};
+    double prof_ms[TCMI_K_NKERNELS] = {0, 0, 0, 0};
+    int64_t prof_n[TCMI_K_NKERNELS] = {0, 0, 0, 0};
     // workspace of tcmi_step / host-buffer conveniences
     int64_t ws_L = 0, ws_ld = 0;
     int32_t *d_counts = nullptr;
     uint8_t *d_plain = nullptr, *d_alt = nullptr, *d_flags = nullptr;
     uint8_t *h_rec = nullptr;       // pinned: plain | alt | flags, each ws_ld bytes
     int32_t *h_counts = nullptr;    // pinned [7][ws_ld]
-    int tally_variant = 0;          // 0 = default; see tally.hip
+    int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
 };
 
@@ -75,6 +104,7 @@ void tcmi_prof_end(tcmi_ctx *ctx, int k);
 
 // kernels (tally.hip / call.hip)
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
+int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_call(tcmi_ctx *ctx, const int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov,
                      int include_ambig, uint8_t *d_plain, uint8_t *d_alt, uint8_t *d_flags,
                      int32_t *d_events, int32_t *d_event_counts);

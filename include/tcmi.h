@@ -85,7 +85,9 @@ int  tcmi_ctx_create(int device, tcmi_ctx **out);  /* fails with TCMI_E_NODEVICE
 int  tcmi_ctx_destroy(tcmi_ctx *ctx);
 int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
 void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
-/* tuning knobs: "tally_variant" (0 = default kernel), "rounds_per_wg" (0 = auto)               */
+/* tuning knobs, read at tcmi_readset_upload / launch: "tally_variant" (0 = aligned reads through
+ * the fast kernel, 1 = every read through the CIGAR-walk kernel), "fast_nw" (grid words per lane
+ * of the fast kernel: 2 or 4), "rounds_per_wg" (CIGAR-walk kernel, 0 = auto)                    */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

@@ -67,6 +67,8 @@ int tcmi_ctx_create(int device, tcmi_ctx **out)
     if (v) c->tally_variant = std::atoi(v);
     v = std::getenv("TCMI_ROUNDS_PER_WG");
     if (v) c->rounds_per_wg = std::atoi(v);
+    v = std::getenv("TCMI_FAST_NW");
+    if (v && (std::atoi(v) == 2 || std::atoi(v) == 4)) c->fast_nw = std::atoi(v);
     *out = c;
     return TCMI_OK;
 }
@@ -111,6 +113,10 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     if (!c || !key) return tcmi_fail(c, TCMI_E_ARG, "null argument");
     if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
+    else if (!std::strcmp(key, "fast_nw")) {
+        if (value != 2 && value != 4) return tcmi_fail(c, TCMI_E_ARG, "fast_nw must be 2 or 4");
+        c->fast_nw = value;
+    }
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
     return TCMI_OK;
 }

@@ -103,7 +103,7 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_fpos, rs->d_flen, rs->d_fseq, rs->d_fchunk, rs->d_pos, rs->d_meta,
+    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fother, rs->d_fchunk, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -146,23 +146,26 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
         else { gsel.push_back(i); g_cig += nc; g_seqw += (lq + 7) / 8; }
     }
 
-    // ---- aligned set: chunks + sanitized bases -------------------------------------------
+    // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
-    std::vector<int32_t> f_pos((size_t)nf), f_len((size_t)nf);
+    const int NW = ctx->fast_nw == 4 ? 4 : 2, PAD = NW + 1;
+    std::vector<int32_t> f_pos((size_t)nf), f_other;
+    std::vector<uint32_t> f_lenoff((size_t)nf);
     std::vector<tcmi_fast_chunk> chunks;
     std::vector<uint32_t> f_seq;
-    f_seq.reserve((size_t)(nf * 20 + 16));
+    f_seq.reserve((size_t)(nf * (19 + PAD) + 64));
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
         auto close = [&](int64_t next_read) {
             if (c_n == 0) return;
             tcmi_fast_chunk c;
+            std::memset(&c, 0, sizeof c);
             c.read0 = c_read0;
-            c.word0 = 0;                        // filled below, when the bases are packed
             c.n_reads = (int32_t)c_n;
             c.P0 = (int32_t)c_lo;
             c.Wn = (int32_t)((c_hi - c_lo + 7) / 8);
-            int64_t sub = (TCMI_F_SEQCAP - 8) / c_maxnw / 64 * 64;
+            // a stage holds pad + sub_reads * (nw + pad) words and must fit the LDS buffer
+            int64_t sub = (TCMI_F_SEQCAP - 16 - PAD) / (c_maxnw + PAD) / 64 * 64;
             c.sub_reads = (int32_t)std::min<int64_t>(TCMI_F_SUB, sub);
             chunks.push_back(c);
             c_read0 = next_read;
@@ -179,20 +182,21 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             if (c_n == 0) { c_read0 = j; c_lo = lo; c_hi = e; c_maxnw = nw; }
             ++c_n;
             f_pos[(size_t)j] = (int32_t)p;
-            f_len[(size_t)j] = (int32_t)fsel[(size_t)j].len;
         }
         close(nf);
-        // pack the aligned bases chunk by chunk, each chunk starting on a 16-byte boundary
+        // the base stream, chunk by chunk: [pad] read [pad] read [pad] ... each chunk 16-byte aligned
         for (auto &c : chunks) {
             while (f_seq.size() & 3) f_seq.push_back(0);
             c.word0 = (int64_t)f_seq.size();
+            f_seq.resize(f_seq.size() + (size_t)PAD, 0);
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const uint8_t *src = r->seq + r->seq_off[s.i];
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
                 const size_t base = f_seq.size();
-                f_seq.resize(base + (size_t)nw, 0);
+                f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
+                f_seq.resize(base + (size_t)(nw + PAD), 0);
                 uint8_t *dst = reinterpret_cast<uint8_t *>(&f_seq[base]);
                 const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
                 if ((s.y0 & 1) == 0) {
@@ -208,6 +212,22 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                         dst[k >> 1] |= (uint8_t)(oh << ((k & 1) * 4));
                     }
                 }
+                // bases that are no A/C/G/T: rare, found a word at a time
+                const uint32_t *w = &f_seq[base];
+                for (int64_t k = 0; k < nw; ++k) {
+                    const uint32_t v = w[k];
+                    uint32_t nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;   // 1 per non-zero nibble
+                    const int64_t in_read = std::min<int64_t>(8, s.len - 8 * k);
+                    const uint32_t want = in_read >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - in_read)));
+                    uint32_t miss = want & ~nz;
+                    while (miss) {
+                        const int bit = __builtin_ctz(miss);
+                        f_other.push_back((int32_t)(r->pos[s.i] + 8 * k + bit / 4));
+                        miss &= miss - 1;
+                    }
+                }
+                if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads)
+                    c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(f_seq.size() - (size_t)c.word0);
             }
         }
         while (f_seq.size() & 3) f_seq.push_back(0);
@@ -244,11 +264,13 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     tcmi_readset *rs = new tcmi_readset();
     rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
+    rs->f_other = (int64_t)f_other.size(); rs->f_nw = NW;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
     Up up{ctx, rs};
     if (nf) {
         rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
-        if (!rc) rc = up((void **)&rs->d_flen, f_len.data(), (size_t)nf * 4);
+        if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
+        if (!rc && !f_other.empty()) rc = up((void **)&rs->d_fother, f_other.data(), f_other.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fseq, f_seq.data(), f_seq.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
     }

@@ -1,22 +1,26 @@
-// tally_fast.hip — stage A for ALIGNED reads (one match op) on gfx950, without atomics in the
-// inner loop.  Counterpart of the per-token loop of indexing.py:102-132 for the tokens that
+// tally_fast.hip — stage A for ALIGNED reads (one run of match ops) on gfx950, without atomics in
+// the inner loop.  Counterpart of the per-token loop of indexing.py:102-132 for the tokens that
 // are plain bases: coverage += 1 and, if the base is A/C/G/T, that class += 1.
 //
-// Data (tcmi_internal.h): per read (pos, len) and its aligned bases as one-hot nibbles
-// (A=1 C=2 G=4 T=8, anything else 0), 8 bases per 32-bit word.  The genome is cut in GRID WORDS
-// of 8 positions; a CHUNK of <= 1024 coordinate-sorted reads touches a window of Wn <= 96 grid
-// words (24 at 5000x coverage with 150-bp reads).
+// Data (tcmi_internal.h): per read 8 bytes of header and its aligned bases as one-hot nibbles
+// (A=1 C=2 G=4 T=8, anything else 0), 8 bases per 32-bit word, `pad` zero words after each read.
+// The genome is cut in GRID WORDS of 8 positions; a CHUNK of <= 1024 coordinate-sorted reads
+// touches a window of Wn <= 96 grid words (24 at 5000x coverage with 150-bp reads).
 //
 // One workgroup (256 lanes) per chunk:
-//   lane (g, s)  owns TWO adjacent grid words (16 positions) g of the window and DEPTH SLICE s of
-//                the reads; S = 256 / ceil(Wn/2) slices work in parallel on different reads.
-//   stage        <= 256 reads at a time: headers -> LDS (block scan for word offsets), bases ->
-//                LDS with 16-byte coalesced loads: every input byte leaves HBM once.
-//   inner loop   per read of the slice: three LDS words -> two v_alignbit funnel shifts bring the
-//                read's nibbles onto the lane's grid words; `& 0x11111111` of the word shifted by
-//                0..3 isolates one class as eight 4-bit counters, added to 8 registers; every 15
-//                reads the 4-bit counters are widened into 8-bit counters (16 registers).
-//                No atomics, no branches on the data.
+//   lane (g, s)  owns NW adjacent grid words (8*NW positions) g of the window and DEPTH SLICE s
+//                of the reads; S = 256 / ceil(Wn/NW) slices work in parallel on different reads.
+//   stage        <= 256 reads at a time: headers and bases -> LDS with coalesced loads (16 bytes
+//                per lane for the bases); the loads of stage i+1 are issued before the inner loop
+//                of stage i runs and land in registers meanwhile.  Every input byte leaves HBM once.
+//   inner loop   per read of the slice: NW+1 LDS words (the zero padding makes bounds tests
+//                unnecessary: one v_med3 clamps the word index) -> NW v_alignbit funnel shifts
+//                bring the read's nibbles onto the lane's grid words; `(w >> c) & 0x11111111`
+//                isolates class c as eight 4-bit counters, added to a register.  Only A, C, G are
+//                counted: T = coverage - A - C - G - (bases that are no A/C/G/T; rare, kept in a
+//                side list and subtracted by the tail blocks of the same launch).  Every <= 12
+//                reads the 4-bit counters are widened into 8-bit counters.  No atomics, no
+//                data-dependent branches.
 //   coverage     difference array in LDS, one (+run, -run) pair per run of equal (pos, len)
 //                reads found with a wave ballot, then a block prefix sum.
 //   reduce       slices are summed through LDS (plain stores / loads) into 16-bit window counters,
@@ -29,18 +33,22 @@ namespace {
 
 constexpr int FB = 256;                         // lanes per workgroup
 constexpr int MAXPOS = TCMI_F_MAXW * 8;         // positions in the largest window
+constexpr int NLD = TCMI_F_SEQCAP / (4 * FB);   // 16-byte loads per lane that cover the largest stage
+constexpr int UNR = 4;                          // reads in flight per lane in the inner loop
+constexpr int WIDEN = 12;                       // reads between widenings of the 4-bit counters (<= 15, multiple of UNR)
 
 struct FastArgs {
     const int32_t *pos;
-    const int32_t *len;
+    const uint32_t *lenoff;
     const uint32_t *seq;
     const tcmi_fast_chunk *chunks;
+    const int32_t *other;
     int32_t *counts;
     int64_t ld;
+    int64_t n_other;
+    int32_t n_chunks;
     int32_t L;
 };
-
-__device__ constexpr int plane_col(int k) { return k == 0 ? TCMI_A : k == 1 ? TCMI_C : k == 2 ? TCMI_G : TCMI_T; }
 
 // inclusive block scan of one int over 256 lanes (4 waves)
 __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
@@ -61,46 +69,89 @@ __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
     return v + base;
 }
 
+template <int NW>
 __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
 {
+    constexpr int PAD = NW + 1;
+    constexpr int NREG = NW * 3 * 2;                                          // 8-bit counter registers per lane
     __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged bases; later the slice partials
-    __shared__ uint2 s_hdr[TCMI_F_SUB];                                       // {pos - P0, word offset | nw << 20}
+    __shared__ __attribute__((aligned(16))) uint4 s_hdr[TCMI_F_SUB + 1];     // {pos - P0, byte offset in s_seq, words, -}
     __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
-    __shared__ uint16_t s_fin[4][MAXPOS];                                     // window counters per class
+    __shared__ uint16_t s_fin[3][MAXPOS];                                     // window counters of A, C, G
     __shared__ int s_scan[4];
-    __shared__ int s_total;
+    static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
 
-    const tcmi_fast_chunk ch = a.chunks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int P0 = ch.P0, Wn = ch.Wn, npos = Wn * 8;
-    const int Gn = (Wn + 1) >> 1;               // lane groups (two grid words each)
+    if ((int)blockIdx.x >= a.n_chunks) {
+        // tail blocks: aligned bases that are no A/C/G/T were counted as T by subtraction
+        const int64_t i = (int64_t)((int)blockIdx.x - a.n_chunks) * FB + tid;
+        if (i < a.n_other) {
+            const int p = a.other[i];
+            if ((unsigned)p < (unsigned)a.L) atomicSub(&a.counts[(int64_t)TCMI_T * a.ld + p], 1);
+        }
+        return;
+    }
+    const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
+    const int64_t read0 = chp->read0, word0 = chp->word0;
+    const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
+    const int npos = Wn * 8;
+    const int Gn = (Wn + NW - 1) / NW;          // lane groups
     const int S = FB / Gn;                      // depth slices
     const int s = tid / Gn, gi = tid - s * Gn;
-    const bool active = s < S;
-    const int base8 = gi * 16;                  // first position of the lane's words, relative to P0
+    const int base8 = gi * (8 * NW);            // first owned position, relative to P0
+    const int s_eff = s < S ? s : (1 << 20);     // lanes beyond the last slice only ever see the dummy read
+    const int n_stage = (n_reads + sub_reads - 1) / sub_reads;
 
     for (int i = tid; i <= npos; i += FB) s_cov[i] = 0;
 
-    uint32_t nib[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};          // [word][class]: eight 4-bit counters
-    uint32_t byt[2][4][2] = {};                                  // [word][class][even|odd position]: four 8-bit counters
-    int since_flush = 0;
-    int64_t word_base = ch.word0;
+    uint32_t nib[NW][3];                        // [word][class A,C,G]: eight 4-bit counters
+    uint32_t byt[NW][3][2];                     // [word][class][even|odd position]: four 8-bit counters
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nib[w][c] = byt[w][c][0] = byt[w][c][1] = 0;
 
-    for (int sub0 = 0; sub0 < ch.n_reads; sub0 += ch.sub_reads) {
-        const int ns = min(ch.sub_reads, ch.n_reads - sub0);
-        // ---- headers: one read per lane ---------------------------------------------------
+    // ---- prefetch registers: the next stage's headers and bases ------------------------------------
+    int h_pos = 0;
+    uint32_t h_lo = 0;
+    uint4 pre0, pre1, pre2, pre3, pre4, pre5;            // (named registers: an array ended up in scratch)
+    static_assert(NLD == 6, "prefetch registers are written out for 6 loads per lane");
+    int st_begin = 0, st_end = chp->stage_end[0];                // word range of the stage (from word0)
+    // every lane loads (indices clamped into the stage): no exec-masked branch, so the compiler can leave
+    // the loads in flight across the inner loop instead of waiting at a branch join.  (A macro, not a
+    // lambda: the closure kept `pre` in scratch memory.)
+#define TCMI_ISSUE_STAGE(stage_, begin_, end_)                                                        \
+    do {                                                                                              \
+        const int r_ = min((stage_) * sub_reads + tid, n_reads - 1);                                  \
+        h_pos = a.pos[read0 + r_];                                                                    \
+        h_lo = a.lenoff[read0 + r_];                                                                  \
+        const int mis_ = (int)((word0 + (begin_)) & 3); /* keep the 16-byte loads aligned */          \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(a.seq + (word0 + (begin_) - mis_));       \
+        const int last_ = ((end_) - (begin_) + mis_ + 3) / 4 - 1;                                     \
+        pre0 = src_[min(0 * FB + tid, last_)];                                                        \
+        pre1 = src_[min(1 * FB + tid, last_)];                                                        \
+        pre2 = src_[min(2 * FB + tid, last_)];                                                        \
+        pre3 = src_[min(3 * FB + tid, last_)];                                                        \
+        pre4 = src_[min(4 * FB + tid, last_)];                                                        \
+        pre5 = src_[min(5 * FB + tid, last_)];                                                        \
+    } while (0)
+    TCMI_ISSUE_STAGE(0, st_begin, st_end);
+
+    for (int stage = 0; stage < n_stage; ++stage) {
+        const int ns = min(sub_reads, n_reads - stage * sub_reads);
+        const int mis = (int)((word0 + st_begin) & 3);
+        const int tw = st_end - st_begin + mis;
+        // ---- A: headers, coverage runs and bases of this stage -> LDS -------------------------------
         const bool valid = tid < ns;
         int rel = 0, len = 0;
         if (valid) {
-            rel = a.pos[ch.read0 + sub0 + tid] - P0;
-            len = a.len[ch.read0 + sub0 + tid];
+            rel = h_pos - P0;
+            len = (int)(h_lo & 1023u);
+            const int off = (int)(h_lo >> 10) - st_begin + mis;   // word index of the read in s_seq
+            s_hdr[tid] = make_uint4((uint32_t)rel, (uint32_t)off * 4u, (uint32_t)(len + 7) >> 3, 0u);
         }
-        const int nw = (len + 7) >> 3;
-        const int incl = block_scan_incl(nw, s_scan);           // (two barriers: previous stage fully consumed)
-        const int mis = (int)(word_base & 3);                    // keep the 16-byte loads aligned
-        if (valid) s_hdr[tid] = make_uint2((uint32_t)rel, (uint32_t)(incl - nw + mis) | ((uint32_t)nw << 20));
-        if (tid == FB - 1) s_total = incl;                       // total words of this stage
-        // coverage: one (+run, -run) pair per run of equal (pos, len) inside the wave
+        if (tid == 0)                                            // dummy: a read far to the right, no words
+            s_hdr[ns] = make_uint4(0x7FFFu, (uint32_t)(mis + PAD) * 4u, 0u, 0u);
         {
             const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
             const bool lead = valid && (lane == 0 || rel != prel || len != plen);
@@ -113,76 +164,81 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
                 atomicAdd(&s_cov[rel + len], -run);
             }
         }
-        __syncthreads();
-        const int total = s_total;
-        const int tw = total + mis;
-        // ---- bases: coalesced 16-byte loads into LDS ----------------------------------------
         {
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + (word_base - mis));
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            for (int i = tid; i * 4 < tw; i += FB) dst[i] = src[i];
+            if ((0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
+            if ((1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
+            if ((2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
+            if ((3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
+            if ((4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
+            if ((5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
         }
-        word_base += total;
         __syncthreads();
-        // ---- inner loop: this lane's slice of the staged reads ------------------------------
+        // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
+        if (stage + 1 < n_stage) {
+            st_begin = st_end - PAD;
+            st_end = chp->stage_end[stage + 1];
+            TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
+        }
+        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free: indices
+        //      past the stage are clamped onto a dummy header whose read lies entirely in the zero padding.
         const int Rs = (ns + S - 1) / S;
-        const int r0 = s * Rs;
-        for (int k = 0; k < Rs; ++k) {
-            const int r = r0 + k;
-            if (active && r < ns) {
-                const uint2 h = s_hdr[r];
-                const int off = (int)(h.y & 0xFFFFFu), rnw = (int)(h.y >> 20);
-                const int d = base8 - (int)h.x;                 // first owned position relative to the read start
-                const int q = d >> 3;                           // read word holding it (floor)
-                const uint32_t c4 = (uint32_t)(d & 7) << 2;
-                const bool v0 = (unsigned)q < (unsigned)rnw, v1 = (unsigned)(q + 1) < (unsigned)rnw,
-                           v2 = (unsigned)(q + 2) < (unsigned)rnw;
-                uint32_t w0 = s_seq[off + (v0 ? q : 0)];
-                uint32_t w1 = s_seq[off + (v1 ? q + 1 : 0)];
-                uint32_t w2 = s_seq[off + (v2 ? q + 2 : 0)];
-                w0 = v0 ? w0 : 0u;
-                w1 = v1 ? w1 : 0u;
-                w2 = v2 ? w2 : 0u;
-                const uint32_t A0 = __builtin_amdgcn_alignbit(w1, w0, c4);      // bases d .. d+7
-                const uint32_t A1 = __builtin_amdgcn_alignbit(w2, w1, c4);      // bases d+8 .. d+15
+        const int hbytes_end = ns * 16;
+        int hb = s_eff * 16;                                    // byte offset of the lane's next header
+        for (int k0 = 0; k0 < Rs; k0 += WIDEN) {
+            const int k1 = min(k0 + WIDEN, Rs);
+            for (int k = k0; k < k1; k += UNR) {
+                uint4 h[UNR];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    nib[0][c] += (A0 >> c) & 0x11111111u;
-                    nib[1][c] += (A1 >> c) & 0x11111111u;
+                for (int u = 0; u < UNR; ++u) {
+                    h[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
+                    hb += S * 16;
                 }
-            }
-            if (++since_flush == 15) {                          // 4-bit counters are full: widen
-                since_flush = 0;
+                uint32_t w[UNR][NW + 1];
+                uint32_t c4[UNR];
 #pragma unroll
-                for (int w = 0; w < 2; ++w)
+                for (int u = 0; u < UNR; ++u) {
+                    const int d = base8 - (int)h[u].x;          // first owned position relative to the read start
+                    // word of the read holding it, clamped into the zero padding on either side
+                    const int q = max(-PAD, min(d >> 3, (int)h[u].z));
+                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(
+                        reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 4);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        byt[w][c][0] += nib[w][c] & 0x0F0F0F0Fu;
-                        byt[w][c][1] += (nib[w][c] >> 4) & 0x0F0F0F0Fu;
-                        nib[w][c] = 0;
+                    for (int j = 0; j <= NW; ++j) w[u][j] = wp[j];
+                    c4[u] = (uint32_t)d << 2;                   // v_alignbit uses bits [4:0]: 4 * (d mod 8)
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const uint32_t A = __builtin_amdgcn_alignbit(w[u][j + 1], w[u][j], c4[u]);   // bases d+8j ..
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) nib[j][c] += (A >> c) & 0x11111111u;
                     }
             }
+            // the 4-bit counters may be full (<= WIDEN reads since the last widening): widen
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    byt[w][c][0] += nib[w][c] & 0x0F0F0F0Fu;
+                    byt[w][c][1] += (nib[w][c] >> 4) & 0x0F0F0F0Fu;
+                    nib[w][c] = 0;
+                }
         }
+        __syncthreads();                                        // every lane is done with this stage's LDS
     }
-#pragma unroll
-    for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            byt[w][c][0] += nib[w][c] & 0x0F0F0F0Fu;
-            byt[w][c][1] += (nib[w][c] >> 4) & 0x0F0F0F0Fu;
-        }
-    __syncthreads();                                            // every lane is done with s_seq
-    // ---- slice partials -> LDS, layout [register j][lane] (conflict-free both ways) -----------
+    // ---- slice partials -> LDS, layout [register j][lane] (conflict-free both ways) -----------------
     uint32_t *s_part = s_seq;
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) s_part[((w * 4 + c) * 2 + h) * FB + tid] = byt[w][c][h];
+            for (int h = 0; h < 2; ++h) s_part[((w * 3 + c) * 2 + h) * FB + tid] = byt[w][c][h];
     __syncthreads();
-    // ---- sum the slices; register j of group gi holds 4 positions of one class ----------------
-    for (int item = tid; item < Gn * 16; item += FB) {
+    // ---- sum the slices; register j of group g holds 4 positions of one class -----------------------
+    for (int item = tid; item < Gn * NREG; item += FB) {
         const int j = item / Gn, g = item - j * Gn;
         uint32_t e = 0, o = 0;                                  // bytes 0,2 and bytes 1,3 as 16-bit sums
         for (int t = 0; t < S; ++t) {
@@ -190,9 +246,9 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
             e += v & 0x00FF00FFu;
             o += (v >> 8) & 0x00FF00FFu;
         }
-        const int w = j >> 3, c = (j >> 1) & 3, h = j & 1;
-        const int p = (g * 2 + w) * 8 + h;                      // byte i of the register <-> position p + 2*i
-        if (p < npos) {                                         // (odd Wn: the last lane group's 2nd word is outside)
+        const int w = j / 6, c = (j >> 1) % 3, h = j & 1;
+        const int p = (g * NW + w) * 8 + h;                     // byte i of the register <-> position p + 2*i
+        if (p < npos) {                                         // (the last group's trailing words may lie outside)
             uint16_t *f = &s_fin[c][p];
             f[0] = (uint16_t)(e & 0xFFFFu);
             f[4] = (uint16_t)(e >> 16);
@@ -200,7 +256,7 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
             f[6] = (uint16_t)(o >> 16);
         }
     }
-    // ---- coverage: inclusive prefix sum of the difference array, 3 entries per lane ------------
+    // ---- coverage: inclusive prefix sum of the difference array, 3 entries per lane -----------------
     {
         const int i0 = tid * 3;
         const int d0 = i0 < npos ? s_cov[i0] : 0, d1 = i0 + 1 < npos ? s_cov[i0 + 1] : 0,
@@ -213,30 +269,37 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
         if (i0 + 2 < npos) s_cov[i0 + 2] = before + d0 + d1 + d2;
     }
     __syncthreads();
-    // ---- one coalesced global atomic per touched (class, position) ------------------------------
+    // ---- one coalesced global atomic per touched (class, position) -----------------------------------
     for (int p = tid; p < npos; p += FB) {
         const int gp = P0 + p;
         if (gp >= a.L) continue;
         const int cv = s_cov[p];
-        if (cv) atomicAdd(&a.counts[(int64_t)TCMI_COV * a.ld + gp], cv);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int v = s_fin[c][p];
-            if (v) atomicAdd(&a.counts[(int64_t)plane_col(c) * a.ld + gp], v);
-        }
+        if (cv == 0) continue;
+        const int nA = s_fin[0][p], nC = s_fin[1][p], nG = s_fin[2][p];
+        const int nT = cv - nA - nC - nG;                       // includes the "other" bases, subtracted by the tail blocks
+        atomicAdd(&a.counts[(int64_t)TCMI_COV * a.ld + gp], cv);
+        if (nA) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA);
+        if (nC) atomicAdd(&a.counts[(int64_t)TCMI_C * a.ld + gp], nC);
+        if (nG) atomicAdd(&a.counts[(int64_t)TCMI_G * a.ld + gp], nG);
+        if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
     }
 }
+
+#undef TCMI_ISSUE_STAGE
 
 } // namespace
 
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
     FastArgs a;
-    a.pos = rs->d_fpos; a.len = rs->d_flen; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk;
-    a.counts = d_counts; a.ld = ld; a.L = (int32_t)L;
-    if (rs->f_chunks > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
+    a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.other = rs->d_fother;
+    a.counts = d_counts; a.ld = ld; a.n_other = rs->f_other; a.L = (int32_t)L;
+    const int64_t grid = rs->f_chunks + (rs->f_other + FB - 1) / FB;
+    if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
+    a.n_chunks = (int32_t)rs->f_chunks;
     tcmi_prof_begin(ctx, TCMI_K_TALLY);
-    hipLaunchKernelGGL(tally_fast_kernel, dim3((unsigned)rs->f_chunks), dim3(FB), 0, ctx->stream, a);
+    if (rs->f_nw == 4) hipLaunchKernelGGL(tally_fast_kernel<4>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;

@@ -14,33 +14,39 @@
 // Only reads that pile up (mapped, tid >= 0, pos >= 0, reference span > 0)
 // are kept, split in two sets at upload time:
 //
-//  * ALIGNED set (fast kernel): reads whose CIGAR is one match op (M / = / X), optionally
-//    flanked by S / H clips, no longer than TCMI_F_MAXSPAN positions.  Kept as
-//    (pos, len) + the aligned bases only, 8 bases per 32-bit word in linear nibble order,
-//    each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for anything else (N, IUPAC, '=',
-//    base beyond SEQ): exactly what indexing.py:115-132 distinguishes.  Consecutive reads are
-//    grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW grid words of 8
-//    positions); one workgroup tallies one chunk.
+//  * ALIGNED set (fast kernel): reads whose CIGAR is one run of match ops (M / = / X),
+//    optionally flanked by S / H clips, no longer than TCMI_F_MAXSPAN positions.  Kept as
+//    8 bytes of header (pos; len | word offset << 10) + the aligned bases only, 8 bases per
+//    32-bit word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for
+//    anything else (N, IUPAC, '=', base beyond SEQ) — exactly what indexing.py:115-132
+//    distinguishes — followed by `pad` zero words, so that a lane may read the words just
+//    outside a read without a bounds test.  The reference positions of those "other" bases are
+//    kept in a side list (they count toward coverage but toward no class).
+//    Consecutive reads are grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW
+//    grid words of 8 positions); one workgroup tallies one chunk in STAGES of <= sub_reads reads.
 //  * GENERAL set (CIGAR-walk kernel): every other read (indels, ref-skips, pads, long reads),
 //    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
 //    offsets with a block scan), raw 4-bit codes.
 //
-// HBM traffic per read stays the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes or less
-// (aligned reads carry 8 bytes of header and no CIGAR) plus <= 3 bytes of word padding.
+// HBM traffic per read stays at or below the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes
+// (aligned reads: 8 + 4*ceil(l/8) + 4*pad bytes, i.e. 96 vs 91 for a 150-bp read at pad 3).
 #define TCMI_ROUND 256
 #define TCMI_F_CHUNK 1024          // max reads per chunk
 #define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
+#define TCMI_F_MAXSTAGE 16         // stages per chunk (TCMI_F_CHUNK / 64)
 
-struct tcmi_fast_chunk {           // 32 bytes
-    int64_t read0;                 // first read (index into f_pos / f_len)
-    int64_t word0;                 // first base word (multiple of 4)
+struct tcmi_fast_chunk {           // 96 bytes
+    int64_t read0;                 // first read (index into f_pos / f_lenoff)
+    int64_t word0;                 // first word of the chunk's base stream (multiple of 4)
     int32_t n_reads;
     int32_t P0;                    // window start, multiple of 8
     int32_t Wn;                    // window length in grid words
-    int32_t sub_reads;             // reads per LDS stage (multiple of 64, <= TCMI_F_SUB)
+    int32_t sub_reads;             // reads per stage (multiple of 64, <= TCMI_F_SUB)
+    int32_t stage_end[TCMI_F_MAXSTAGE];   // word offset (from word0) one past stage i, trailing pad included;
+                                          // stage i starts at stage_end[i-1] - pad (0 for i = 0)
 };
 
 struct tcmi_readset {
@@ -51,10 +57,12 @@ struct tcmi_readset {
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
     int device = -1;
     // aligned set
-    int64_t f_reads = 0, f_chunks = 0, f_words = 0;
+    int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_other = 0;
+    int32_t f_nw = 2;           // grid words per lane the stream was padded for (pad = f_nw + 1)
     int32_t *d_fpos = nullptr;  // [f_reads]
-    int32_t *d_flen = nullptr;  // [f_reads]
+    uint32_t *d_flenoff = nullptr; // [f_reads] len | (word offset from the chunk's word0) << 10
     uint32_t *d_fseq = nullptr; // [f_words]
+    int32_t *d_fother = nullptr;// [f_other] reference positions of aligned bases that are not A/C/G/T
     tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]
     // general set
     int64_t g_reads = 0, n_rounds = 0, n_cigar = 0, n_seqw = 0;
@@ -87,6 +95,7 @@ struct tcmi_ctx {
     int32_t *h_counts = nullptr;    // pinned [7][ws_ld]
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
+    int fast_nw = 2;                // grid words per lane in the fast kernel: 2 or 4
 };
 
 int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...);

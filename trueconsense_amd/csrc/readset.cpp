@@ -156,6 +156,20 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     f_seq.reserve((size_t)(nf * (19 + PAD) + 64));
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
+        // Stage size for a window of `words` grid words and reads of <= maxnw words: the kernel splits a
+        // stage over S = 256 / ceil(words / NW) depth slices and runs ceil(stage / S) inner-loop bodies per
+        // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
+        auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
+            const int64_t S = 256 / ((words + NW - 1) / NW);
+            const int64_t cap = std::min<int64_t>(TCMI_F_SUB, (TCMI_F_SEQCAP - 16 - PAD) / (maxnw + PAD));
+            int64_t sub = S * 12 * std::max<int64_t>(1, cap / (S * 12));
+            if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);            // window too wide for 12 per slice
+            while (sub * TCMI_F_MAXSTAGE < TCMI_F_CHUNK && sub + S <= cap) sub += S;   // keep <= 16 stages
+            return sub;
+        };
+        auto chunk_reads = [&](int64_t sub) -> int64_t {                         // whole stages, <= 1024 reads
+            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, 4 * sub) / sub * sub);
+        };
         auto close = [&](int64_t next_read) {
             if (c_n == 0) return;
             tcmi_fast_chunk c;
@@ -164,9 +178,8 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             c.n_reads = (int32_t)c_n;
             c.P0 = (int32_t)c_lo;
             c.Wn = (int32_t)((c_hi - c_lo + 7) / 8);
-            // a stage holds pad + sub_reads * (nw + pad) words and must fit the LDS buffer
-            int64_t sub = (TCMI_F_SEQCAP - 16 - PAD) / (c_maxnw + PAD) / 64 * 64;
-            c.sub_reads = (int32_t)std::min<int64_t>(TCMI_F_SUB, sub);
+            c.sub_reads = (int32_t)stage_reads(c.Wn, c_maxnw);
+            while ((c_n + c.sub_reads - 1) / c.sub_reads > TCMI_F_MAXSTAGE) c.sub_reads += 1;   // (cannot happen: see stage_reads)
             chunks.push_back(c);
             c_read0 = next_read;
             c_n = 0;
@@ -175,9 +188,10 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             const int64_t p = r->pos[fsel[(size_t)j].i], e = p + fsel[(size_t)j].len;
             const int64_t lo = p & ~(int64_t)7, nw = (fsel[(size_t)j].len + 7) / 8;
             if (c_n > 0) {
-                const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e);
-                if (c_n == TCMI_F_CHUNK || (nhi - nlo + 7) / 8 > TCMI_F_MAXW) close(j);
-                else { c_lo = nlo; c_hi = nhi; c_maxnw = std::max(c_maxnw, nw); }
+                const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e), nmax = std::max(c_maxnw, nw);
+                const int64_t words = (nhi - nlo + 7) / 8;
+                if (words > TCMI_F_MAXW || c_n >= chunk_reads(stage_reads(words, nmax))) close(j);
+                else { c_lo = nlo; c_hi = nhi; c_maxnw = nmax; }
             }
             if (c_n == 0) { c_read0 = j; c_lo = lo; c_hi = e; c_maxnw = nw; }
             ++c_n;

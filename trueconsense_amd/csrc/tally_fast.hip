@@ -75,7 +75,7 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
     constexpr int PAD = NW + 1;
     constexpr int NREG = NW * 3 * 2;                                          // 8-bit counter registers per lane
     __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged bases; later the slice partials
-    __shared__ __attribute__((aligned(16))) uint4 s_hdr[TCMI_F_SUB + 1];     // {pos - P0, byte offset in s_seq, words, -}
+    __shared__ __attribute__((aligned(8))) uint2 s_hdr[TCMI_F_SUB + 1];      // {pos - P0 | words << 16, byte offset in s_seq}
     __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
     __shared__ uint16_t s_fin[3][MAXPOS];                                     // window counters of A, C, G
     __shared__ int s_scan[4];
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
             rel = h_pos - P0;
             len = (int)(h_lo & 1023u);
             const int off = (int)(h_lo >> 10) - st_begin + mis;   // word index of the read in s_seq
-            s_hdr[tid] = make_uint4((uint32_t)rel, (uint32_t)off * 4u, (uint32_t)(len + 7) >> 3, 0u);
+            s_hdr[tid] = make_uint2((uint32_t)rel | ((uint32_t)(len + 7) >> 3) << 16, (uint32_t)off * 4u);
         }
         if (tid == 0)                                            // dummy: a read far to the right, no words
-            s_hdr[ns] = make_uint4(0x7FFFu, (uint32_t)(mis + PAD) * 4u, 0u, 0u);
+            s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)(mis + PAD) * 4u);
         {
             const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
             const bool lead = valid && (lane == 0 || rel != prel || len != plen);
@@ -183,24 +183,24 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free: indices
         //      past the stage are clamped onto a dummy header whose read lies entirely in the zero padding.
         const int Rs = (ns + S - 1) / S;
-        const int hbytes_end = ns * 16;
-        int hb = s_eff * 16;                                    // byte offset of the lane's next header
+        const int hbytes_end = ns * 8;
+        int hb = s_eff * 8;                                    // byte offset of the lane's next header
         for (int k0 = 0; k0 < Rs; k0 += WIDEN) {
             const int k1 = min(k0 + WIDEN, Rs);
             for (int k = k0; k < k1; k += UNR) {
-                uint4 h[UNR];
+                uint2 h[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    h[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
-                    hb += S * 16;
+                    h[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
+                    hb += S * 8;
                 }
                 uint32_t w[UNR][NW + 1];
                 uint32_t c4[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int d = base8 - (int)h[u].x;          // first owned position relative to the read start
+                    const int d = base8 - (int)(h[u].x & 0xFFFFu);   // first owned position relative to the read start
                     // word of the read holding it, clamped into the zero padding on either side
-                    const int q = max(-PAD, min(d >> 3, (int)h[u].z));
+                    const int q = max(-PAD, min(d >> 3, (int)(h[u].x >> 16)));
                     const uint32_t *wp = reinterpret_cast<const uint32_t *>(
                         reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 4);
 #pragma unroll

@@ -79,6 +79,11 @@ def main():
     ap.add_argument("--mincov", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-only", action="store_true", help="leave the host consensus walk out of the step")
+    ap.add_argument("--walkers", type=int, default=0, help="host threads for the consensus walks (0 = auto: min(8, cores/ranks))")
+    ap.add_argument("--serial", action="store_true", help="no overlap: finish each BAM (GPU + walk) before starting the next")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (diagnostic)")
+    ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
+    ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,11 +103,14 @@ def main():
 
     from trueconsense_amd import _ffi
     from trueconsense_amd import synthetic as sy
-    from trueconsense_amd.engine import Context, consensus_walk
+    from trueconsense_amd.engine import Pipeline, Walker
 
     ref, orfs = sy.make_reference()
     L = len(ref)
-    ctx = Context(local_rank)
+    n_walkers = a.walkers or max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
+    ctx = pipe.ctx
+    ctxs = [pipe.slot_context(k) for k in range(a.slots)]
     readsets, host_reads0 = [], None
     for b in range(a.bams):
         reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1)
@@ -113,15 +121,22 @@ def main():
             del reads
     alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
     alg_tally = alg_reads + 28 * L                              # + one write of the [L,7] int32 matrix
-    o_start = [o["start"] for o in orfs]
-    o_end = [o["end"] for o in orfs]
-    o_plus = [1] * len(orfs)
+    pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
 
-    def step(i):
-        plain, alt, flags, _ = ctx.step(readsets[i % len(readsets)], L, a.mincov, True, want_counts=False)
-        if a.gpu_only:
+    def run(n_steps):
+        """n_steps BAMs to consensus; returns the last consensus."""
+        if n_steps <= 0:
             return None
-        return consensus_walk(plain, alt, flags, o_start, o_end, o_plus, [], [], [], True)[0]
+        if a.serial or a.gpu_only:
+            cons = None
+            for i in range(n_steps):
+                plain, alt, flags, _ = ctx.step(readsets[i % len(readsets)], L, a.mincov, True, want_counts=False)
+                if not a.gpu_only:
+                    cons = walker(plain, alt, flags)[0]
+            return cons
+        out, _ = pipe.run([readsets[i % len(readsets)] for i in range(n_steps)], L, a.mincov, True, extra=64)
+        return out[-1]
 
     def fence():
         ctx.sync()
@@ -130,19 +145,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    ctx.profile(True)                                           # HIP events around every kernel, on ctx's stream
+    run(a.warmup)
+    for c in ([] if a.no_kernel_events else ctxs):
+        c.set_option("profile_every", a.profile_every)
+        c.profile(True)                                         # HIP events around every kernel, on the pipeline's stream
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        cons = step(i)
+    cons = run(a.steps)
     fence()
     dt = time.perf_counter() - t0
-    tally_ms, tally_n = ctx.profile_get(_ffi.K_TALLY)
-    call_ms, call_n = ctx.profile_get(_ffi.K_CALL)
-    zero_ms, _ = ctx.profile_get(_ffi.K_ZERO)
-    ctx.profile(False)
+    tally_ms = tally_n = call_ms = call_n = zero_ms = 0
+    for c in ctxs:
+        m, n = c.profile_get(_ffi.K_TALLY)
+        tally_ms, tally_n = tally_ms + m, tally_n + n
+        m, n = c.profile_get(_ffi.K_CALL)
+        call_ms, call_n = call_ms + m, call_n + n
+        zero_ms += c.profile_get(_ffi.K_ZERO)[0]
+        c.profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,14 +188,16 @@ def main():
                                    % (a.reads, a.reads * 150 // L, a.bams,
                                       "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
                        "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
-                       "step": "memset + tally kernel + call kernel + D2H records" + ("" if a.gpu_only else " + host consensus walk")},
+                       "step": "memset + tally kernel + call kernel + D2H records" + ("" if a.gpu_only else " + host consensus walk"),
+                       "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
+                                  "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},
             "kernels_us": {"tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
             "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_tally, "avg_launch_us": tally_us},
         }
         if not a.gpu_only:
-            out["consensus_len"] = len(cons)
+            out["consensus_len"] = len(cons) if cons is not None else 0
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_reads0, L, a.mincov, orfs)
             out["cpu_baseline"]["cores_on_box"] = os.cpu_count()

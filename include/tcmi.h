@@ -82,12 +82,19 @@ const char *tcmi_last_error(const tcmi_ctx *ctx);  /* ctx may be NULL: last erro
 int         tcmi_device_count(int *out_count);     /* 0 devices is not an error                  */
 
 int  tcmi_ctx_create(int device, tcmi_ctx **out);  /* fails with TCMI_E_NODEVICE without a GPU    */
+/* A context on a stream the caller owns (a hipStream_t, e.g. torch's current stream, or the
+ * stream of another tcmi_ctx: two contexts on one stream give two workspaces whose launches
+ * run back to back, so steps can be queued ahead without overlapping each other).            */
+int  tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out);
 int  tcmi_ctx_destroy(tcmi_ctx *ctx);
 int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
 void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
 /* tuning knobs, read at tcmi_readset_upload / launch: "tally_variant" (0 = aligned reads through
  * the fast kernel, 1 = every read through the CIGAR-walk kernel), "fast_nw" (grid words per lane
- * of the fast kernel: 2 or 4), "rounds_per_wg" (CIGAR-walk kernel, 0 = auto)                    */
+ * of the fast kernel: 2 or 4), "rounds_per_wg" (CIGAR-walk kernel, 0 = auto), "profile_every" (with
+ * profiling enabled, every n-th tcmi_step_begin is launched directly with its kernels bracketed by
+ * events, the others replay the graph unmeasured; default 1), "use_graph"
+ * (tcmi_step_begin replays the step as one hipGraph per read set; default 1)                    */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
@@ -154,6 +161,12 @@ int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, i
 int tcmi_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig,
               const uint8_t **plain, const uint8_t **alt, const uint8_t **flags,
               const int32_t **counts_planes /* host [7][ld] */, int64_t *ld);
+/* The same in two halves, so that the host walk of one BAM can overlap the GPU work of the next
+ * (two contexts, two streams): _begin only enqueues, _end waits for the context's stream.     */
+int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov,
+                    int include_ambig, int want_counts);
+int tcmi_step_end(tcmi_ctx *ctx, const uint8_t **plain, const uint8_t **alt, const uint8_t **flags,
+                  const int32_t **counts_planes, int64_t *ld);
 
 /* ---- stage B (sequential part, HOST): the consensus walk
  *      replaces the loop of Sequences.BuildConsensus (Sequences.py:179-322) with
@@ -190,6 +203,27 @@ int tcmi_modal_tokens(const tcmi_reads *reads, int32_t n_pos, const int64_t *pos
                       int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans,
                       int64_t max_depth, char *tokens, int64_t tokens_cap, int64_t *token_off,
                       int64_t *n_tokens, int32_t *depth_exceeded);
+
+/* ---- many BAMs: native batch runner (BASELINE.json configs[3]: independent BAMs, no collective).
+ * The calling thread queues step i+1 behind step i on one stream over `n_slots` workspaces while
+ * `n_walkers` host threads turn finished call records into consensus sequences
+ * (Events.ListInserts + Sequences.BuildConsensus(..., includeINS=True), the FASTA content).
+ *   readsets[i]   reads of BAM i resident in HBM (same device)
+ *   host_reads[i] the same reads on the host, needed only to resolve insert tokens
+ *                 (Events.py:47-82); the array or an entry may be NULL: an item that then has
+ *                 insert candidates fails with TCMI_E_UNSUPPORTED
+ *   out_cons      n_items * stride bytes, consensus i at out_cons + i*stride, length out_len[i];
+ *                 stride >= L + 1 + total inserted bases
+ *   status[i]     TCMI_OK or the error of item i (e.g. TCMI_E_KEYERROR where the reference raises) */
+typedef struct tcmi_pipeline tcmi_pipeline;
+int tcmi_pipeline_create(int device, int n_slots, int n_walkers, tcmi_pipeline **out);
+int tcmi_pipeline_destroy(tcmi_pipeline *p);
+int tcmi_pipeline_set_orfs(tcmi_pipeline *p, int32_t n_orf, const int64_t *start, const int64_t *end,
+                           const uint8_t *is_plus);
+tcmi_ctx *tcmi_pipeline_ctx(tcmi_pipeline *p, int slot);   /* slot contexts (upload reads with slot 0's) */
+int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets,
+                      const tcmi_reads *const *host_reads, int64_t L, int32_t mincov, int include_ambig,
+                      char *out_cons, int64_t stride, int64_t *out_len, int32_t *status);
 
 /* ---- BAM reader (pysam's role; SAM spec §4.2), HOST, zlib inflate -------- */
 typedef struct tcmi_bam tcmi_bam;

@@ -285,3 +285,39 @@ def test_cli_bam_to_outputs_matches_reference(ctx, tmp_path, monkeypatch):
             assert got == want
             n_done += 1
     assert n_done >= 20
+
+
+def test_self_cleaning_steps_and_pipeline(ctx):
+    """Steps that do not fetch the counts leave the matrix zeroed by the call kernel (no memset
+    between them); the native pipeline must give what the step-by-step path gives, inserts included."""
+    from trueconsense_amd.engine import Pipeline
+    ref, orfs = sy.make_reference(L=6000, cds=[(100, 2500), (2600, 5800)])
+    L = len(ref)
+    sites = [(500, "I", "ACG", 0.9), (1200, "D", 3, 0.95), (3000, "D", 1, 0.9), (4000, "I", "T", 0.6)]
+    sets = [sy.make_reads(ref, 30_000, seed=31, indel_sites=sites),
+            sy.make_reads(ref, 25_000, seed=32)]
+    pipe = Pipeline(0, slots=3, walkers=2)
+    pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    rss = [pipe.ctx.upload(r) for r in sets]
+    want = []
+    for reads, rs in zip(sets, rss):
+        # three steps on one workspace: no counts, no counts, counts -> the last must still be exact
+        pipe.ctx.step(rs, L, 30, True, want_counts=False)
+        p1, a1, f1, _ = pipe.ctx.step(rs, L, 30, True, want_counts=False)
+        p2, a2, f2, counts = pipe.ctx.step(rs, L, 30, True, want_counts=True)
+        assert np.array_equal(counts, c_oracle.tally(reads, L))
+        assert np.array_equal(p1, p2) and np.array_equal(f1, f2) and np.array_equal(a1, a2)
+        has, ins = Events.inserts_from_flags(f2, reads)
+        gff = {k: {"start": o["start"], "end": o["end"], "strand": "+"} for k, o in enumerate(orfs)}
+        want.append(Sequences.consensus_from_records(p2, a2, f2, gff, ins, True)[0])
+    assert "-" in want[0] and len(want[0]) > L                     # deletions and spliced inserts are present
+    order = [0, 1, 1, 0, 0, 1, 0]
+    out, status = pipe.run([rss[i] for i in order], L, 30, True, host_reads=[sets[i] for i in order])
+    assert not status.any()
+    assert [o.decode() for o in out] == [want[i] for i in order]
+    with pytest.raises(_ffi.TcmiError):                             # insert candidates but no host reads
+        pipe.run([rss[0]], L, 30, True)
+    assert pipe.last_status[0] == _ffi.E_UNSUPPORTED
+    out, _ = pipe.run([rss[1]], L, 30, True)                        # no candidates: fine without host reads
+    assert out[0].decode() == want[1]
+    pipe.close()

@@ -44,6 +44,7 @@ _SIGS = {
     "tcmi_last_error": (C.c_char_p, [_vp]),
     "tcmi_device_count": (_int, [_P(_int)]),
     "tcmi_ctx_create": (_int, [_int, _P(_vp)]),
+    "tcmi_ctx_create_on_stream": (_int, [_int, _vp, _P(_vp)]),
     "tcmi_ctx_destroy": (_int, [_vp]),
     "tcmi_ctx_sync": (_int, [_vp]),
     "tcmi_ctx_stream": (_vp, [_vp]),
@@ -63,9 +64,16 @@ _SIGS = {
     "tcmi_call_dev": (_int, [_vp, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp, _vp, _vp]),
     "tcmi_call": (_int, [_vp, _vp, _i64, _i32, _int, _vp, _vp, _vp, _vp, _P(_i64)]),
     "tcmi_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
+    "tcmi_step_begin": (_int, [_vp, _vp, _i64, _i32, _int, _int]),
+    "tcmi_step_end": (_int, [_vp, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_consensus_walk": (_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, C.c_char_p, _vp,
                                    _int, _vp, _i64, _P(_i64), _vp, _vp, _P(_i64)]),
     "tcmi_modal_tokens": (_int, [_P(Reads), _i32, _vp, _i32, _u32, _int, _i64, _vp, _i64, _vp, _vp, _P(_i32)]),
+    "tcmi_pipeline_create": (_int, [_int, _int, _int, _P(_vp)]),
+    "tcmi_pipeline_destroy": (_int, [_vp]),
+    "tcmi_pipeline_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "tcmi_pipeline_ctx": (_vp, [_vp, _int]),
+    "tcmi_pipeline_run": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _vp, _i64, _vp, _vp]),
     "tcmi_bam_load": (_int, [C.c_char_p, _int, _P(_vp)]),
     "tcmi_bam_free": (_int, [_vp]),
     "tcmi_bam_reads": (_int, [_vp, _P(Reads)]),

@@ -35,7 +35,19 @@ int tcmi_device_count(int *out_count)
     return TCMI_OK;
 }
 
-int tcmi_ctx_create(int device, tcmi_ctx **out)
+static int ctx_create(int device, void *stream, tcmi_ctx **out);
+
+int tcmi_ctx_create(int device, tcmi_ctx **out) { return ctx_create(device, nullptr, out); }
+
+int tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out)
+{
+    if (!stream) return tcmi_fail(nullptr, TCMI_E_ARG, "stream is NULL");
+    return ctx_create(device, stream, out);
+}
+
+} // extern "C"
+
+static int ctx_create(int device, void *stream, tcmi_ctx **out)
 {
     if (!out) return tcmi_fail(nullptr, TCMI_E_ARG, "out is NULL");
     *out = nullptr;
@@ -59,9 +71,17 @@ int tcmi_ctx_create(int device, tcmi_ctx **out)
                          device, prop.gcnArchName);
     tcmi_ctx *c = new tcmi_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return tcmi_fail(nullptr, TCMI_E_HIP, "hipStreamCreate failed");
+    }
+    if (hipEventCreateWithFlags(&c->step_done, hipEventDisableTiming) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return tcmi_fail(nullptr, TCMI_E_HIP, "hipEventCreate failed");
     }
     const char *v = std::getenv("TCMI_TALLY_VARIANT");
     if (v) c->tally_variant = std::atoi(v);
@@ -72,6 +92,10 @@ int tcmi_ctx_create(int device, tcmi_ctx **out)
     *out = c;
     return TCMI_OK;
 }
+
+extern "C" {
+
+void tcmi_drop_graphs(tcmi_ctx *ctx);
 
 static void free_ws(tcmi_ctx *c)
 {
@@ -94,7 +118,9 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     free_ws(c);
-    (void)hipStreamDestroy(c->stream);
+    tcmi_drop_graphs(c);
+    if (c->step_done) (void)hipEventDestroy(c->step_done);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TCMI_OK;
 }
@@ -113,6 +139,8 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     if (!c || !key) return tcmi_fail(c, TCMI_E_ARG, "null argument");
     if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
+    else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
+    else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "fast_nw")) {
         if (value != 2 && value != 4) return tcmi_fail(c, TCMI_E_ARG, "fast_nw must be 2 or 4");
         c->fast_nw = value;
@@ -172,9 +200,29 @@ static hipEvent_t get_event(tcmi_ctx *c)
     return e;
 }
 
+// recycle the events of launches that have finished, so a long profiled run does not keep
+// creating events (hipEventCreate is far more expensive than hipEventRecord)
+static void reap(tcmi_ctx *c)
+{
+    size_t done = 0;
+    while (done < c->pending.size() && hipEventQuery(c->pending[done].b) == hipSuccess) {
+        auto &p = c->pending[done];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->prof_ms[p.k] += ms; c->prof_n[p.k] += 1; }
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+        ++done;
+    }
+    (void)hipGetLastError();                                 // hipErrorNotReady from the query is expected
+    if (done) c->pending.erase(c->pending.begin(), c->pending.begin() + (long)done);
+}
+
 void tcmi_prof_begin(tcmi_ctx *c, int k)
 {
-    if (!c->prof) return;
+    c->prof_open = false;
+    if (!c->prof || c->prof_mute) return;
+    c->prof_open = true;
+    if (c->pending.size() >= 24) reap(c);
     tcmi_ctx::Pending p{k, get_event(c), get_event(c)};
     (void)hipEventRecord(p.a, c->stream);
     c->pending.push_back(p);
@@ -182,7 +230,8 @@ void tcmi_prof_begin(tcmi_ctx *c, int k)
 
 void tcmi_prof_end(tcmi_ctx *c, int k)
 {
-    if (!c->prof || c->pending.empty()) return;
+    if (!c->prof || !c->prof_open || c->pending.empty()) return;
+    c->prof_open = false;
     (void)k;
     (void)hipEventRecord(c->pending.back().b, c->stream);
 }
@@ -213,6 +262,8 @@ static int ensure_ws(tcmi_ctx *ctx, int64_t L)
 {
     if (ctx->ws_L >= L && ctx->d_counts) return TCMI_OK;
     free_ws(ctx);
+    tcmi_drop_graphs(ctx);                                   // they hold the old workspace pointers
+    ctx->counts_clean = false;
     int64_t ld = tcmi_round_up(L, 256);
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4));
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_plain, (size_t)ld * 3));
@@ -264,6 +315,7 @@ int tcmi_tally(tcmi_ctx *ctx, const tcmi_reads *reads, int64_t L, int32_t *count
                          (long long)L, (long long)rs->max_end);
     }
     rc = ensure_ws(ctx, L);
+    ctx->counts_clean = false;
     if (!rc) rc = tcmi_tally_dev(ctx, rs, L, ctx->ws_ld, ctx->d_counts, 1);
     if (!rc) rc = tcmi_counts_download(ctx, ctx->d_counts, L, ctx->ws_ld, counts);
     tcmi_readset_free(ctx, rs);
@@ -279,7 +331,7 @@ int tcmi_call_dev(tcmi_ctx *ctx, const void *d_counts, int64_t L, int64_t ld, in
     if ((d_events == nullptr) != (d_event_counts == nullptr))
         return tcmi_fail(ctx, TCMI_E_ARG, "d_events and d_event_counts must both be given or both NULL");
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
-    return tcmi_launch_call(ctx, (const int32_t *)d_counts, L, ld, mincov, include_ambig, (uint8_t *)d_plain,
+    return tcmi_launch_call(ctx, (int32_t *)const_cast<void *>(d_counts), L, ld, mincov, include_ambig, 0, (uint8_t *)d_plain,
                             (uint8_t *)d_alt, (uint8_t *)d_flags, (int32_t *)d_events, (int32_t *)d_event_counts);
 }
 
@@ -291,6 +343,7 @@ int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, i
     int rc = ensure_ws(ctx, L);
     if (rc) return rc;
     const int64_t ld = ctx->ws_ld;
+    ctx->counts_clean = false;
     rc = tcmi_counts_upload(ctx, counts, L, ld, ctx->d_counts);
     if (rc) return rc;
     int32_t *d_ev = nullptr, *d_evc = nullptr;
@@ -325,29 +378,126 @@ int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, i
     return rc;
 }
 
+// the launches of one step, on ctx->stream (directly, or while the stream is being captured)
+static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, int want_counts,
+                        bool memset_first, hipEvent_t ev_a, hipEvent_t ev_b)
+{
+    const int64_t ld = ctx->ws_ld;
+    if (memset_first) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
+    if (ev_a) TCMI_HIP(ctx, hipEventRecord(ev_a, ctx->stream));
+    int rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 0);
+    if (rc) return rc;
+    if (ev_b) TCMI_HIP(ctx, hipEventRecord(ev_b, ctx->stream));
+    // when the counts are not wanted on the host, the call kernel zeroes them behind itself and the
+    // next step into this workspace needs no memset
+    rc = tcmi_launch_call(ctx, ctx->d_counts, L, ld, mincov, include_ambig, want_counts ? 0 : 1, ctx->d_plain, ctx->d_alt,
+                          ctx->d_flags, nullptr, nullptr);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (want_counts)
+        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return TCMI_OK;
+}
+
+static void drop_graph(tcmi_ctx::StepGraph &g)
+{
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.ev_a) (void)hipEventDestroy(g.ev_a);
+    if (g.ev_b) (void)hipEventDestroy(g.ev_b);
+    g.exec = nullptr;
+    g.ev_a = g.ev_b = nullptr;
+}
+
+void tcmi_drop_graphs(tcmi_ctx *ctx)
+{
+    for (auto &g : ctx->graphs) drop_graph(g);
+    ctx->graphs.clear();
+}
+
+int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, int want_counts)
+{
+    if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || rs->max_end > L) return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld does not cover the reads (extent %lld)", (long long)L, (long long)rs->max_end);
+    if (rs->device != ctx->device) return tcmi_fail(ctx, TCMI_E_ARG, "read set lives on device %d, context on %d", rs->device, ctx->device);
+    int rc = ensure_ws(ctx, L);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    const bool memset_first = !ctx->counts_clean;
+    ctx->counts_clean = false;
+    ctx->step_graph = -1;
+    // with profiling on, every prof_every-th step goes out as direct launches bracketed by events
+    const bool sampled = ctx->prof && (ctx->step_tick++ % ctx->prof_every) == 0;
+    if (ctx->use_graph && !sampled) {
+        // The step is launch-bound (five launches for ~40 us of GPU work): replay it as one hipGraph.
+        // Graphs are kept per (read set, parameters).
+        int hit = -1;
+        for (size_t k = 0; k < ctx->graphs.size(); ++k) {
+            const auto &g = ctx->graphs[k];
+            if (g.rs_uid == rs->uid && g.L == L && g.mincov == mincov && g.amb == include_ambig && g.counts == want_counts &&
+                g.memset_first == memset_first) { hit = (int)k; break; }
+        }
+        if (hit < 0) {
+            if (ctx->graphs.size() >= 32) { drop_graph(ctx->graphs.front()); ctx->graphs.erase(ctx->graphs.begin()); }
+            tcmi_ctx::StepGraph g;
+            g.rs_uid = rs->uid; g.L = L; g.mincov = mincov; g.amb = include_ambig; g.counts = want_counts; g.memset_first = memset_first;
+            const bool prof = ctx->prof;
+            ctx->prof = false;                               // no pool events inside the capture
+            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+            hipGraph_t graph = nullptr;
+            if (e == hipSuccess) {
+                rc = enqueue_step(ctx, rs, L, mincov, include_ambig, want_counts, memset_first, nullptr, nullptr);
+                e = hipStreamEndCapture(ctx->stream, &graph);
+            }
+            ctx->prof = prof;
+            if (e == hipSuccess && !rc) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess || rc) {
+                drop_graph(g);
+                (void)hipGetLastError();
+                if (rc) return rc;
+                return tcmi_fail(ctx, TCMI_E_HIP, "hipGraph capture of the step failed: %s", hipGetErrorString(e));
+            }
+            ctx->graphs.push_back(g);
+            hit = (int)ctx->graphs.size() - 1;
+        }
+        TCMI_HIP(ctx, hipGraphLaunch(ctx->graphs[(size_t)hit].exec, ctx->stream));
+        ctx->step_graph = hit;
+    } else {
+        ctx->prof_mute = !sampled;
+        rc = enqueue_step(ctx, rs, L, mincov, include_ambig, want_counts, memset_first, nullptr, nullptr);
+        ctx->prof_mute = false;
+        if (rc) return rc;
+    }
+    ctx->counts_clean = !want_counts;
+    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->stream));
+    ctx->step_L = L;
+    ctx->step_counts = want_counts != 0;
+    return TCMI_OK;
+}
+
+int tcmi_step_end(tcmi_ctx *ctx, const uint8_t **plain, const uint8_t **alt, const uint8_t **flags,
+                  const int32_t **counts_planes, int64_t *ld_out)
+{
+    if (!ctx) return tcmi_fail(ctx, TCMI_E_ARG, "ctx is NULL");
+    if (ctx->step_L <= 0) return tcmi_fail(ctx, TCMI_E_ARG, "tcmi_step_end without tcmi_step_begin");
+    TCMI_HIP(ctx, hipEventSynchronize(ctx->step_done));      // only this step: the stream may be shared
+    const int64_t ld = ctx->ws_ld;
+    if (plain) *plain = ctx->h_rec;
+    if (alt) *alt = ctx->h_rec + ld;
+    if (flags) *flags = ctx->h_rec + 2 * ld;
+    if (counts_planes) *counts_planes = ctx->step_counts ? ctx->h_counts : nullptr;
+    if (ld_out) *ld_out = ld;
+    ctx->step_L = 0;
+    return TCMI_OK;
+}
+
 int tcmi_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig,
               const uint8_t **plain, const uint8_t **alt, const uint8_t **flags, const int32_t **counts_planes,
               int64_t *ld_out)
 {
-    if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
-    if (L <= 0 || rs->max_end > L) return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld does not cover the reads (extent %lld)", (long long)L, (long long)rs->max_end);
-    int rc = ensure_ws(ctx, L);
+    const int rc = tcmi_step_begin(ctx, rs, L, mincov, include_ambig, counts_planes != nullptr);
     if (rc) return rc;
-    const int64_t ld = ctx->ws_ld;
-    rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 1);
-    if (rc) return rc;
-    rc = tcmi_call_dev(ctx, ctx->d_counts, L, ld, mincov, include_ambig, ctx->d_plain, ctx->d_alt, ctx->d_flags, nullptr, nullptr);
-    if (rc) return rc;
-    TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream));
-    if (counts_planes)
-        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (plain) *plain = ctx->h_rec;
-    if (alt) *alt = ctx->h_rec + ld;
-    if (flags) *flags = ctx->h_rec + 2 * ld;
-    if (counts_planes) *counts_planes = ctx->h_counts;
-    if (ld_out) *ld_out = ld;
-    return TCMI_OK;
+    return tcmi_step_end(ctx, plain, alt, flags, counts_planes, ld_out);
 }
 
 } // extern "C"

@@ -34,8 +34,8 @@ __device__ inline char letter_of(unsigned rank)
     return (char)((0x5854474341ull >> (8u * rank)) & 0xFFu);
 }
 
-__global__ __launch_bounds__(BLOCK) void call_kernel(const int32_t *__restrict__ counts, int64_t L, int64_t ld,
-                                                      int32_t mincov, int include_ambig, uint8_t *__restrict__ plain,
+__global__ __launch_bounds__(BLOCK) void call_kernel(int32_t *__restrict__ counts, int64_t L, int64_t ld,
+                                                      int32_t mincov, int include_ambig, int clean, uint8_t *__restrict__ plain,
                                                       uint8_t *__restrict__ alt, uint8_t *__restrict__ flags,
                                                       int32_t *__restrict__ events, int32_t *__restrict__ event_counts)
 {
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(BLOCK) void call_kernel(const int32_t *__restrict__
         const int64_t nA = counts[(int64_t)TCMI_A * ld + p], nT = counts[(int64_t)TCMI_T * ld + p];
         const int64_t nC = counts[(int64_t)TCMI_C * ld + p], nG = counts[(int64_t)TCMI_G * ld + p];
         const int64_t nX = counts[(int64_t)TCMI_X * ld + p], nI = counts[(int64_t)TCMI_I * ld + p];
+        if (clean) {    // leave the matrix zeroed for the next tally into this workspace (saves a memset launch)
+#pragma unroll
+            for (int c = 0; c < TCMI_NCOL; ++c) counts[(int64_t)c * ld + p] = 0;
+        }
         // key = count*8 + letter rank (A<C<G<T<X): Python's sort of (count, letter) tuples
         int64_t k0 = nA * 8 + 0, k1 = nC * 8 + 1, k2 = nG * 8 + 2, k3 = nT * 8 + 3, k4 = nX * 8 + 4;
         // 9-comparator sorting network for 5 keys, descending
@@ -103,13 +107,13 @@ __global__ __launch_bounds__(BLOCK) void call_kernel(const int32_t *__restrict__
 
 } // namespace
 
-int tcmi_launch_call(tcmi_ctx *ctx, const int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov, int include_ambig,
+int tcmi_launch_call(tcmi_ctx *ctx, int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov, int include_ambig, int clean,
                      uint8_t *d_plain, uint8_t *d_alt, uint8_t *d_flags, int32_t *d_events, int32_t *d_event_counts)
 {
     const int64_t grid = (L + BLOCK - 1) / BLOCK;
     tcmi_prof_begin(ctx, TCMI_K_CALL);
     hipLaunchKernelGGL(call_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream, d_counts, L, ld, mincov,
-                       include_ambig, d_plain, d_alt, d_flags, d_events, d_event_counts);
+                       include_ambig, clean, d_plain, d_alt, d_flags, d_events, d_event_counts);
     tcmi_prof_end(ctx, TCMI_K_CALL);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;

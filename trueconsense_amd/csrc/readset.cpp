@@ -1,6 +1,7 @@
 // readset.cpp — HOST: selects the reads that pile up, splits them into the
 // ALIGNED and GENERAL device sets (layout: tcmi_internal.h) and copies them into HBM.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 
 #include "tcmi_internal.h"
@@ -275,7 +276,9 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     h_rc[(size_t)n_rounds] = co;
     h_rs[(size_t)n_rounds] = so;
 
+    static std::atomic<uint64_t> next_uid{1};
     tcmi_readset *rs = new tcmi_readset();
+    rs->uid = next_uid.fetch_add(1);
     rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
     rs->f_other = (int64_t)f_other.size(); rs->f_nw = NW;

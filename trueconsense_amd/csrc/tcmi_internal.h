@@ -50,6 +50,7 @@ struct tcmi_fast_chunk {           // 96 bytes
 };
 
 struct tcmi_readset {
+    uint64_t uid = 0;           // unique per upload (graphs are cached against it, not the pointer)
     int64_t n_reads = 0;        // as handed in
     int64_t n_piled = 0;        // kept on device (aligned + general)
     int64_t alg_bytes = 0;      // sum over kept reads of 12 + 4*n_cigar + ceil(l_qseq/2)
@@ -78,6 +79,8 @@ struct tcmi_readset {
 struct tcmi_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin
     std::string err;
     // profiling
     bool prof = false;
@@ -93,6 +96,20 @@ struct tcmi_ctx {
     uint8_t *d_plain = nullptr, *d_alt = nullptr, *d_flags = nullptr;
     uint8_t *h_rec = nullptr;       // pinned: plain | alt | flags, each ws_ld bytes
     int32_t *h_counts = nullptr;    // pinned [7][ws_ld]
+    int64_t step_L = 0;             // > 0 between tcmi_step_begin and tcmi_step_end
+    bool step_counts = false;
+    bool counts_clean = false;      // the workspace matrix was left zeroed by the last call kernel
+    // hipGraph replay of whole steps (tcmi_step_begin)
+    struct StepGraph {
+        uint64_t rs_uid = 0; int64_t L = 0; int32_t mincov = 0; int amb = 0, counts = 0; bool memset_first = false;
+        hipGraphExec_t exec = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    };
+    std::vector<StepGraph> graphs;
+    bool use_graph = true;
+    int step_graph = -1;            // graph used by the step in flight, -1 = direct launches
+    int prof_every = 1;             // tcmi_step_begin: every n-th step is launched directly and bracketed with events
+    int64_t step_tick = 0;
+    bool prof_open = false, prof_mute = false;
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int fast_nw = 2;                // grid words per lane in the fast kernel: 2 or 4
@@ -114,8 +131,8 @@ void tcmi_prof_end(tcmi_ctx *ctx, int k);
 // kernels (tally.hip / call.hip)
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
-int tcmi_launch_call(tcmi_ctx *ctx, const int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov,
-                     int include_ambig, uint8_t *d_plain, uint8_t *d_alt, uint8_t *d_flags,
+int tcmi_launch_call(tcmi_ctx *ctx, int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov,
+                     int include_ambig, int clean, uint8_t *d_plain, uint8_t *d_alt, uint8_t *d_flags,
                      int32_t *d_events, int32_t *d_event_counts);
 
 static inline int64_t tcmi_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

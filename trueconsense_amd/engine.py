@@ -39,9 +39,13 @@ class ReadSet:
 class Context:
     """One device + stream.  Raises TcmiError(E_NODEVICE) when no gfx950 GPU is usable."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: a hipStream_t (int / c_void_p) to run on, e.g. another Context's `.stream`."""
         h = C.c_void_p()
-        check(lib().tcmi_ctx_create(int(device), C.byref(h)))
+        if stream is None:
+            check(lib().tcmi_ctx_create(int(device), C.byref(h)))
+        else:
+            check(lib().tcmi_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h)))
         self.handle = h
         self.device = device
 
@@ -116,21 +120,31 @@ class Context:
 
     # ---- whole resident step: zero + tally + call + records to pinned host memory
     def step(self, readset, L, mincov, include_ambig, want_counts=True):
+        self.step_begin(readset, L, mincov, include_ambig, want_counts)
+        return self.step_end()
+
+    def step_begin(self, readset, L, mincov, include_ambig, want_counts=True):
+        """Enqueue the step on this context's stream and return at once."""
+        check(lib().tcmi_step_begin(self.handle, readset.handle, int(L), int(mincov), int(bool(include_ambig)),
+                                    int(bool(want_counts))), self.handle)
+        self._step = (int(L), bool(want_counts))
+
+    def step_end(self):
+        """Wait for the stream; -> (plain, alt, flags, counts or None) as fresh numpy arrays."""
+        L, want_counts = self._step
         p, a, f, c = (C.c_void_p() for _ in range(4))
         ld = C.c_int64(0)
-        check(lib().tcmi_step(self.handle, readset.handle, int(L), int(mincov), int(bool(include_ambig)),
-                              C.byref(p), C.byref(a), C.byref(f), C.byref(c) if want_counts else None,
-                              C.byref(ld)), self.handle)
+        check(lib().tcmi_step_end(self.handle, C.byref(p), C.byref(a), C.byref(f), C.byref(c), C.byref(ld)),
+              self.handle)
 
-        def view(vp, dt, n):
-            return np.ctypeslib.as_array(C.cast(vp, C.POINTER(dt)), shape=(n,))
-        L = int(L)
-        plain = view(p, C.c_uint8, L).copy()
-        alt = view(a, C.c_uint8, L).copy()
-        flags = view(f, C.c_uint8, L).copy()
+        def grab(vp, dt, n):
+            out = np.empty(n, dt)
+            C.memmove(out.ctypes.data, vp, out.nbytes)
+            return out
+        plain, alt, flags = grab(p, np.uint8, L), grab(a, np.uint8, L), grab(f, np.uint8, L)
         counts = None
         if want_counts:
-            planes = view(c, C.c_int32, 7 * ld.value).reshape(7, ld.value)
+            planes = grab(c, np.int32, 7 * ld.value).reshape(7, ld.value)
             counts = np.ascontiguousarray(planes[:, :L].T)
         return plain, alt, flags, counts
 
@@ -175,6 +189,94 @@ def consensus_walk(plain, alt, flags, orf_start, orf_end, orf_is_plus, ins_pos, 
         raise ZeroDivisionError("division by zero")
     check(rc)
     return out.raw[:n_out.value].decode("ascii"), ns, ne
+
+
+class Pipeline:
+    """Native batch runner (tcmi_pipeline): many resident BAMs -> consensus sequences, GPU steps
+    queued ahead on one stream, walks on `walkers` host threads."""
+
+    def __init__(self, device=0, slots=4, walkers=4):
+        h = C.c_void_p()
+        check(lib().tcmi_pipeline_create(int(device), int(slots), int(walkers), C.byref(h)))
+        self.handle, self.slots = h, int(slots)
+        self.ctx = Context.__new__(Context)            # slot 0's context, owned by the pipeline
+        self.ctx.handle, self.ctx.device = C.c_void_p(lib().tcmi_pipeline_ctx(h, 0)), device
+        self.ctx.close = lambda: None
+
+    def slot_context(self, k):
+        c = Context.__new__(Context)
+        c.handle, c.device = C.c_void_p(lib().tcmi_pipeline_ctx(self.handle, k)), self.ctx.device
+        c.close = lambda: None
+        return c
+
+    def set_orfs(self, start, end, is_plus):
+        s_, e_ = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(end, np.int64)
+        p_ = np.ascontiguousarray(is_plus, np.uint8)
+        check(lib().tcmi_pipeline_set_orfs(self.handle, len(s_), ptr(s_), ptr(e_), ptr(p_)))
+
+    def run(self, readsets, L, mincov, include_ambig, host_reads=None, extra=4096):
+        """-> (list of consensus bytes, int32 status array).  Raises on the first failed item."""
+        n = len(readsets)
+        rs = (C.c_void_p * n)(*[r.handle for r in readsets])
+        keep, hr = [], None
+        if host_reads is not None:
+            structs = []
+            for r in host_reads:
+                st, k = r.as_struct() if isinstance(r, BamFile) else _ffi.as_reads(r)
+                structs.append(st)
+                keep.append(k)
+            hr = (C.POINTER(_ffi.Reads) * n)(*[C.pointer(s) for s in structs])
+            keep.append(structs)
+        stride = int(L) + 1 + int(extra)
+        out = np.empty(n * stride, np.uint8)
+        lens = np.zeros(n, np.int64)
+        status = np.zeros(n, np.int32)
+        rc = lib().tcmi_pipeline_run(self.handle, n, rs, hr, int(L), int(mincov), int(bool(include_ambig)), ptr(out),
+                                     stride, ptr(lens), ptr(status))
+        self.last_status = status
+        check(rc)
+        return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(n)], status
+
+    def close(self):
+        if self.handle:
+            lib().tcmi_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Walker:
+    """consensus_walk with the GFF rows fixed and no inserts: the arrays are converted once, so a
+    call is one ctypes crossing (the GIL is released meanwhile: walks of different BAMs can run
+    on several host threads)."""
+
+    def __init__(self, orf_start, orf_end, orf_is_plus, include_ins=True):
+        self.os = np.ascontiguousarray(orf_start, np.int64)
+        self.oe = np.ascontiguousarray(orf_end, np.int64)
+        self.op = np.ascontiguousarray(orf_is_plus, np.uint8)
+        self.off = np.zeros(1, np.int64)
+        self.include_ins = int(bool(include_ins))
+        self._fn = lib().tcmi_consensus_walk
+
+    def __call__(self, plain, alt, flags):
+        L = len(plain)
+        out = C.create_string_buffer(L + 1)
+        n_out, err = C.c_int64(0), C.c_int64(0)
+        n = len(self.os)
+        ns, ne = np.empty(n, np.int64), np.empty(n, np.int64)
+        rc = self._fn(ptr(plain), ptr(alt), ptr(flags), L, n, ptr(self.os), ptr(self.oe), ptr(self.op),
+                      0, None, None, b"", ptr(self.off), self.include_ins, C.cast(out, C.c_void_p), L + 1,
+                      C.byref(n_out), ptr(ns), ptr(ne), C.byref(err))
+        if rc == _ffi.E_KEYERROR:
+            raise WalkKeyError(err.value)
+        if rc == _ffi.E_ZERODIV:
+            raise ZeroDivisionError("division by zero")
+        check(rc)
+        return out.raw[:n_out.value], ns, ne
 
 
 # pysam's defaults for AlignmentFile.pileup() (Events.py:66 passes none): SURVEY §8-Q8

@@ -82,7 +82,8 @@ const char *tcmi_last_error(const tcmi_ctx *ctx);  /* ctx may be NULL: last erro
 int         tcmi_device_count(int *out_count);     /* 0 devices is not an error                  */
 
 int  tcmi_ctx_create(int device, tcmi_ctx **out);  /* fails with TCMI_E_NODEVICE without a GPU    */
-/* A context on a stream the caller owns (a hipStream_t, e.g. torch's current stream, or the
+/* A context on a stream the caller owns (a hipStream_t; NULL = the default stream; e.g. torch's
+ * current stream, or the
  * stream of another tcmi_ctx: two contexts on one stream give two workspaces whose launches
  * run back to back, so steps can be queued ahead without overlapping each other).            */
 int  tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out);

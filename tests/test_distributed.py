@@ -1,0 +1,98 @@
+"""The N > 1 paths: shard bookkeeping, and the one-BAM-split all-reduce over a real process
+group (gloo, world_size 2, 127.0.0.1).  On CPU the per-shard tally is the oracle's; the gpu-marked
+test runs the HIP tally in both ranks on one MI355X and still reduces through gloo (RCCL needs one
+GPU per rank; the driver's 8-GPU run covers that)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, use_gpu, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    from oracle import c_oracle
+    from trueconsense_amd import distributed as td
+    from trueconsense_amd import synthetic as sy
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _work(rank, world, use_gpu, q, td, sy, c_oracle)
+    except Exception as e:                                   # make a failing rank visible to the parent
+        q.put((rank, False, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _work(rank, world, use_gpu, q, td, sy, c_oracle):
+    if True:
+        ref, orfs = sy.make_reference(L=4000, cds=[(100, 3000)])
+        reads = sy.make_reads(ref, 9001, seed=77, indel_sites=[(800, "D", 2, 0.5), (1500, "I", "AC", 0.7)])
+        L = len(ref)
+        fn = None if use_gpu else (lambda shard, L_: c_oracle.tally(shard, L_))
+        got = td.tally_split_bam(reads, L, rank, world, device=0, tally_fn=fn)
+        want = c_oracle.tally(reads, L)
+        q.put((rank, bool(np.array_equal(got, want)), int(got[:, 0].sum())))
+
+
+def _run(world, use_gpu):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_gpu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert len({r[2] for r in res}) == 1
+
+
+def test_shard_bookkeeping():
+    from trueconsense_amd import distributed as td
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [td.read_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[k][1] == edges[k + 1][0] for k in range(world - 1))
+            assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
+    assert td.shard_items(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((td.shard_items(512, r, 8) for r in range(8)), [])) == list(range(512))
+
+
+def test_shards_partition_the_reads():
+    from tests import synth_small as ss
+    from trueconsense_amd import distributed as td
+    from oracle import c_oracle
+    import json
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "outputs.json")))[3]
+    reads = ss.reads_from_spec(case["spec"])
+    L = len(case["counts"])
+    for world in (2, 3, 5):
+        parts = [c_oracle.tally(td.shard_reads(reads, r, world), L) for r in range(world)]
+        assert np.array_equal(sum(parts), np.array(case["counts"]))
+
+
+def test_split_bam_allreduce_gloo_world2():
+    _run(2, use_gpu=False)
+
+
+@pytest.mark.gpu
+def test_split_bam_allreduce_gpu_tally_gloo_world2():
+    _run(2, use_gpu=True)

@@ -35,19 +35,16 @@ int tcmi_device_count(int *out_count)
     return TCMI_OK;
 }
 
-static int ctx_create(int device, void *stream, tcmi_ctx **out);
+static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out);
 
-int tcmi_ctx_create(int device, tcmi_ctx **out) { return ctx_create(device, nullptr, out); }
+int tcmi_ctx_create(int device, tcmi_ctx **out) { return ctx_create(device, true, nullptr, out); }
 
-int tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out)
-{
-    if (!stream) return tcmi_fail(nullptr, TCMI_E_ARG, "stream is NULL");
-    return ctx_create(device, stream, out);
-}
+// stream may be NULL: the device's default (null) stream, e.g. torch's default current stream
+int tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out) { return ctx_create(device, false, stream, out); }
 
 } // extern "C"
 
-static int ctx_create(int device, void *stream, tcmi_ctx **out)
+static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
 {
     if (!out) return tcmi_fail(nullptr, TCMI_E_ARG, "out is NULL");
     *out = nullptr;
@@ -71,7 +68,7 @@ static int ctx_create(int device, void *stream, tcmi_ctx **out)
                          device, prop.gcnArchName);
     tcmi_ctx *c = new tcmi_ctx();
     c->device = device;
-    if (stream) {
+    if (!own) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -1,0 +1,91 @@
+"""One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+Two shard shapes (BASELINE.json configs[3] and [4]):
+
+* many BAMs  — independent objects: rank r takes BAMs r, r+world, ...; NO data-path collective.
+* one BAM    — the tally is a commutative integer sum: the coordinate-sorted reads are cut into
+               `world` contiguous ranges, every rank tallies its range into a full-length
+               int32 [7][ld] matrix in HBM and ONE all-reduce (sum) of that matrix (837 284 B at
+               L = 29 903) makes it whole on every rank; base calling then runs on one GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+
+def shard_items(n_items, rank, world):
+    """Indices of the independent BAMs rank `rank` processes (round-robin)."""
+    return list(range(rank, n_items, world))
+
+
+def read_range(n_reads, rank, world):
+    """Contiguous read range [a, b) of rank `rank`; ranges partition [0, n_reads)."""
+    base, rem = divmod(int(n_reads), int(world))
+    a = rank * base + min(rank, rem)
+    return a, a + base + (1 if rank < rem else 0)
+
+
+def shard_reads(reads, rank, world):
+    """The rank's contiguous slice of a dict of flat read arrays (tcmi_reads layout); a read that
+    straddles a boundary simply belongs to one range."""
+    n = int(reads["n_reads"])
+    a, b = read_range(n, rank, world)
+    co, so = np.asarray(reads["cigar_off"]), np.asarray(reads["seq_off"])
+    out = {"n_reads": b - a, "pos": reads["pos"][a:b], "flag": reads["flag"][a:b], "l_qseq": reads["l_qseq"][a:b],
+           "cigar_off": (co[a:b + 1] - co[a]).astype(np.uint64), "cigar": reads["cigar"][int(co[a]):int(co[b])],
+           "seq_off": (so[a:b + 1] - so[a]).astype(np.uint64), "seq": reads["seq"][int(so[a]):int(so[b])]}
+    if reads.get("tid") is not None:
+        out["tid"] = reads["tid"][a:b]
+    if reads.get("qual") is not None:
+        lq = np.asarray(reads["l_qseq"], np.int64)
+        q0 = int(lq[:a].sum())
+        out["qual"] = reads["qual"][q0:q0 + int(lq[a:b].sum())]
+    return out
+
+
+def allreduce_counts(t, group=None):
+    """In-place sum of the [7][ld] int32 matrix over the ranks.  A CUDA tensor goes through the
+    process group's own backend (RCCL when it is "nccl"); under gloo it is staged through the host."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def tally_split_bam(reads, L, rank, world, device=0, group=None, tally_fn=None):
+    """BASELINE configs[4]: one BAM over `world` ranks -> the whole int32 [L,7] matrix on every rank.
+
+    tally_fn(shard, L) -> int [L,7] replaces the GPU tally (tests on CPU-only boxes pass the
+    oracle's; the product path leaves it None and needs an MI355X)."""
+    import torch
+    shard = shard_reads(reads, rank, world)
+    L = int(L)
+    if tally_fn is not None:
+        part = torch.from_numpy(np.ascontiguousarray(np.asarray(tally_fn(shard, L)).T.astype(np.int32)))   # [7][L]
+        allreduce_counts(part, group)
+        return np.ascontiguousarray(part.numpy().T)
+    from .engine import Context
+    ld = (L + 255) // 256 * 256
+    torch.cuda.set_device(device)
+    t = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream                 # tally and collective on torch's stream
+    ctx = Context(device, stream=stream)
+    rs = ctx.upload(shard)
+    check(lib().tcmi_tally_dev(ctx.handle, rs.handle, L, ld, C.c_void_p(t.data_ptr()), 0), ctx.handle)
+    allreduce_counts(t, group)
+    counts = np.ascontiguousarray(t[:, :L].T.cpu().numpy())
+    rs.free()
+    ctx.close()
+    return counts

@@ -40,7 +40,8 @@ class Context:
     """One device + stream.  Raises TcmiError(E_NODEVICE) when no gfx950 GPU is usable."""
 
     def __init__(self, device=0, stream=None):
-        """stream: a hipStream_t (int / c_void_p) to run on, e.g. another Context's `.stream`."""
+        """stream: a hipStream_t as an int (0 = the default stream) to run on, e.g. another Context's
+        `.stream` or torch.cuda.current_stream().cuda_stream; None = a stream of its own."""
         h = C.c_void_p()
         if stream is None:
             check(lib().tcmi_ctx_create(int(device), C.byref(h)))

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="no overlap: finish each BAM (GPU + walk) before starting the next")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (diagnostic)")
     ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
+    ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
     ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
@@ -111,13 +112,15 @@ def main():
     pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
     ctx = pipe.ctx
     ctxs = [pipe.slot_context(k) for k in range(a.slots)]
-    readsets, host_reads0 = [], None
+    readsets, host_reads0, all_reads = [], None, []
     for b in range(a.bams):
-        reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1)
+        reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1,
+                              indel_sites=sy.default_indel_sites(orfs) if a.indels else None)
+        all_reads.append(reads if a.indels else None)
         if b == 0:
             host_reads0 = reads
         readsets.append(ctx.upload(reads))
-        if b:
+        if b and not a.indels:
             del reads
     alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
     alg_tally = alg_reads + 28 * L                              # + one write of the [L,7] int32 matrix
@@ -135,7 +138,8 @@ def main():
                 if not a.gpu_only:
                     cons = walker(plain, alt, flags)[0]
             return cons
-        out, _ = pipe.run([readsets[i % len(readsets)] for i in range(n_steps)], L, a.mincov, True, extra=64)
+        out, _ = pipe.run([readsets[i % len(readsets)] for i in range(n_steps)], L, a.mincov, True,
+                          host_reads=[all_reads[i % len(readsets)] for i in range(n_steps)] if a.indels else None, extra=4096)
         return out[-1]
 
     def fence():
@@ -154,13 +158,15 @@ def main():
     cons = run(a.steps)
     fence()
     dt = time.perf_counter() - t0
-    tally_ms = tally_n = call_ms = call_n = zero_ms = 0
+    tally_ms = tally_n = call_ms = call_n = zero_ms = gen_ms = gen_n = 0
     for c in ctxs:
         m, n = c.profile_get(_ffi.K_TALLY)
         tally_ms, tally_n = tally_ms + m, tally_n + n
         m, n = c.profile_get(_ffi.K_CALL)
         call_ms, call_n = call_ms + m, call_n + n
         zero_ms += c.profile_get(_ffi.K_ZERO)[0]
+        m, n = c.profile_get(_ffi.K_TALLY_GENERAL)
+        gen_ms, gen_n = gen_ms + m, gen_n + n
         c.profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -191,7 +197,7 @@ def main():
                        "step": "memset + tally kernel + call kernel + D2H records" + ("" if a.gpu_only else " + host consensus walk"),
                        "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
                                   "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},
-            "kernels_us": {"tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
+            "kernels_us": {"tally_general": 1e3 * gen_ms / max(1, gen_n), "tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
             "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_tally, "avg_launch_us": tally_us},

@@ -109,18 +109,22 @@ def test_both_tally_kernels_agree(ctx):
     L = len(ref)
     want = c_oracle.tally(reads, L)
     want_x = c_oracle.tally(extra, L)
-    for variant in (0, 1):
+    for variant, project in ((0, 1), (0, 0), (1, 1)):
         ctx.set_option("tally_variant", variant)
+        ctx.set_option("project_reads", project)
         rs = ctx.upload(reads)
         a, c, g = (C2.c_int64(0) for _ in range(3))
         _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
-        if variant == 0:
-            assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 1024
-        else:
+        if variant == 1:
             assert a.value == 0 and g.value == rs.n_piled
+        elif project:
+            assert g.value == 0 and a.value == rs.n_piled        # indel reads are projected onto the reference
+        else:
+            assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 1024
         rs.free()
-        assert np.array_equal(ctx.tally(reads, L=L), want), variant
-        assert np.array_equal(ctx.tally(extra, L=L), want_x), variant
+        assert np.array_equal(ctx.tally(reads, L=L), want), (variant, project)
+        assert np.array_equal(ctx.tally(extra, L=L), want_x), (variant, project)
+    ctx.set_option("project_reads", 1)
     ctx.set_option("tally_variant", 0)
     rs = ctx.upload(extra)
     a, c, g = (C2.c_int64(0) for _ in range(3))

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtcmi.so")
+LIB_PATH = os.environ.get("TCMI_LIB") or os.path.join(_HERE, "lib", "libtcmi.so")   # TCMI_LIB: A/B builds
 
 TCMI_OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_FORMAT, E_IO, E_KEYERROR, E_ZERODIV, E_UNSUPPORTED = range(-1, -10, -1)

@@ -136,6 +136,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     if (!c || !key) return tcmi_fail(c, TCMI_E_ARG, "null argument");
     if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
+    else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "fast_nw")) {

@@ -37,6 +37,29 @@ int check_reads(tcmi_ctx *ctx, const tcmi_reads *r)
     return TCMI_OK;
 }
 
+// htslib resolve_cigar2's peek at the last reference base of op k: is an insertion reported there?
+bool ins_after(const uint32_t *cg, int64_t n, int64_t k)
+{
+    if (k + 1 >= n) return false;
+    const unsigned op2 = cg[k + 1] & 0xF;
+    int64_t tot = 0;
+    if (op2 == 1) {
+        tot = cg[k + 1] >> 4;
+        for (int64_t j = k + 2; j < n; ++j) {
+            const unsigned o = cg[j] & 0xF;
+            if (o == 1) tot += cg[j] >> 4;
+            else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        for (int64_t j = k + 2; j < n; ++j) {
+            const unsigned o = cg[j] & 0xF;
+            if (o == 1) tot += cg[j] >> 4;
+            else if (consumes_ref(o)) break;
+        }
+    }
+    return tot > 0;
+}
+
 // [H]*[S]* (M|=|X)+ [S]*[H]*  ->  query offset of the first aligned base, aligned length
 bool aligned_shape(const uint32_t *cg, int64_t n, int64_t *y0, int64_t *len)
 {
@@ -104,7 +127,7 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fother, rs->d_fchunk, rs->d_pos, rs->d_meta,
+    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -122,7 +145,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     const bool use_fast = ctx->tally_variant != 1;
 
     // pass 1: select, classify, size
-    struct Sel { int64_t i, y0, len; };
+    struct Sel { int64_t i, y0, len; bool projected; };
     std::vector<Sel> fsel;                  // aligned set (len > 0)
     std::vector<int64_t> gsel;              // general set
     int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
@@ -143,14 +166,17 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
         alg += 12 + 4 * nc + (lq + 1) / 2;
         if (r->pos[i] + span > max_end) max_end = r->pos[i] + span;
         int64_t y0, len;
-        if (use_fast && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({i, y0, len});
+        if (use_fast && r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({i, y0, len, false});
+        else if (use_fast && ctx->project_reads && span <= TCMI_F_MAXSPAN && r->pos[i] + span < TCMI_F_EVPOS)
+            fsel.push_back({i, 0, span, true});               // any CIGAR, projected onto the reference
         else { gsel.push_back(i); g_cig += nc; g_seqw += (lq + 7) / 8; }
     }
 
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
-    const int NW = ctx->fast_nw == 4 ? 4 : 2, PAD = NW + 1;
-    std::vector<int32_t> f_pos((size_t)nf), f_other;
+    const int NW = (ctx->fast_nw == 4 && TCMI_F_BLOCK == 256) ? 4 : 2, PAD = NW + 1;
+    std::vector<int32_t> f_pos((size_t)nf);
+    std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);
     std::vector<tcmi_fast_chunk> chunks;
     std::vector<uint32_t> f_seq;
@@ -161,7 +187,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
         // stage over S = 256 / ceil(words / NW) depth slices and runs ceil(stage / S) inner-loop bodies per
         // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
-            const int64_t S = 256 / ((words + NW - 1) / NW);
+            const int64_t S = TCMI_F_BLOCK / ((words + NW - 1) / NW);
             const int64_t cap = std::min<int64_t>(TCMI_F_SUB, (TCMI_F_SEQCAP - 16 - PAD) / (maxnw + PAD));
             int64_t sub = S * 12 * std::max<int64_t>(1, cap / (S * 12));
             if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);            // window too wide for 12 per slice
@@ -214,7 +240,37 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                 f_seq.resize(base + (size_t)(nw + PAD), 0);
                 uint8_t *dst = reinterpret_cast<uint8_t *>(&f_seq[base]);
                 const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
-                if ((s.y0 & 1) == 0) {
+                if (s.projected) {
+                    // Walk the CIGAR once: matched bases land on their reference offset, D / N leave zero
+                    // nibbles (coverage only), and the tokens that are not plain bases become events
+                    // (SURVEY §8-P6): X for a deleted base whose token is exactly "*", I on the last
+                    // reference base before an insertion (also "*+..": I but not X).
+                    const uint32_t *cg = r->cigar + r->cigar_off[s.i];
+                    const int64_t nc = (int64_t)(r->cigar_off[s.i + 1] - r->cigar_off[s.i]);
+                    int64_t x = 0, y = 0;
+                    for (int64_t k = 0; k < nc; ++k) {
+                        const unsigned op = cg[k] & 0xF;
+                        const int64_t len = cg[k] >> 4;
+                        if (consumes_ref(op)) {
+                            const bool ins = len > 0 && ins_after(cg, nc, k);
+                            if (is_match(op)) {
+                                for (int64_t t = 0; t < len; ++t) {
+                                    const int64_t q = y + t;
+                                    if (q >= lq) break;
+                                    const unsigned code = (q & 1) ? (src[q >> 1] & 15u) : (src[q >> 1] >> 4);
+                                    const unsigned oh = (code == 1 || code == 2 || code == 4 || code == 8) ? code : 0;
+                                    dst[(x + t) >> 1] |= (uint8_t)(oh << (((x + t) & 1) * 4));
+                                }
+                            } else if (op == 2) {
+                                for (int64_t t = 0; t < (ins ? len - 1 : len); ++t)
+                                    f_event.push_back((uint32_t)(r->pos[s.i] + x + t) | TCMI_F_EV_X);
+                            }
+                            if (ins) f_event.push_back((uint32_t)(r->pos[s.i] + x + len - 1) | TCMI_F_EV_I);
+                            x += len;
+                        }
+                        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
+                    }
+                } else if ((s.y0 & 1) == 0) {
                     const uint8_t *b = src + (s.y0 >> 1);
                     const int64_t full = have >> 1;
                     for (int64_t k = 0; k < full; ++k) dst[k] = kSwap.t[b[k]];
@@ -237,7 +293,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                     uint32_t miss = want & ~nz;
                     while (miss) {
                         const int bit = __builtin_ctz(miss);
-                        f_other.push_back((int32_t)(r->pos[s.i] + 8 * k + bit / 4));
+                        f_event.push_back((uint32_t)(r->pos[s.i] + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
                         miss &= miss - 1;
                     }
                 }
@@ -281,13 +337,13 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     rs->uid = next_uid.fetch_add(1);
     rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
-    rs->f_other = (int64_t)f_other.size(); rs->f_nw = NW;
+    rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
     Up up{ctx, rs};
     if (nf) {
         rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
         if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
-        if (!rc && !f_other.empty()) rc = up((void **)&rs->d_fother, f_other.data(), f_other.size() * 4);
+        if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fseq, f_seq.data(), f_seq.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
     }

@@ -7,9 +7,9 @@
 // The genome is cut in GRID WORDS of 8 positions; a CHUNK of <= 1024 coordinate-sorted reads
 // touches a window of Wn <= 96 grid words (24 at 5000x coverage with 150-bp reads).
 //
-// One workgroup (256 lanes) per chunk:
+// One workgroup (TCMI_F_BLOCK lanes) per chunk:
 //   lane (g, s)  owns NW adjacent grid words (8*NW positions) g of the window and DEPTH SLICE s
-//                of the reads; S = 256 / ceil(Wn/NW) slices work in parallel on different reads.
+//                of the reads; S = lanes / ceil(Wn/NW) slices work in parallel on different reads.
 //   stage        <= 256 reads at a time: headers and bases -> LDS with coalesced loads (16 bytes
 //                per lane for the bases); the loads of stage i+1 are issued before the inner loop
 //                of stage i runs and land in registers meanwhile.  Every input byte leaves HBM once.
@@ -17,8 +17,8 @@
 //                unnecessary: one v_med3 clamps the word index) -> NW v_alignbit funnel shifts
 //                bring the read's nibbles onto the lane's grid words; `(w >> c) & 0x11111111`
 //                isolates class c as eight 4-bit counters, added to a register.  Only A, C, G are
-//                counted: T = coverage - A - C - G - (bases that are no A/C/G/T; rare, kept in a
-//                side list and subtracted by the tail blocks of the same launch).  Every <= 12
+//                counted: T = coverage - A - C - G - (covered positions without an A/C/G/T base:
+//                rare, kept as event words and subtracted by the tail blocks of the same launch).  Every <= 12
 //                reads the 4-bit counters are widened into 8-bit counters.  No atomics, no
 //                data-dependent branches.
 //   coverage     difference array in LDS, one (+run, -run) pair per run of equal (pos, len)
@@ -31,10 +31,10 @@
 
 namespace {
 
-constexpr int FB = 256;                         // lanes per workgroup
+constexpr int FB = TCMI_F_BLOCK;                // lanes per workgroup
 constexpr int MAXPOS = TCMI_F_MAXW * 8;         // positions in the largest window
 constexpr int NLD = TCMI_F_SEQCAP / (4 * FB);   // 16-byte loads per lane that cover the largest stage
-constexpr int UNR = 4;                          // reads in flight per lane in the inner loop
+constexpr int UNR = TCMI_F_BLOCK == 512 ? 3 : 4;                          // reads in flight per lane in the inner loop
 constexpr int WIDEN = 12;                       // reads between widenings of the 4-bit counters (<= 15, multiple of UNR)
 
 struct FastArgs {
@@ -42,15 +42,18 @@ struct FastArgs {
     const uint32_t *lenoff;
     const uint32_t *seq;
     const tcmi_fast_chunk *chunks;
-    const int32_t *other;
+    const uint32_t *events;
     int32_t *counts;
     int64_t ld;
-    int64_t n_other;
+    int64_t n_events;
     int32_t n_chunks;
     int32_t L;
 };
 
-// inclusive block scan of one int over 256 lanes (4 waves)
+constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum
+static_assert(NLD >= 1 && NLD <= 6, "prefetch registers are written out for up to 6 loads per lane");
+
+// inclusive block scan of one int over the workgroup
 __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,13 +67,13 @@ __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
     __syncthreads();
     int base = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < FB / 64; ++w)
         if (w < wave) base += wave_tot[w];
     return v + base;
 }
 
 template <int NW>
-__global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
+__global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastArgs a)
 {
     constexpr int PAD = NW + 1;
     constexpr int NREG = NW * 3 * 2;                                          // 8-bit counter registers per lane
@@ -78,16 +81,32 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
     __shared__ __attribute__((aligned(8))) uint2 s_hdr[TCMI_F_SUB + 1];      // {pos - P0 | words << 16, byte offset in s_seq}
     __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
     __shared__ uint16_t s_fin[3][MAXPOS];                                     // window counters of A, C, G
-    __shared__ int s_scan[4];
+    __shared__ int s_scan[FB / 64];
     static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
 
     const int tid = threadIdx.x, lane = tid & 63;
     if ((int)blockIdx.x >= a.n_chunks) {
-        // tail blocks: aligned bases that are no A/C/G/T were counted as T by subtraction
+        // Tail blocks: the tokens that are no plain A/C/G/T bases, as event words (position | kind).
+        // Equal words are counted inside the wave (ballot match), one atomic per distinct word and
+        // wave: at an indel site thousands of reads carry the same event.
         const int64_t i = (int64_t)((int)blockIdx.x - a.n_chunks) * FB + tid;
-        if (i < a.n_other) {
-            const int p = a.other[i];
-            if ((unsigned)p < (unsigned)a.L) atomicSub(&a.counts[(int64_t)TCMI_T * a.ld + p], 1);
+        const bool valid = i < a.n_events;
+        const uint32_t key = valid ? a.events[i] : 0u;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+            const unsigned long long same = __ballot(valid && key == k);
+            if (lane == leader) {
+                const int n = __popcll(same);
+                const int p = (int)(k & (TCMI_F_EVPOS - 1u));
+                if (p < a.L) {
+                    if (k & TCMI_F_EV_OTHER) atomicSub(&a.counts[(int64_t)TCMI_T * a.ld + p], n);   // was counted as T by subtraction
+                    if (k & TCMI_F_EV_X) atomicAdd(&a.counts[(int64_t)TCMI_X * a.ld + p], n);
+                    if (k & TCMI_F_EV_I) atomicAdd(&a.counts[(int64_t)TCMI_I * a.ld + p], n);
+                }
+            }
+            todo &= ~same;
         }
         return;
     }
@@ -103,6 +122,7 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
     const int n_stage = (n_reads + sub_reads - 1) / sub_reads;
 
     for (int i = tid; i <= npos; i += FB) s_cov[i] = 0;
+    __syncthreads();                            // before any wave adds coverage runs into it
 
     uint32_t nib[NW][3];                        // [word][class A,C,G]: eight 4-bit counters
     uint32_t byt[NW][3][2];                     // [word][class][even|odd position]: four 8-bit counters
@@ -114,8 +134,7 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
     // ---- prefetch registers: the next stage's headers and bases ------------------------------------
     int h_pos = 0;
     uint32_t h_lo = 0;
-    uint4 pre0, pre1, pre2, pre3, pre4, pre5;            // (named registers: an array ended up in scratch)
-    static_assert(NLD == 6, "prefetch registers are written out for 6 loads per lane");
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};   // (named registers: an array ended up in scratch)
     int st_begin = 0, st_end = chp->stage_end[0];                // word range of the stage (from word0)
     // every lane loads (indices clamped into the stage): no exec-masked branch, so the compiler can leave
     // the loads in flight across the inner loop instead of waiting at a branch join.  (A macro, not a
@@ -128,12 +147,12 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
         const int mis_ = (int)((word0 + (begin_)) & 3); /* keep the 16-byte loads aligned */          \
         const uint4 *src_ = reinterpret_cast<const uint4 *>(a.seq + (word0 + (begin_) - mis_));       \
         const int last_ = ((end_) - (begin_) + mis_ + 3) / 4 - 1;                                     \
-        pre0 = src_[min(0 * FB + tid, last_)];                                                        \
-        pre1 = src_[min(1 * FB + tid, last_)];                                                        \
-        pre2 = src_[min(2 * FB + tid, last_)];                                                        \
-        pre3 = src_[min(3 * FB + tid, last_)];                                                        \
-        pre4 = src_[min(4 * FB + tid, last_)];                                                        \
-        pre5 = src_[min(5 * FB + tid, last_)];                                                        \
+        if (NLD > 0) pre0 = src_[min(0 * FB + tid, last_)];                                           \
+        if (NLD > 1) pre1 = src_[min(1 * FB + tid, last_)];                                           \
+        if (NLD > 2) pre2 = src_[min(2 * FB + tid, last_)];                                           \
+        if (NLD > 3) pre3 = src_[min(3 * FB + tid, last_)];                                           \
+        if (NLD > 4) pre4 = src_[min(4 * FB + tid, last_)];                                           \
+        if (NLD > 5) pre5 = src_[min(5 * FB + tid, last_)];                                           \
     } while (0)
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
 
@@ -166,12 +185,12 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
         }
         {
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            if ((0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
-            if ((1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
-            if ((2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
-            if ((3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
-            if ((4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
-            if ((5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
+            if (NLD > 0 && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
+            if (NLD > 1 && (1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
+            if (NLD > 2 && (2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
+            if (NLD > 3 && (3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
+            if (NLD > 4 && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
+            if (NLD > 5 && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
         }
         __syncthreads();
         // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
@@ -256,17 +275,19 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
             f[6] = (uint16_t)(o >> 16);
         }
     }
-    // ---- coverage: inclusive prefix sum of the difference array, 3 entries per lane -----------------
+    // ---- coverage: inclusive prefix sum of the difference array, CPL entries per lane ----------------
     {
-        const int i0 = tid * 3;
-        const int d0 = i0 < npos ? s_cov[i0] : 0, d1 = i0 + 1 < npos ? s_cov[i0 + 1] : 0,
-                  d2 = i0 + 2 < npos ? s_cov[i0 + 2] : 0;
-        const int incl = block_scan_incl(d0 + d1 + d2, s_scan);
-        const int before = incl - (d0 + d1 + d2);
+        const int i0 = tid * CPL;
+        int d[CPL], sum = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { d[k] = i0 + k < npos ? s_cov[i0 + k] : 0; sum += d[k]; }
+        int run = block_scan_incl(sum, s_scan) - sum;
         __syncthreads();
-        if (i0 < npos) s_cov[i0] = before + d0;
-        if (i0 + 1 < npos) s_cov[i0 + 1] = before + d0 + d1;
-        if (i0 + 2 < npos) s_cov[i0 + 2] = before + d0 + d1 + d2;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            run += d[k];
+            if (i0 + k < npos) s_cov[i0 + k] = run;
+        }
     }
     __syncthreads();
     // ---- one coalesced global atomic per touched (class, position) -----------------------------------
@@ -292,14 +313,17 @@ __global__ __launch_bounds__(FB) void tally_fast_kernel(FastArgs a)
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
     FastArgs a;
-    a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.other = rs->d_fother;
-    a.counts = d_counts; a.ld = ld; a.n_other = rs->f_other; a.L = (int32_t)L;
-    const int64_t grid = rs->f_chunks + (rs->f_other + FB - 1) / FB;
+    a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent;
+    a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
+    const int64_t grid = rs->f_chunks + (rs->f_events + FB - 1) / FB;
     if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
     a.n_chunks = (int32_t)rs->f_chunks;
     tcmi_prof_begin(ctx, TCMI_K_TALLY);
+#if TCMI_F_BLOCK == 256
     if (rs->f_nw == 4) hipLaunchKernelGGL(tally_fast_kernel<4>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    else
+#endif
+        hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;

@@ -14,8 +14,12 @@
 // Only reads that pile up (mapped, tid >= 0, pos >= 0, reference span > 0)
 // are kept, split in two sets at upload time:
 //
-//  * ALIGNED set (fast kernel): reads whose CIGAR is one run of match ops (M / = / X),
-//    optionally flanked by S / H clips, no longer than TCMI_F_MAXSPAN positions.  Kept as
+//  * ALIGNED set (fast kernel): reads no longer than TCMI_F_MAXSPAN reference positions.  A read
+//    whose CIGAR is one run of match ops (M / = / X, optionally flanked by S / H clips) is taken
+//    as it is; any other CIGAR is PROJECTED onto the reference while it is packed: matched bases
+//    land on their reference offset, deleted / skipped positions become empty nibbles, inserted
+//    and clipped bases are dropped, and the tokens that are not plain bases ("*", "..+n..") become
+//    EVENT words (position | kind) that the tail blocks of the same launch count.  Kept as
 //    8 bytes of header (pos; len | word offset << 10) + the aligned bases only, 8 bases per
 //    32-bit word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for
 //    anything else (N, IUPAC, '=', base beyond SEQ) — exactly what indexing.py:115-132
@@ -24,19 +28,28 @@
 //    kept in a side list (they count toward coverage but toward no class).
 //    Consecutive reads are grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW
 //    grid words of 8 positions); one workgroup tallies one chunk in STAGES of <= sub_reads reads.
-//  * GENERAL set (CIGAR-walk kernel): every other read (indels, ref-skips, pads, long reads),
+//  * GENERAL set (CIGAR-walk kernel): what the fast path does not take (reads spanning more than
+//    TCMI_F_MAXSPAN positions, positions >= 2^29, or everything when option tally_variant = 1),
 //    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
 //    offsets with a block scan), raw 4-bit codes.
 //
 // HBM traffic per read stays at or below the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes
 // (aligned reads: 8 + 4*ceil(l/8) + 4*pad bytes, i.e. 96 vs 91 for a 150-bp read at pad 3).
 #define TCMI_ROUND 256
+#ifndef TCMI_F_BLOCK
+#define TCMI_F_BLOCK 256           // lanes per workgroup of the fast kernel (256 or 512; 256 measured faster)
+#endif
 #define TCMI_F_CHUNK 1024          // max reads per chunk
 #define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
 #define TCMI_F_MAXSTAGE 16         // stages per chunk (TCMI_F_CHUNK / 64)
+// event word = reference position | kind; kinds may be combined
+#define TCMI_F_EVPOS   (1u << 29)  // positions must stay below this for the fast path
+#define TCMI_F_EV_OTHER (1u << 29) // a covered position whose token is no A/C/G/T base: was counted as T by subtraction
+#define TCMI_F_EV_X     (1u << 30) // token "*"
+#define TCMI_F_EV_I     (1u << 31) // token carries an insertion
 
 struct tcmi_fast_chunk {           // 96 bytes
     int64_t read0;                 // first read (index into f_pos / f_lenoff)
@@ -58,12 +71,12 @@ struct tcmi_readset {
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
     int device = -1;
     // aligned set
-    int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_other = 0;
+    int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
     int32_t f_nw = 2;           // grid words per lane the stream was padded for (pad = f_nw + 1)
     int32_t *d_fpos = nullptr;  // [f_reads]
     uint32_t *d_flenoff = nullptr; // [f_reads] len | (word offset from the chunk's word0) << 10
     uint32_t *d_fseq = nullptr; // [f_words]
-    int32_t *d_fother = nullptr;// [f_other] reference positions of aligned bases that are not A/C/G/T
+    uint32_t *d_fevent = nullptr;// [f_events] position | TCMI_F_EV_*: tokens that are not plain A/C/G/T bases
     tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]
     // general set
     int64_t g_reads = 0, n_rounds = 0, n_cigar = 0, n_seqw = 0;
@@ -113,6 +126,7 @@ struct tcmi_ctx {
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int fast_nw = 2;                // grid words per lane in the fast kernel: 2 or 4
+    int project_reads = 1;          // reads with indels / skips go to the fast kernel projected onto the reference
 };
 
 int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...);

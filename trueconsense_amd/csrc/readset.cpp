@@ -191,11 +191,10 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             const int64_t cap = std::min<int64_t>(TCMI_F_SUB, (TCMI_F_SEQCAP - 16 - PAD) / (maxnw + PAD));
             int64_t sub = S * 12 * std::max<int64_t>(1, cap / (S * 12));
             if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);            // window too wide for 12 per slice
-            while (sub * TCMI_F_MAXSTAGE < TCMI_F_CHUNK && sub + S <= cap) sub += S;   // keep <= 16 stages
             return sub;
         };
         auto chunk_reads = [&](int64_t sub) -> int64_t {                         // whole stages, <= 1024 reads
-            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, 4 * sub) / sub * sub);
+            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) * sub) / sub * sub);
         };
         auto close = [&](int64_t next_read) {
             if (c_n == 0) return;
@@ -206,7 +205,6 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             c.P0 = (int32_t)c_lo;
             c.Wn = (int32_t)((c_hi - c_lo + 7) / 8);
             c.sub_reads = (int32_t)stage_reads(c.Wn, c_maxnw);
-            while ((c_n + c.sub_reads - 1) / c.sub_reads > TCMI_F_MAXSTAGE) c.sub_reads += 1;   // (cannot happen: see stage_reads)
             chunks.push_back(c);
             c_read0 = next_read;
             c_n = 0;

@@ -34,6 +34,10 @@ namespace {
 constexpr int FB = TCMI_F_BLOCK;                // lanes per workgroup
 constexpr int MAXPOS = TCMI_F_MAXW * 8;         // positions in the largest window
 constexpr int NLD = TCMI_F_SEQCAP / (4 * FB);   // 16-byte loads per lane that cover the largest stage
+#ifndef TCMI_ABL
+#define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 1 no class extraction, 2 no inner loop,
+                        // 4 no global loads / staging, 8 no final reduce + atomics, 16 no coverage runs
+#endif
 constexpr int UNR = TCMI_F_BLOCK == 512 ? 3 : 4;                          // reads in flight per lane in the inner loop
 constexpr int WIDEN = 12;                       // reads between widenings of the 4-bit counters (<= 15, multiple of UNR)
 
@@ -135,7 +139,11 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
     int h_pos = 0;
     uint32_t h_lo = 0;
     uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};   // (named registers: an array ended up in scratch)
-    int st_begin = 0, st_end = chp->stage_end[0];                // word range of the stage (from word0)
+    // all four stage ends up front (scalar loads with the rest of the chunk record): a load of
+    // stage_end[stage + 1] inside the loop put a full memory round trip in front of every prefetch
+    const int se0 = chp->stage_end[0], se1 = chp->stage_end[1], se2 = chp->stage_end[2], se3 = chp->stage_end[3];
+    static_assert(TCMI_F_MAXSTAGE == 4, "stage ends are held in four scalars");
+    int st_begin = 0, st_end = se0;                              // word range of the stage (from word0)
     // every lane loads (indices clamped into the stage): no exec-masked branch, so the compiler can leave
     // the loads in flight across the inner loop instead of waiting at a branch join.  (A macro, not a
     // lambda: the closure kept `pre` in scratch memory.)
@@ -172,39 +180,41 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
         if (tid == 0)                                            // dummy: a read far to the right, no words
             s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)(mis + PAD) * 4u);
         {
-            const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
-            const bool lead = valid && (lane == 0 || rel != prel || len != plen);
-            const unsigned long long leads = __ballot(lead), valids = __ballot(valid);
-            const unsigned long long above = lane == 63 ? 0ull : (leads >> (lane + 1)) << (lane + 1);
-            const int next = above ? (__ffsll((long long)above) - 1) : __popcll(valids);
-            if (lead) {
-                const int run = next - lane;
-                atomicAdd(&s_cov[rel], run);
-                atomicAdd(&s_cov[rel + len], -run);
-            }
-        }
-        {
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            if (NLD > 0 && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
-            if (NLD > 1 && (1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
-            if (NLD > 2 && (2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
-            if (NLD > 3 && (3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
-            if (NLD > 4 && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
-            if (NLD > 5 && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
+            if (!(TCMI_ABL & 4) && NLD > 0 && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
+            if (!(TCMI_ABL & 4) && NLD > 1 && (1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
+            if (!(TCMI_ABL & 4) && NLD > 2 && (2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
+            if (!(TCMI_ABL & 4) && NLD > 3 && (3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
+            if (!(TCMI_ABL & 4) && NLD > 4 && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
+            if (!(TCMI_ABL & 4) && NLD > 5 && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
         }
         __syncthreads();
         // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
         if (stage + 1 < n_stage) {
             st_begin = st_end - PAD;
-            st_end = chp->stage_end[stage + 1];
+            st_end = stage == 0 ? se1 : stage == 1 ? se2 : se3;
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
+        }
+        // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave; placed here so
+        // that the LDS atomics complete under the inner loop instead of in front of the barrier
+        {
+            const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
+            const bool lead = valid && (lane == 0 || rel != prel || len != plen);
+            const unsigned long long leads = __ballot(lead), valids = __ballot(valid);
+            const unsigned long long above = lane == 63 ? 0ull : (leads >> (lane + 1)) << (lane + 1);
+            const int next = above ? (__ffsll((long long)above) - 1) : __popcll(valids);
+            if (lead && !(TCMI_ABL & 16)) {
+                const int run = next - lane;
+                atomicAdd(&s_cov[rel], run);
+                atomicAdd(&s_cov[rel + len], -run);
+            }
         }
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free: indices
         //      past the stage are clamped onto a dummy header whose read lies entirely in the zero padding.
         const int Rs = (ns + S - 1) / S;
         const int hbytes_end = ns * 8;
         int hb = s_eff * 8;                                    // byte offset of the lane's next header
-        for (int k0 = 0; k0 < Rs; k0 += WIDEN) {
+        for (int k0 = 0; k0 < ((TCMI_ABL & 2) ? 0 : Rs); k0 += WIDEN) {
             const int k1 = min(k0 + WIDEN, Rs);
             for (int k = k0; k < k1; k += UNR) {
                 uint2 h[UNR];
@@ -231,8 +241,12 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const uint32_t A = __builtin_amdgcn_alignbit(w[u][j + 1], w[u][j], c4[u]);   // bases d+8j ..
+#if TCMI_ABL & 1
+                        nib[j][0] ^= A;
+#else
 #pragma unroll
                         for (int c = 0; c < 3; ++c) nib[j][c] += (A >> c) & 0x11111111u;
+#endif
                     }
             }
             // the 4-bit counters may be full (<= WIDEN reads since the last widening): widen
@@ -247,6 +261,9 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
         }
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
+#if TCMI_ABL & 8
+    if (byt[0][0][0] != 0x12345678u) return;
+#endif
     // ---- slice partials -> LDS, layout [register j][lane] (conflict-free both ways) -----------------
     uint32_t *s_part = s_seq;
 #pragma unroll
@@ -260,10 +277,14 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
     for (int item = tid; item < Gn * NREG; item += FB) {
         const int j = item / Gn, g = item - j * Gn;
         uint32_t e = 0, o = 0;                                  // bytes 0,2 and bytes 1,3 as 16-bit sums
-        for (int t = 0; t < S; ++t) {
-            const uint32_t v = s_part[j * FB + t * Gn + g];
-            e += v & 0x00FF00FFu;
-            o += (v >> 8) & 0x00FF00FFu;
+        const uint32_t *row = s_part + j * FB + g;
+        for (int t = 0; t < S; t += 4) {                        // four independent LDS loads in flight
+            const uint32_t v0 = row[t * Gn];
+            const uint32_t v1 = t + 1 < S ? row[(t + 1) * Gn] : 0u;
+            const uint32_t v2 = t + 2 < S ? row[(t + 2) * Gn] : 0u;
+            const uint32_t v3 = t + 3 < S ? row[(t + 3) * Gn] : 0u;
+            e += (v0 & 0x00FF00FFu) + (v1 & 0x00FF00FFu) + (v2 & 0x00FF00FFu) + (v3 & 0x00FF00FFu);
+            o += ((v0 >> 8) & 0x00FF00FFu) + ((v1 >> 8) & 0x00FF00FFu) + ((v2 >> 8) & 0x00FF00FFu) + ((v3 >> 8) & 0x00FF00FFu);
         }
         const int w = j / 6, c = (j >> 1) % 3, h = j & 1;
         const int p = (g * NW + w) * 8 + h;                     // byte i of the register <-> position p + 2*i

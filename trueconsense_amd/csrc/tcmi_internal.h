@@ -44,14 +44,14 @@
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
-#define TCMI_F_MAXSTAGE 16         // stages per chunk (TCMI_F_CHUNK / 64)
+#define TCMI_F_MAXSTAGE 4          // stages per chunk
 // event word = reference position | kind; kinds may be combined
 #define TCMI_F_EVPOS   (1u << 29)  // positions must stay below this for the fast path
 #define TCMI_F_EV_OTHER (1u << 29) // a covered position whose token is no A/C/G/T base: was counted as T by subtraction
 #define TCMI_F_EV_X     (1u << 30) // token "*"
 #define TCMI_F_EV_I     (1u << 31) // token carries an insertion
 
-struct tcmi_fast_chunk {           // 96 bytes
+struct tcmi_fast_chunk {           // 48 bytes
     int64_t read0;                 // first read (index into f_pos / f_lenoff)
     int64_t word0;                 // first word of the chunk's base stream (multiple of 4)
     int32_t n_reads;
@@ -126,6 +126,7 @@ struct tcmi_ctx {
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int fast_nw = 2;                // grid words per lane in the fast kernel: 2 or 4
+    int chunk_stages = 4;           // stages per chunk of the fast kernel (1..4)
     int project_reads = 1;          // reads with indels / skips go to the fast kernel projected onto the reference
 };
 

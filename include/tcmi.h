@@ -94,7 +94,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  * the fast kernel, 1 = every read through the CIGAR-walk kernel), "fast_nw" (grid words per lane
  * of the fast kernel: 2 or 4), "rounds_per_wg" (CIGAR-walk kernel, 0 = auto), "profile_every" (with
  * profiling enabled, every n-th tcmi_step_begin is launched directly with its kernels bracketed by
- * events, the others replay the graph unmeasured; default 1), "project_reads" (1: reads with
+ * events, the others replay the graph unmeasured; default 1), "host_threads" (threads tcmi_readset_upload packs with; default
+ * min(16, cores)), "chunk_stages" (1..4 stages per fast-kernel chunk), "project_reads" (1: reads with
  * indels / ref-skips are projected onto the reference at upload and take the fast kernel; 0: they
  * take the CIGAR-walk kernel), "use_graph"
  * (tcmi_step_begin replays the step as one hipGraph per read set; default 1)                    */

@@ -325,3 +325,23 @@ def test_self_cleaning_steps_and_pipeline(ctx):
     out, _ = pipe.run([rss[1]], L, 30, True)                        # no candidates: fine without host reads
     assert out[0].decode() == want[1]
     pipe.close()
+
+
+def test_fuzz_random_cigars_all_paths(ctx):
+    """20k random reads with every CIGAR op, odd SEQ content and flags: the fast kernel with reads
+    projected onto the reference, the fast + CIGAR-walk split, and the CIGAR-walk kernel alone must
+    all reproduce the oracle, sorted or not, short windows or long reads."""
+    from tests import fuzz_reads as fz
+    rng = np.random.default_rng(20251121)
+    for rep, (n, L, long_reads, sort) in enumerate(((20000, 3000, False, True), (4000, 20000, True, True),
+                                                   (3000, 1500, False, False), (500, 100000, True, True))):
+        reads = fz.random_reads(rng, n, L, long_reads=long_reads, sort=sort)
+        Lx = engine.reads_extent(reads, L)
+        want = c_oracle.tally(reads, Lx)
+        for variant, project in ((0, 1), (0, 0), (1, 1)):
+            ctx.set_option("tally_variant", variant)
+            ctx.set_option("project_reads", project)
+            got = ctx.tally(reads, L=Lx)
+            assert np.array_equal(got, want), (rep, variant, project, np.argwhere(got != want)[:5])
+    ctx.set_option("tally_variant", 0)
+    ctx.set_option("project_reads", 1)

@@ -1,7 +1,9 @@
 // api.cpp — context, error text, profiling brackets and the host-buffer
 // conveniences of the C ABI declared in include/tcmi.h.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 
 #include "tcmi_internal.h"
 
@@ -84,6 +86,12 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     if (v) c->tally_variant = std::atoi(v);
     v = std::getenv("TCMI_ROUNDS_PER_WG");
     if (v) c->rounds_per_wg = std::atoi(v);
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        c->host_threads = hc ? (int)std::min(hc, 16u) : 4;
+    }
+    v = std::getenv("TCMI_HOST_THREADS");
+    if (v && std::atoi(v) >= 1) c->host_threads = std::atoi(v);
     v = std::getenv("TCMI_CHUNK_STAGES");
     if (v && std::atoi(v) >= 1 && std::atoi(v) <= 4) c->chunk_stages = std::atoi(v);
     v = std::getenv("TCMI_FAST_NW");
@@ -138,6 +146,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     if (!c || !key) return tcmi_fail(c, TCMI_E_ARG, "null argument");
     if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
+    else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 1 ? 1 : value > 4 ? 4 : value;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;

@@ -112,6 +112,7 @@ int tcmi_launch_call(tcmi_ctx *ctx, int32_t *d_counts, int64_t L, int64_t ld, in
 {
     const int64_t grid = (L + BLOCK - 1) / BLOCK;
     tcmi_prof_begin(ctx, TCMI_K_CALL);
+    (void)hipGetLastError();                               // drop any stale error of this thread
     hipLaunchKernelGGL(call_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream, d_counts, L, ld, mincov,
                        include_ambig, clean, d_plain, d_alt, d_flags, d_events, d_event_counts);
     tcmi_prof_end(ctx, TCMI_K_CALL);

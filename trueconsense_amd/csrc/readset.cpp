@@ -2,6 +2,9 @@
 // ALIGNED and GENERAL device sets (layout: tcmi_internal.h) and copies them into HBM.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 
 #include "tcmi_internal.h"
@@ -143,6 +146,12 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     if (rc) return rc;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     const bool use_fast = ctx->tally_variant != 1;
+    const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
 
     // pass 1: select, classify, size
     struct Sel { int64_t i, y0, len; bool projected; };
@@ -172,6 +181,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
         else { gsel.push_back(i); g_cig += nc; g_seqw += (lq + 7) / 8; }
     }
 
+    const auto t1 = now();
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
     const int NW = (ctx->fast_nw == 4 && TCMI_F_BLOCK == 256) ? 4 : 2, PAD = NW + 1;
@@ -180,7 +190,6 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     std::vector<uint32_t> f_lenoff((size_t)nf);
     std::vector<tcmi_fast_chunk> chunks;
     std::vector<uint32_t> f_seq;
-    f_seq.reserve((size_t)(nf * (19 + PAD) + 64));
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
         // Stage size for a window of `words` grid words and reads of <= maxnw words: the kernel splits a
@@ -223,19 +232,35 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             f_pos[(size_t)j] = (int32_t)p;
         }
         close(nf);
-        // the base stream, chunk by chunk: [pad] read [pad] read [pad] ... each chunk 16-byte aligned
-        for (auto &c : chunks) {
-            while (f_seq.size() & 3) f_seq.push_back(0);
-            c.word0 = (int64_t)f_seq.size();
-            f_seq.resize(f_seq.size() + (size_t)PAD, 0);
+        // the base stream, chunk by chunk: [pad] read [pad] read [pad] ... each chunk 16-byte aligned.
+        // Sizes first (sequential, cheap), then the chunks are packed by `n_threads` host threads.
+        {
+            size_t total = 0;
+            for (auto &c : chunks) {
+                total = (total + 3) & ~(size_t)3;
+                c.word0 = (int64_t)total;
+                total += (size_t)PAD;
+                for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) total += (size_t)((fsel[(size_t)j].len + 7) / 8 + PAD);
+            }
+            total = (total + 3) & ~(size_t)3;
+            f_seq.assign(total, 0u);
+        }
+        const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, (int64_t)chunks.size(), 64}));
+        std::vector<std::vector<uint32_t>> ev_parts((size_t)n_threads);
+        auto pack_range = [&](int t) {
+            std::vector<uint32_t> &ev = ev_parts[(size_t)t];
+            const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;
+            for (size_t ci = c0; ci < c1; ++ci) {
+                tcmi_fast_chunk &c = chunks[ci];
+                size_t cursor = (size_t)c.word0 + (size_t)PAD;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const uint8_t *src = r->seq + r->seq_off[s.i];
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
-                const size_t base = f_seq.size();
+                const size_t base = cursor;
                 f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
-                f_seq.resize(base + (size_t)(nw + PAD), 0);
+                cursor += (size_t)(nw + PAD);
                 uint8_t *dst = reinterpret_cast<uint8_t *>(&f_seq[base]);
                 const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
                 if (s.projected) {
@@ -261,9 +286,9 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                                 }
                             } else if (op == 2) {
                                 for (int64_t t = 0; t < (ins ? len - 1 : len); ++t)
-                                    f_event.push_back((uint32_t)(r->pos[s.i] + x + t) | TCMI_F_EV_X);
+                                    ev.push_back((uint32_t)(r->pos[s.i] + x + t) | TCMI_F_EV_X);
                             }
-                            if (ins) f_event.push_back((uint32_t)(r->pos[s.i] + x + len - 1) | TCMI_F_EV_I);
+                            if (ins) ev.push_back((uint32_t)(r->pos[s.i] + x + len - 1) | TCMI_F_EV_I);
                             x += len;
                         }
                         if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
@@ -291,17 +316,25 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                     uint32_t miss = want & ~nz;
                     while (miss) {
                         const int bit = __builtin_ctz(miss);
-                        f_event.push_back((uint32_t)(r->pos[s.i] + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
+                        ev.push_back((uint32_t)(r->pos[s.i] + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
                         miss &= miss - 1;
                     }
                 }
                 if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads)
-                    c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(f_seq.size() - (size_t)c.word0);
+                    c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(cursor - (size_t)c.word0);
             }
+            }
+        };
+        if (n_threads == 1) pack_range(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; ++t) th.emplace_back(pack_range, t);
+            for (auto &x : th) x.join();
         }
-        while (f_seq.size() & 3) f_seq.push_back(0);
+        for (auto &part : ev_parts) f_event.insert(f_event.end(), part.begin(), part.end());
     }
 
+    const auto t2 = now();
     // ---- general set: rounds, raw codes --------------------------------------------------
     const int64_t ng = (int64_t)gsel.size();
     const int64_t n_rounds = (ng + TCMI_ROUND - 1) / TCMI_ROUND;
@@ -331,6 +364,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     h_rs[(size_t)n_rounds] = so;
 
     static std::atomic<uint64_t> next_uid{1};
+    const auto t3 = now();
     tcmi_readset *rs = new tcmi_readset();
     rs->uid = next_uid.fetch_add(1);
     rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
@@ -356,6 +390,9 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "sync after upload failed");
     if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    if (timing)
+        std::fprintf(stderr, "[tcmi upload] classify %.1f ms, pack aligned %.1f ms (%d threads), pack general %.1f ms, H2D %.1f ms (%.1f MB)\n",
+                     ms(t0, t1), ms(t1, t2), ctx->host_threads, ms(t2, t3), ms(t3, now()), rs->dev_bytes / 1e6);
     *out = rs;
     return TCMI_OK;
 }

@@ -227,6 +227,7 @@ int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t 
     const int64_t grid = (rs->n_rounds + rpw - 1) / rpw;
     if (grid <= 0 || grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_ARG, "bad grid %lld", (long long)grid);
     tcmi_prof_begin(ctx, TCMI_K_TALLY_GENERAL);
+    (void)hipGetLastError();                               // drop any stale error of this thread
     hipLaunchKernelGGL(tally_atomic_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_TALLY_GENERAL);
     TCMI_HIP(ctx, hipGetLastError());

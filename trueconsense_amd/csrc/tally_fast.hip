@@ -344,6 +344,7 @@ int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int
     if (rs->f_nw == 4) hipLaunchKernelGGL(tally_fast_kernel<4>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
     else
 #endif
+        (void)hipGetLastError();                               // drop any stale error of this thread
         hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());

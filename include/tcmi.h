@@ -90,15 +90,16 @@ int  tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out);
 int  tcmi_ctx_destroy(tcmi_ctx *ctx);
 int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
 void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
-/* tuning knobs, read at tcmi_readset_upload / launch: "tally_variant" (0 = aligned reads through
- * the fast kernel, 1 = every read through the CIGAR-walk kernel), "fast_nw" (grid words per lane
- * of the fast kernel: 2 or 4), "rounds_per_wg" (CIGAR-walk kernel, 0 = auto), "profile_every" (with
- * profiling enabled, every n-th tcmi_step_begin is launched directly with its kernels bracketed by
- * events, the others replay the graph unmeasured; default 1), "host_threads" (threads tcmi_readset_upload packs with; default
- * min(16, cores)), "chunk_stages" (1..4 stages per fast-kernel chunk), "project_reads" (1: reads with
- * indels / ref-skips are projected onto the reference at upload and take the fast kernel; 0: they
- * take the CIGAR-walk kernel), "use_graph"
- * (tcmi_step_begin replays the step as one hipGraph per read set; default 1)                    */
+/* tuning knobs (tcmi_readset_upload reads the packing ones, the launches the others):
+ *   "tally_variant"  0 = reads take the fast kernel (default), 1 = every read takes the CIGAR-walk kernel
+ *   "project_reads"  1 = reads with indels / ref-skips are projected onto the reference at upload and
+ *                    take the fast kernel (default); 0 = they take the CIGAR-walk kernel
+ *   "chunk_stages"   1..4 stages per fast-kernel chunk (default 4)
+ *   "host_threads"   threads tcmi_readset_upload packs with (default min(16, cores))
+ *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
+ *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set (default)
+ *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin is launched directly with its
+ *                    kernels bracketed by events, the others replay the graph unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

@@ -147,3 +147,83 @@ def test_bam_reader_rejects_garbage(tmp_path):
         engine.BamFile(str(p))
     with pytest.raises(TcmiError):
         engine.BamFile(str(tmp_path / "missing.bam"))
+
+
+def test_walk_fast_runs_equal_position_by_position():
+    """The walk skips over quiet runs in bulk; with that switched off it goes position by position.
+    Both must agree on long random inputs (events, inserts of every size, rows of both strands,
+    overlapping rows, premature stops), including where they raise."""
+    import ctypes as C
+    from oracle import c_oracle
+    from trueconsense_amd import _ffi
+    lib = _ffi.lib()
+    lib.tcmi_walk_set_fast_runs.argtypes = [C.c_int]
+    lib.tcmi_walk_set_fast_runs.restype = None
+    rng = np.random.default_rng(99)
+    n_diff_checked = n_raised = 0
+    try:
+        for rep in range(60):
+            L = int(rng.integers(300, 4000))
+            seq = rng.integers(0, 4, L)
+            cov = int(rng.choice([40, 100, 300]))
+            m = np.zeros((L, 7), np.int32)
+            m[:, 0] = cov
+            m[np.arange(L), 1 + np.array([0, 1, 2, 3])[seq]] = cov      # columns A,T,C,G
+            mincov = int(rng.choice([1, 30, 50]))
+            ins_pos, ins_shift, ins_seqs = [], [], []
+            for _ in range(int(rng.integers(0, 25))):
+                p = int(rng.integers(1, L - 12))
+                kind = int(rng.integers(0, 7))
+                if kind == 0:                                            # deletion run
+                    n = int(rng.integers(1, 9))
+                    x = int(cov * float(rng.choice([0.95, 0.6])))
+                    for q in range(p, min(L - 1, p + n)):
+                        row = m[q - 1].copy(); b = int(np.argmax(row[1:5])) + 1
+                        m[q - 1, 1:] = 0; m[q - 1, b] = cov - x; m[q - 1, 5] = x
+                elif kind == 1:                                          # minority deletion + run
+                    x = int(cov * 0.2)
+                    b = int(np.argmax(m[p - 1, 1:5])) + 1
+                    m[p - 1, 1:] = 0; m[p - 1, b] = cov - x; m[p - 1, 5] = x
+                    for q in range(p + 1, min(L - 1, p + 1 + int(rng.integers(1, 5)))):
+                        b = int(np.argmax(m[q - 1, 1:5])) + 1
+                        m[q - 1, 1:] = 0; m[q - 1, b] = cov // 10; m[q - 1, 5] = cov - cov // 10
+                elif kind == 2:                                          # low / zero coverage
+                    for q in range(p, min(L, p + int(rng.integers(1, 30)))):
+                        m[q - 1] = 0
+                        m[q - 1, 0] = int(rng.choice([0, mincov - 1 if mincov > 1 else 0]))
+                elif kind == 3 and p not in ins_pos:                      # insert
+                    ins_pos.append(p)
+                    ins = "".join("ACGT"[int(k)] for k in rng.integers(0, 4, int(rng.choice([1, 2, 3, 12]))))
+                    ins_seqs.append(ins)
+                    ins_shift.append(int(str(len(ins))[-1]))
+                    m[p - 1, 6] = cov
+                elif kind == 4:                                          # stop codon TAA
+                    for j, col in enumerate((2, 1, 1)):
+                        m[p - 1 + j, 1:5] = 0
+                        m[p - 1 + j, col] = cov
+                elif kind == 5:                                          # ambiguity / lower case
+                    b = int(np.argmax(m[p - 1, 1:5])) + 1
+                    m[p - 1, 1:5] = 0; m[p - 1, b] = cov // 2; m[p - 1, 1 + (b % 4)] = cov - cov // 2
+            order = np.argsort(ins_pos)
+            ins_pos = [ins_pos[i] for i in order]; ins_shift = [ins_shift[i] for i in order]; ins_seqs = [ins_seqs[i] for i in order]
+            orfs = []
+            for _ in range(int(rng.integers(1, 6))):
+                a = int(rng.integers(1, L - 30))
+                orfs.append((a, min(L, a + 3 * int(rng.integers(3, 300))), bool(rng.random() < 0.8)))
+            plain, alt, flags = c_oracle.call(m, mincov, bool(rng.random() < 0.5))
+            res = []
+            for fast in (1, 0):
+                lib.tcmi_walk_set_fast_runs(fast)
+                for inc in (True, False):
+                    try:
+                        c, ns, ne = engine.consensus_walk(plain, alt, flags, [o[0] for o in orfs], [o[1] for o in orfs],
+                                                          [o[2] for o in orfs], ins_pos, ins_shift, ins_seqs, inc)
+                        res.append((c, ns.tolist(), ne.tolist()))
+                    except (engine.WalkKeyError, ZeroDivisionError) as e:
+                        res.append((type(e).__name__, e.args))
+                        n_raised += 1
+            assert res[0] == res[2] and res[1] == res[3], rep
+            n_diff_checked += 1
+    finally:
+        lib.tcmi_walk_set_fast_runs(1)
+    assert n_diff_checked == 60

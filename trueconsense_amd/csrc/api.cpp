@@ -94,8 +94,7 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     if (v && std::atoi(v) >= 1) c->host_threads = std::atoi(v);
     v = std::getenv("TCMI_CHUNK_STAGES");
     if (v && std::atoi(v) >= 1 && std::atoi(v) <= 4) c->chunk_stages = std::atoi(v);
-    v = std::getenv("TCMI_FAST_NW");
-    if (v && (std::atoi(v) == 2 || std::atoi(v) == 4)) c->fast_nw = std::atoi(v);
+
     *out = c;
     return TCMI_OK;
 }
@@ -151,10 +150,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
-    else if (!std::strcmp(key, "fast_nw")) {
-        if (value != 2 && value != 4) return tcmi_fail(c, TCMI_E_ARG, "fast_nw must be 2 or 4");
-        c->fast_nw = value;
-    }
+
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
     return TCMI_OK;
 }

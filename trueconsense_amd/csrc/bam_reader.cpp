@@ -172,58 +172,82 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         o += 4;
     }
 
-    // ---- records: pass 1 sizes, pass 2 fill ----
+    // ---- records: pass 1 walks the record lengths (sequential, light) and lays out the flat arrays,
+    //      pass 2 fills them with `n_threads` workers over disjoint record ranges ----
     const size_t rec0 = o;
-    int64_t n = 0, n_cig = 0, n_seqb = 0, n_qual = 0;
+    std::vector<size_t> rec_at;
+    rec_at.reserve(N / 200 + 16);
     while (o < N) {
         if (!need(4)) return fail("truncated record length");
         const size_t bs = rd32(p + o);
         if (bs < 32 || !need(4 + bs)) return fail("truncated alignment record");
-        const uint8_t *r = p + o + 4;
-        const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
-        if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) return fail("alignment record fields overrun block_size");
-        ++n; n_cig += (int64_t)n_c; n_seqb += (int64_t)((l_seq + 1) / 2); n_qual += (int64_t)l_seq;
+        rec_at.push_back(o);
         o += 4 + bs;
     }
+    (void)rec0;
+    const int64_t n = (int64_t)rec_at.size();
     bam->n = n;
     bam->pos.resize((size_t)n); bam->l_qseq.resize((size_t)n); bam->tid.resize((size_t)n);
     bam->flag.resize((size_t)n); bam->mapq.resize((size_t)n);
     bam->cigar_off.resize((size_t)n + 1); bam->seq_off.resize((size_t)n + 1);
-    bam->cigar.resize((size_t)n_cig + 1); bam->seq.resize((size_t)n_seqb + 1); bam->qual.resize((size_t)n_qual + 1);
-    o = rec0;
-    uint64_t co = 0, so = 0, qo = 0;
-    int32_t last_tid = 0, last_pos = -1;
-    bool seen_unplaced = false;
-    for (int64_t i = 0; i < n; ++i) {
-        const size_t bs = rd32(p + o);
-        const uint8_t *r = p + o + 4;
-        const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
-        const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
-        bam->tid[(size_t)i] = tid;
-        bam->pos[(size_t)i] = pos;
-        bam->mapq[(size_t)i] = r[9];
-        bam->flag[(size_t)i] = rd16(r + 14);
-        bam->l_qseq[(size_t)i] = (int32_t)l_seq;
-        bam->cigar_off[(size_t)i] = co;
-        bam->seq_off[(size_t)i] = so;
-        const uint8_t *c = r + 32 + l_name;
-        std::memcpy(bam->cigar.data() + co, c, 4 * n_c);           // little-endian host
-        co += n_c;
-        const uint8_t *s = c + 4 * n_c;
-        std::memcpy(bam->seq.data() + so, s, (l_seq + 1) / 2);
-        so += (l_seq + 1) / 2;
-        std::memcpy(bam->qual.data() + qo, s + (l_seq + 1) / 2, l_seq);
-        qo += l_seq;
-        if (tid < 0) seen_unplaced = true;
-        else {
-            if (seen_unplaced || tid < last_tid || (tid == last_tid && pos < last_pos)) bam->sorted = 0;
-            last_tid = tid;
-            last_pos = pos;
+    std::vector<uint64_t> qual_off((size_t)n + 1);
+    {
+        uint64_t co = 0, so = 0, qo = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint8_t *r = p + rec_at[(size_t)i] + 4;
+            const size_t bs = rd32(r - 4), l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
+            if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) { o = rec_at[(size_t)i]; return fail("alignment record fields overrun block_size"); }
+            bam->cigar_off[(size_t)i] = co; bam->seq_off[(size_t)i] = so; qual_off[(size_t)i] = qo;
+            co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
         }
-        o += 4 + bs;
+        bam->cigar_off[(size_t)n] = co; bam->seq_off[(size_t)n] = so; qual_off[(size_t)n] = qo;
+        bam->cigar.resize((size_t)co + 1); bam->seq.resize((size_t)so + 1); bam->qual.resize((size_t)qo + 1);
     }
-    bam->cigar_off[(size_t)n] = co;
-    bam->seq_off[(size_t)n] = so;
+    {
+        int nt = n_threads;
+        if ((int64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
+        std::vector<int> unsorted((size_t)nt, 0);
+        auto fill = [&](int t) {
+            const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+            int32_t last_tid = 0, last_pos = -1;
+            bool seen_unplaced = false;
+            if (i0 > 0) {                                        // order is checked across the range boundary too
+                const uint8_t *r = p + rec_at[(size_t)i0 - 1] + 4;
+                const int32_t tid = (int32_t)rd32(r);
+                if (tid < 0) seen_unplaced = true; else { last_tid = tid; last_pos = (int32_t)rd32(r + 4); }
+            }
+            for (int64_t i = i0; i < i1; ++i) {
+                const uint8_t *r = p + rec_at[(size_t)i] + 4;
+                const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+                const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
+                bam->tid[(size_t)i] = tid;
+                bam->pos[(size_t)i] = pos;
+                bam->mapq[(size_t)i] = r[9];
+                bam->flag[(size_t)i] = rd16(r + 14);
+                bam->l_qseq[(size_t)i] = (int32_t)l_seq;
+                const uint8_t *c = r + 32 + l_name;
+                std::memcpy(bam->cigar.data() + bam->cigar_off[(size_t)i], c, 4 * n_c);     // little-endian host
+                const uint8_t *sq = c + 4 * n_c;
+                std::memcpy(bam->seq.data() + bam->seq_off[(size_t)i], sq, (l_seq + 1) / 2);
+                std::memcpy(bam->qual.data() + qual_off[(size_t)i], sq + (l_seq + 1) / 2, l_seq);
+                if (tid < 0) seen_unplaced = true;
+                else {
+                    // (a range that starts inside the unplaced tail sees a placed read only if the file is unsorted)
+                    if (seen_unplaced || tid < last_tid || (tid == last_tid && pos < last_pos)) unsorted[(size_t)t] = 1;
+                    last_tid = tid;
+                    last_pos = pos;
+                }
+            }
+        };
+        if (nt <= 1) fill(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(fill, t);
+            for (auto &x : th) x.join();
+        }
+        for (int u : unsorted)
+            if (u) bam->sorted = 0;
+    }
     *out = bam;
     return TCMI_OK;
 }

@@ -14,10 +14,15 @@
 //     included), '-' characters are counted as `gaps` and stripped before codon splitting,
 //     only upper-case TAG/TAA/TGA are stops;
 //   * end := newend only when p == newend; with the last appended element "-" end := original.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "tcmi_internal.h"
+
+static bool g_fast_runs = true;      // tests switch the run fast path off to compare both walks
+
+extern "C" void tcmi_walk_set_fast_runs(int on) { g_fast_runs = on != 0; }
 
 namespace {
 
@@ -44,6 +49,22 @@ struct Orf {
             else if (!it_stop && c0 == 'T' &&
                      ((c1 == 'A' && (ch == 'G' || ch == 'A')) || (c1 == 'G' && ch == 'A')))
                 it_stop = n_bare / 3;
+        }
+    }
+    // the same, but returns right after the character that completes the first stop codon
+    void feed_until_stop(const char *J, int64_t len)
+    {
+        while (consumed < len) {
+            const char ch = J[consumed++];
+            if (ch == '-') { ++gaps; continue; }
+            const int ph = (int)(n_bare % 3);
+            ++n_bare;
+            if (ph == 0) c0 = ch;
+            else if (ph == 1) c1 = ch;
+            else if (c0 == 'T' && ((c1 == 'A' && (ch == 'G' || ch == 'A')) || (c1 == 'G' && ch == 'A'))) {
+                it_stop = n_bare / 3;
+                return;
+            }
         }
     }
 };
@@ -115,6 +136,43 @@ extern "C" int tcmi_consensus_walk(const uint8_t *plain, const uint8_t *alt, con
             if (p >= orfs[(size_t)live[a]].end) { live[a] = live.back(); live.pop_back(); } else ++a;
         while (next_ins < n_ins && ins_pos[next_ins] < p) ++next_ins;
         const bool ins_here = next_ins < n_ins && ins_pos[next_ins] == p;
+
+        // ---- fast path: a run of positions where nothing sequential happens (primary is a base, no
+        //      minority deletion, no pending skip, no insert, no row starting or ending): the characters
+        //      are the call kernel's, and each live '+' row only has to be scanned for its first stop.
+        if (g_fast_runs && p >= skip_end && !(f & (TCMI_F_PRIMX | TCMI_F_MINDEL)) && !ins_here) {
+            int64_t lim = L + 1;
+            if (!pending.empty()) lim = std::min(lim, orfs[(size_t)pending.back()].start);
+            for (int32_t k : live) lim = std::min(lim, orfs[(size_t)k].end);
+            if (next_ins < n_ins) lim = std::min(lim, ins_pos[next_ins]);
+            int64_t q = p + 1;
+            while (q < lim && !(flags[q - 1] & (TCMI_F_PRIMX | TCMI_F_MINDEL))) ++q;
+            const int64_t n = q - p, len0 = len;
+            if (len + n > cap) return tcmi_fail(nullptr, TCMI_E_ARG, "consensus buffer too small");
+            std::memcpy(J + len, plain + (p - 1), (size_t)n);
+            len += n;
+            for (int32_t k : live) {
+                Orf &o = orfs[(size_t)k];
+                if (!o.plus) continue;
+                if (!o.scanning) { o.scanning = true; o.consumed = o.start - 1; }
+                // position t of the run has appended J[.. len0 + (t - p) + 1)
+                int64_t t_stop = p;                                    // first position at which it_stop is known
+                if (!o.it_stop) {
+                    o.feed(J, len0 + 1);                              // catch up to position p (may cross older '-')
+                    if (!o.it_stop) o.feed_until_stop(J, len);         // then one character per position
+                    t_stop = o.it_stop ? std::max<int64_t>(p, p + (o.consumed - len0) - 1) : q;
+                }
+                if (o.it_stop) {
+                    // from t_stop on the check of ORFs.py:183-189 sees a constant newend (no '-' is added in a run)
+                    const int64_t gaps_at = o.gaps;                   // '-' never occurs inside the run
+                    const int64_t newend = o.start + 3 * o.it_stop + gaps_at - 1;
+                    if (newend >= t_stop && newend < q) o.end = newend;
+                    o.feed(J, len);                                    // keep the scanner in step with J
+                }
+            }
+            p = q - 1;
+            continue;
+        }
 
         if (len + 1 > cap) return tcmi_fail(nullptr, TCMI_E_ARG, "consensus buffer too small");
         bool last_is_dash = false;

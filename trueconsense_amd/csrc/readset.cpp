@@ -184,7 +184,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     const auto t1 = now();
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
-    const int NW = (ctx->fast_nw == 4 && TCMI_F_BLOCK == 256) ? 4 : 2, PAD = NW + 1;
+    const int NW = 2, PAD = NW + 1;             // grid words per lane of tally_fast_kernel<2>
     std::vector<int32_t> f_pos((size_t)nf);
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);

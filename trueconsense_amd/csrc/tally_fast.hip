@@ -340,12 +340,9 @@ int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int
     if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
     a.n_chunks = (int32_t)rs->f_chunks;
     tcmi_prof_begin(ctx, TCMI_K_TALLY);
-#if TCMI_F_BLOCK == 256
-    if (rs->f_nw == 4) hipLaunchKernelGGL(tally_fast_kernel<4>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
-    else
-#endif
-        (void)hipGetLastError();                               // drop any stale error of this thread
-        hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    if (rs->f_nw != 2) return tcmi_fail(ctx, TCMI_E_ARG, "read set was packed for %d grid words per lane", rs->f_nw);
+    (void)hipGetLastError();                                   // drop any stale error of this thread
+    hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);   // (<4> measured slower)
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;

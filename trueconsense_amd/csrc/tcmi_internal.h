@@ -125,7 +125,6 @@ struct tcmi_ctx {
     bool prof_open = false, prof_mute = false;
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
-    int fast_nw = 2;                // grid words per lane in the fast kernel: 2 or 4
     int host_threads = 8;           // threads tcmi_readset_upload packs with
     int chunk_stages = 4;           // stages per chunk of the fast kernel (1..4)
     int project_reads = 1;          // reads with indels / skips go to the fast kernel projected onto the reference

@@ -72,8 +72,8 @@ def cpu_baseline(reads, L, mincov, orfs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--bams", type=int, default=4, help="distinct resident BAMs cycled through per rank")
     ap.add_argument("--mincov", type=int, default=30)

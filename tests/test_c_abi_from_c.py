@@ -1,0 +1,93 @@
+"""include/tcmi.h must be plain C and libtcmi.so usable without Python: a small C program is compiled
+with gcc against the header, linked with the library and run on the host-only entry points."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C_SRC = r'''
+#include <stdio.h>
+#include <string.h>
+#include "tcmi.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    if (tcmi_abi_version() != TCMI_ABI_VERSION) return 3;
+    int ndev = -1;
+    if (tcmi_device_count(&ndev) != TCMI_OK || ndev < 0) return 4;
+    tcmi_bam *bam = NULL;
+    if (tcmi_bam_load(argv[1], 2, &bam) != TCMI_OK) { fprintf(stderr, "%s\n", tcmi_last_error(NULL)); return 5; }
+    tcmi_reads reads;
+    memset(&reads, 0, sizeof reads);
+    if (tcmi_bam_reads(bam, &reads) != TCMI_OK) return 6;
+    int32_t n_ref = 0; const char *name = NULL; int64_t ref_len = 0;
+    if (tcmi_bam_header(bam, &n_ref, &name, &ref_len) != TCMI_OK) return 7;
+    int64_t L = 0;
+    if (tcmi_reads_extent(&reads, ref_len, &L) != TCMI_OK) return 8;
+    int64_t positions[2] = {5, 20}, off[3], cnt[2];
+    char toks[4096]; int32_t deep = 0;
+    if (tcmi_modal_tokens(&reads, 2, positions, 13, 0x704, 1, 8000, toks, sizeof toks, off, cnt, &deep) != TCMI_OK) return 9;
+    /* the host walk on hand-made call records: ACG with a deletion run outside any ORF */
+    const uint8_t plain[6] = {'A','C','G','T','A','C'}, alt[6] = {'a','c','g','t','a','c'};
+    const uint8_t flags[6] = {0, TCMI_F_PRIMX, TCMI_F_PRIMX, 0, 0, 0};
+    char cons[16]; int64_t n = 0, err = 0;
+    if (tcmi_consensus_walk(plain, alt, flags, 6, 0, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, 1, cons, sizeof cons, &n,
+                            NULL, NULL, &err) != TCMI_OK) { fprintf(stderr, "%s\n", tcmi_last_error(NULL)); return 10; }
+    cons[n] = 0;
+    tcmi_ctx *ctx = NULL;
+    int rc = tcmi_ctx_create(0, &ctx);               /* fails cleanly without a GPU */
+    if (rc == TCMI_OK) tcmi_ctx_destroy(ctx);
+    printf("{\"reads\": %lld, \"ref\": \"%s\", \"ref_len\": %lld, \"L\": %lld, \"tok0\": \"%.*s\", \"n0\": %lld, "
+           "\"cons\": \"%s\", \"ndev\": %d, \"ctx_rc\": %d}\n",
+           (long long)reads.n_reads, name, (long long)ref_len, (long long)L, (int)(off[1] - off[0]), toks + off[0],
+           (long long)cnt[0], cons, ndev, rc);
+    tcmi_bam_free(bam);
+    return 0;
+}
+'''
+
+
+def test_c_program_uses_the_abi(tmp_path):
+    sys.path.insert(0, ROOT)
+    from tests import synth_small as ss
+    from trueconsense_amd import _ffi, engine
+    from trueconsense_amd.io import bamwriter
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "outputs.json")))[0]
+    reads = ss.reads_from_spec(case["spec"])
+    bam = str(tmp_path / "in.bam")
+    bamwriter.write_bam(bam, reads, "refid", len(case["spec"]["ref"]))
+    src = tmp_path / "use_tcmi.c"
+    src.write_text(C_SRC)
+    exe = str(tmp_path / "use_tcmi")
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", libdir, "-ltcmi", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = json.loads(subprocess.check_output([exe, bam]).decode())
+    assert out["reads"] == reads["n_reads"] and out["ref"] == "refid" and out["ref_len"] == len(case["spec"]["ref"])
+    assert out["L"] == engine.reads_extent(reads, len(case["spec"]["ref"]))
+    want = engine.modal_tokens(reads, [5, 20])
+    assert (out["tok0"] or None, out["n0"]) == (want[5][0], want[5][1])
+    assert out["cons"] == "A--TAC"
+    assert out["ctx_rc"] in (_ffi.TCMI_OK, _ffi.E_NODEVICE)
+
+
+def test_index_override_matches_reference(tmp_path):
+    """indexing.read_override_index / Override_index_positions (indexing.py:39-72) against the
+    vector produced by the real reference."""
+    import gzip
+    import pandas as pd
+    from trueconsense_amd import indexing
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "override.json")))
+    p = tmp_path / "o.csv.gz"
+    with gzip.open(p, "wt") as fh:
+        fh.write(g["csv"])
+    cols = ["coverage", "A", "T", "C", "G", "X", "I"]
+    base = pd.DataFrame(np.array(g["base"]), columns=cols, index=[1, 2, 3, 4])
+    merged = indexing.Override_index_positions(base, indexing.read_override_index(str(p)))
+    assert merged.values.tolist() == g["merged"]

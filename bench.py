@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (diagnostic)")
     ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option on every workspace (diagnostic)")
     ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
@@ -118,6 +119,10 @@ def main():
     pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
     ctx = pipe.ctx
     ctxs = [pipe.slot_context(k) for k in range(a.slots)]
+    for kv in a.ctx_option:
+        k, v = kv.split("=")
+        for c in ctxs:
+            c.set_option(k, int(v))
     readsets, host_reads0, all_reads = [], None, []
     for b in range(a.bams):
         reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1,

@@ -119,6 +119,7 @@ struct tcmi_ctx {
     };
     std::vector<StepGraph> graphs;
     bool use_graph = true;
+    bool records_to_host = true;    // tcmi_step_begin: the call kernel stores its records in pinned host memory itself
     int step_graph = -1;            // graph used by the step in flight, -1 = direct launches
     int prof_every = 1;             // tcmi_step_begin: every n-th step is launched directly and bracketed with events
     int64_t step_tick = 0;

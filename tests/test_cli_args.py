@@ -1,0 +1,48 @@
+"""Command-line surface (TrueConsense.py:25-220 of the reference): flags, required-ness and exit codes.
+No GPU: only argument handling runs."""
+import pytest
+
+from trueconsense_amd import TrueConsense as cli
+
+
+def _files(tmp_path):
+    p = {}
+    for name in ("x.bam", "r.fa", "r.fasta", "f.gff", "o.csv.gz", "bad.txt"):
+        (tmp_path / name).write_text("x")
+        p[name] = str(tmp_path / name)
+    return p
+
+
+def test_all_flags_parse(tmp_path):
+    f = _files(tmp_path)
+    a = cli.GetArgs(["-i", f["x.bam"], "-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "30", "-name", "S", "-o", "out.fa",
+                     "-vcf", "v.vcf", "-doc", "d.tsv", "-ogff", "g.gff", "-t", "3", "-noambig", "--index-override", f["o.csv.gz"]])
+    assert (a.input, a.reference, a.features, a.coverage_level, a.samplename, a.output) == \
+        (f["x.bam"], f["r.fa"], f["f.gff"], 30, "S", "out.fa")
+    assert (a.variants, a.depth_of_coverage, a.output_gff, a.threads, a.noambiguity, a.index_override) == \
+        ("v.vcf", "d.tsv", "g.gff", 3, True, f["o.csv.gz"])
+    b = cli.GetArgs(["--input", f["x.bam"], "--reference", f["r.fasta"], "--features", f["f.gff"], "--coverage-level", "5",
+                     "--samplename", "S", "--output", "o.fa"])
+    assert b.noambiguity is False and b.variants is None and b.coverage_level == 5
+
+
+def test_exit_codes_match_the_reference(tmp_path, capsys):
+    f = _files(tmp_path)
+    base = ["-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "30", "-name", "S", "-o", "out.fa"]
+    with pytest.raises(SystemExit) as e:                      # missing BAM: exit -1 (TrueConsense.py:34-35)
+        cli.GetArgs(["-i", str(tmp_path / "nope.bam")] + base)
+    assert e.value.code == -1 and "is not a file" in capsys.readouterr().out
+    with pytest.raises(SystemExit) as e:                      # other missing files: exit 1
+        cli.GetArgs(["-i", f["x.bam"], "-ref", str(tmp_path / "nope.fa"), "-gff", f["f.gff"], "-cov", "30", "-name", "S", "-o", "o"])
+    assert e.value.code == 1
+    for argv in (["-i", f["bad.txt"]] + base,                 # wrong extensions: parser.error -> 2
+                 ["-i", f["x.bam"], "-ref", f["bad.txt"], "-gff", f["f.gff"], "-cov", "30", "-name", "S", "-o", "o"],
+                 ["-i", f["x.bam"], "-ref", f["r.fa"], "-gff", f["bad.txt"], "-cov", "30", "-name", "S", "-o", "o"],
+                 ["-i", f["x.bam"]] + base + ["--index-override", f["bad.txt"]],
+                 ["-i", f["x.bam"], "-ref", f["r.fa"], "-gff", f["f.gff"], "-name", "S", "-o", "o"]):   # -cov is required
+        with pytest.raises(SystemExit) as e:
+            cli.GetArgs(argv)
+        assert e.value.code == 2
+    with pytest.raises(SystemExit) as e:                      # no arguments at all: message + exit 1 (:216-220)
+        cli.main([])
+    assert e.value.code == 1

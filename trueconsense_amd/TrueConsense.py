@@ -18,85 +18,72 @@ import time
 from . import _state
 from .Coverage import BuildCoverage
 from .func import MyHelpFormatter, color
-from .indexing import Gffindex, Override_index_positions, Readbam, build_counts, read_override_index
+from .indexing import Gffindex, Override_index_positions, build_counts, read_override_index
 from .Outputs import WriteOutputs
 from .version import __version__
 
 
+def _file_arg(parser, suffixes, what, missing_exit, multi_suffix=False):
+    """argparse `type=` callable: the path must exist (else print + exit with the reference's code,
+    TrueConsense.py:26-73) and carry one of `suffixes` (else parser.error, exit code 2)."""
+    def check(fname):
+        if not os.path.isfile(fname):
+            print(f'"{fname}" is not a file. Exiting...')
+            sys.exit(missing_exit)
+        p = pathlib.Path(fname)
+        ext = "".join(p.suffixes) if multi_suffix else p.suffix
+        ok = all(sfx in ext for sfx in suffixes) if multi_suffix else ext in suffixes
+        if not ok:
+            parser.error(f"{what[0]} {color.YELLOW}({fname}){color.END} doesn't seem to be {what[1]}.")
+        return fname
+    return check
+
+
 def GetArgs(givenargs):
-    """TrueConsense.py:25-209."""
-    def isfile_or_exit(fname, code):
-        if os.path.isfile(fname):
-            return True
-        print(f'"{fname}" is not a file. Exiting...')
-        sys.exit(code)
-
-    def checkbam(fname):
-        isfile_or_exit(fname, -1)
-        if pathlib.Path(fname).suffix != ".bam":
-            parser.error(f"Input file {color.YELLOW}({fname}){color.END} doesn't seem to be a BAM-file.")
-        return fname
-
-    def checkfasta(fname):
-        isfile_or_exit(fname, 1)
-        if pathlib.Path(fname).suffix not in (".fasta", ".fa"):
-            parser.error(f"Reference file {color.YELLOW}({fname}){color.END} doesn't seem to be a Fasta-file.")
-        return fname
-
-    def checkgff(fname):
-        isfile_or_exit(fname, 1)
-        if pathlib.Path(fname).suffix != ".gff":
-            parser.error(f"Given file {color.YELLOW}({fname}){color.END} doesn't seem to be a GFF file.")
-        return fname
-
-    def check_index_override(fname):
-        isfile_or_exit(fname, 1)
-        ext = "".join(pathlib.Path(fname).suffixes)
-        if ".csv" not in ext or ".gz" not in ext:
-            parser.error(f"Given file {color.YELLOW}({fname}){color.END} doesn't seem to be a compressed csv file.")
-        return fname
-
+    """Same flags, defaults, required-ness and exit codes as TrueConsense.py:25-209; table-driven."""
     parser = argparse.ArgumentParser(
         prog="TrueConsense", usage="%(prog)s [required options] [optional arguments]",
         description="TrueConsense: Creating biologically valid consensus sequences from reference-based alignments",
         formatter_class=MyHelpFormatter, add_help=False)
-    standard_threads = min(multiprocessing.cpu_count(), 128)
-
-    reqs = parser.add_argument_group("Required arguments")
-    reqs.add_argument("--input", "-i", type=checkbam, metavar="File", help="Input file in BAM format", required=True)
-    reqs.add_argument("--output", "-o", type=str, default=os.getcwd() + "consensus.fasta", metavar="File",
-                      help="Output consensus fasta", required=True)
-    reqs.add_argument("--reference", "-ref", type=checkfasta, metavar="File", help="Reference Fasta file",
-                      required=True)
-    reqs.add_argument("--features", "-gff", type=checkgff, metavar="File", help="File with genome features (GFF)",
-                      required=True)
-    reqs.add_argument("--coverage-level", "-cov", type=int, default=30, metavar="100",
-                      help="The minimum coverage level of the consensus and variant calls", required=True)
-    reqs.add_argument("--samplename", "-name", metavar="Text",
-                      help="Name of the sample that is being processed, will be used to create the fasta header",
-                      required=True)
-
-    opts = parser.add_argument_group("Optional arguments")
-    opts.add_argument("--variants", "-vcf", type=str, metavar="File", help="Output VCF file")
-    opts.add_argument("--depth-of-coverage", "-doc", type=str, metavar="File",
-                      help="Output TSV file listing the coverage per position")
-    opts.add_argument("--output-gff", "-ogff", type=str, metavar="File", help="Ouput location a corrected GFF file")
-    opts.add_argument("--threads", "-t", default=standard_threads, metavar="N", type=int,
-                      help="Number of threads that can be used by TrueConsense")
-    opts.add_argument("--noambiguity", "-noambig", action="store_true",
-                      help="Turn off ambiguity nucleotides in the generated consensus sequence")
-    opts.add_argument("--index-override", type=check_index_override, metavar="File",
-                      help="Override the positional index of certain genome positions with 'known' information if "
-                           "the given alignment is not sufficient for these positions\nMust be a compressed csv.\n"
-                           "Please use with caution as this will overwrite the generated index at the given "
-                           "positions!\n")
-    opts.add_argument("--version", "-v", action="version", version=__version__,
-                      help="Show the TrueConsense version and exit")
-    opts.add_argument("--help", "-h", action="help", default=argparse.SUPPRESS,
-                      help="Show this help message and exit")
-    extra = parser.add_argument_group("MI355X arguments (additive)")
-    extra.add_argument("--device", type=int, default=None, metavar="N", help="GPU ordinal (default: 0)")
-    extra.add_argument("--stats", type=str, default=None, metavar="File", help="Write stage timings as JSON")
+    bam_t = _file_arg(parser, (".bam",), ("Input file", "a BAM-file"), -1)
+    fasta_t = _file_arg(parser, (".fasta", ".fa"), ("Reference file", "a Fasta-file"), 1)
+    gff_t = _file_arg(parser, (".gff",), ("Given file", "a GFF file"), 1)
+    csvgz_t = _file_arg(parser, (".csv", ".gz"), ("Given file", "a compressed csv file"), 1, multi_suffix=True)
+    threads = min(multiprocessing.cpu_count(), 128)
+    #          flags                          keyword arguments
+    required = [
+        (("--input", "-i"), dict(type=bam_t, metavar="File", help="alignment to call the consensus from (BAM)")),
+        (("--output", "-o"), dict(type=str, default=os.getcwd() + "consensus.fasta", metavar="File",
+                                  help="where the consensus FASTA goes")),
+        (("--reference", "-ref"), dict(type=fasta_t, metavar="File", help="reference sequence (FASTA)")),
+        (("--features", "-gff"), dict(type=gff_t, metavar="File", help="genome features of the reference (GFF)")),
+        (("--coverage-level", "-cov"), dict(type=int, default=30, metavar="100",
+                                            help="minimum coverage for a position to be called")),
+        (("--samplename", "-name"), dict(metavar="Text", help="sample name, used in the FASTA header")),
+    ]
+    optional = [
+        (("--variants", "-vcf"), dict(type=str, metavar="File", help="also write a VCF")),
+        (("--depth-of-coverage", "-doc"), dict(type=str, metavar="File", help="also write position<TAB>coverage (TSV)")),
+        (("--output-gff", "-ogff"), dict(type=str, metavar="File", help="also write the corrected GFF")),
+        (("--threads", "-t"), dict(default=threads, metavar="N", type=int, help="host threads (BAM decoding, packing)")),
+        (("--noambiguity", "-noambig"), dict(action="store_true", help="no IUPAC ambiguity codes in the consensus")),
+        (("--index-override",), dict(type=csvgz_t, metavar="File",
+                                     help="gzipped CSV (position,coverage,A,T,C,G,X,I) whose rows replace the tallied\n"
+                                          "counts at those positions; use with caution")),
+        (("--version", "-v"), dict(action="version", version=__version__, help="print the version and exit")),
+        (("--help", "-h"), dict(action="help", default=argparse.SUPPRESS, help="print this help and exit")),
+    ]
+    additive = [
+        (("--device",), dict(type=int, default=None, metavar="N", help="GPU ordinal (default: 0)")),
+        (("--stats",), dict(type=str, default=None, metavar="File", help="write stage timings as JSON")),
+    ]
+    for title, rows, req in (("Required arguments", required, True), ("Optional arguments", optional, False),
+                             ("MI355X arguments (additive)", additive, False)):
+        group = parser.add_argument_group(title)
+        for flags, kw in rows:
+            if req:
+                kw["required"] = True
+            group.add_argument(*flags, **kw)
     return parser.parse_args(givenargs)
 
 

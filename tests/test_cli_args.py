@@ -26,7 +26,7 @@ def test_all_flags_parse(tmp_path):
     assert b.noambiguity is False and b.variants is None and b.coverage_level == 5
 
 
-def test_exit_codes_match_the_reference(tmp_path, capsys):
+def test_exit_codes_match_the_reference(tmp_path, capsys, monkeypatch):
     f = _files(tmp_path)
     base = ["-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "30", "-name", "S", "-o", "out.fa"]
     with pytest.raises(SystemExit) as e:                      # missing BAM: exit -1 (TrueConsense.py:34-35)
@@ -43,6 +43,7 @@ def test_exit_codes_match_the_reference(tmp_path, capsys):
         with pytest.raises(SystemExit) as e:
             cli.GetArgs(argv)
         assert e.value.code == 2
+    monkeypatch.setattr("sys.argv", ["TrueConsense"])
     with pytest.raises(SystemExit) as e:                      # no arguments at all: message + exit 1 (:216-220)
         cli.main([])
     assert e.value.code == 1

@@ -345,3 +345,21 @@ def test_fuzz_random_cigars_all_paths(ctx):
             assert np.array_equal(got, want), (rep, variant, project, np.argwhere(got != want)[:5])
     ctx.set_option("tally_variant", 0)
     ctx.set_option("project_reads", 1)
+
+
+def test_long_reference_sparse_reads(ctx):
+    """A 5 Mb reference with a few thousand scattered reads: one-read chunks, a large matrix, the call
+    kernel and the host walk over millions of positions."""
+    from tests import fuzz_reads as fz
+    rng = np.random.default_rng(7)
+    L = 5_000_000
+    reads = fz.random_reads(rng, 3000, L, long_reads=True)
+    want = c_oracle.tally(reads, L)
+    rs = ctx.upload(reads)
+    plain, alt, flags, counts = ctx.step(rs, L, 1, True)
+    rs.free()
+    assert np.array_equal(counts, want)
+    wp, wa, wf = c_oracle.call(want, 1, True)
+    assert np.array_equal(plain, wp) and np.array_equal(alt, wa) and np.array_equal(flags, wf)
+    cons, ns, ne = engine.consensus_walk(plain, alt, flags, [10, 2_000_000], [1_000_000, 4_999_990], [1, 1], [], [], [], True)
+    assert len(cons) == L and cons.count("-") > 0

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the pileup-tally + base-calling hot path on MI355X.
 
-A "step" = one pass of the hot path over one synthetic 1M-read x 29 903-bp BAM whose reads
-are already resident in HBM: zero the count matrix, HIP tally kernel, HIP call kernel, copy
-the call records (3 bytes / position) to pinned host memory, native host consensus walk to the
-FASTA sequence.  Metric: reference positions per second (BASELINE.json), whole job.
+A "step" = one pass of the hot path over one batch of synthetic input: `--batch` (default 4)
+independent BAMs of BASELINE configs[1] (1M reads x 29 903 bp each) whose reads are already resident in
+HBM as ONE read set (BAM b at positions shifted by b * 29 952), so one HIP tally launch and one HIP call
+launch process the batch; the call kernel stores the call records (3 bytes / position) in pinned host
+memory and zeroes the count matrix behind itself; native host threads walk each BAM's records to its
+consensus sequence (the FASTA content).  Metric: reference positions per second (BASELINE.json), whole job.
+The same BAMs one per launch are measured right after and reported as "single_bam_per_launch".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--reads R] [--no-cpu-baseline]
 
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank
 processes its own independent BAMs (BASELINE config 4: many-BAM shard, no data-path
@@ -72,10 +75,10 @@ def cpu_baseline(reads, L, mincov, orfs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--reads", type=int, default=1_000_000)
-    ap.add_argument("--bams", type=int, default=4, help="distinct resident BAMs cycled through per rank")
+    ap.add_argument("--bams", type=int, default=2, help="distinct resident read sets (each --batch BAMs) cycled through per rank")
     ap.add_argument("--mincov", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-only", action="store_true", help="leave the host consensus walk out of the step")
@@ -85,6 +88,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option on every workspace (diagnostic)")
+    ap.add_argument("--batch", type=int, default=4, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
     ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
@@ -123,62 +127,89 @@ def main():
         k, v = kv.split("=")
         for c in ctxs:
             c.set_option(k, int(v))
-    readsets, host_reads0, all_reads = [], None, []
+    readsets, host_reads0, all_reads, group0 = [], None, [], []
+    B = max(1, a.batch)
+    pos_stride = (L + 255) // 256 * 256
     for b in range(a.bams):
-        reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b + 1,
-                              indel_sites=sy.default_indel_sites(orfs) if a.indels else None)
-        all_reads.append(reads if a.indels else None)
-        if b == 0:
-            host_reads0 = reads
-        readsets.append(ctx.upload(reads))
-        if b and not a.indels:
-            del reads
+        group = []
+        for k in range(B):
+            reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b * B + k + 1,
+                                  indel_sites=sy.default_indel_sites(orfs) if a.indels else None)
+            if host_reads0 is None:
+                host_reads0 = reads
+            if b == 0:
+                group0.append(reads)
+            group.append(reads)
+            all_reads.append(reads if a.indels else None)
+        readsets.append(ctx.upload(group[0]) if B == 1 else ctx.upload_batch(group, pos_stride))
+        del group
     alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
-    alg_tally = alg_reads + 28 * L                              # + one write of the [L,7] int32 matrix
+    alg_tally = alg_reads + 28 * L * B                          # + one write of the [L,7] int32 matrix per BAM
     pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
     walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
 
-    def run(n_steps):
-        """n_steps BAMs to consensus; returns the last consensus."""
-        if n_steps <= 0:
-            return None
-        if a.serial or a.gpu_only:
-            cons = None
-            for i in range(n_steps):
-                plain, alt, flags, _ = ctx.step(readsets[i % len(readsets)], L, a.mincov, True, want_counts=False)
-                if not a.gpu_only:
-                    cons = walker(plain, alt, flags)[0]
-            return cons
-        out, _ = pipe.run([readsets[i % len(readsets)] for i in range(n_steps)], L, a.mincov, True,
-                          host_reads=[all_reads[i % len(readsets)] for i in range(n_steps)] if a.indels else None, extra=4096)
-        return out[-1]
+    def measure(rsets, B, n_steps, n_warm, hreads):
+        """n_steps steps of B BAMs each over the read sets `rsets`; -> (seconds, last consensus, kernel times)."""
+        def run(n):
+            if n <= 0:
+                return None
+            if a.serial or a.gpu_only:
+                cons = None
+                for i in range(n):
+                    Lg = L if B == 1 else B * pos_stride
+                    plain, alt, flags, _ = ctx.step(rsets[i % len(rsets)], Lg, a.mincov, True, want_counts=False)
+                    if not a.gpu_only:
+                        for k in range(B):
+                            o = k * pos_stride
+                            cons = walker(plain[o:o + L], alt[o:o + L], flags[o:o + L])[0]
+                return cons
+            hr = None
+            if a.indels:
+                hr = [hreads[(i % len(rsets)) * B + k] for i in range(n) for k in range(B)]
+            out, _ = pipe.run([rsets[i % len(rsets)] for i in range(n)], L, a.mincov, True,
+                              host_reads=hr, extra=4096 if a.indels else 64, batch=B, pos_stride=pos_stride)
+            return out[-1]
 
-    def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def fence():
+            ctx.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    run(a.warmup)
-    for c in ([] if a.no_kernel_events else ctxs):
-        c.set_option("profile_every", a.profile_every)
-        c.profile(True)                                         # HIP events around every kernel, on the pipeline's stream
-    fence()
-    t0 = time.perf_counter()
-    cons = run(a.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    tally_ms = tally_n = call_ms = call_n = zero_ms = gen_ms = gen_n = 0
-    for c in ctxs:
-        m, n = c.profile_get(_ffi.K_TALLY)
-        tally_ms, tally_n = tally_ms + m, tally_n + n
-        m, n = c.profile_get(_ffi.K_CALL)
-        call_ms, call_n = call_ms + m, call_n + n
-        zero_ms += c.profile_get(_ffi.K_ZERO)[0]
-        m, n = c.profile_get(_ffi.K_TALLY_GENERAL)
-        gen_ms, gen_n = gen_ms + m, gen_n + n
-        c.profile(False)
+        run(n_warm)
+        for c in ([] if a.no_kernel_events else ctxs):
+            c.set_option("profile_every", a.profile_every)
+            c.profile(True)                                     # HIP events around the kernels, on the pipeline's stream
+        fence()
+        t0 = time.perf_counter()
+        cons = run(n_steps)
+        fence()
+        dt = time.perf_counter() - t0
+        k = {"tally_ms": 0.0, "tally_n": 0, "call_ms": 0.0, "call_n": 0, "gen_ms": 0.0, "gen_n": 0}
+        for c in ctxs:
+            for name, kid in (("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL), ("gen", _ffi.K_TALLY_GENERAL)):
+                m, n = c.profile_get(kid)
+                k[name + "_ms"] += m
+                k[name + "_n"] += n
+            c.profile(False)
+        return dt, cons, k
+
+    dt, cons, k = measure(readsets, B, a.steps, a.warmup, all_reads)
+    tally_ms, tally_n, call_ms, call_n, gen_ms, gen_n, zero_ms = (k["tally_ms"], k["tally_n"], k["call_ms"], k["call_n"],
+                                                                  k["gen_ms"], k["gen_n"], 0.0)
+    single = None
+    if world == 1 and B > 1 and not a.indels and not (a.serial or a.gpu_only):
+        # the same BAMs one per launch (plain BASELINE configs[1] shape), for comparison
+        srs = [ctx.upload(r) for r in group0]
+        dt1, _, k1 = measure(srs, 1, max(100, a.steps), a.warmup, None)
+        us1 = 1e3 * k1["tally_ms"] / max(1, k1["tally_n"])
+        alg1 = srs[0].algorithmic_bytes + 28 * L
+        single = {"value": L * max(100, a.steps) / dt1, "unit": "positions/s", "ms_per_step": 1e3 * dt1 / max(100, a.steps),
+                  "tally_us": us1, "roofline_frac": (alg1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS) if us1 > 0 else None,
+                  "algorithmic_bytes_per_launch": alg1}
+        for r in srs:
+            r.free()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,21 +222,22 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")      # PMC passes are separate runs (see profiles/README)
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch") * B      # measured per 1M-read BAM
             except Exception:
                 traffic = None
         out = {
             "metric": "reference positions/sec (1M reads x 29 903 bp per BAM, reads resident in HBM, BAM -> consensus)",
-            "value": L * a.steps * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps,
+            "value": L * a.steps * B * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32 tallies, f64 thresholds", "data": "synthetic",
-            "bams_per_min": 60.0 * a.steps * world / dt,
+            "bams_per_min": 60.0 * a.steps * B * world / dt,
             "config": {"workload": "BASELINE configs[1]: 29 903-bp reference, %d synthetic 150-bp reads per BAM "
-                                   "(~%dx coverage), %d distinct BAMs resident per GPU, one BAM per step%s"
-                                   % (a.reads, a.reads * 150 // L, a.bams,
+                                   "(~%dx coverage), %d distinct BAMs resident per GPU, %d BAM(s) per step and launch%s"
+                                   % (a.reads, a.reads * 150 // L, a.bams * B, B,
                                       "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
                        "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
-                       "step": "memset + tally kernel + call kernel + D2H records" + ("" if a.gpu_only else " + host consensus walk"),
+                       "step": "tally kernel + call kernel (zeroes the matrix behind itself, stores its records in pinned host memory)"
+                               + ("" if a.gpu_only else " + host consensus walk per BAM"),
                        "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
                                   "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},
             "kernels_us": {"tally_general": 1e3 * gen_ms / max(1, gen_n), "tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
@@ -215,6 +247,8 @@ def main():
         }
         if not a.gpu_only:
             out["consensus_len"] = len(cons) if cons is not None else 0
+        if single is not None:
+            out["single_bam_per_launch"] = single
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_reads0, L, a.mincov, orfs)
             out["cpu_baseline"]["cores_on_box"] = os.cpu_count()

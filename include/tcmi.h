@@ -121,6 +121,12 @@ int tcmi_reads_extent(const tcmi_reads *reads, int64_t ref_len, int64_t *out_L);
 /* Copy reads into HBM in the kernel's layout (SoA headers, CIGAR stream, 4-bit SEQ
  * stream in linear nibble order padded to 4 bytes per read).                     */
 int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *reads, tcmi_readset **out);
+/* Several BAMs in ONE read set (BASELINE configs[3], many independent BAMs): BAM b's positions are
+ * shifted by b * stride (a multiple of 256, >= the extent of every BAM), so one tally launch and one
+ * call launch process the whole batch over n * stride positions; BAM b's counts / records are the
+ * slice [b * stride, b * stride + L) of every plane.                                             */
+int tcmi_readset_upload_batch(tcmi_ctx *ctx, const tcmi_reads *const *reads, int32_t n, int64_t stride,
+                              tcmi_readset **out);
 int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs);
 int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled,
                       int64_t *algorithmic_bytes, int64_t *device_bytes, int64_t *max_end);
@@ -231,6 +237,12 @@ tcmi_ctx *tcmi_pipeline_ctx(tcmi_pipeline *p, int slot);   /* slot contexts (upl
 int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets,
                       const tcmi_reads *const *host_reads, int64_t L, int32_t mincov, int include_ambig,
                       char *out_cons, int64_t stride, int64_t *out_len, int32_t *status);
+/* The same over BATCHED read sets (tcmi_readset_upload_batch with `batch` BAMs at `pos_stride`):
+ * item i yields consensus i*batch .. i*batch + batch - 1 (host_reads, out_len, status likewise).   */
+int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets,
+                              int32_t batch, int64_t pos_stride, const tcmi_reads *const *host_reads,
+                              int64_t L, int32_t mincov, int include_ambig, char *out_cons,
+                              int64_t stride, int64_t *out_len, int32_t *status);
 
 /* ---- BAM reader (pysam's role; SAM spec §4.2), HOST, zlib inflate -------- */
 typedef struct tcmi_bam tcmi_bam;

@@ -363,3 +363,33 @@ def test_long_reference_sparse_reads(ctx):
     assert np.array_equal(plain, wp) and np.array_equal(alt, wa) and np.array_equal(flags, wf)
     cons, ns, ne = engine.consensus_walk(plain, alt, flags, [10, 2_000_000], [1_000_000, 4_999_990], [1, 1], [], [], [], True)
     assert len(cons) == L and cons.count("-") > 0
+
+
+def test_batched_readset_and_pipeline(ctx):
+    """Several BAMs in one read set at shifted positions: one tally launch and one call launch for the
+    batch; every BAM's slice must equal what it gives on its own, through ctx.step and the pipeline."""
+    from trueconsense_amd.engine import Pipeline
+    ref, orfs = sy.make_reference(L=5000, cds=[(100, 2400), (2600, 4800)])
+    L, stride = len(ref), 5120
+    sites = [(700, "I", "GT", 0.8), (1500, "D", 3, 0.9), (3000, "D", 2, 0.6)]
+    bams = [sy.make_reads(ref, 12_000 + 1000 * k, seed=50 + k, indel_sites=sites if k % 2 == 0 else None) for k in range(5)]
+    pipe = Pipeline(0, slots=2, walkers=3)
+    pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    single = [pipe.ctx.upload(r) for r in bams]
+    want_counts = [c_oracle.tally(r, L) for r in bams]
+    want_cons, _ = pipe.run(single, L, 30, True, host_reads=bams)
+    # batch of 3 + batch of 2 (different sizes: two read sets, run separately)
+    for group in ([0, 1, 2], [3, 4]):
+        rs = pipe.ctx.upload_batch([bams[i] for i in group], stride)
+        plain, alt, flags, counts = pipe.ctx.step(rs, len(group) * stride, 30, True)
+        for k, i in enumerate(group):
+            assert np.array_equal(counts[k * stride:k * stride + L], want_counts[i]), i
+            assert not counts[k * stride + L:(k + 1) * stride].any()
+        out, status = pipe.run([rs, rs], L, 30, True, host_reads=[bams[i] for i in group] * 2, batch=len(group),
+                               pos_stride=stride)
+        assert not status.any()
+        assert out == [want_cons[i] for i in group] * 2
+        rs.free()
+    with pytest.raises(_ffi.TcmiError):
+        pipe.ctx.upload_batch(bams[:2], 1024)                       # stride smaller than the reads' extent
+    pipe.close()

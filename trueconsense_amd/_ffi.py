@@ -54,6 +54,7 @@ _SIGS = {
     "tcmi_profile_get": (_int, [_vp, _int, _P(C.c_double), _P(_i64)]),
     "tcmi_reads_extent": (_int, [_P(Reads), _i64, _P(_i64)]),
     "tcmi_readset_upload": (_int, [_vp, _P(Reads), _P(_vp)]),
+    "tcmi_readset_upload_batch": (_int, [_vp, _vp, _i32, _i64, _P(_vp)]),
     "tcmi_readset_free": (_int, [_vp, _vp]),
     "tcmi_readset_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "tcmi_readset_sets": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64)]),
@@ -74,6 +75,7 @@ _SIGS = {
     "tcmi_pipeline_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "tcmi_pipeline_ctx": (_vp, [_vp, _int]),
     "tcmi_pipeline_run": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _vp, _i64, _vp, _vp]),
+    "tcmi_pipeline_run_batched": (_int, [_vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _int, _vp, _i64, _vp, _vp]),
     "tcmi_bam_load": (_int, [C.c_char_p, _int, _P(_vp)]),
     "tcmi_bam_free": (_int, [_vp]),
     "tcmi_bam_reads": (_int, [_vp, _P(Reads)]),

@@ -27,7 +27,10 @@ struct tcmi_pipeline {
     std::vector<int64_t> orf_start, orf_end;
     std::vector<uint8_t> orf_plus;
     // walker pool
-    struct Job { int slot; int64_t item; };
+    struct Job { int slot; int64_t item; int b; };
+    std::vector<int> slot_jobs;                     // walk jobs still open per slot (a batched item has several)
+    int batch = 1;
+    int64_t pos_stride = 0;
     std::deque<Job> jobs;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
@@ -61,11 +64,13 @@ bool parse_token(const char *t, int64_t n, int *size_digit, const char **bases, 
     return false;
 }
 
-int walk_item(tcmi_pipeline *p, int slot, int64_t item)
+int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
 {
+    const int64_t item = item_in * p->batch + b;               // output index
+    const int64_t shift = (int64_t)b * p->pos_stride;           // BAM b's slice of every record plane
     tcmi_ctx *c = p->slots[(size_t)slot];
     const int64_t L = p->L, ld = c->ws_ld;
-    const uint8_t *plain = c->h_rec, *alt = c->h_rec + ld, *flags = c->h_rec + 2 * ld;
+    const uint8_t *plain = c->h_rec + shift, *alt = c->h_rec + ld + shift, *flags = c->h_rec + 2 * ld + shift;
     // insert candidates (Events.py:29-36 evaluated by the call kernel) -> accepted inserts
     std::vector<int64_t> cand;
     for (int64_t i = 0; i < L; ++i)
@@ -124,11 +129,11 @@ void worker_main(tcmi_pipeline *p)
             job = p->jobs.front();
             p->jobs.pop_front();
         }
-        const int rc = walk_item(p, job.slot, job.item);
+        const int rc = walk_item(p, job.slot, job.item, job.b);
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            if (p->status) p->status[job.item] = rc;
-            p->slot_busy[(size_t)job.slot] = 0;
+            if (p->status) p->status[job.item * p->batch + job.b] = rc;
+            if (--p->slot_jobs[(size_t)job.slot] == 0) p->slot_busy[(size_t)job.slot] = 0;
             --p->jobs_open;
         }
         p->cv_done.notify_all();
@@ -157,6 +162,7 @@ int tcmi_pipeline_create(int device, int n_slots, int n_walkers, tcmi_pipeline *
         p->slots.push_back(c);
     }
     p->slot_busy.assign((size_t)n_slots, 0);
+    p->slot_jobs.assign((size_t)n_slots, 0);
     for (int w = 0; w < n_walkers; ++w) p->workers.emplace_back(worker_main, p);
     *out = p;
     return TCMI_OK;
@@ -190,12 +196,17 @@ tcmi_ctx *tcmi_pipeline_ctx(tcmi_pipeline *p, int slot)
     return (p && slot >= 0 && slot < (int)p->slots.size()) ? p->slots[(size_t)slot] : nullptr;
 }
 
-int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets,
-                      const tcmi_reads *const *host_reads, int64_t L, int32_t mincov, int include_ambig,
-                      char *out_cons, int64_t stride, int64_t *out_len, int32_t *status)
+int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets, int32_t batch,
+                              int64_t pos_stride, const tcmi_reads *const *host_reads, int64_t L, int32_t mincov,
+                              int include_ambig, char *out_cons, int64_t stride, int64_t *out_len, int32_t *status)
 {
     if (!p || n_items < 0 || (n_items > 0 && (!readsets || !out_cons || !out_len || !status)) || stride < L + 1)
         return tcmi_fail(nullptr, TCMI_E_ARG, "bad argument (stride must be >= L + 1 + inserted bases)");
+    if (batch < 1 || (batch > 1 && (pos_stride < L || pos_stride % 256)))
+        return tcmi_fail(nullptr, TCMI_E_ARG, "bad batch / position stride");
+    p->batch = batch;
+    p->pos_stride = batch > 1 ? pos_stride : 0;
+    const int64_t L_gpu = batch > 1 ? (int64_t)batch * pos_stride : L;   // positions one step covers
     p->L = L; p->host_reads = host_reads; p->out = out_cons; p->stride = stride; p->out_len = out_len; p->status = status;
     const int n_slots = (int)p->slots.size();
     int64_t submitted = 0;
@@ -212,10 +223,9 @@ int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *con
                 }
                 p->slot_busy[(size_t)slot] = 1;
             }
-            const int rc = tcmi_step_begin(p->slots[(size_t)slot], readsets[submitted], L, mincov, include_ambig, 0);
+            const int rc = tcmi_step_begin(p->slots[(size_t)slot], readsets[submitted], L_gpu, mincov, include_ambig, 0);
             if (rc) {
-                status[submitted] = rc;
-                out_len[submitted] = 0;
+                for (int b = 0; b < batch; ++b) { status[submitted * batch + b] = rc; out_len[submitted * batch + b] = 0; }
                 if (!first_err) { first_err = rc; p->err = tcmi_last_error(p->slots[(size_t)slot]); }
                 std::lock_guard<std::mutex> lk(p->mu);
                 p->slot_busy[(size_t)slot] = 2;                  // nothing queued for this item
@@ -232,8 +242,7 @@ int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *con
         if (!queued) continue;
         const int rc = tcmi_step_end(p->slots[(size_t)slot], nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc) {
-            status[waited] = rc;
-            out_len[waited] = 0;
+            for (int b = 0; b < batch; ++b) { status[waited * batch + b] = rc; out_len[waited * batch + b] = 0; }
             if (!first_err) { first_err = rc; p->err = tcmi_last_error(p->slots[(size_t)slot]); }
             std::lock_guard<std::mutex> lk(p->mu);
             p->slot_busy[(size_t)slot] = 0;
@@ -241,19 +250,28 @@ int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *con
         }
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            p->jobs.push_back({slot, waited});
-            ++p->jobs_open;
+            p->slot_jobs[(size_t)slot] = batch;
+            for (int b = 0; b < batch; ++b) p->jobs.push_back({slot, waited, b});
+            p->jobs_open += batch;
         }
-        p->cv_job.notify_one();
+        p->cv_job.notify_all();
     }
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->cv_done.wait(lk, [&] { return p->jobs_open == 0; });
     }
     if (first_err) return tcmi_fail(nullptr, first_err, "%s", p->err.c_str());
-    for (int64_t i = 0; i < n_items; ++i)
+    for (int64_t i = 0; i < n_items * batch; ++i)
         if (status[i]) return tcmi_fail(nullptr, status[i], "item %lld: the consensus walk failed (status %d)", (long long)i, status[i]);
     return TCMI_OK;
+}
+
+int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *const *readsets,
+                      const tcmi_reads *const *host_reads, int64_t L, int32_t mincov, int include_ambig,
+                      char *out_cons, int64_t stride, int64_t *out_len, int32_t *status)
+{
+    return tcmi_pipeline_run_batched(p, n_items, readsets, 1, 0, host_reads, L, mincov, include_ambig, out_cons, stride,
+                                     out_len, status);
 }
 
 } // extern "C"

@@ -138,12 +138,19 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
     return TCMI_OK;
 }
 
-int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
+// One or several BAMs into one read set; BAM b's positions are shifted by b * stride, so that the
+// kernels see one long coordinate axis and a single launch tallies the whole batch.
+static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_batch, int64_t stride, tcmi_readset **out)
 {
-    if (!ctx || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (!ctx || !out || !batch || n_batch < 1) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     *out = nullptr;
-    int rc = check_reads(ctx, r);
-    if (rc) return rc;
+    int rc = TCMI_OK;
+    int64_t n_reads_in = 0;
+    for (int32_t b = 0; b < n_batch; ++b) {
+        rc = check_reads(ctx, batch[b]);
+        if (rc) return rc;
+        n_reads_in += batch[b]->n_reads;
+    }
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     const bool use_fast = ctx->tally_variant != 1;
     const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
@@ -154,10 +161,14 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     const auto t0 = now();
 
     // pass 1: select, classify, size
-    struct Sel { int64_t i, y0, len; bool projected; };
+    struct Sel { const tcmi_reads *r; int64_t i, off, y0, len; bool projected; };
+    struct GSel { const tcmi_reads *r; int64_t i, off; };
     std::vector<Sel> fsel;                  // aligned set (len > 0)
-    std::vector<int64_t> gsel;              // general set
+    std::vector<GSel> gsel;                 // general set
     int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
+    for (int32_t bi = 0; bi < n_batch; ++bi) {
+    const tcmi_reads *r = batch[bi];
+    const int64_t off = (int64_t)bi * stride;
     for (int64_t i = 0; i < r->n_reads; ++i) {
         int64_t span;
         if (!piles_up(r, i, &span)) continue;
@@ -170,15 +181,19 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
         const int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
         if (nbytes < (lq + 1) / 2)
             return tcmi_fail(ctx, TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)", (long long)i, (long long)nbytes);
-        if (span > INT32_MAX || r->pos[i] + span > INT32_MAX - 4096)
+        if (n_batch > 1 && r->pos[i] + span > stride)
+            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld of BAM %d ends at %lld, beyond the batch stride %lld", (long long)i, bi,
+                             (long long)(r->pos[i] + span), (long long)stride);
+        if (span > INT32_MAX || off + r->pos[i] + span > INT32_MAX - 4096)
             return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31", (long long)i);
         alg += 12 + 4 * nc + (lq + 1) / 2;
-        if (r->pos[i] + span > max_end) max_end = r->pos[i] + span;
+        if (off + r->pos[i] + span > max_end) max_end = off + r->pos[i] + span;
         int64_t y0, len;
-        if (use_fast && r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({i, y0, len, false});
-        else if (use_fast && ctx->project_reads && span <= TCMI_F_MAXSPAN && r->pos[i] + span < TCMI_F_EVPOS)
-            fsel.push_back({i, 0, span, true});               // any CIGAR, projected onto the reference
-        else { gsel.push_back(i); g_cig += nc; g_seqw += (lq + 7) / 8; }
+        if (use_fast && off + r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({r, i, off, y0, len, false});
+        else if (use_fast && ctx->project_reads && span <= TCMI_F_MAXSPAN && off + r->pos[i] + span < TCMI_F_EVPOS)
+            fsel.push_back({r, i, off, 0, span, true});       // any CIGAR, projected onto the reference
+        else { gsel.push_back({r, i, off}); g_cig += nc; g_seqw += (lq + 7) / 8; }
+    }
     }
 
     const auto t1 = now();
@@ -219,7 +234,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
             c_n = 0;
         };
         for (int64_t j = 0; j < nf; ++j) {
-            const int64_t p = r->pos[fsel[(size_t)j].i], e = p + fsel[(size_t)j].len;
+            const int64_t p = fsel[(size_t)j].r->pos[fsel[(size_t)j].i] + fsel[(size_t)j].off, e = p + fsel[(size_t)j].len;
             const int64_t lo = p & ~(int64_t)7, nw = (fsel[(size_t)j].len + 7) / 8;
             if (c_n > 0) {
                 const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e), nmax = std::max(c_maxnw, nw);
@@ -255,6 +270,8 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                 size_t cursor = (size_t)c.word0 + (size_t)PAD;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
+                const tcmi_reads *r = s.r;
+                const int64_t rpos = r->pos[s.i] + s.off;
                 const uint8_t *src = r->seq + r->seq_off[s.i];
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
@@ -286,9 +303,9 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                                 }
                             } else if (op == 2) {
                                 for (int64_t t = 0; t < (ins ? len - 1 : len); ++t)
-                                    ev.push_back((uint32_t)(r->pos[s.i] + x + t) | TCMI_F_EV_X);
+                                    ev.push_back((uint32_t)(rpos + x + t) | TCMI_F_EV_X);
                             }
-                            if (ins) ev.push_back((uint32_t)(r->pos[s.i] + x + len - 1) | TCMI_F_EV_I);
+                            if (ins) ev.push_back((uint32_t)(rpos + x + len - 1) | TCMI_F_EV_I);
                             x += len;
                         }
                         if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
@@ -316,7 +333,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                     uint32_t miss = want & ~nz;
                     while (miss) {
                         const int bit = __builtin_ctz(miss);
-                        ev.push_back((uint32_t)(r->pos[s.i] + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
+                        ev.push_back((uint32_t)(rpos + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
                         miss &= miss - 1;
                     }
                 }
@@ -343,11 +360,12 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     std::vector<int64_t> h_rc((size_t)n_rounds + 1), h_rs((size_t)n_rounds + 1);
     int64_t co = 0, so = 0;
     for (int64_t j = 0; j < ng; ++j) {
-        const int64_t i = gsel[(size_t)j];
+        const tcmi_reads *r = gsel[(size_t)j].r;
+        const int64_t i = gsel[(size_t)j].i;
         if (j % TCMI_ROUND == 0) { h_rc[(size_t)(j / TCMI_ROUND)] = co; h_rs[(size_t)(j / TCMI_ROUND)] = so; }
         const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
         const int64_t lq = r->l_qseq[i];
-        h_pos[(size_t)j] = r->pos[i];
+        h_pos[(size_t)j] = (int32_t)(r->pos[i] + gsel[(size_t)j].off);
         h_lseq[(size_t)j] = (int32_t)lq;
         h_meta[(size_t)j] = ((uint32_t)r->flag[i] << 16) | (uint32_t)nc;
         std::memcpy(&h_cig[(size_t)co], r->cigar + r->cigar_off[i], (size_t)nc * 4);
@@ -367,7 +385,7 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
     const auto t3 = now();
     tcmi_readset *rs = new tcmi_readset();
     rs->uid = next_uid.fetch_add(1);
-    rs->n_reads = r->n_reads; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
+    rs->n_reads = n_reads_in; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
     rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
@@ -395,6 +413,17 @@ int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
                      ms(t0, t1), ms(t1, t2), ctx->host_threads, ms(t2, t3), ms(t3, now()), rs->dev_bytes / 1e6);
     *out = rs;
     return TCMI_OK;
+}
+
+int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset **out)
+{
+    return upload_impl(ctx, &r, 1, 0, out);
+}
+
+int tcmi_readset_upload_batch(tcmi_ctx *ctx, const tcmi_reads *const *reads, int32_t n, int64_t stride, tcmi_readset **out)
+{
+    if (n < 1 || n > 4096 || stride <= 0 || stride % 256) return tcmi_fail(ctx, TCMI_E_ARG, "need 1 <= n <= 4096 and a positive stride that is a multiple of 256");
+    return upload_impl(ctx, reads, n, stride, out);
 }
 
 int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled, int64_t *alg, int64_t *dev,

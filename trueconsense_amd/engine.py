@@ -95,6 +95,18 @@ class Context:
         check(lib().tcmi_readset_upload(self.handle, C.byref(r), C.byref(h)), self.handle)
         return ReadSet(self, h, keep)
 
+    def upload_batch(self, reads_list, stride):
+        """Several BAMs in one read set: BAM b's positions are shifted by b * stride (multiple of 256)."""
+        structs, keep = [], []
+        for r in reads_list:
+            st, k = r.as_struct() if isinstance(r, BamFile) else _ffi.as_reads(r)
+            structs.append(st)
+            keep.append(k)
+        arr = (C.POINTER(_ffi.Reads) * len(structs))(*[C.pointer(s) for s in structs])
+        h = C.c_void_p()
+        check(lib().tcmi_readset_upload_batch(self.handle, arr, len(structs), int(stride), C.byref(h)), self.handle)
+        return ReadSet(self, h, (keep, structs))
+
     def tally(self, reads, L=None, ref_len=0):
         """reads -> int32 [L,7] (coverage,A,T,C,G,X,I); L defaults to max(ref_len, read extent)."""
         r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
@@ -215,10 +227,13 @@ class Pipeline:
         p_ = np.ascontiguousarray(is_plus, np.uint8)
         check(lib().tcmi_pipeline_set_orfs(self.handle, len(s_), ptr(s_), ptr(e_), ptr(p_)))
 
-    def run(self, readsets, L, mincov, include_ambig, host_reads=None, extra=4096):
-        """-> (list of consensus bytes, int32 status array).  Raises on the first failed item."""
-        n = len(readsets)
-        rs = (C.c_void_p * n)(*[r.handle for r in readsets])
+    def run(self, readsets, L, mincov, include_ambig, host_reads=None, extra=4096, batch=1, pos_stride=0):
+        """-> (list of consensus bytes, int32 status array).  Raises on the first failed item.
+        batch > 1: every read set holds `batch` BAMs (Context.upload_batch at `pos_stride`); the outputs
+        (and host_reads) are then per BAM, item-major."""
+        n_items = len(readsets)
+        rs = (C.c_void_p * n_items)(*[r.handle for r in readsets])
+        n = n_items * int(batch)
         keep, hr = [], None
         if host_reads is not None:
             structs = []
@@ -232,8 +247,8 @@ class Pipeline:
         out = np.empty(n * stride, np.uint8)
         lens = np.zeros(n, np.int64)
         status = np.zeros(n, np.int32)
-        rc = lib().tcmi_pipeline_run(self.handle, n, rs, hr, int(L), int(mincov), int(bool(include_ambig)), ptr(out),
-                                     stride, ptr(lens), ptr(status))
+        rc = lib().tcmi_pipeline_run_batched(self.handle, n_items, rs, int(batch), int(pos_stride), hr, int(L), int(mincov),
+                                             int(bool(include_ambig)), ptr(out), stride, ptr(lens), ptr(status))
         self.last_status = status
         check(rc)
         return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(n)], status

@@ -7,7 +7,8 @@ HBM as ONE read set (BAM b at positions shifted by b * 29 952), so one HIP tally
 launch process the batch; the call kernel stores the call records (3 bytes / position) in pinned host
 memory and zeroes the count matrix behind itself; native host threads walk each BAM's records to its
 consensus sequence (the FASTA content).  Metric: reference positions per second (BASELINE.json), whole job.
-The same BAMs one per launch are measured right after and reported as "single_bam_per_launch".
+`--also-single` measures the same BAMs one per launch afterwards ("single_bam_per_launch"); `--batch 1`
+makes that the primary measurement.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--reads R] [--no-cpu-baseline]
 
@@ -88,6 +89,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option on every workspace (diagnostic)")
+    ap.add_argument("--also-single", action="store_true", help="afterwards also measure the same BAMs one per launch (adds a second launch shape)")
     ap.add_argument("--batch", type=int, default=4, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
     ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
@@ -199,7 +201,7 @@ def main():
     tally_ms, tally_n, call_ms, call_n, gen_ms, gen_n, zero_ms = (k["tally_ms"], k["tally_n"], k["call_ms"], k["call_n"],
                                                                   k["gen_ms"], k["gen_n"], 0.0)
     single = None
-    if world == 1 and B > 1 and not a.indels and not (a.serial or a.gpu_only):
+    if a.also_single and world == 1 and B > 1 and not a.indels and not (a.serial or a.gpu_only):
         # the same BAMs one per launch (plain BASELINE configs[1] shape), for comparison
         srs = [ctx.upload(r) for r in group0]
         dt1, _, k1 = measure(srs, 1, max(100, a.steps), a.warmup, None)

@@ -1,8 +1,6 @@
 """Random reads with arbitrary CIGARs (every op of SAM spec §4.2: M I D N S H P = X), odd SEQ
 content (N, IUPAC codes, '=', SEQ '*'), flags and placements — for differential tests between
 the column-major Python emulator, the read-major C oracle and the HIP kernels."""
-import numpy as np
-
 from tests import synth_small as ss
 
 _BASES = "ACGT"

@@ -14,7 +14,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _ffi
 from ._ffi import check, lib
 
 

@@ -84,7 +84,6 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
     __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged bases; later the slice partials
     __shared__ __attribute__((aligned(8))) uint2 s_hdr[TCMI_F_SUB + 1];      // {pos - P0 | words << 16, byte offset in s_seq}
     __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
-    __shared__ uint16_t s_fin[3][MAXPOS];                                     // window counters of A, C, G
     __shared__ int s_scan[FB / 64];
     static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
 
@@ -266,6 +265,10 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
 #endif
     // ---- slice partials -> LDS, layout [register j][lane] (conflict-free both ways) -----------------
     uint32_t *s_part = s_seq;
+    // window counters of A, C, G (16-bit), behind the partials in the same buffer: 34 -> 30 KB of LDS per
+    // workgroup, i.e. five workgroups per CU instead of four
+    uint16_t (*s_fin)[MAXPOS] = reinterpret_cast<uint16_t (*)[MAXPOS]>(s_seq + NREG * FB);
+    static_assert((NREG * FB + 3 * MAXPOS / 2) <= TCMI_F_SEQCAP, "partials and window counters must fit the stage buffer");
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll

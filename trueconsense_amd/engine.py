@@ -236,13 +236,18 @@ class Pipeline:
         n = n_items * int(batch)
         keep, hr = [], None
         if host_reads is not None:
-            structs = []
+            by_id = {}                                   # the same reads object may back many items: convert it once
+            ptrs = []
             for r in host_reads:
-                st, k = r.as_struct() if isinstance(r, BamFile) else _ffi.as_reads(r)
-                structs.append(st)
-                keep.append(k)
-            hr = (C.POINTER(_ffi.Reads) * n)(*[C.pointer(s) for s in structs])
-            keep.append(structs)
+                if r is None:
+                    ptrs.append(None)
+                    continue
+                if id(r) not in by_id:
+                    st, k = r.as_struct() if isinstance(r, BamFile) else _ffi.as_reads(r)
+                    by_id[id(r)] = (st, k, C.pointer(st))
+                ptrs.append(by_id[id(r)][2])
+            hr = (C.POINTER(_ffi.Reads) * n)(*ptrs)
+            keep.append(by_id)
         stride = int(L) + 1 + int(extra)
         out = np.empty(n * stride, np.uint8)
         lens = np.zeros(n, np.int64)

@@ -393,3 +393,31 @@ def test_batched_readset_and_pipeline(ctx):
     with pytest.raises(_ffi.TcmiError):
         pipe.ctx.upload_batch(bams[:2], 1024)                       # stride smaller than the reads' extent
     pipe.close()
+
+
+def test_mid_size_consensus_against_the_oracle_chain(ctx):
+    """BAM-shaped reads -> HIP tally/call -> native inserts + walk, against the oracle's whole chain
+    (emulated pileup -> reference-pinned list_inserts / build_consensus) on 30k reads with accepted
+    inserts, deletions inside and outside ORFs, with and without ambiguity codes."""
+    ref, orfs = sy.make_reference(L=3000, cds=[(100, 1300), (1500, 2800)])
+    L = len(ref)
+    sites = [(400, "I", "ACG", 0.95), (700, "D", 3, 0.95), (1400, "D", 2, 0.9), (2000, "I", "T", 0.9),
+             (2300, "D", 1, 0.3), (2500, "I", "GGTTACGTACGT", 0.92)]
+    reads = sy.make_reads(ref, 30_000, seed=77, indel_sites=sites)
+    counts = ctx.tally(reads, L=L)
+    ocounts = orc.tally_matrix({k: v for k, v in reads.items()}, L)
+    assert np.array_equal(counts, ocounts)
+    gff = {k: {"start": o["start"], "end": o["end"], "strand": o["strand"]} for k, o in enumerate(orfs)}
+    olist = [dict(o) for o in orfs]
+    for amb in (True, False):
+        has, ins = orc.list_inserts(ocounts, 30, lambda p: orc.region_tokens(reads, p))
+        assert has and len(ins) == 3
+        plain, alt, flags = ctx.call(counts, 30, amb)
+        h2, ins2 = Events.inserts_from_flags(flags, reads)
+        assert ins2 == ins
+        for inc in (True, False):
+            want, worfs = orc.build_consensus(30, ocounts, olist, amb, ins, inc)
+            got, ggff = Sequences.consensus_from_records(plain, alt, flags, gff, ins2, inc)
+            assert got == want, (amb, inc)
+            assert [[ggff[k]["start"], ggff[k]["end"]] for k in sorted(ggff)] == [[o["start"], o["end"]] for o in worfs]
+        assert len(want) == L and "-" in want

@@ -73,6 +73,75 @@ def cpu_baseline(reads, L, mincov, orfs):
                                       "BuildConsensus restatement on 3 000 positions" % n_s}}
 
 
+def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
+    """BASELINE configs[4]: one BAM split into `world` contiguous read ranges (genome tiles)."""
+    import numpy as np
+    from trueconsense_amd import _ffi
+    from trueconsense_amd import distributed as td
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.engine import Context, Walker
+    L = len(ref)
+    ld = (L + 255) // 256 * 256
+    tile = L - 150 + 1
+    reads = sy.make_reads(ref, a.reads, seed=7000 + rank, start_range=(tile * rank // world, tile * (rank + 1) // world))
+    ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)     # tally, collective and call on torch's stream
+    rs = ctx.upload(reads)
+    counts = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
+    rec = torch.zeros((3, ld), dtype=torch.uint8, device="cuda")
+    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+
+    def step():
+        counts.zero_()
+        ctx.tally_dev(rs, L, ld, counts.data_ptr(), zero=False)
+        td.allreduce_counts(counts)                              # ONE exchange: int32 sum of 7 x ld over the ranks
+        ctx.call_dev(counts.data_ptr(), L, ld, a.mincov, True, rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr())
+        if rank == 0:
+            h = rec.cpu().numpy()
+            return walker(h[0, :L], h[1, :L], h[2, :L])[0]
+        return None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cons = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tally_ms, tally_n = ctx.profile_get(_ffi.K_TALLY)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        tally_us = 1e3 * tally_ms / max(1, tally_n)
+        alg = rs.algorithmic_bytes + 28 * L
+        achieved = alg / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
+        total_cov = int(counts[0, :L].sum().item())
+        print(json.dumps({
+            "metric": "reference positions/sec (ONE BAM of %d reads split over %d GPU(s), BAM -> consensus)" % (a.reads * world, world),
+            "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32 tallies, f64 thresholds", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, one BAM of %d x %d synthetic 150-bp reads, rank r holds "
+                                   "the contiguous read range of genome tile r; per step: tally, ONE all-reduce (sum) of the int32 "
+                                   "[7][%d] matrix (%d bytes), call kernel, walk on rank 0" % (world, a.reads, ld, 28 * ld),
+                       "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL all_reduce" if world > 1 else "none")},
+            "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": tally_us},
+            "consensus_len": len(cons), "coverage_sum": total_cov, "coverage_sum_expected": 150 * a.reads * world}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +158,9 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option on every workspace (diagnostic)")
+    ap.add_argument("--split-bam", action="store_true",
+                    help="BASELINE configs[4]: ONE BAM of gpus x --reads reads, each rank tallies its contiguous read range, "
+                         "one all-reduce (RCCL) of the count matrix per step, base calling on every rank")
     ap.add_argument("--also-single", action="store_true", help="afterwards also measure the same BAMs one per launch (adds a second launch shape)")
     ap.add_argument("--batch", type=int, default=4, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
     ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
@@ -121,6 +193,8 @@ def main():
 
     ref, orfs = sy.make_reference()
     L = len(ref)
+    if a.split_bam:
+        return run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs)
     n_walkers = a.walkers or max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
     pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
     ctx = pipe.ctx

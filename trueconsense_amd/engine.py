@@ -117,6 +117,18 @@ class Context:
         del keep
         return counts
 
+    def tally_dev(self, readset, L, ld, d_counts, zero=True):
+        """Device-resident tally into int32 [7][ld] planes at device address `d_counts` (e.g. a torch
+        tensor's data_ptr()), on this context's stream."""
+        check(lib().tcmi_tally_dev(self.handle, readset.handle, int(L), int(ld), C.c_void_p(int(d_counts)), int(bool(zero))),
+              self.handle)
+
+    def call_dev(self, d_counts, L, ld, mincov, include_ambig, d_plain, d_alt, d_flags):
+        """Device-resident call: counts planes -> three uint8[ld] record planes (device addresses)."""
+        check(lib().tcmi_call_dev(self.handle, C.c_void_p(int(d_counts)), int(L), int(ld), int(mincov), int(bool(include_ambig)),
+                                  C.c_void_p(int(d_plain)), C.c_void_p(int(d_alt)), C.c_void_p(int(d_flags)), None, None),
+              self.handle)
+
     # ---- stage B, position-local
     def call(self, counts, mincov, include_ambig, want_events=False):
         """counts [L,7] -> (plain, alt, flags) uint8 [L] (+ ascending 0-based event indices)."""

@@ -40,13 +40,15 @@ def gff_text(orfs, seqid="MN908947.3"):
     return "".join(lines), "".join(body)
 
 
-def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True, indel_sites=None):
+def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True, indel_sites=None, start_range=None):
     """Coordinate-sorted reads, CIGAR `<read_len>M` except carriers of `indel_sites`.
 
     indel_sites: list of (pos1, kind, payload, fraction): kind 'I' with payload = inserted bases
     placed after 1-based reference position pos1; kind 'D' with payload = number of deleted
     bases starting at pos1 + 1.  Reads spanning the site with >= 5 bases either side carry it
     with probability `fraction`.
+    start_range: (lo, hi) restricts the 0-based read starts to [lo, hi) — one genome tile of a BAM that is
+    split over several GPUs.
     Returns the dict of flat arrays (tcmi_reads layout) with constant quality 30.
     """
     rng = np.random.default_rng(seed)
@@ -56,7 +58,8 @@ def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True,
     for ch, code in zip(b"ACGT", _CODE):
         lut[ch] = code
     refc[:L] = lut[np.frombuffer(ref.encode(), np.uint8)]
-    starts = np.sort(rng.integers(0, L - read_len + 1, n_reads)).astype(np.int32)
+    s_lo, s_hi = (0, L - read_len + 1) if start_range is None else (max(0, start_range[0]), min(L - read_len + 1, start_range[1]))
+    starts = np.sort(rng.integers(s_lo, s_hi, n_reads)).astype(np.int32)
     flag = (rng.integers(0, 2, n_reads) * 16).astype(np.uint16)
     nb = (read_len + 1) // 2
     seq = np.empty((n_reads, nb), np.uint8)

@@ -421,3 +421,33 @@ def test_mid_size_consensus_against_the_oracle_chain(ctx):
             assert got == want, (amb, inc)
             assert [[ggff[k]["start"], ggff[k]["end"]] for k in sorted(ggff)] == [[o["start"], o["end"]] for o in worfs]
         assert len(want) == L and "-" in want
+
+
+def test_api_misuse_is_reported(ctx):
+    """Bad arguments come back as TCMI_E_* with a message, not as a crash."""
+    ref, _ = sy.make_reference(L=2000, cds=[(10, 900)])
+    reads = sy.make_reads(ref, 500, seed=1)
+    rs = ctx.upload(reads)
+    with pytest.raises(_ffi.TcmiError) as e:
+        ctx.step(rs, 100, 30, True)                                  # L smaller than the reads' extent
+    assert e.value.code == _ffi.E_ARG and "extent" in str(e.value)
+    ctx.step_begin(rs, 2000, 30, True, want_counts=False)
+    with pytest.raises(_ffi.TcmiError) as e:
+        ctx.step_begin(rs, 2000, 30, True, want_counts=False)        # second begin without an end
+    assert "not been ended" in str(e.value)
+    plain, _, flags, _ = ctx.step_end()
+    assert len(plain) == 2000
+    with pytest.raises(_ffi.TcmiError):
+        _ffi.check(_ffi.lib().tcmi_step_end(ctx.handle, None, None, None, None, None), ctx.handle)   # end without begin
+    with pytest.raises(_ffi.TcmiError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(_ffi.TcmiError):
+        ctx.call(np.zeros((0, 7), np.int32), 30, True)                # L must be positive
+    bad = dict(reads)
+    bad["seq"] = reads["seq"][:10]                                    # SEQ shorter than the offsets say
+    bad["seq_off"] = reads["seq_off"].copy()
+    bad["seq_off"][1:] = 10
+    bad["seq_off"][0] = 8
+    with pytest.raises(_ffi.TcmiError):
+        ctx.upload(bad)
+    rs.free()

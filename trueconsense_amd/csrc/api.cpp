@@ -430,6 +430,7 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
     if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     if (L <= 0 || rs->max_end > L) return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld does not cover the reads (extent %lld)", (long long)L, (long long)rs->max_end);
     if (rs->device != ctx->device) return tcmi_fail(ctx, TCMI_E_ARG, "read set lives on device %d, context on %d", rs->device, ctx->device);
+    if (ctx->step_L > 0) return tcmi_fail(ctx, TCMI_E_ARG, "tcmi_step_begin: the previous step of this context has not been ended");
     int rc = ensure_ws(ctx, L);
     if (rc) return rc;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));

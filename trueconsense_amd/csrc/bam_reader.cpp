@@ -10,11 +10,23 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "tcmi_internal.h"
+
+// a buffer that is not zero-filled on allocation: the decode passes write every byte they hand out, and
+// zero-filling hundreds of MB on one thread (page faults included) cost more than the decoding itself
+template <class T> struct RawBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t count) { p.reset(new T[count]); n = count; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
 
 struct tcmi_bam {
     std::string text;                          // SAM header text
@@ -25,8 +37,8 @@ struct tcmi_bam {
     std::vector<uint16_t> flag;
     std::vector<uint8_t> mapq;
     std::vector<uint64_t> cigar_off, seq_off;
-    std::vector<uint32_t> cigar;
-    std::vector<uint8_t> seq, qual;
+    RawBuf<uint32_t> cigar;
+    RawBuf<uint8_t> seq, qual;
     int sorted = 1;                            // coordinate-sorted (tid, pos) among mapped reads
     int64_t file_bytes = 0, inflated_bytes = 0, n_blocks = 0;
 };
@@ -115,7 +127,8 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
     size_t total = 0;
     int rc = scan_blocks(file, blocks, &total);
     if (rc) return rc;
-    std::vector<uint8_t> raw(total + 8);
+    RawBuf<uint8_t> raw;
+    raw.alloc(total + 8);
 
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
@@ -201,7 +214,8 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
             co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
         }
         bam->cigar_off[(size_t)n] = co; bam->seq_off[(size_t)n] = so; qual_off[(size_t)n] = qo;
-        bam->cigar.resize((size_t)co + 1); bam->seq.resize((size_t)so + 1); bam->qual.resize((size_t)qo + 1);
+        bam->cigar.alloc((size_t)co + 1); bam->seq.alloc((size_t)so + 1); bam->qual.alloc((size_t)qo + 1);
+        bam->cigar.data()[co] = 0; bam->seq.data()[so] = 0; bam->qual.data()[qo] = 0;
     }
     {
         int nt = n_threads;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <thread>
 #include <cstring>
+#include <memory>
 
 #include "tcmi_internal.h"
 
@@ -204,7 +205,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);
     std::vector<tcmi_fast_chunk> chunks;
-    std::vector<uint32_t> f_seq;
+    std::unique_ptr<uint32_t[]> f_seq;          // not zero-filled on allocation: every packing thread clears its own chunks
+    size_t f_seq_n = 0;
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
         // Stage size for a window of `words` grid words and reads of <= maxnw words: the kernel splits a
@@ -258,7 +260,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) total += (size_t)((fsel[(size_t)j].len + 7) / 8 + PAD);
             }
             total = (total + 3) & ~(size_t)3;
-            f_seq.assign(total, 0u);
+            f_seq.reset(new uint32_t[total + 4]);
+            f_seq_n = total;
         }
         const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, (int64_t)chunks.size(), 64}));
         std::vector<std::vector<uint32_t>> ev_parts((size_t)n_threads);
@@ -267,6 +270,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;
             for (size_t ci = c0; ci < c1; ++ci) {
                 tcmi_fast_chunk &c = chunks[ci];
+                const size_t c_end = ci + 1 < chunks.size() ? (size_t)chunks[ci + 1].word0 : f_seq_n;
+                std::memset(&f_seq[(size_t)c.word0], 0, (c_end - (size_t)c.word0) * 4);      // pads and alignment gaps stay zero
                 size_t cursor = (size_t)c.word0 + (size_t)PAD;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
@@ -386,7 +391,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     tcmi_readset *rs = new tcmi_readset();
     rs->uid = next_uid.fetch_add(1);
     rs->n_reads = n_reads_in; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
-    rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq.size();
+    rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq_n;
     rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
     Up up{ctx, rs};
@@ -394,7 +399,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
         if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
-        if (!rc) rc = up((void **)&rs->d_fseq, f_seq.data(), f_seq.size() * 4);
+        if (!rc) rc = up((void **)&rs->d_fseq, f_seq.get(), f_seq_n * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
     }
     if (!rc && ng) {

@@ -129,7 +129,7 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
             "metric": "reference positions/sec (ONE BAM of %d reads split over %d GPU(s), BAM -> consensus)" % (a.reads * world, world),
             "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32 tallies, f64 thresholds", "data": "synthetic",
+            "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, one BAM of %d x %d synthetic 150-bp reads, rank r holds "
                                    "the contiguous read range of genome tile r; per step: tally, ONE all-reduce (sum) of the int32 "
                                    "[7][%d] matrix (%d bytes), call kernel, walk on rank 0" % (world, a.reads, ld, 28 * ld),
@@ -305,7 +305,7 @@ def main():
             "metric": "reference positions/sec (1M reads x 29 903 bp per BAM, reads resident in HBM, BAM -> consensus)",
             "value": L * a.steps * B * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32 tallies, f64 thresholds", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "bams_per_min": 60.0 * a.steps * B * world / dt,
             "config": {"workload": "BASELINE configs[1]: 29 903-bp reference, %d synthetic 150-bp reads per BAM "
                                    "(~%dx coverage), %d distinct BAMs resident per GPU, %d BAM(s) per step and launch%s"

@@ -56,16 +56,16 @@ def main():
         ctx.step(rs, len(ref), 30, True, want_counts=False)
         ts.append((t1 - t, time.perf_counter() - t1))
         rs.free()
-    # parity of the file path with the oracle
-    from oracle import c_oracle
-    want = c_oracle.tally(reads, len(ref))
+    # sanity of the file path (parity itself is the tests' job): every base is one pileup token, deletions add theirs
     got = np.loadtxt(os.path.join(d, "out.tsv"), dtype=np.int64)[:, 1]
+    cg = np.asarray(reads["cigar"], np.int64)
+    tokens = int(((cg >> 4) * np.isin(cg & 15, (0, 2, 3, 7, 8))).sum())
     out = {"reads": n, "bam_bytes": os.path.getsize(os.path.join(d, "in.bam")), "generate_s": t_gen, "write_bam_s": t_write,
            "cli_wall_s": [r[0] for r in runs], "cli_stages_s": runs[-1][1]["seconds"],
            "upload_pack_h2d_s": [a for a, _ in ts], "step_s": [b for _, b in ts],
            "positions_per_s_cli": len(ref) / min(r[0] for r in runs),
            "positions_per_s_host_resident_reads": len(ref) / min(a + b for a, b in ts),
-           "coverage_matches_oracle": bool(np.array_equal(got, want[:, 0])),
+           "coverage_sum_equals_pileup_tokens": bool(int(got.sum()) == tokens),
            "fasta_len": len(open(os.path.join(d, "out.fa")).read().split("\n")[1]), "cpus": os.cpu_count()}
     print(json.dumps(out))
 

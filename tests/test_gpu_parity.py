@@ -118,7 +118,7 @@ def test_both_tally_kernels_agree(ctx):
         if variant == 1:
             assert a.value == 0 and g.value == rs.n_piled
         elif project:
-            assert g.value == 0 and a.value == rs.n_piled        # indel reads are projected onto the reference
+            assert g.value == 0 and a.value >= rs.n_piled        # indel reads are projected onto the reference
         else:
             assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 1024
         rs.free()
@@ -129,7 +129,7 @@ def test_both_tally_kernels_agree(ctx):
     rs = ctx.upload(extra)
     a, c, g = (C2.c_int64(0) for _ in range(3))
     _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
-    assert (a.value, g.value) == (4, 1)
+    assert (a.value, g.value) == (6, 0)                              # the 700M read is cut into two pieces
     rs.free()
 
 
@@ -451,3 +451,38 @@ def test_api_misuse_is_reported(ctx):
     with pytest.raises(_ffi.TcmiError):
         ctx.upload(bad)
     rs.free()
+
+
+def test_long_reads_take_the_fast_kernel_in_pieces(ctx):
+    """Nanopore-like reads (5-15 kb, dozens of small indels each): projected, cut into 512-position pieces,
+    re-sorted by position and tallied by the fast kernel; nothing is left for the CIGAR-walk kernel."""
+    import ctypes as C2
+    rng = np.random.default_rng(31)
+    L = 40_000
+    specs = []
+    for _ in range(400):
+        ops, span, qlen = [], 0, 0
+        target = int(rng.integers(5000, 15000))
+        while span < target:
+            m = int(rng.integers(20, 400))
+            ops.append("%dM" % m); span += m; qlen += m
+            r = rng.random()
+            if r < 0.4:
+                k = int(rng.integers(1, 6)); ops.append("%dD" % k); span += k
+            elif r < 0.8:
+                k = int(rng.integers(1, 6)); ops.append("%dI" % k); qlen += k
+        ops.append("30M"); span += 30; qlen += 30
+        pos = int(rng.integers(0, L - span))
+        seq = "".join("ACGTN"[int(c)] for c in rng.choice(5, qlen, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        specs.append({"pos": pos, "flag": int(rng.choice([0, 16])), "cigar": "".join(ops), "seq": seq})
+    specs.sort(key=lambda r: r["pos"])
+    reads = ss.reads_from_spec({"reads": specs})
+    want = c_oracle.tally(reads, L)
+    rs = ctx.upload(reads)
+    a, c, g = (C2.c_int64(0) for _ in range(3))
+    _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
+    assert g.value == 0 and a.value > 4000                              # ~ span / 512 pieces per read
+    plain, alt, flags, counts = ctx.step(rs, L, 5, True)
+    rs.free()
+    assert np.array_equal(counts, want)
+    assert counts[:, 5].sum() > 1000 and counts[:, 6].sum() > 1000

@@ -162,11 +162,14 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     const auto t0 = now();
 
     // pass 1: select, classify, size
-    struct Sel { const tcmi_reads *r; int64_t i, off, y0, len; bool projected; };
+    // one entry of the aligned set: read i of BAM r (positions shifted by off); for a projected read the piece
+    // [seg, seg + len) of its reference span (long reads are cut into pieces of <= TCMI_F_SEG positions)
+    struct Sel { const tcmi_reads *r; int64_t i, off, y0, len, seg; bool projected; };
     struct GSel { const tcmi_reads *r; int64_t i, off; };
     std::vector<Sel> fsel;                  // aligned set (len > 0)
     std::vector<GSel> gsel;                 // general set
     int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
+    bool any_cut = false;
     for (int32_t bi = 0; bi < n_batch; ++bi) {
     const tcmi_reads *r = batch[bi];
     const int64_t off = (int64_t)bi * stride;
@@ -190,13 +193,22 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         alg += 12 + 4 * nc + (lq + 1) / 2;
         if (off + r->pos[i] + span > max_end) max_end = off + r->pos[i] + span;
         int64_t y0, len;
-        if (use_fast && off + r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({r, i, off, y0, len, false});
-        else if (use_fast && ctx->project_reads && span <= TCMI_F_MAXSPAN && off + r->pos[i] + span < TCMI_F_EVPOS)
-            fsel.push_back({r, i, off, 0, span, true});       // any CIGAR, projected onto the reference
+        if (use_fast && off + r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({r, i, off, y0, len, 0, false});
+        else if (use_fast && ctx->project_reads && off + r->pos[i] + span < TCMI_F_EVPOS) {
+            // any CIGAR, projected onto the reference; a long read in pieces (the count matrix is a sum over
+            // positions, so cutting a read changes nothing)
+            for (int64_t seg = 0; seg < span; seg += TCMI_F_SEG)
+                fsel.push_back({r, i, off, 0, std::min<int64_t>(TCMI_F_SEG, span - seg), seg, true});
+            if (span > TCMI_F_SEG) any_cut = true;
+        }
         else { gsel.push_back({r, i, off}); g_cig += nc; g_seqw += (lq + 7) / 8; }
     }
     }
 
+    if (any_cut)                                // pieces of long reads start further right than the reads that follow them
+        std::stable_sort(fsel.begin(), fsel.end(), [](const Sel &a, const Sel &b) {
+            return a.r->pos[a.i] + a.off + a.seg < b.r->pos[b.i] + b.off + b.seg;
+        });
     const auto t1 = now();
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
@@ -236,7 +248,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             c_n = 0;
         };
         for (int64_t j = 0; j < nf; ++j) {
-            const int64_t p = fsel[(size_t)j].r->pos[fsel[(size_t)j].i] + fsel[(size_t)j].off, e = p + fsel[(size_t)j].len;
+            const int64_t p = fsel[(size_t)j].r->pos[fsel[(size_t)j].i] + fsel[(size_t)j].off + fsel[(size_t)j].seg, e = p + fsel[(size_t)j].len;
             const int64_t lo = p & ~(int64_t)7, nw = (fsel[(size_t)j].len + 7) / 8;
             if (c_n > 0) {
                 const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e), nmax = std::max(c_maxnw, nw);
@@ -276,7 +288,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const tcmi_reads *r = s.r;
-                const int64_t rpos = r->pos[s.i] + s.off;
+                const int64_t rpos = r->pos[s.i] + s.off + s.seg;      // reference position of the entry's first base
                 const uint8_t *src = r->seq + r->seq_off[s.i];
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
@@ -292,14 +304,16 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                     // reference base before an insertion (also "*+..": I but not X).
                     const uint32_t *cg = r->cigar + r->cigar_off[s.i];
                     const int64_t nc = (int64_t)(r->cigar_off[s.i + 1] - r->cigar_off[s.i]);
-                    int64_t x = 0, y = 0;
-                    for (int64_t k = 0; k < nc; ++k) {
+                    // x = offset in the read's reference span, relative to this piece [0, s.len)
+                    int64_t x = -s.seg, y = 0;
+                    for (int64_t k = 0; k < nc && x < s.len; ++k) {
                         const unsigned op = cg[k] & 0xF;
                         const int64_t len = cg[k] >> 4;
                         if (consumes_ref(op)) {
                             const bool ins = len > 0 && ins_after(cg, nc, k);
+                            const int64_t t0 = std::max<int64_t>(0, -x), t1 = std::min(len, s.len - x);   // part inside the piece
                             if (is_match(op)) {
-                                for (int64_t t = 0; t < len; ++t) {
+                                for (int64_t t = t0; t < t1; ++t) {
                                     const int64_t q = y + t;
                                     if (q >= lq) break;
                                     const unsigned code = (q & 1) ? (src[q >> 1] & 15u) : (src[q >> 1] >> 4);
@@ -307,10 +321,10 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                                     dst[(x + t) >> 1] |= (uint8_t)(oh << (((x + t) & 1) * 4));
                                 }
                             } else if (op == 2) {
-                                for (int64_t t = 0; t < (ins ? len - 1 : len); ++t)
+                                for (int64_t t = t0; t < std::min(t1, ins ? len - 1 : len); ++t)
                                     ev.push_back((uint32_t)(rpos + x + t) | TCMI_F_EV_X);
                             }
-                            if (ins) ev.push_back((uint32_t)(rpos + x + len - 1) | TCMI_F_EV_I);
+                            if (ins && x + len - 1 >= 0 && x + len - 1 < s.len) ev.push_back((uint32_t)(rpos + x + len - 1) | TCMI_F_EV_I);
                             x += len;
                         }
                         if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;

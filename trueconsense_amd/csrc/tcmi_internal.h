@@ -14,12 +14,14 @@
 // Only reads that pile up (mapped, tid >= 0, pos >= 0, reference span > 0)
 // are kept, split in two sets at upload time:
 //
-//  * ALIGNED set (fast kernel): reads no longer than TCMI_F_MAXSPAN reference positions.  A read
+//  * ALIGNED set (fast kernel).  A read
 //    whose CIGAR is one run of match ops (M / = / X, optionally flanked by S / H clips) is taken
 //    as it is; any other CIGAR is PROJECTED onto the reference while it is packed: matched bases
 //    land on their reference offset, deleted / skipped positions become empty nibbles, inserted
 //    and clipped bases are dropped, and the tokens that are not plain bases ("*", "..+n..") become
-//    EVENT words (position | kind) that the tail blocks of the same launch count.  Kept as
+//    EVENT words (position | kind) that the tail blocks of the same launch count; a projected read
+//    spanning more than TCMI_F_SEG positions is cut into pieces (long reads), and the entries are then
+//    re-sorted by position.  Kept as
 //    8 bytes of header (pos; len | word offset << 10) + the aligned bases only, 8 bases per
 //    32-bit word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for
 //    anything else (N, IUPAC, '=', base beyond SEQ) — exactly what indexing.py:115-132
@@ -28,8 +30,8 @@
 //    kept in a side list (they count toward coverage but toward no class).
 //    Consecutive reads are grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW
 //    grid words of 8 positions); one workgroup tallies one chunk in STAGES of <= sub_reads reads.
-//  * GENERAL set (CIGAR-walk kernel): what the fast path does not take (reads spanning more than
-//    TCMI_F_MAXSPAN positions, positions >= 2^29, or everything when option tally_variant = 1),
+//  * GENERAL set (CIGAR-walk kernel): what the fast path does not take (positions >= 2^29, reads
+//    with indels when option project_reads = 0, or everything when option tally_variant = 1),
 //    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
 //    offsets with a block scan), raw 4-bit codes.
 //
@@ -41,7 +43,8 @@
 #endif
 #define TCMI_F_CHUNK 1024          // max reads per chunk
 #define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
-#define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes
+#define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes in one piece
+#define TCMI_F_SEG 512             // projected reads longer than this are cut into pieces of this many positions
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
 #define TCMI_F_MAXSTAGE 4          // stages per chunk

@@ -8,6 +8,7 @@
 // No Python in the loop, so no GIL between the walkers.
 #include <cctype>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -153,7 +154,11 @@ int tcmi_pipeline_create(int device, int n_slots, int n_walkers, tcmi_pipeline *
     p->device = device;
     for (int s = 0; s < n_slots; ++s) {
         tcmi_ctx *c = nullptr;
-        const int rc = s == 0 ? tcmi_ctx_create(device, &c) : tcmi_ctx_create_on_stream(device, tcmi_ctx_stream(p->slots[0]), &c);
+        // TCMI_PIPE_STREAMS (default 1): with 2, odd and even workspaces alternate between two streams, so the
+        // call kernel of one step can run beside the tally of the next
+        static const int n_streams = [] { const char *v = std::getenv("TCMI_PIPE_STREAMS"); return v && std::atoi(v) == 2 ? 2 : 1; }();
+        const int rc = s < n_streams ? tcmi_ctx_create(device, &c)
+                                     : tcmi_ctx_create_on_stream(device, tcmi_ctx_stream(p->slots[(size_t)(s % n_streams)]), &c);
         if (rc) {
             for (size_t k = p->slots.size(); k-- > 0;) tcmi_ctx_destroy(p->slots[k]);
             delete p;

@@ -227,3 +227,51 @@ def test_walk_fast_runs_equal_position_by_position():
     finally:
         lib.tcmi_walk_set_fast_runs(1)
     assert n_diff_checked == 60
+
+
+def test_bam_reader_survives_damaged_files(tmp_path):
+    """Truncations and bit flips (in the BGZF framing, in the deflate stream, and in the inflated BAM
+    after re-compression): the reader either decodes or raises TcmiError — it never crashes or hangs."""
+    import struct
+    import zlib
+    from trueconsense_amd._ffi import TcmiError
+    reads = ss.reads_from_spec(load("outputs")[2]["spec"])
+    good = tmp_path / "g.bam"
+    bamwriter.write_bam(str(good), reads, "refid", 150, block=900)
+    raw = good.read_bytes()
+    rng = np.random.default_rng(5)
+    p = tmp_path / "d.bam"
+    n_ok = n_err = 0
+    for trial in range(120):
+        data = bytearray(raw)
+        kind = trial % 3
+        if kind == 0:
+            data = data[:int(rng.integers(1, len(data)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                data[int(rng.integers(0, len(data)))] ^= 1 << int(rng.integers(0, 8))
+        else:
+            # damage the *inflated* stream and re-wrap it as one valid BGZF member (CRC matches): exercises the BAM parser
+            blocks, o = [], 0
+            while o < len(raw):
+                bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+                blocks.append(zlib.decompress(raw[o + 18:o + bsize - 8], -15))
+                o += bsize
+            inflated = bytearray(b"".join(blocks))
+            for _ in range(int(rng.integers(1, 6))):
+                inflated[int(rng.integers(0, len(inflated)))] = int(rng.integers(0, 256))
+            if rng.random() < 0.5:
+                inflated = inflated[:int(rng.integers(4, len(inflated)))]
+            data = bytearray()
+            for k in range(0, len(inflated), 60000):
+                data += bamwriter._bgzf_block(bytes(inflated[k:k + 60000]), 1)
+        p.write_bytes(bytes(data))
+        try:
+            bam = engine.BamFile(str(p), threads=2)
+            a = bam.arrays()
+            assert len(a["pos"]) == bam.n_reads
+            engine.reads_extent(bam, 150)
+            n_ok += 1
+        except TcmiError:
+            n_err += 1
+    assert n_ok + n_err == 120 and n_err > 40

@@ -71,6 +71,11 @@ typedef struct tcmi_reads {
     const uint8_t  *seq;        /* BAM 4-bit packed "=ACMGRSVTWYHKDBN", high nibble first */
     const uint8_t  *qual;       /* optional, Σ l_qseq bytes (offsets = prefix of l_qseq) or NULL */
     const int32_t  *tid;        /* optional [n] reference id; reads with tid<0 never pile up */
+    /* optional accelerators for the insert-token sweep (tcmi_modal_tokens); zero / NULL = not given */
+    const uint64_t *qual_off;   /* [n+1] offsets into qual[] (= prefix sums of l_qseq)                  */
+    int64_t sorted_max_span;    /* > 0 promises: reads ascend by pos (unplaced reads last) and no read
+                                   spans more reference positions than this; lets the sweep visit only
+                                   the reads around each candidate position (tcmi_bam_reads fills it)   */
 } tcmi_reads;
 
 typedef struct tcmi_ctx tcmi_ctx;          /* one per device + stream            */

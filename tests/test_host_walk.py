@@ -275,3 +275,32 @@ def test_bam_reader_survives_damaged_files(tmp_path):
         except TcmiError:
             n_err += 1
     assert n_ok + n_err == 120 and n_err > 40
+
+
+def test_windowed_token_sweep_equals_full_sweep(tmp_path):
+    """With the sorted / max-span promise the sweep visits only the reads around each candidate; the result
+    must equal the full sweep (and the BAM reader must compute a correct promise)."""
+    from tests import fuzz_reads as fz
+    rng = np.random.default_rng(12)
+    for rep in range(6):
+        L = 3000
+        reads = fz.random_reads(rng, 1500, L, long_reads=(rep % 2 == 1))
+        positions = sorted(set(int(x) for x in rng.integers(1, L, 60)))
+        if rep < 4:
+            reads["tid"][:] = 0                      # (unplaced reads in between make a BAM unsorted: last two reps)
+        full = engine.modal_tokens(reads, positions)
+        path = str(tmp_path / "w.bam")
+        bamwriter.write_bam(path, reads, "refid", L)
+        bam = engine.BamFile(path, threads=2)
+        st, _ = bam.as_struct()
+        spans = [sum(l for op, l in orc.read_cigar(reads, i) if op in (0, 2, 3, 7, 8)) for i in range(reads["n_reads"])]
+        if rep < 4:
+            assert bam.sorted == 1 and st.sorted_max_span == max(spans)
+        else:
+            assert bam.sorted == 0 and st.sorted_max_span == 0
+        assert engine.modal_tokens(bam, positions) == full
+        if rep >= 4:
+            continue
+        hinted = dict(reads)
+        hinted["sorted_max_span"] = max(spans)
+        assert engine.modal_tokens(hinted, positions) == full

@@ -34,7 +34,8 @@ class Reads(C.Structure):
                 ("l_qseq", C.POINTER(C.c_int32)),
                 ("cigar_off", C.POINTER(C.c_uint64)), ("cigar", C.POINTER(C.c_uint32)),
                 ("seq_off", C.POINTER(C.c_uint64)), ("seq", C.POINTER(C.c_uint8)),
-                ("qual", C.POINTER(C.c_uint8)), ("tid", C.POINTER(C.c_int32))]
+                ("qual", C.POINTER(C.c_uint8)), ("tid", C.POINTER(C.c_int32)),
+                ("qual_off", C.POINTER(C.c_uint64)), ("sorted_max_span", C.c_int64)]
 
 
 _P = C.POINTER
@@ -156,9 +157,10 @@ def as_reads(d):
                              ("l_qseq", np.int32, C.c_int32, True), ("cigar_off", np.uint64, C.c_uint64, True),
                              ("cigar", np.uint32, C.c_uint32, True), ("seq_off", np.uint64, C.c_uint64, True),
                              ("seq", np.uint8, C.c_uint8, True), ("qual", np.uint8, C.c_uint8, False),
-                             ("tid", np.int32, C.c_int32, False)):
+                             ("tid", np.int32, C.c_int32, False), ("qual_off", np.uint64, C.c_uint64, False)):
         a = arr(key, dt, req)
         setattr(r, key, a.ctypes.data_as(C.POINTER(ct)) if a is not None else None)
+    r.sorted_max_span = int(d.get("sorted_max_span", 0) or 0)
     return r, keep
 
 

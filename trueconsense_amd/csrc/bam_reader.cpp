@@ -7,6 +7,7 @@
 // record is decoded once into struct-of-arrays form, the layout tcmi_readset_upload consumes.
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -36,7 +37,8 @@ struct tcmi_bam {
     std::vector<int32_t> pos, l_qseq, tid;
     std::vector<uint16_t> flag;
     std::vector<uint8_t> mapq;
-    std::vector<uint64_t> cigar_off, seq_off;
+    std::vector<uint64_t> cigar_off, seq_off, qual_off;
+    int64_t max_span = 0;                      // over all reads (reference positions consumed by the CIGAR)
     RawBuf<uint32_t> cigar;
     RawBuf<uint8_t> seq, qual;
     int sorted = 1;                            // coordinate-sorted (tid, pos) among mapped reads
@@ -203,7 +205,8 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
     bam->pos.resize((size_t)n); bam->l_qseq.resize((size_t)n); bam->tid.resize((size_t)n);
     bam->flag.resize((size_t)n); bam->mapq.resize((size_t)n);
     bam->cigar_off.resize((size_t)n + 1); bam->seq_off.resize((size_t)n + 1);
-    std::vector<uint64_t> qual_off((size_t)n + 1);
+    std::vector<uint64_t> &qual_off = bam->qual_off;
+    qual_off.resize((size_t)n + 1);
     {
         uint64_t co = 0, so = 0, qo = 0;
         for (int64_t i = 0; i < n; ++i) {
@@ -221,6 +224,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         int nt = n_threads;
         if ((int64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
         std::vector<int> unsorted((size_t)nt, 0);
+        std::vector<int64_t> spans((size_t)nt, 0);
         auto fill = [&](int t) {
             const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
             int32_t last_tid = 0, last_pos = -1;
@@ -241,6 +245,15 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
                 bam->l_qseq[(size_t)i] = (int32_t)l_seq;
                 const uint8_t *c = r + 32 + l_name;
                 std::memcpy(bam->cigar.data() + bam->cigar_off[(size_t)i], c, 4 * n_c);     // little-endian host
+                {
+                    int64_t span = 0;
+                    const uint32_t *cg = bam->cigar.data() + bam->cigar_off[(size_t)i];
+                    for (size_t k = 0; k < n_c; ++k) {
+                        const unsigned op = cg[k] & 0xF;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cg[k] >> 4;
+                    }
+                    if (span > spans[(size_t)t]) spans[(size_t)t] = span;
+                }
                 const uint8_t *sq = c + 4 * n_c;
                 std::memcpy(bam->seq.data() + bam->seq_off[(size_t)i], sq, (l_seq + 1) / 2);
                 std::memcpy(bam->qual.data() + qual_off[(size_t)i], sq + (l_seq + 1) / 2, l_seq);
@@ -261,6 +274,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         }
         for (int u : unsorted)
             if (u) bam->sorted = 0;
+        for (int64_t sp : spans) bam->max_span = std::max(bam->max_span, sp);
     }
     *out = bam;
     return TCMI_OK;
@@ -285,6 +299,8 @@ int tcmi_bam_reads(const tcmi_bam *bam, tcmi_reads *reads)
     reads->seq = bam->seq.data();
     reads->qual = bam->qual.data();
     reads->tid = bam->tid.data();
+    reads->qual_off = bam->qual_off.data();
+    reads->sorted_max_span = bam->sorted ? std::max<int64_t>(1, bam->max_span) : 0;
     return TCMI_OK;
 }
 

@@ -69,8 +69,37 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         if (positions[k] <= positions[k - 1]) return tcmi_fail(nullptr, TCMI_E_ARG, "positions must ascend");
     if (depth_exceeded) *depth_exceeded = 0;
     std::vector<Column> cols((size_t)n_pos);
+    // Which reads to visit: all of them, or — when the caller promises sorted reads and a span bound
+    // (tcmi_reads.sorted_max_span) — only those that can reach one of the candidate columns.
+    std::vector<std::pair<int64_t, int64_t>> ranges;           // [first, last) read indices, ascending, disjoint
+    const bool windowed = r->sorted_max_span > 0 && (!r->qual || r->qual_off) && n_pos > 0;
+    if (windowed) {
+        int64_t n_placed = r->n_reads;                         // unplaced reads (tid < 0 / pos < 0) sit at the end
+        {
+            int64_t lo = 0, hi = r->n_reads;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                if ((r->tid && r->tid[mid] < 0) || r->pos[mid] < 0) hi = mid; else lo = mid + 1;
+            }
+            n_placed = lo;
+        }
+        const int32_t *pb = r->pos, *pe = r->pos + n_placed;
+        for (int32_t k = 0; k < n_pos; ++k) {
+            const int64_t col = positions[k] - 1;
+            const int64_t a = std::lower_bound(pb, pe, (int32_t)std::max<int64_t>(col - r->sorted_max_span + 1, INT32_MIN / 2),
+                                               [](int32_t v, int32_t key) { return v < key; }) - pb;
+            const int64_t b = std::upper_bound(pb, pe, (int32_t)std::min<int64_t>(col, INT32_MAX)) - pb;
+            if (a >= b) continue;
+            if (!ranges.empty() && a <= ranges.back().second) ranges.back().second = std::max(ranges.back().second, b);
+            else ranges.emplace_back(a, b);
+        }
+    } else {
+        ranges.emplace_back(0, r->n_reads);
+    }
     int64_t qoff = 0;
-    for (int64_t i = 0; i < r->n_reads; ++i) {
+    for (const auto &range : ranges)
+    for (int64_t i = range.first; i < range.second; ++i) {
+        if (windowed && r->qual) qoff = (int64_t)r->qual_off[i];
         const int64_t lq = r->l_qseq[i];
         const int64_t my_qoff = qoff;
         qoff += lq;

@@ -130,7 +130,9 @@ def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True,
     return {"n_reads": n_reads, "pos": starts, "flag": flag, "l_qseq": np.full(n_reads, read_len, np.int32),
             "tid": np.zeros(n_reads, np.int32), "cigar_off": cigar_off, "cigar": cigar, "seq_off": seq_off,
             "seq": seq.reshape(-1), "qual": np.full(n_reads * read_len, 30, np.uint8),
-            "qual_off": np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)}
+            "qual_off": np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len),
+            # reads are sorted by pos and span at most read_len + the longest planted deletion (see tcmi_reads)
+            "sorted_max_span": read_len + max([int(p) for _, k, p, _ in (indel_sites or []) if k == "D"] + [0])}
 
 
 def default_indel_sites(orfs, seed=7):
@@ -138,15 +140,18 @@ def default_indel_sites(orfs, seed=7):
     with carrier fractions {10,15,20,50,55,56,60,90} %."""
     rng = np.random.default_rng(seed)
     fracs = [0.10, 0.15, 0.20, 0.50, 0.55, 0.56, 0.60, 0.90]
+    order_i = [0, 7, 5, 2, 6, 4, 1, 3]            # insertions and deletions each run through all eight fractions,
+    order_d = [7, 1, 3, 6, 0, 5, 2, 4]            # starting with a clear minority and a clear majority
     sites, k = [], 0
     for o in orfs:
         for edge in (o["start"] + 5, o["end"] - 7):
-            f = fracs[k % len(fracs)]
             if k % 2 == 0:
+                f = fracs[order_i[(k // 2) % 8]]
                 n = 12 if k == 4 else 1 + (k // 2) % 3
                 payload = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
                 sites.append((edge, "I", payload, f))
             else:
+                f = fracs[order_d[(k // 2) % 8]]
                 sites.append((edge, "D", 1 + (k // 2) % 3, f))
             k += 1
     return sites

@@ -50,11 +50,53 @@ int64_t indel_after(const uint32_t *cg, int64_t n, int64_t k)
     return tot;
 }
 
+// Distinct tokens of one column in first-seen order.  A column holds a handful of distinct tokens and one of
+// them nearly always repeats, so a move-to-front probe of a short list beats hashing every token.
 struct Column {
-    std::unordered_map<std::string, std::pair<int64_t, int64_t>> seen;   // token -> (count, first order)
+    struct Entry { std::string tok; int64_t count; };
+    std::vector<Entry> seen;
+    size_t last = 0;       // entry the previous token matched
     int64_t n = 0;
     int64_t depth = 0;     // reads overlapping the column before base-quality filtering
+
+    void add(const std::string &t)
+    {
+        ++n;
+        if (last < seen.size() && seen[last].tok == t) {
+            ++seen[last].count;
+            return;
+        }
+        if (index.empty()) {
+            for (size_t e = 0; e < seen.size(); ++e)
+                if (seen[e].tok == t) {
+                    ++seen[e].count;
+                    last = e;
+                    return;
+                }
+        } else {
+            auto it = index.find(t);
+            if (it != index.end()) {
+                ++seen[it->second].count;
+                last = it->second;
+                return;
+            }
+        }
+        seen.push_back(Entry{t, 1});
+        last = seen.size() - 1;
+        if (!index.empty()) index.emplace(t, last);
+        else if (seen.size() > 64)                                 // many distinct tokens (noisy long inserts): hash them
+            for (size_t e = 0; e < seen.size(); ++e) index.emplace(seen[e].tok, e);
+    }
+    std::unordered_map<std::string, size_t> index;                 // only past 64 distinct tokens
 };
+
+inline void append_number(std::string &s, int64_t v)
+{
+    char d[24];
+    int n = 0;
+    do { d[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(d[--n]);
+}
 
 } // namespace
 
@@ -97,6 +139,7 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         ranges.emplace_back(0, r->n_reads);
     }
     int64_t qoff = 0;
+    std::string tok;
     for (const auto &range : ranges)
     for (int64_t i = range.first; i < range.second; ++i) {
         if (windowed && r->qual) qoff = (int64_t)r->qual_off[i];
@@ -139,23 +182,22 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                         int q = 255;
                         if (r->qual) q = qpos < lq ? r->qual[my_qoff + qpos] : 0;
                         if (q < min_base_quality) break;                     // pileup_base_qual_skip
-                        std::string tok;
+                        tok.clear();
                         if (is_match(op)) tok.push_back(base(qpos));
                         else tok.push_back(op == 3 ? (rev ? '<' : '>') : '*');
                         if (col == x + len - 1) {
                             const int64_t indel = indel_after(cg, nc, k);
                             if (indel > 0) {
-                                tok += "+" + std::to_string(indel);
+                                tok.push_back('+');
+                                append_number(tok, indel);
                                 for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
                             } else if (indel < 0) {
-                                tok += "-" + std::to_string(-indel);
+                                tok.push_back('-');
+                                append_number(tok, -indel);
                                 tok.append((size_t)(-indel), 'N');
                             }
                         }
-                        auto it = C.seen.find(tok);
-                        if (it == C.seen.end()) C.seen.emplace(std::move(tok), std::make_pair((int64_t)1, C.n));
-                        else ++it->second.first;
-                        ++C.n;
+                        C.add(tok);
                         break;
                     }
                     x += len;
@@ -170,10 +212,10 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         n_tokens[k] = cols[(size_t)k].n;
         if (max_depth > 0 && cols[(size_t)k].depth > max_depth && depth_exceeded) *depth_exceeded = 1;
         const std::string *best = nullptr;
-        int64_t bc = 0, bo = 0;
-        for (auto &kv : cols[(size_t)k].seen)
-            if (!best || kv.second.first > bc || (kv.second.first == bc && kv.second.second < bo)) {
-                best = &kv.first; bc = kv.second.first; bo = kv.second.second;
+        int64_t bc = 0;
+        for (auto &e : cols[(size_t)k].seen)                     // first-seen order: ties go to the earliest
+            if (e.count > bc) {
+                best = &e.tok; bc = e.count;
             }
         if (best) {
             if (off + (int64_t)best->size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");

@@ -45,8 +45,8 @@ def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True,
 
     indel_sites: list of (pos1, kind, payload, fraction): kind 'I' with payload = inserted bases
     placed after 1-based reference position pos1; kind 'D' with payload = number of deleted
-    bases starting at pos1 + 1.  Reads spanning the site with >= 5 bases either side carry it
-    with probability `fraction`.
+    bases starting at pos1 + 1.  `fraction` of the reads covering pos1 carry it (drawn from those spanning
+    the site with >= 5 bases either side; a read may carry several sites).
     start_range: (lo, hi) restricts the 0-based read starts to [lo, hi) — one genome tile of a BAM that is
     split over several GPUs.
     Returns the dict of flat arrays (tcmi_reads layout) with constant quality 30.
@@ -87,52 +87,64 @@ def make_reads(ref, n_reads, read_len=150, seed=1, sub_rate=0.005, planted=True,
     n_cig = np.ones(n_reads, np.int64)
     cig_first = np.full(n_reads, (read_len << 4) | 0, np.uint32)
     extra = {}                                       # read index -> list of cigar words
+    max_span = read_len
     if indel_sites:
-        for pos1, kind, payload, frac in indel_sites:
+        events = {}                                  # read index -> [(pos1, kind, payload)] in site order
+        for pos1, kind, payload, frac in sorted(indel_sites, key=lambda t: t[0]):
             lo = np.searchsorted(starts, pos1 - read_len + 5, side="left")
             hi = np.searchsorted(starts, pos1 - 5, side="right")
-            cand = np.arange(lo, hi)
-            cand = cand[rng.random(len(cand)) < frac]
-            for i in cand.tolist():
-                if i in extra:
-                    continue
-                st = int(starts[i])
-                a = pos1 - st                        # bases of the read up to and including pos1
+            n_cover = int(np.searchsorted(starts, pos1 - 1, side="right") - np.searchsorted(starts, pos1 - read_len, side="left"))
+            want = min(int(hi - lo), int(round(frac * n_cover)))      # `fraction` of the reads covering pos1
+            for i in (lo + rng.choice(int(hi - lo), want, replace=False)).tolist() if want > 0 else []:
+                events.setdefault(int(i), []).append((pos1, kind, payload))
+        for i, evs in events.items():
+            st = int(starts[i])
+            cur, used, words, parts = st, 0, [], []  # reference cursor (0-based), read bases used so far
+            for pos1, kind, payload in evs:
+                m = pos1 - cur                       # matched bases up to and including pos1
+                k = len(payload) if kind == "I" else int(payload)
+                left = read_len - used - m - (k if kind == "I" else 0)
+                if m < 5 or left < 5 or cur + m + (k if kind == "D" else 0) + left > L:
+                    continue                         # the event does not fit this read (an earlier one moved it)
+                parts.append(refc[cur:cur + m])
+                words.append((m << 4) | 0)
+                cur += m
+                used += m
                 if kind == "I":
-                    k = len(payload)
-                    if a < 5 or read_len - a - k < 5:
-                        continue
-                    ins = lut[np.frombuffer(payload.encode(), np.uint8)]
-                    codes = np.concatenate([refc[st:st + a], ins, refc[st + a:st + read_len - k]])
-                    words = [(a << 4) | 0, (k << 4) | 1, ((read_len - a - k) << 4) | 0]
+                    parts.append(lut[np.frombuffer(payload.encode(), np.uint8)])
+                    words.append((k << 4) | 1)
+                    used += k
                 else:
-                    k = int(payload)
-                    if a < 5 or read_len - a < 5 or st + read_len + k > L:
-                        continue
-                    codes = np.concatenate([refc[st:st + a], refc[st + a + k:st + read_len + k]])
-                    words = [(a << 4) | 0, (k << 4) | 2, ((read_len - a) << 4) | 0]
-                codes = codes.copy()
-                sub = rng.random(read_len) < sub_rate
-                codes[sub] = _CODE[rng.integers(0, 4, int(sub.sum()))]
-                if read_len & 1:
-                    codes = np.concatenate([codes, np.zeros(1, np.uint8)])
-                seq[i] = (codes[0::2] << 4) | codes[1::2]
-                extra[i] = words
-                n_cig[i] = 3
+                    words.append((k << 4) | 2)
+                    cur += k
+            if not words:
+                continue
+            rest = read_len - used
+            parts.append(refc[cur:cur + rest])
+            words.append((rest << 4) | 0)
+            max_span = max(max_span, cur + rest - st)
+            codes = np.concatenate(parts).copy()
+            sub = rng.random(read_len) < sub_rate
+            codes[sub] = _CODE[rng.integers(0, 4, int(sub.sum()))]
+            if read_len & 1:
+                codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+            seq[i] = (codes[0::2] << 4) | codes[1::2]
+            extra[i] = words
+            n_cig[i] = len(words)
     cigar_off = np.zeros(n_reads + 1, np.uint64)
     cigar_off[1:] = np.cumsum(n_cig)
     cigar = np.empty(int(cigar_off[-1]), np.uint32)
     cigar[cigar_off[:-1].astype(np.int64)] = cig_first
     for i, words in extra.items():
         o = int(cigar_off[i])
-        cigar[o:o + 3] = words
+        cigar[o:o + len(words)] = words
     seq_off = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(nb))
     return {"n_reads": n_reads, "pos": starts, "flag": flag, "l_qseq": np.full(n_reads, read_len, np.int32),
             "tid": np.zeros(n_reads, np.int32), "cigar_off": cigar_off, "cigar": cigar, "seq_off": seq_off,
             "seq": seq.reshape(-1), "qual": np.full(n_reads * read_len, 30, np.uint8),
             "qual_off": np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len),
-            # reads are sorted by pos and span at most read_len + the longest planted deletion (see tcmi_reads)
-            "sorted_max_span": read_len + max([int(p) for _, k, p, _ in (indel_sites or []) if k == "D"] + [0])}
+            # reads are sorted by pos and none spans more reference than this (see tcmi_reads)
+            "sorted_max_span": int(max_span)}
 
 
 def default_indel_sites(orfs, seed=7):

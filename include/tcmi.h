@@ -102,11 +102,14 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "chunk_stages"   1..4 stages per fast-kernel chunk (default 4)
  *   "host_threads"   threads tcmi_readset_upload packs with (default min(16, cores))
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
- *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set (default)
+ *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches
+ *                    (default: with two launches per step they queue with smaller gaps than graph replays)
+ *   "fuse_call"      1 = tcmi_step_begin without counts runs tally + call as ONE launch: the workgroup that
+ *                    completes a 256-position tile of the matrix calls it (default 0)
  *   "records_to_host" 1 = in tcmi_step_begin the call kernel stores its records in pinned host memory
  *                    itself (default); 0 = device buffer + a separate D2H copy
  *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin is launched directly with its
- *                    kernels bracketed by events, the others replay the graph unmeasured (default 1) */
+ *                    kernels bracketed by events, the others go out unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

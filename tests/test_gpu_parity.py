@@ -173,6 +173,16 @@ def test_full_size_1m_reads_exact_and_deterministic(ctx):
     assert np.array_equal(c1, want)
     wp, wa, wf = c_oracle.call(want, 30, True)
     assert np.array_equal(p1, wp) and np.array_equal(a1, wa) and np.array_equal(f1, wf)
+    # the one-launch step (the workgroup completing a tile calls it): 3 900 workgroups race to sign tiles off;
+    # every repetition must give the same records, and the matrix must be left zeroed each time
+    ctx.set_option("fuse_call", 1)
+    try:
+        for rep in range(25):
+            p3, a3, f3, _ = ctx.step(rs, L, 30, True, want_counts=False)
+            assert np.array_equal(p3, wp) and np.array_equal(a3, wa) and np.array_equal(f3, wf), rep
+        assert np.array_equal(ctx.step(rs, L, 30, True)[3], want)
+    finally:
+        ctx.set_option("fuse_call", 0)
     rs.free()
 
 
@@ -486,3 +496,72 @@ def test_long_reads_take_the_fast_kernel_in_pieces(ctx):
     rs.free()
     assert np.array_equal(counts, want)
     assert counts[:, 5].sum() > 1000 and counts[:, 6].sum() > 1000
+
+
+def test_fused_step_equals_two_launch_step(ctx):
+    """With option fuse_call, tcmi_step_begin without counts runs tally + call as ONE launch (the workgroup that
+    completes a tile of the matrix calls it).  Its records must equal the two-launch path and the oracle on dense, sparse, empty, batched
+    and long-read inputs, repeatedly on one workspace (the launch leaves matrix and sign-off counters zeroed)."""
+    from tests import fuzz_reads as fz
+    rng = np.random.default_rng(2024)
+    ref, orfs = sy.make_reference()
+    cases = []
+    cases.append(("dense+indels", sy.make_reads(ref, 120_000, seed=5, indel_sites=sy.default_indel_sites(orfs)), len(ref)))
+    cases.append(("few reads, long reference", sy.make_reads(ref, 300, seed=6), 400_000))
+    cases.append(("L just past the reads", sy.make_reads(ref, 5000, seed=8, start_range=(1000, 3000)), 3150))
+    fr = fz.random_reads(rng, 20_000, 9000, long_reads=True)
+    cases.append(("fuzz cigars, long reads", fr, int(engine.reads_extent(fr, 9000))))
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v)
+             for k, v in sy.make_reads(ref, 10, seed=1).items()}
+    empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))
+    cases.append(("no reads", empty, 1000))
+    try:
+        for name, reads, L in cases:
+            rs = ctx.upload(reads)
+            want_counts = c_oracle.tally(reads, L)
+            want = c_oracle.call(want_counts, 30, True)
+            ctx.set_option("fuse_call", 0)
+            two = ctx.step(rs, L, 30, True, want_counts=False)
+            ctx.set_option("fuse_call", 1)
+            for rep in range(3):
+                one = ctx.step(rs, L, 30, True, want_counts=False)
+                for k in range(3):
+                    assert np.array_equal(one[k], two[k]), (name, rep, k)
+                    assert np.array_equal(one[k], want[k]), (name, rep, k)
+            p, a, f, counts = ctx.step(rs, L, 30, True, want_counts=True)      # the matrix was left zeroed
+            assert np.array_equal(counts, want_counts), name
+            rs.free()
+        # a batch: four BAMs at shifted positions, one launch
+        stride = 29952
+        group = [sy.make_reads(ref, 20_000 + 3000 * k, seed=60 + k) for k in range(4)]
+        rs = ctx.upload_batch(group, stride)
+        for rep in range(2):
+            p, a, f, _ = ctx.step(rs, 4 * stride, 30, True, want_counts=False)
+            for k, reads in enumerate(group):
+                w = c_oracle.call(c_oracle.tally(reads, len(ref)), 30, True)
+                for got, exp in zip((p, a, f), w):
+                    assert np.array_equal(got[k * stride:k * stride + len(ref)], exp), (rep, k)
+        rs.free()
+    finally:
+        ctx.set_option("fuse_call", 0)
+
+
+def test_graph_replay_equals_direct_launches(ctx):
+    """Option use_graph replays a step as one hipGraph per read set; direct launches are the default."""
+    ref, orfs = sy.make_reference()
+    reads = sy.make_reads(ref, 50_000, seed=15, indel_sites=sy.default_indel_sites(orfs))
+    L = len(ref)
+    rs = ctx.upload(reads)
+    want = c_oracle.call(c_oracle.tally(reads, L), 30, True)
+    try:
+        for fuse in (0, 1):
+            ctx.set_option("fuse_call", fuse)
+            for graph in (1, 0):
+                ctx.set_option("use_graph", graph)
+                for rep in range(3):                                   # capture, then replays
+                    got = ctx.step(rs, L, 30, True, want_counts=False)
+                    assert all(np.array_equal(g, w) for g, w in zip(got, want)), (fuse, graph, rep)
+    finally:
+        ctx.set_option("fuse_call", 0)
+        ctx.set_option("use_graph", 0)
+    rs.free()

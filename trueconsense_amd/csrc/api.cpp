@@ -106,6 +106,9 @@ void tcmi_drop_graphs(tcmi_ctx *ctx);
 static void free_ws(tcmi_ctx *c)
 {
     if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_tile_done) (void)hipFree(c->d_tile_done);
+    c->d_tile_done = nullptr;
+    c->ws_tiles = 0;
     if (c->d_plain) (void)hipFree(c->d_plain);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -148,6 +151,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 1 ? 1 : value > 4 ? 4 : value;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
+    else if (!std::strcmp(key, "fuse_call")) { c->fuse_call = value != 0; tcmi_drop_graphs(c); }
     else if (!std::strcmp(key, "records_to_host")) { c->records_to_host = value != 0; tcmi_drop_graphs(c); }
     else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
@@ -273,6 +277,9 @@ static int ensure_ws(tcmi_ctx *ctx, int64_t L)
     ctx->counts_clean = false;
     int64_t ld = tcmi_round_up(L, 256);
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4));
+    ctx->ws_tiles = ld / TCMI_F_BLOCK + 16;
+    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_tile_done, (size_t)ctx->ws_tiles * 4));
+    TCMI_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)ctx->ws_tiles * 4, ctx->stream));
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_plain, (size_t)ld * 3));
     ctx->d_alt = ctx->d_plain + ld;
     ctx->d_flags = ctx->d_plain + 2 * ld;
@@ -392,6 +399,12 @@ static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_
     const int64_t ld = ctx->ws_ld;
     if (memset_first) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
     if (ev_a) TCMI_HIP(ctx, hipEventRecord(ev_a, ctx->stream));
+    // One launch for tally + call when nothing but the fast kernel adds into the matrix and the counts stay on
+    // the device: the workgroup that completes a tile of the matrix calls it (tally_fast.hip, "fused call").
+    if (ctx->fuse_call && !want_counts && ctx->records_to_host && ctx->tally_variant == 0 && rs->g_reads == 0 &&
+        std::max<int64_t>((L + TCMI_F_BLOCK - 1) / TCMI_F_BLOCK, rs->f_tiles) <= ctx->ws_tiles)
+        return tcmi_launch_step_fused(ctx, rs, L, ld, ctx->d_counts, ctx->d_tile_done, ctx->ws_tiles, mincov, include_ambig,
+                                      ctx->h_rec, ctx->h_rec + ld, ctx->h_rec + 2 * ld);
     int rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 0);
     if (rc) return rc;
     if (ev_b) TCMI_HIP(ctx, hipEventRecord(ev_b, ctx->stream));

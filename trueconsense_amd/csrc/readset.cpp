@@ -131,7 +131,8 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_pos, rs->d_meta,
+    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_ftile_need, rs->d_fev_tile_off,
+                    rs->d_fev_tile, rs->d_forphan, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -408,8 +409,38 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq_n;
     rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
+    // fused call (tally_fast.hip): who adds into which tile of TCMI_F_BLOCK positions
+    std::vector<int32_t> tile_need, ev_tile_off, ev_tile, orphans;
+    {
+        constexpr int64_t T = TCMI_F_BLOCK;
+        int64_t n_tiles = 0;
+        for (const auto &c : chunks) n_tiles = std::max<int64_t>(n_tiles, ((int64_t)c.P0 + (int64_t)c.Wn * 8 - 1) / T + 1);
+        for (uint32_t e : f_event) n_tiles = std::max<int64_t>(n_tiles, (int64_t)(e & (TCMI_F_EVPOS - 1u)) / T + 1);
+        tile_need.assign((size_t)n_tiles, 0);
+        for (const auto &c : chunks)
+            for (int64_t t = c.P0 / T; t <= ((int64_t)c.P0 + (int64_t)c.Wn * 8 - 1) / T; ++t) ++tile_need[(size_t)t];
+        const size_t n_tail = (f_event.size() + (size_t)T - 1) / (size_t)T;
+        ev_tile_off.assign(n_tail + 1, 0);
+        for (size_t b = 0; b < n_tail; ++b) {
+            const size_t first = ev_tile.size();
+            for (size_t i = b * (size_t)T; i < std::min(f_event.size(), (b + 1) * (size_t)T); ++i) {
+                const int32_t t = (int32_t)((f_event[i] & (TCMI_F_EVPOS - 1u)) / (uint32_t)T);
+                if (std::find(ev_tile.begin() + (std::ptrdiff_t)first, ev_tile.end(), t) == ev_tile.end()) ev_tile.push_back(t);
+            }
+            for (size_t k = first; k < ev_tile.size(); ++k) ++tile_need[(size_t)ev_tile[k]];
+            ev_tile_off[b + 1] = (int32_t)ev_tile.size();
+        }
+        for (int64_t t = 0; t < n_tiles; ++t)
+            if (tile_need[(size_t)t] == 0) orphans.push_back((int32_t)t);
+        rs->f_tiles = n_tiles;
+        rs->f_orphans = (int64_t)orphans.size();
+    }
     Up up{ctx, rs};
-    if (nf) {
+    if (!tile_need.empty()) rc = up((void **)&rs->d_ftile_need, tile_need.data(), tile_need.size() * 4);
+    if (!rc) rc = up((void **)&rs->d_fev_tile_off, ev_tile_off.data(), ev_tile_off.size() * 4);
+    if (!rc && !ev_tile.empty()) rc = up((void **)&rs->d_fev_tile, ev_tile.data(), ev_tile.size() * 4);
+    if (!rc && !orphans.empty()) rc = up((void **)&rs->d_forphan, orphans.data(), orphans.size() * 4);
+    if (!rc && nf) {
         rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
         if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);

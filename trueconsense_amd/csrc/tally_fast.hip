@@ -26,7 +26,17 @@
 //   reduce       slices are summed through LDS (plain stores / loads) into 16-bit window counters,
 //                then ONE coalesced global atomic per touched (class, position) of the window.
 //
+//   fused call   (FUSED launches, tcmi_step_begin) the matrix is cut in TILES of 256 positions; the read set knows
+//                how many workgroups add into each tile (chunk windows and tail blocks).  Every workgroup
+//                signs off the tiles it touched (release fence + one atomic per tile); the one that signs
+//                off last reads the finished counters of the tile, CALLS its 256 positions (call_device.h),
+//                stores the records and leaves counters and sign-off count zeroed for the next launch.
+//                No workgroup ever waits for another; the separate call launch and its kernel boundary go.
+//
 // HBM-streaming integer work: no MFMA (BASELINE.json north_star).
+#include <algorithm>
+
+#include "call_device.h"
 #include "tcmi_internal.h"
 
 namespace {
@@ -52,7 +62,78 @@ struct FastArgs {
     int64_t n_events;
     int32_t n_chunks;
     int32_t L;
+    // fused call (FUSED launches only)
+    const int32_t *tile_need;       // [n_tiles] workgroups that add into tile t
+    int32_t *tile_done;             // [>= all tiles below L] sign-offs so far; zero between launches
+    const int32_t *ev_tile_off;     // [n_tail + 1] tiles touched by tail block b: ev_tile[ev_tile_off[b] .. ev_tile_off[b+1])
+    const int32_t *ev_tile;
+    const int32_t *orphans;         // [n_orphans] tiles below n_tiles nobody adds into
+    int32_t n_tail, n_tiles, n_orphans;
+    int32_t mincov, include_ambig;
+    uint8_t *plain, *alt, *flags;
 };
+
+constexpr int TILE = FB;            // positions per tile of the fused call: one lane each
+
+// Memory ordering of the fused call.  Everything the workgroups tell each other goes through AGENT-scope atomics
+// (the adds into the matrix, the sign-off counter, the caller's loads of the finished counters): on gfx942/950
+// those carry sc1 and are performed at the device's coherence point, never held dirty in one XCD's L2 (two XCDs
+// adding into one counter is what the tally relies on anyway).  So a lane only has to WAIT until its adds have
+// been performed (s_waitcnt vmcnt(0)) before the workgroup signs off — no `__threadfence()`: its agent-scope
+// release / acquire would write back and invalidate a whole L2 per wave (measured: 1.2 ms instead of 80 us).
+__device__ inline void wait_until_adds_are_performed()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler: nothing moves below
+    __builtin_amdgcn_s_waitcnt(0);                              // vmcnt(0) expcnt(0) lgkmcnt(0)
+}
+
+// The calling workgroup of tile t: every workgroup that adds into the tile has signed off, so the counters are
+// final.  Agent-scope atomic loads: they must not hit in a stale L1 / another XCD's L2 line.
+__device__ inline void call_tile(const FastArgs &a, int t)
+{
+    const int64_t p = (int64_t)t * TILE + threadIdx.x;
+    if (p < a.L) {
+        int32_t v[TCMI_NCOL];
+#pragma unroll
+        for (int c = 0; c < TCMI_NCOL; ++c) {
+            int32_t *q = &a.counts[(int64_t)c * a.ld + p];
+            v[c] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int c = 0; c < TCMI_NCOL; ++c)                     // zero for the next launch (visible after the kernel boundary)
+            __hip_atomic_store(&a.counts[(int64_t)c * a.ld + p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const tcmi_calldev::Record rec = tcmi_calldev::call_position(v[TCMI_COV], v[TCMI_A], v[TCMI_T], v[TCMI_C], v[TCMI_G],
+                                                                     v[TCMI_X], v[TCMI_I], a.mincov, a.include_ambig);
+        a.plain[p] = rec.plain;
+        a.alt[p] = rec.alt;
+        a.flags[p] = rec.flags;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&a.tile_done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sign off `nt` tiles (tile index for slot k from `tile_of(k)`), then call those this workgroup completed.
+// All lanes of the workgroup must arrive; every lane has issued its adds into the matrix before.
+template <class TileOf>
+__device__ inline void sign_off_and_call(const FastArgs &a, int nt, TileOf tile_of, int *s_last /* LDS [FB] */)
+{
+    wait_until_adds_are_performed();
+    __syncthreads();
+    for (int k0 = 0; k0 < nt; k0 += FB) {
+        const int k = k0 + (int)threadIdx.x;
+        const int n = min(FB, nt - k0);
+        if (k < nt) {
+            const int t = tile_of(k);
+            const int old = __hip_atomic_fetch_add(&a.tile_done[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last[threadIdx.x] = old == a.tile_need[t] - 1 ? t : -1;
+        }
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const int t = s_last[j];
+            if (t >= 0) call_tile(a, t);
+        }
+        __syncthreads();
+    }
+}
 
 constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum
 static_assert(NLD >= 1 && NLD <= 6, "prefetch registers are written out for up to 6 loads per lane");
@@ -76,7 +157,7 @@ __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
     return v + base;
 }
 
-template <int NW>
+template <int NW, bool FUSED>
 __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastArgs a)
 {
     constexpr int PAD = NW + 1;
@@ -110,6 +191,17 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
                 }
             }
             todo &= ~same;
+        }
+        if constexpr (FUSED) {
+            const int b = (int)blockIdx.x - a.n_chunks;
+            if (b < a.n_tail) {
+                const int o = a.ev_tile_off[b];
+                sign_off_and_call(a, a.ev_tile_off[b + 1] - o, [&](int k) { return a.ev_tile[o + k]; },
+                                  reinterpret_cast<int *>(s_hdr));
+            } else {                            // a tile nobody adds into: call it straight away
+                const int k = b - a.n_tail;
+                call_tile(a, k < a.n_orphans ? a.orphans[k] : a.n_tiles + (k - a.n_orphans));
+            }
         }
         return;
     }
@@ -328,25 +420,55 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
         if (nG) atomicAdd(&a.counts[(int64_t)TCMI_G * a.ld + gp], nG);
         if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
     }
+    if constexpr (FUSED) {
+        const int t0 = P0 / TILE;
+        sign_off_and_call(a, (P0 + npos - 1) / TILE - t0 + 1, [&](int k) { return t0 + k; }, reinterpret_cast<int *>(s_hdr));
+    }
 }
 
 #undef TCMI_ISSUE_STAGE
 
 } // namespace
 
-int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
+static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts, bool fused, int32_t *d_tile_done,
+                  int64_t tile_cap, int32_t mincov, int include_ambig, uint8_t *plain, uint8_t *alt, uint8_t *flags)
 {
-    FastArgs a;
+    FastArgs a = {};
     a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent;
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
-    const int64_t grid = rs->f_chunks + (rs->f_events + FB - 1) / FB;
+    a.n_tail = (int32_t)((rs->f_events + FB - 1) / FB);
+    int64_t grid = rs->f_chunks + a.n_tail;
+    if (fused) {
+        const int64_t tiles_L = (L + TILE - 1) / TILE;
+        if (std::max<int64_t>(tiles_L, rs->f_tiles) > tile_cap) return tcmi_fail(ctx, TCMI_E_ARG, "workspace holds %lld tiles, need %lld", (long long)tile_cap, (long long)std::max<int64_t>(tiles_L, rs->f_tiles));
+        a.tile_need = rs->d_ftile_need; a.tile_done = d_tile_done; a.ev_tile_off = rs->d_fev_tile_off; a.ev_tile = rs->d_fev_tile;
+        a.orphans = rs->d_forphan; a.n_tiles = (int32_t)rs->f_tiles; a.n_orphans = (int32_t)rs->f_orphans;
+        a.mincov = mincov; a.include_ambig = include_ambig; a.plain = plain; a.alt = alt; a.flags = flags;
+        grid += rs->f_orphans + std::max<int64_t>(0, tiles_L - rs->f_tiles);
+    }
     if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
+    if (grid == 0) return TCMI_OK;
     a.n_chunks = (int32_t)rs->f_chunks;
     tcmi_prof_begin(ctx, TCMI_K_TALLY);
     if (rs->f_nw != 2) return tcmi_fail(ctx, TCMI_E_ARG, "read set was packed for %d grid words per lane", rs->f_nw);
     (void)hipGetLastError();                                   // drop any stale error of this thread
-    hipLaunchKernelGGL(tally_fast_kernel<2>, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);   // (<4> measured slower)
+    if (fused) hipLaunchKernelGGL((tally_fast_kernel<2, true>), dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((tally_fast_kernel<2, false>), dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);   // (<4> measured slower)
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());
     return TCMI_OK;
+}
+
+int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
+{
+    return launch(ctx, rs, L, ld, d_counts, false, nullptr, 0, 0, 0, nullptr, nullptr, nullptr);
+}
+
+// Tally + call in one launch (see "fused call" above).  Only for read sets without a GENERAL part; `d_counts` and
+// `d_tile_done` must be zero on entry and are zero again when the kernel has finished.
+int tcmi_launch_step_fused(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts, int32_t *d_tile_done,
+                           int64_t tile_cap, int32_t mincov, int include_ambig, uint8_t *plain, uint8_t *alt, uint8_t *flags)
+{
+    if (rs->g_reads) return tcmi_fail(ctx, TCMI_E_ARG, "fused step needs a read set without a general part");
+    return launch(ctx, rs, L, ld, d_counts, true, d_tile_done, tile_cap, mincov, include_ambig, plain, alt, flags);
 }

@@ -109,9 +109,10 @@ def test_both_tally_kernels_agree(ctx):
     L = len(ref)
     want = c_oracle.tally(reads, L)
     want_x = c_oracle.tally(extra, L)
-    for variant, project in ((0, 1), (0, 0), (1, 1)):
+    for variant, project, fmt in ((0, 1, 2), (0, 1, 1), (0, 0, 2), (0, 0, 1), (1, 1, 2)):
         ctx.set_option("tally_variant", variant)
         ctx.set_option("project_reads", project)
+        ctx.set_option("fast_format", fmt)          # 2 = bit planes (default), 1 = one-hot nibbles
         rs = ctx.upload(reads)
         a, c, g = (C2.c_int64(0) for _ in range(3))
         _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
@@ -120,12 +121,13 @@ def test_both_tally_kernels_agree(ctx):
         elif project:
             assert g.value == 0 and a.value >= rs.n_piled        # indel reads are projected onto the reference
         else:
-            assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 1024
+            assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 4096
         rs.free()
-        assert np.array_equal(ctx.tally(reads, L=L), want), (variant, project)
-        assert np.array_equal(ctx.tally(extra, L=L), want_x), (variant, project)
+        assert np.array_equal(ctx.tally(reads, L=L), want), (variant, project, fmt)
+        assert np.array_equal(ctx.tally(extra, L=L), want_x), (variant, project, fmt)
     ctx.set_option("project_reads", 1)
     ctx.set_option("tally_variant", 0)
+    ctx.set_option("fast_format", 2)
     rs = ctx.upload(extra)
     a, c, g = (C2.c_int64(0) for _ in range(3))
     _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
@@ -348,13 +350,15 @@ def test_fuzz_random_cigars_all_paths(ctx):
         reads = fz.random_reads(rng, n, L, long_reads=long_reads, sort=sort)
         Lx = engine.reads_extent(reads, L)
         want = c_oracle.tally(reads, Lx)
-        for variant, project in ((0, 1), (0, 0), (1, 1)):
+        for variant, project, fmt in ((0, 1, 2), (0, 1, 1), (0, 0, 2), (0, 0, 1), (1, 1, 2)):
             ctx.set_option("tally_variant", variant)
             ctx.set_option("project_reads", project)
+            ctx.set_option("fast_format", fmt)
             got = ctx.tally(reads, L=Lx)
-            assert np.array_equal(got, want), (rep, variant, project, np.argwhere(got != want)[:5])
+            assert np.array_equal(got, want), (rep, variant, project, fmt, np.argwhere(got != want)[:5])
     ctx.set_option("tally_variant", 0)
     ctx.set_option("project_reads", 1)
+    ctx.set_option("fast_format", 2)
 
 
 def test_long_reference_sparse_reads(ctx):

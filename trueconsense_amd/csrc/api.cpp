@@ -93,7 +93,9 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     v = std::getenv("TCMI_HOST_THREADS");
     if (v && std::atoi(v) >= 1) c->host_threads = std::atoi(v);
     v = std::getenv("TCMI_CHUNK_STAGES");
-    if (v && std::atoi(v) >= 1 && std::atoi(v) <= 4) c->chunk_stages = std::atoi(v);
+    if (v && std::atoi(v) >= 1 && std::atoi(v) <= TCMI_F_MAXSTAGE) c->chunk_stages = std::atoi(v);
+    v = std::getenv("TCMI_FAST_FORMAT");
+    if (v) c->fast_format = std::atoi(v) == 1 ? 1 : 2;
 
     *out = c;
     return TCMI_OK;
@@ -149,7 +151,8 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     if (!std::strcmp(key, "tally_variant")) c->tally_variant = value;
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
-    else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 1 ? 1 : value > 4 ? 4 : value;
+    else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
+    else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "fuse_call")) { c->fuse_call = value != 0; tcmi_drop_graphs(c); }
     else if (!std::strcmp(key, "records_to_host")) { c->records_to_host = value != 0; tcmi_drop_graphs(c); }

@@ -214,6 +214,14 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
     const int NW = 2, PAD = NW + 1;             // grid words per lane of tally_fast_kernel<2>
+    // Layout of the base stream (tcmi_internal.h): format 1 = one-hot nibbles, format 2 = {lo, hi} plane pairs.
+    const int fmt = ctx->fast_format == 1 ? 1 : 2;
+    const int64_t prefix = fmt == 1 ? PAD : 4;                                   // zero words in front of a chunk's first read
+    auto read_words = [&](int64_t len) -> int64_t {                              // words of one read, trailing zeros included
+        return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 4;
+    };
+    const int max_stages = fmt == 1 ? 4 : TCMI_F_MAXSTAGE;
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : max_stages;
     std::vector<int32_t> f_pos((size_t)nf);
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);
@@ -226,14 +234,26 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         // stage over S = 256 / ceil(words / NW) depth slices and runs ceil(stage / S) inner-loop bodies per
         // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
+            if (fmt == 2) {
+                // lanes own 32 positions; an inner-loop body takes 4 reads per lane
+                const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
+                const int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
+                int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
+                if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
+                return sub;
+            }
             const int64_t S = TCMI_F_BLOCK / ((words + NW - 1) / NW);
             const int64_t cap = std::min<int64_t>(TCMI_F_SUB, (TCMI_F_SEQCAP - 16 - PAD) / (maxnw + PAD));
             int64_t sub = S * 12 * std::max<int64_t>(1, cap / (S * 12));
             if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);            // window too wide for 12 per slice
             return sub;
         };
-        auto chunk_reads = [&](int64_t sub) -> int64_t {                         // whole stages, <= 1024 reads
-            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) * sub) / sub * sub);
+        auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages
+            if (fmt == 2) {                                                      // <= 255 reads per lane: 8 counter planes
+                const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
+                return std::max<int64_t>(sub, std::min<int64_t>(255 * S, n_stages * sub) / sub * sub);
+            }
+            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, n_stages * sub) / sub * sub);   // <= 1024 reads
         };
         auto close = [&](int64_t next_read) {
             if (c_n == 0) return;
@@ -254,7 +274,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             if (c_n > 0) {
                 const int64_t nlo = std::min(c_lo, lo), nhi = std::max(c_hi, e), nmax = std::max(c_maxnw, nw);
                 const int64_t words = (nhi - nlo + 7) / 8;
-                if (words > TCMI_F_MAXW || c_n >= chunk_reads(stage_reads(words, nmax))) close(j);
+                if (words > TCMI_F_MAXW || c_n >= chunk_reads(stage_reads(words, nmax), words)) close(j);
                 else { c_lo = nlo; c_hi = nhi; c_maxnw = nmax; }
             }
             if (c_n == 0) { c_read0 = j; c_lo = lo; c_hi = e; c_maxnw = nw; }
@@ -269,8 +289,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             for (auto &c : chunks) {
                 total = (total + 3) & ~(size_t)3;
                 c.word0 = (int64_t)total;
-                total += (size_t)PAD;
-                for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) total += (size_t)((fsel[(size_t)j].len + 7) / 8 + PAD);
+                total += (size_t)prefix;
+                for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) total += (size_t)read_words(fsel[(size_t)j].len);
             }
             total = (total + 3) & ~(size_t)3;
             f_seq.reset(new uint32_t[total + 4]);
@@ -280,12 +300,13 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         std::vector<std::vector<uint32_t>> ev_parts((size_t)n_threads);
         auto pack_range = [&](int t) {
             std::vector<uint32_t> &ev = ev_parts[(size_t)t];
+            std::vector<uint32_t> scratch;                                        // format 2: a read's nibbles before they become planes
             const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;
             for (size_t ci = c0; ci < c1; ++ci) {
                 tcmi_fast_chunk &c = chunks[ci];
                 const size_t c_end = ci + 1 < chunks.size() ? (size_t)chunks[ci + 1].word0 : f_seq_n;
                 std::memset(&f_seq[(size_t)c.word0], 0, (c_end - (size_t)c.word0) * 4);      // pads and alignment gaps stay zero
-                size_t cursor = (size_t)c.word0 + (size_t)PAD;
+                size_t cursor = (size_t)c.word0 + (size_t)prefix;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const tcmi_reads *r = s.r;
@@ -295,8 +316,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 const int64_t nw = (s.len + 7) / 8;
                 const size_t base = cursor;
                 f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
-                cursor += (size_t)(nw + PAD);
-                uint8_t *dst = reinterpret_cast<uint8_t *>(&f_seq[base]);
+                cursor += (size_t)read_words(s.len);
+                if (fmt == 2) scratch.assign((size_t)nw + 1, 0u);
+                uint8_t *dst = reinterpret_cast<uint8_t *>(fmt == 2 ? scratch.data() : &f_seq[base]);
                 const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
                 if (s.projected) {
                     // Walk the CIGAR once: matched bases land on their reference offset, D / N leave zero
@@ -344,7 +366,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                     }
                 }
                 // bases that are no A/C/G/T: rare, found a word at a time
-                const uint32_t *w = &f_seq[base];
+                const uint32_t *w = fmt == 2 ? scratch.data() : &f_seq[base];
                 for (int64_t k = 0; k < nw; ++k) {
                     const uint32_t v = w[k];
                     uint32_t nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;   // 1 per non-zero nibble
@@ -355,6 +377,25 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                         const int bit = __builtin_ctz(miss);
                         ev.push_back((uint32_t)(rpos + 8 * k + bit / 4) | TCMI_F_EV_OTHER);
                         miss &= miss - 1;
+                    }
+                }
+                if (fmt == 2) {
+                    // one-hot nibbles -> codes A=0 C=1 G=2 T=3 (class-less = 0) as {lo plane, hi plane} per 32 bases
+                    auto squeeze = [](uint32_t x) -> uint32_t {                 // bits 0,4,..,28 -> bits 0..7
+                        x = (x | (x >> 3)) & 0x03030303u;
+                        x = (x | (x >> 6)) & 0x000F000Fu;
+                        return (x | (x >> 12)) & 0xFFu;
+                    };
+                    uint32_t *out = &f_seq[base];
+                    for (int64_t q = 0; q < (s.len + 31) / 32; ++q) {
+                        uint32_t lo = 0, hi = 0;
+                        for (int64_t k = 0; k < 4 && 4 * q + k < nw; ++k) {
+                            const uint32_t v = w[4 * q + k];
+                            lo |= squeeze(((v >> 1) | (v >> 3)) & 0x11111111u) << (8 * k);   // C or T
+                            hi |= squeeze(((v >> 2) | (v >> 3)) & 0x11111111u) << (8 * k);   // G or T
+                        }
+                        out[2 * q] = lo;
+                        out[2 * q + 1] = hi;
                     }
                 }
                 if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads)
@@ -407,7 +448,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     rs->uid = next_uid.fetch_add(1);
     rs->n_reads = n_reads_in; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq_n;
-    rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW;
+    rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW; rs->f_fmt = fmt;
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
     // fused call (tally_fast.hip): who adds into which tile of TCMI_F_BLOCK positions
     std::vector<int32_t> tile_need, ev_tile_off, ev_tile, orphans;

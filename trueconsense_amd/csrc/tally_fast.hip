@@ -36,14 +36,10 @@
 // HBM-streaming integer work: no MFMA (BASELINE.json north_star).
 #include <algorithm>
 
-#include "call_device.h"
-#include "tcmi_internal.h"
+#include "tally_fast_common.h"
 
 namespace {
 
-constexpr int FB = TCMI_F_BLOCK;                // lanes per workgroup
-constexpr int MAXPOS = TCMI_F_MAXW * 8;         // positions in the largest window
-constexpr int NLD = TCMI_F_SEQCAP / (4 * FB);   // 16-byte loads per lane that cover the largest stage
 #ifndef TCMI_ABL
 #define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 1 no class extraction, 2 no inner loop,
                         // 4 no global loads / staging, 8 no final reduce + atomics, 16 no coverage runs
@@ -51,111 +47,7 @@ constexpr int NLD = TCMI_F_SEQCAP / (4 * FB);   // 16-byte loads per lane that c
 constexpr int UNR = TCMI_F_BLOCK == 512 ? 3 : 4;                          // reads in flight per lane in the inner loop
 constexpr int WIDEN = 12;                       // reads between widenings of the 4-bit counters (<= 15, multiple of UNR)
 
-struct FastArgs {
-    const int32_t *pos;
-    const uint32_t *lenoff;
-    const uint32_t *seq;
-    const tcmi_fast_chunk *chunks;
-    const uint32_t *events;
-    int32_t *counts;
-    int64_t ld;
-    int64_t n_events;
-    int32_t n_chunks;
-    int32_t L;
-    // fused call (FUSED launches only)
-    const int32_t *tile_need;       // [n_tiles] workgroups that add into tile t
-    int32_t *tile_done;             // [>= all tiles below L] sign-offs so far; zero between launches
-    const int32_t *ev_tile_off;     // [n_tail + 1] tiles touched by tail block b: ev_tile[ev_tile_off[b] .. ev_tile_off[b+1])
-    const int32_t *ev_tile;
-    const int32_t *orphans;         // [n_orphans] tiles below n_tiles nobody adds into
-    int32_t n_tail, n_tiles, n_orphans;
-    int32_t mincov, include_ambig;
-    uint8_t *plain, *alt, *flags;
-};
-
-constexpr int TILE = FB;            // positions per tile of the fused call: one lane each
-
-// Memory ordering of the fused call.  Everything the workgroups tell each other goes through AGENT-scope atomics
-// (the adds into the matrix, the sign-off counter, the caller's loads of the finished counters): on gfx942/950
-// those carry sc1 and are performed at the device's coherence point, never held dirty in one XCD's L2 (two XCDs
-// adding into one counter is what the tally relies on anyway).  So a lane only has to WAIT until its adds have
-// been performed (s_waitcnt vmcnt(0)) before the workgroup signs off — no `__threadfence()`: its agent-scope
-// release / acquire would write back and invalidate a whole L2 per wave (measured: 1.2 ms instead of 80 us).
-__device__ inline void wait_until_adds_are_performed()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler: nothing moves below
-    __builtin_amdgcn_s_waitcnt(0);                              // vmcnt(0) expcnt(0) lgkmcnt(0)
-}
-
-// The calling workgroup of tile t: every workgroup that adds into the tile has signed off, so the counters are
-// final.  Agent-scope atomic loads: they must not hit in a stale L1 / another XCD's L2 line.
-__device__ inline void call_tile(const FastArgs &a, int t)
-{
-    const int64_t p = (int64_t)t * TILE + threadIdx.x;
-    if (p < a.L) {
-        int32_t v[TCMI_NCOL];
-#pragma unroll
-        for (int c = 0; c < TCMI_NCOL; ++c) {
-            int32_t *q = &a.counts[(int64_t)c * a.ld + p];
-            v[c] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int c = 0; c < TCMI_NCOL; ++c)                     // zero for the next launch (visible after the kernel boundary)
-            __hip_atomic_store(&a.counts[(int64_t)c * a.ld + p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const tcmi_calldev::Record rec = tcmi_calldev::call_position(v[TCMI_COV], v[TCMI_A], v[TCMI_T], v[TCMI_C], v[TCMI_G],
-                                                                     v[TCMI_X], v[TCMI_I], a.mincov, a.include_ambig);
-        a.plain[p] = rec.plain;
-        a.alt[p] = rec.alt;
-        a.flags[p] = rec.flags;
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(&a.tile_done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Sign off `nt` tiles (tile index for slot k from `tile_of(k)`), then call those this workgroup completed.
-// All lanes of the workgroup must arrive; every lane has issued its adds into the matrix before.
-template <class TileOf>
-__device__ inline void sign_off_and_call(const FastArgs &a, int nt, TileOf tile_of, int *s_last /* LDS [FB] */)
-{
-    wait_until_adds_are_performed();
-    __syncthreads();
-    for (int k0 = 0; k0 < nt; k0 += FB) {
-        const int k = k0 + (int)threadIdx.x;
-        const int n = min(FB, nt - k0);
-        if (k < nt) {
-            const int t = tile_of(k);
-            const int old = __hip_atomic_fetch_add(&a.tile_done[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last[threadIdx.x] = old == a.tile_need[t] - 1 ? t : -1;
-        }
-        __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            const int t = s_last[j];
-            if (t >= 0) call_tile(a, t);
-        }
-        __syncthreads();
-    }
-}
-
 constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum
-static_assert(NLD >= 1 && NLD <= 6, "prefetch registers are written out for up to 6 loads per lane");
-
-// inclusive block scan of one int over the workgroup
-__device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    __syncthreads();                            // wave_tot may still be read from a previous scan
-    if (lane == 63) wave_tot[wave] = v;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int w = 0; w < FB / 64; ++w)
-        if (w < wave) base += wave_tot[w];
-    return v + base;
-}
 
 template <int NW, bool FUSED>
 __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastArgs a)
@@ -170,39 +62,7 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
 
     const int tid = threadIdx.x, lane = tid & 63;
     if ((int)blockIdx.x >= a.n_chunks) {
-        // Tail blocks: the tokens that are no plain A/C/G/T bases, as event words (position | kind).
-        // Equal words are counted inside the wave (ballot match), one atomic per distinct word and
-        // wave: at an indel site thousands of reads carry the same event.
-        const int64_t i = (int64_t)((int)blockIdx.x - a.n_chunks) * FB + tid;
-        const bool valid = i < a.n_events;
-        const uint32_t key = valid ? a.events[i] : 0u;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
-            const unsigned long long same = __ballot(valid && key == k);
-            if (lane == leader) {
-                const int n = __popcll(same);
-                const int p = (int)(k & (TCMI_F_EVPOS - 1u));
-                if (p < a.L) {
-                    if (k & TCMI_F_EV_OTHER) atomicSub(&a.counts[(int64_t)TCMI_T * a.ld + p], n);   // was counted as T by subtraction
-                    if (k & TCMI_F_EV_X) atomicAdd(&a.counts[(int64_t)TCMI_X * a.ld + p], n);
-                    if (k & TCMI_F_EV_I) atomicAdd(&a.counts[(int64_t)TCMI_I * a.ld + p], n);
-                }
-            }
-            todo &= ~same;
-        }
-        if constexpr (FUSED) {
-            const int b = (int)blockIdx.x - a.n_chunks;
-            if (b < a.n_tail) {
-                const int o = a.ev_tile_off[b];
-                sign_off_and_call(a, a.ev_tile_off[b + 1] - o, [&](int k) { return a.ev_tile[o + k]; },
-                                  reinterpret_cast<int *>(s_hdr));
-            } else {                            // a tile nobody adds into: call it straight away
-                const int k = b - a.n_tail;
-                call_tile(a, k < a.n_orphans ? a.orphans[k] : a.n_tiles + (k - a.n_orphans));
-            }
-        }
+        tally_tail_block<FUSED>(a, reinterpret_cast<int *>(s_hdr));
         return;
     }
     const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
@@ -233,7 +93,7 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
     // all four stage ends up front (scalar loads with the rest of the chunk record): a load of
     // stage_end[stage + 1] inside the loop put a full memory round trip in front of every prefetch
     const int se0 = chp->stage_end[0], se1 = chp->stage_end[1], se2 = chp->stage_end[2], se3 = chp->stage_end[3];
-    static_assert(TCMI_F_MAXSTAGE == 4, "stage ends are held in four scalars");
+    static_assert(TCMI_F_MAXSTAGE >= 4, "stage ends are held in four scalars: format 1 has at most four stages per chunk");
     int st_begin = 0, st_end = se0;                              // word range of the stage (from word0)
     // every lane loads (indices clamped into the stage): no exec-masked branch, so the compiler can leave
     // the loads in flight across the inner loop instead of waiting at a branch join.  (A macro, not a
@@ -436,6 +296,7 @@ static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, 
     FastArgs a = {};
     a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent;
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
+    a.other_col = rs->f_fmt == 2 ? TCMI_A : TCMI_T;
     a.n_tail = (int32_t)((rs->f_events + FB - 1) / FB);
     int64_t grid = rs->f_chunks + a.n_tail;
     if (fused) {
@@ -452,7 +313,8 @@ static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, 
     tcmi_prof_begin(ctx, TCMI_K_TALLY);
     if (rs->f_nw != 2) return tcmi_fail(ctx, TCMI_E_ARG, "read set was packed for %d grid words per lane", rs->f_nw);
     (void)hipGetLastError();                                   // drop any stale error of this thread
-    if (fused) hipLaunchKernelGGL((tally_fast_kernel<2, true>), dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    if (rs->f_fmt == 2) tcmi_dispatch_tally_planes(a, (unsigned)grid, ctx->stream, fused);
+    else if (fused) hipLaunchKernelGGL((tally_fast_kernel<2, true>), dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
     else hipLaunchKernelGGL((tally_fast_kernel<2, false>), dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);   // (<4> measured slower)
     tcmi_prof_end(ctx, TCMI_K_TALLY);
     TCMI_HIP(ctx, hipGetLastError());

@@ -1,0 +1,339 @@
+// tally_planes.hip — stage A for ALIGNED reads on gfx950, bases as 2-bit codes in two bit planes.
+// Counterpart of the per-token loop of indexing.py:102-132 for the tokens that are plain bases
+// (SURVEY §8-P2), like tally_fast.hip, with a denser layout and a cheaper inner loop:
+//
+// Data (tcmi_internal.h, format 2): per read 8 bytes of header and its aligned bases as codes
+// A=0 C=1 G=2 T=3 (anything else 0, listed as an OTHER event), 32 bases per pair of 32-bit words
+// {lo plane, hi plane}, followed by two zero pairs: 64 bytes for a 150-bp read instead of 96.
+//
+// One workgroup per chunk (<= 8 stages of <= 438 reads), lane (g, s) owns 32 positions g of the
+// window and depth slice s of the reads.  Per read of the slice: one 64-bit LDS header, ONE
+// ds_read2_b64 (two pairs), two v_alignbit funnel shifts bring the read's planes onto the lane's
+// 32 positions; lo, hi and lo&hi (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders
+// (3 VALU ops: xor, bfi, xor) fold four reads into the ones / twos planes and a fours carry; every
+// second time two fours carries fold into an eights carry that ripples through the upper planes
+// (8 planes: <= 255 reads per lane and chunk).  ~20 VALU instructions per read and 32 positions
+// (the nibble kernel: ~24 per 16).  At the end of the chunk the planes are spread into byte
+// counters once, the slices are summed through LDS, and per position
+//     C = n(lo) - n(lo&hi),  G = n(hi) - n(lo&hi),  T = n(lo&hi),  A = coverage - C - G - T
+// (covered positions without an A/C/G/T base land in A and are taken out by the tail blocks).
+// Staging, prefetch, coverage runs, final atomics and the fused call are those of tally_fast.hip.
+//
+// HBM-streaming integer work: no MFMA (BASELINE.json north_star).
+#include <algorithm>
+
+#include "tally_fast_common.h"
+
+namespace {
+
+constexpr int NPL = 8;                          // counter planes per vector
+constexpr int NVEC = 3;                         // lo, hi, lo & hi
+constexpr int NREG = NVEC * 8;                  // byte-counter registers per lane after the spread
+constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum
+constexpr int HSLOTS = 576;                     // header slots (TCMI_P_SUB + the dummy); the buffer later holds the window counters
+static_assert(FB == 256, "two header slots per lane cover a stage of up to 512 reads");
+static_assert(TCMI_P_SUB <= 2 * FB && TCMI_P_SUB < HSLOTS && HSLOTS * 8 >= NVEC * MAXPOS * 2, "s_hdr doubles as the 16-bit window counters");
+static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
+static_assert(TCMI_F_MAXSTAGE == 8, "stage ends are held in eight scalars");
+
+// carry-save adder: (sum, carry) of three bit vectors
+#define TCMI_CSA(sum_, carry_, a_, b_, c_)                      \
+    do {                                                        \
+        const uint32_t u_ = (a_) ^ (b_);                        \
+        const uint32_t cc_ = (u_ & (c_)) | (~u_ & (a_));        \
+        (sum_) = u_ ^ (c_);                                     \
+        (carry_) = cc_;                                         \
+    } while (0)
+
+struct Planes {                                 // one bit-sliced counter per bit position: value = sum p[k] << k
+    uint32_t p[NPL];
+    uint32_t pend;                              // a fours-weight carry waiting for its partner
+};
+
+// add an eights-weight carry into planes 3..7
+__device__ inline void ripple8(Planes &c, uint32_t e)
+{
+#pragma unroll
+    for (int k = 3; k < NPL - 1; ++k) {
+        const uint32_t t = c.p[k] & e;
+        c.p[k] ^= e;
+        e = t;
+    }
+    c.p[NPL - 1] ^= e;
+}
+
+// fold four bit vectors into the counter; `second` (uniform) says whether a fours carry is pending
+__device__ inline void add4(Planes &c, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, bool second)
+{
+    uint32_t tA, tB, fA;
+    TCMI_CSA(c.p[0], tA, c.p[0], x0, x1);
+    TCMI_CSA(c.p[0], tB, c.p[0], x2, x3);
+    TCMI_CSA(c.p[1], fA, c.p[1], tA, tB);
+    if (!second) c.pend = fA;
+    else {
+        uint32_t e;
+        TCMI_CSA(c.p[2], e, c.p[2], c.pend, fA);
+        ripple8(c, e);
+    }
+}
+
+// a pending fours carry without a partner (end of the chunk)
+__device__ inline void flush_pending(Planes &c)
+{
+    const uint32_t e = c.p[2] & c.pend;
+    c.p[2] ^= c.pend;
+    ripple8(c, e);
+}
+
+// byte i of the result = count at bit position j + 8 i (planes [0, np) only; the others are known to be zero)
+template <int J>
+__device__ inline uint32_t spread(const Planes &c, int np)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        if (k >= 5 && k >= np) break;           // uniform: few reads per lane leave the top planes empty
+        const uint32_t m = 0x01010101u << k;
+        const uint32_t v = J >= k ? (c.p[k] >> (J - k)) : (c.p[k] << (k - J));
+        r |= v & m;
+    }
+    return r;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged planes; later the slice partials
+    __shared__ __attribute__((aligned(8))) uint2 s_hdr[HSLOTS];              // {pos - P0 | pairs << 16, byte offset in s_seq}
+    __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
+    __shared__ int s_scan[FB / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x >= a.n_chunks) {
+        tally_tail_block<FUSED>(a, reinterpret_cast<int *>(s_hdr));
+        return;
+    }
+    const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
+    const int64_t read0 = chp->read0, word0 = chp->word0;
+    const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
+    const int npos = Wn * 8;
+    const int Gn = (npos + 31) >> 5;            // lane groups of 32 positions
+    const int S = FB / Gn;                      // depth slices
+    const int s = tid / Gn, gi = tid - s * Gn;
+    const int base32 = gi * 32;                 // first owned position, relative to P0
+    const int s_eff = s < S ? s : (1 << 20);    // lanes beyond the last slice only ever see the dummy read
+    const int n_stage = (n_reads + sub_reads - 1) / sub_reads;
+
+    for (int i = tid; i <= npos; i += FB) s_cov[i] = 0;
+    __syncthreads();                            // before any wave adds coverage runs into it
+
+    Planes cnt[NVEC];
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) cnt[v].p[k] = 0;
+        cnt[v].pend = 0;
+    }
+    bool second = false;                        // uniform: a fours carry is pending in cnt[*].pend
+
+    // ---- prefetch registers: the next stage's headers (two slots per lane) and planes --------------
+    int h_pos0 = 0, h_pos1 = 0;
+    uint32_t h_lo0 = 0, h_lo1 = 0;
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};
+    const int se0 = chp->stage_end[0], se1 = chp->stage_end[1], se2 = chp->stage_end[2], se3 = chp->stage_end[3];
+    const int se4 = chp->stage_end[4], se5 = chp->stage_end[5], se6 = chp->stage_end[6], se7 = chp->stage_end[7];
+    int st_begin = 0, st_end = se0;             // word range of the stage (from word0)
+#define TCMI_ISSUE_STAGE(stage_, begin_, end_)                                                        \
+    do {                                                                                              \
+        const int r0_ = min((stage_) * sub_reads + tid, n_reads - 1);                                 \
+        const int r1_ = min((stage_) * sub_reads + FB + tid, n_reads - 1);                            \
+        h_pos0 = a.pos[read0 + r0_];                                                                  \
+        h_lo0 = a.lenoff[read0 + r0_];                                                                \
+        h_pos1 = a.pos[read0 + r1_];                                                                  \
+        h_lo1 = a.lenoff[read0 + r1_];                                                                \
+        const int mis_ = (int)((word0 + (begin_)) & 3); /* keep the 16-byte loads aligned */          \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(a.seq + (word0 + (begin_) - mis_));       \
+        const int last_ = ((end_) - (begin_) + mis_ + 3) / 4 - 1;                                     \
+        pre0 = src_[min(0 * FB + tid, last_)];                                                        \
+        pre1 = src_[min(1 * FB + tid, last_)];                                                        \
+        pre2 = src_[min(2 * FB + tid, last_)];                                                        \
+        pre3 = src_[min(3 * FB + tid, last_)];                                                        \
+        pre4 = src_[min(4 * FB + tid, last_)];                                                        \
+        pre5 = src_[min(5 * FB + tid, last_)];                                                        \
+    } while (0)
+    static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
+    TCMI_ISSUE_STAGE(0, st_begin, st_end);
+
+    for (int stage = 0; stage < n_stage; ++stage) {
+        const int ns = min(sub_reads, n_reads - stage * sub_reads);
+        const int mis = (int)((word0 + st_begin) & 3);
+        const int tw = st_end - st_begin + mis;
+        // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
+        const bool valid0 = tid < ns, valid1 = tid + FB < ns;
+        int rel0 = 0, len0 = 0, rel1 = 0, len1 = 0;
+        if (valid0) {
+            rel0 = h_pos0 - P0;
+            len0 = (int)(h_lo0 & 1023u);
+            const int off = (int)(h_lo0 >> 10) - st_begin + mis;   // word index of the read in s_seq (even)
+            s_hdr[tid] = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)off * 4u);
+        }
+        if (valid1) {
+            rel1 = h_pos1 - P0;
+            len1 = (int)(h_lo1 & 1023u);
+            const int off = (int)(h_lo1 >> 10) - st_begin + mis;
+            s_hdr[tid + FB] = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)off * 4u);
+        }
+        if (tid == 0)                                            // dummy: a read far to the right, no pairs; two zero pairs lie
+            s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)(mis + 4) * 4u);   // in front of the stage's first read
+        {
+            uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
+            if ((0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
+            if ((1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
+            if ((2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
+            if ((3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
+            if ((4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
+            if ((5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
+        }
+        __syncthreads();
+        // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
+        if (stage + 1 < n_stage) {
+            st_begin = st_end - 4;                               // the two zero pairs behind the last read come along
+            st_end = stage == 0 ? se1 : stage == 1 ? se2 : stage == 2 ? se3 : stage == 3 ? se4 : stage == 4 ? se5 : stage == 5 ? se6 : se7;
+            TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
+        }
+        // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bool valid = half ? valid1 : valid0;
+            const int rel = half ? rel1 : rel0, len = half ? len1 : len0;
+            const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
+            const bool lead = valid && (lane == 0 || rel != prel || len != plen);
+            const unsigned long long leads = __ballot(lead), valids = __ballot(valid);
+            const unsigned long long above = lane == 63 ? 0ull : (leads >> (lane + 1)) << (lane + 1);
+            const int next = above ? (__ffsll((long long)above) - 1) : __popcll(valids);
+            if (lead) {
+                const int run = next - lane;
+                atomicAdd(&s_cov[rel], run);
+                atomicAdd(&s_cov[rel + len], -run);
+            }
+        }
+        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free inside a body
+        //      of four reads: indices past the stage are clamped onto the dummy header.
+        const int Rs = (ns + S - 1) / S;
+        const int hbytes_end = ns * 8;
+        int hb = s_eff * 8;                                      // byte offset of the lane's next header
+        for (int k = 0; k < Rs; k += 4) {
+            uint2 h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
+                hb += S * 8;
+            }
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = base32 - (int)(h[u].x & 0xFFFFu);      // first owned position relative to the read start
+                // pair of the read holding it, clamped into the zero pairs on either side
+                const int q = max(-2, min(d >> 5, (int)(h[u].x >> 16)));
+                const uint2 *wp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 8);
+                const uint2 w0 = wp[0], w1 = wp[1];                  // {lo, hi} of pairs q and q + 1
+                lo[u] = __builtin_amdgcn_alignbit(w1.x, w0.x, (uint32_t)d);   // v_alignbit uses bits [4:0] = d mod 32
+                hi[u] = __builtin_amdgcn_alignbit(w1.y, w0.y, (uint32_t)d);
+            }
+            add4(cnt[0], lo[0], lo[1], lo[2], lo[3], second);
+            add4(cnt[1], hi[0], hi[1], hi[2], hi[3], second);
+            add4(cnt[2], lo[0] & hi[0], lo[1] & hi[1], lo[2] & hi[2], lo[3] & hi[3], second);
+            second = !second;
+        }
+        __syncthreads();                                        // every lane is done with this stage's LDS
+    }
+    if (second) {
+#pragma unroll
+        for (int v = 0; v < NVEC; ++v) flush_pending(cnt[v]);
+    }
+    // ---- planes -> byte counters -> LDS, layout [register j][lane] (conflict-free both ways) ---------
+    uint32_t *s_part = s_seq;
+    uint16_t (*s_fin)[MAXPOS] = reinterpret_cast<uint16_t (*)[MAXPOS]>(s_hdr);   // window counters of lo, hi, lo&hi
+    {
+        const int per_lane = n_stage * ((sub_reads + S - 1) / S);                  // bound on the reads per lane (dummies count nothing)
+        const int np = 32 - __clz(per_lane);                                       // planes that can be non-zero
+#pragma unroll
+        for (int v = 0; v < NVEC; ++v) {
+            s_part[(v * 8 + 0) * FB + tid] = spread<0>(cnt[v], np);
+            s_part[(v * 8 + 1) * FB + tid] = spread<1>(cnt[v], np);
+            s_part[(v * 8 + 2) * FB + tid] = spread<2>(cnt[v], np);
+            s_part[(v * 8 + 3) * FB + tid] = spread<3>(cnt[v], np);
+            s_part[(v * 8 + 4) * FB + tid] = spread<4>(cnt[v], np);
+            s_part[(v * 8 + 5) * FB + tid] = spread<5>(cnt[v], np);
+            s_part[(v * 8 + 6) * FB + tid] = spread<6>(cnt[v], np);
+            s_part[(v * 8 + 7) * FB + tid] = spread<7>(cnt[v], np);
+        }
+    }
+    __syncthreads();
+    // ---- sum the slices; register j of group g holds 4 positions (j%8 + 8 i) of one vector ------------
+    for (int item = tid; item < Gn * NREG; item += FB) {
+        const int j = item / Gn, g = item - j * Gn;
+        uint32_t e = 0, o = 0;                                  // bytes 0,2 and bytes 1,3 as 16-bit sums
+        const uint32_t *row = s_part + j * FB + g;
+        for (int t = 0; t < S; t += 4) {                        // four independent LDS loads in flight
+            const uint32_t v0 = row[t * Gn];
+            const uint32_t v1 = t + 1 < S ? row[(t + 1) * Gn] : 0u;
+            const uint32_t v2 = t + 2 < S ? row[(t + 2) * Gn] : 0u;
+            const uint32_t v3 = t + 3 < S ? row[(t + 3) * Gn] : 0u;
+            e += (v0 & 0x00FF00FFu) + (v1 & 0x00FF00FFu) + (v2 & 0x00FF00FFu) + (v3 & 0x00FF00FFu);
+            o += ((v0 >> 8) & 0x00FF00FFu) + ((v1 >> 8) & 0x00FF00FFu) + ((v2 >> 8) & 0x00FF00FFu) + ((v3 >> 8) & 0x00FF00FFu);
+        }
+        const int v = j >> 3;
+        const int p = g * 32 + (j & 7);                         // byte i of the register <-> position p + 8 i
+        uint16_t *f = &s_fin[v][p];
+        if (p < npos) f[0] = (uint16_t)(e & 0xFFFFu);
+        if (p + 8 < npos) f[8] = (uint16_t)(o & 0xFFFFu);
+        if (p + 16 < npos) f[16] = (uint16_t)(e >> 16);
+        if (p + 24 < npos) f[24] = (uint16_t)(o >> 16);
+    }
+    // ---- coverage: inclusive prefix sum of the difference array, CPL entries per lane ----------------
+    {
+        const int i0 = tid * CPL;
+        int d[CPL], sum = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { d[k] = i0 + k < npos ? s_cov[i0 + k] : 0; sum += d[k]; }
+        int run = block_scan_incl(sum, s_scan) - sum;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            run += d[k];
+            if (i0 + k < npos) s_cov[i0 + k] = run;
+        }
+    }
+    __syncthreads();
+    // ---- one coalesced global atomic per touched (class, position) -----------------------------------
+    for (int p = tid; p < npos; p += FB) {
+        const int gp = P0 + p;
+        if (gp >= a.L) continue;
+        const int cv = s_cov[p];
+        if (cv == 0) continue;
+        const int nT = s_fin[2][p], nC = s_fin[0][p] - nT, nG = s_fin[1][p] - nT;
+        const int nA = cv - nC - nG - nT;                       // includes the class-less positions, taken out by the tail blocks
+        atomicAdd(&a.counts[(int64_t)TCMI_COV * a.ld + gp], cv);
+        if (nA) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA);
+        if (nC) atomicAdd(&a.counts[(int64_t)TCMI_C * a.ld + gp], nC);
+        if (nG) atomicAdd(&a.counts[(int64_t)TCMI_G * a.ld + gp], nG);
+        if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
+    }
+    if constexpr (FUSED) {
+        __syncthreads();                                        // s_hdr held the window counters until here
+        const int t0 = P0 / TILE;
+        sign_off_and_call(a, (P0 + npos - 1) / TILE - t0 + 1, [&](int k) { return t0 + k; }, reinterpret_cast<int *>(s_hdr));
+    }
+}
+
+#undef TCMI_ISSUE_STAGE
+#undef TCMI_CSA
+
+} // namespace
+
+void tcmi_dispatch_tally_planes(const FastArgs &a, unsigned grid, hipStream_t stream, bool fused)
+{
+    if (fused) hipLaunchKernelGGL((tally_planes_kernel<true>), dim3(grid), dim3(FB), 0, stream, a);
+    else hipLaunchKernelGGL((tally_planes_kernel<false>), dim3(grid), dim3(FB), 0, stream, a);
+}

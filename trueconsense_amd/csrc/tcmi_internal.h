@@ -47,14 +47,15 @@
 #define TCMI_F_SEG 512             // projected reads longer than this are cut into pieces of this many positions
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
-#define TCMI_F_MAXSTAGE 4          // stages per chunk
+#define TCMI_F_MAXSTAGE 8          // stages per chunk (format 1 uses up to 4)
+#define TCMI_P_SUB 512             // format 2: max reads staged in LDS at a time
 // event word = reference position | kind; kinds may be combined
 #define TCMI_F_EVPOS   (1u << 29)  // positions must stay below this for the fast path
 #define TCMI_F_EV_OTHER (1u << 29) // a covered position whose token is no A/C/G/T base: was counted as T by subtraction
 #define TCMI_F_EV_X     (1u << 30) // token "*"
 #define TCMI_F_EV_I     (1u << 31) // token carries an insertion
 
-struct tcmi_fast_chunk {           // 48 bytes
+struct tcmi_fast_chunk {           // 64 bytes
     int64_t read0;                 // first read (index into f_pos / f_lenoff)
     int64_t word0;                 // first word of the chunk's base stream (multiple of 4)
     int32_t n_reads;
@@ -76,6 +77,7 @@ struct tcmi_readset {
     // aligned set
     int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
     int32_t f_nw = 2;           // grid words per lane the stream was padded for (pad = f_nw + 1)
+    int32_t f_fmt = 2;          // base stream: 1 = one-hot nibbles (tally_fast.hip), 2 = two bit planes (tally_planes.hip)
     int32_t *d_fpos = nullptr;  // [f_reads]
     uint32_t *d_flenoff = nullptr; // [f_reads] len | (word offset from the chunk's word0) << 10
     uint32_t *d_fseq = nullptr; // [f_words]
@@ -138,7 +140,8 @@ struct tcmi_ctx {
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int host_threads = 8;           // threads tcmi_readset_upload packs with
-    int chunk_stages = 4;           // stages per chunk of the fast kernel (1..4)
+    int chunk_stages = 0;           // stages per chunk of the fast kernels, 0 = as many as the format allows (4 / 8)
+    int fast_format = 2;            // tcmi_readset_upload: layout of the aligned set (tcmi_readset::f_fmt)
     int fuse_call = 0;              // tcmi_step_begin: tally + call as one launch when the read set allows it (opt-in:
                                     // 2.5 % faster steps, but the call work lands in the tally kernel's time)
     int project_reads = 1;          // reads with indels / skips go to the fast kernel projected onto the reference

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../trueconsense_amd/csrc"
 name=$1; shift
 out=../lib/variants; mkdir -p $out/obj_$name
-for f in tally.hip tally_fast.hip call.hip api.cpp readset.cpp consensus_walk.cpp insert_tokens.cpp bam_reader.cpp pipeline.cpp; do
+for f in tally.hip tally_fast.hip tally_planes.hip call.hip api.cpp readset.cpp consensus_walk.cpp insert_tokens.cpp bam_reader.cpp pipeline.cpp; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $f -o $out/obj_$name/${f%.*}.o &
 done
 wait

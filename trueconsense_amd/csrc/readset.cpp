@@ -235,10 +235,10 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
             if (fmt == 2) {
-                // lanes own 32 positions; an inner-loop body takes 4 reads per lane
+                // lanes own 32 positions; an inner-loop body takes 8 reads per lane
                 const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
                 const int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
-                int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
+                int64_t sub = S * 8 * std::max<int64_t>(1, cap / (S * 8));
                 if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
                 return sub;
             }

@@ -10,10 +10,9 @@
 // window and depth slice s of the reads.  Per read of the slice: one 64-bit LDS header, ONE
 // ds_read2_b64 (two pairs), two v_alignbit funnel shifts bring the read's planes onto the lane's
 // 32 positions; lo, hi and lo&hi (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders
-// (3 VALU ops: xor, bfi, xor) fold four reads into the ones / twos planes and a fours carry; every
-// second time two fours carries fold into an eights carry that ripples through the upper planes
-// (8 planes: <= 255 reads per lane and chunk).  ~20 VALU instructions per read and 32 positions
-// (the nibble kernel: ~24 per 16).  At the end of the chunk the planes are spread into byte
+// (sum and carry: one v_bitop3_b32 each) fold eight reads into the ones / twos / fours planes and an
+// eights carry that ripples through the upper planes (8 planes: <= 255 reads per lane and chunk).
+// ~19 VALU instructions per read and 32 positions (the nibble kernel: ~24 per 16).  At the end of the chunk the planes are spread into byte
 // counters once, the slices are summed through LDS, and per position
 //     C = n(lo) - n(lo&hi),  G = n(hi) - n(lo&hi),  T = n(lo&hi),  A = coverage - C - G - T
 // (covered positions without an A/C/G/T base land in A and are taken out by the tail blocks).
@@ -26,6 +25,10 @@
 
 namespace {
 
+#ifndef TCMI_ABL
+#define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
+                        // 8 no spread / final reduce / atomics
+#endif
 constexpr int NPL = 8;                          // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
 constexpr int NREG = NVEC * 8;                  // byte-counter registers per lane after the spread
@@ -34,25 +37,29 @@ constexpr int HSLOTS = 576;                     // header slots (TCMI_P_SUB + th
 static_assert(FB == 256, "two header slots per lane cover a stage of up to 512 reads");
 static_assert(TCMI_P_SUB <= 2 * FB && TCMI_P_SUB < HSLOTS && HSLOTS * 8 >= NVEC * MAXPOS * 2, "s_hdr doubles as the 16-bit window counters");
 static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
-static_assert(TCMI_F_MAXSTAGE == 8, "stage ends are held in eight scalars");
 
-// carry-save adder: (sum, carry) of three bit vectors
-#define TCMI_CSA(sum_, carry_, a_, b_, c_)                      \
-    do {                                                        \
-        const uint32_t u_ = (a_) ^ (b_);                        \
-        const uint32_t cc_ = (u_ & (c_)) | (~u_ & (a_));        \
-        (sum_) = u_ ^ (c_);                                     \
-        (carry_) = cc_;                                         \
-    } while (0)
+// carry-save adder on bit vectors: sum and carry of three inputs (one v_bitop3_b32 each on gfx950;
+// truth table: bit i of the immediate = f(a = i >> 2 & 1, b = i >> 1 & 1, c = i & 1))
+#define TCMI_XOR3(a_, b_, c_) __builtin_amdgcn_bitop3_b32((a_), (b_), (c_), 0x96)
+#define TCMI_MAJ(a_, b_, c_) __builtin_amdgcn_bitop3_b32((a_), (b_), (c_), 0xE8)
 
 struct Planes {                                 // one bit-sliced counter per bit position: value = sum p[k] << k
     uint32_t p[NPL];
-    uint32_t pend;                              // a fours-weight carry waiting for its partner
 };
 
-// add an eights-weight carry into planes 3..7
-__device__ inline void ripple8(Planes &c, uint32_t e)
+// fold eight bit vectors into the counter: seven carry-save adders, then the eights carry ripples upward
+__device__ inline void add8(Planes &c, const uint32_t (&x)[8])
 {
+    const uint32_t s1 = TCMI_XOR3(c.p[0], x[0], x[1]), c1 = TCMI_MAJ(c.p[0], x[0], x[1]);
+    const uint32_t s2 = TCMI_XOR3(s1, x[2], x[3]), c2 = TCMI_MAJ(s1, x[2], x[3]);
+    const uint32_t s3 = TCMI_XOR3(s2, x[4], x[5]), c3 = TCMI_MAJ(s2, x[4], x[5]);
+    c.p[0] = TCMI_XOR3(s3, x[6], x[7]);
+    const uint32_t c4 = TCMI_MAJ(s3, x[6], x[7]);
+    const uint32_t t1 = TCMI_XOR3(c.p[1], c1, c2), d1 = TCMI_MAJ(c.p[1], c1, c2);
+    c.p[1] = TCMI_XOR3(t1, c3, c4);
+    const uint32_t d2 = TCMI_MAJ(t1, c3, c4);
+    uint32_t e = TCMI_MAJ(c.p[2], d1, d2);
+    c.p[2] = TCMI_XOR3(c.p[2], d1, d2);
 #pragma unroll
     for (int k = 3; k < NPL - 1; ++k) {
         const uint32_t t = c.p[k] & e;
@@ -60,29 +67,6 @@ __device__ inline void ripple8(Planes &c, uint32_t e)
         e = t;
     }
     c.p[NPL - 1] ^= e;
-}
-
-// fold four bit vectors into the counter; `second` (uniform) says whether a fours carry is pending
-__device__ inline void add4(Planes &c, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, bool second)
-{
-    uint32_t tA, tB, fA;
-    TCMI_CSA(c.p[0], tA, c.p[0], x0, x1);
-    TCMI_CSA(c.p[0], tB, c.p[0], x2, x3);
-    TCMI_CSA(c.p[1], fA, c.p[1], tA, tB);
-    if (!second) c.pend = fA;
-    else {
-        uint32_t e;
-        TCMI_CSA(c.p[2], e, c.p[2], c.pend, fA);
-        ripple8(c, e);
-    }
-}
-
-// a pending fours carry without a partner (end of the chunk)
-__device__ inline void flush_pending(Planes &c)
-{
-    const uint32_t e = c.p[2] & c.pend;
-    c.p[2] ^= c.pend;
-    ripple8(c, e);
 }
 
 // byte i of the result = count at bit position j + 8 i (planes [0, np) only; the others are known to be zero)
@@ -132,41 +116,44 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
     for (int v = 0; v < NVEC; ++v) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) cnt[v].p[k] = 0;
-        cnt[v].pend = 0;
     }
-    bool second = false;                        // uniform: a fours carry is pending in cnt[*].pend
 
     // ---- prefetch registers: the next stage's headers (two slots per lane) and planes --------------
     int h_pos0 = 0, h_pos1 = 0;
     uint32_t h_lo0 = 0, h_lo1 = 0;
     uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};
-    const int se0 = chp->stage_end[0], se1 = chp->stage_end[1], se2 = chp->stage_end[2], se3 = chp->stage_end[3];
-    const int se4 = chp->stage_end[4], se5 = chp->stage_end[5], se6 = chp->stage_end[6], se7 = chp->stage_end[7];
-    int st_begin = 0, st_end = se0;             // word range of the stage (from word0)
+    int st_begin = 0, st_end = chp->stage_end[0];   // word range of the stage (from word0)
+    int st_end_next = chp->stage_end[1];            // fetched one stage ahead (a scalar load: its round trip hides under a stage)
+    // Uniform base pointers + 32-bit lane offsets: the loads take the scalar-base form (no 64-bit address math
+    // per lane).  Every lane loads (indices clamped into the stage): no exec-masked branch, so the loads stay in
+    // flight across the inner loop.  (A macro, not a lambda: a closure kept the registers in scratch memory.)
+    const int32_t *pos_base = a.pos + read0;
+    const uint32_t *lenoff_base = a.lenoff + read0;
+    const uint32_t *seq_base = a.seq + word0;
 #define TCMI_ISSUE_STAGE(stage_, begin_, end_)                                                        \
     do {                                                                                              \
-        const int r0_ = min((stage_) * sub_reads + tid, n_reads - 1);                                 \
-        const int r1_ = min((stage_) * sub_reads + FB + tid, n_reads - 1);                            \
-        h_pos0 = a.pos[read0 + r0_];                                                                  \
-        h_lo0 = a.lenoff[read0 + r0_];                                                                \
-        h_pos1 = a.pos[read0 + r1_];                                                                  \
-        h_lo1 = a.lenoff[read0 + r1_];                                                                \
-        const int mis_ = (int)((word0 + (begin_)) & 3); /* keep the 16-byte loads aligned */          \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>(a.seq + (word0 + (begin_) - mis_));       \
-        const int last_ = ((end_) - (begin_) + mis_ + 3) / 4 - 1;                                     \
-        pre0 = src_[min(0 * FB + tid, last_)];                                                        \
-        pre1 = src_[min(1 * FB + tid, last_)];                                                        \
-        pre2 = src_[min(2 * FB + tid, last_)];                                                        \
-        pre3 = src_[min(3 * FB + tid, last_)];                                                        \
-        pre4 = src_[min(4 * FB + tid, last_)];                                                        \
-        pre5 = src_[min(5 * FB + tid, last_)];                                                        \
+        const uint32_t r0_ = (uint32_t)min((stage_) * sub_reads + tid, n_reads - 1);                  \
+        const uint32_t r1_ = (uint32_t)min((stage_) * sub_reads + FB + tid, n_reads - 1);             \
+        h_pos0 = pos_base[r0_];                                                                       \
+        h_lo0 = lenoff_base[r0_];                                                                     \
+        h_pos1 = pos_base[r1_];                                                                       \
+        h_lo1 = lenoff_base[r1_];                                                                     \
+        const int mis_ = (begin_) & 3; /* keep the 16-byte loads aligned (word0 is a multiple of 4) */ \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(seq_base + ((begin_) - mis_));            \
+        const uint32_t last_ = (uint32_t)(((end_) - (begin_) + mis_ + 3) / 4 - 1);                    \
+        pre0 = src_[min((uint32_t)(0 * FB + tid), last_)];                                            \
+        pre1 = src_[min((uint32_t)(1 * FB + tid), last_)];                                            \
+        pre2 = src_[min((uint32_t)(2 * FB + tid), last_)];                                            \
+        pre3 = src_[min((uint32_t)(3 * FB + tid), last_)];                                            \
+        pre4 = src_[min((uint32_t)(4 * FB + tid), last_)];                                            \
+        pre5 = src_[min((uint32_t)(5 * FB + tid), last_)];                                            \
     } while (0)
     static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
 
     for (int stage = 0; stage < n_stage; ++stage) {
         const int ns = min(sub_reads, n_reads - stage * sub_reads);
-        const int mis = (int)((word0 + st_begin) & 3);
+        const int mis = st_begin & 3;
         const int tw = st_end - st_begin + mis;
         // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
         const bool valid0 = tid < ns, valid1 = tid + FB < ns;
@@ -187,18 +174,19 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
             s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)(mis + 4) * 4u);   // in front of the stage's first read
         {
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            if ((0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
-            if ((1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
-            if ((2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
-            if ((3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
-            if ((4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
-            if ((5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
+            if (!(TCMI_ABL & 4) && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
+            if (!(TCMI_ABL & 4) && (1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
+            if (!(TCMI_ABL & 4) && (2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
+            if (!(TCMI_ABL & 4) && (3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
+            if (!(TCMI_ABL & 4) && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
+            if (!(TCMI_ABL & 4) && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
         }
         __syncthreads();
         // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
         if (stage + 1 < n_stage) {
             st_begin = st_end - 4;                               // the two zero pairs behind the last read come along
-            st_end = stage == 0 ? se1 : stage == 1 ? se2 : stage == 2 ? se3 : stage == 3 ? se4 : stage == 4 ? se5 : stage == 5 ? se6 : se7;
+            st_end = st_end_next;
+            st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
         }
         // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave
@@ -217,40 +205,42 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
                 atomicAdd(&s_cov[rel + len], -run);
             }
         }
-        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free inside a body
-        //      of four reads: indices past the stage are clamped onto the dummy header.
-        const int Rs = (ns + S - 1) / S;
+        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free body of eight
+        //      reads (a stage holds S * 8 * m reads): indices past the stage are clamped onto the dummy header.
+        const int Rs = (TCMI_ABL & 2) ? 0 : (ns + S - 1) / S;
         const int hbytes_end = ns * 8;
         int hb = s_eff * 8;                                      // byte offset of the lane's next header
-        for (int k = 0; k < Rs; k += 4) {
-            uint2 h[4];
+        for (int k = 0; k < Rs; k += 8) {
+            uint32_t lo[8], hi[8], both[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                h[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
-                hb += S * 8;
-            }
-            uint32_t lo[4], hi[4];
+            for (int half = 0; half < 2; ++half) {
+                uint2 h[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int d = base32 - (int)(h[u].x & 0xFFFFu);      // first owned position relative to the read start
-                // pair of the read holding it, clamped into the zero pairs on either side
-                const int q = max(-2, min(d >> 5, (int)(h[u].x >> 16)));
-                const uint2 *wp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 8);
-                const uint2 w0 = wp[0], w1 = wp[1];                  // {lo, hi} of pairs q and q + 1
-                lo[u] = __builtin_amdgcn_alignbit(w1.x, w0.x, (uint32_t)d);   // v_alignbit uses bits [4:0] = d mod 32
-                hi[u] = __builtin_amdgcn_alignbit(w1.y, w0.y, (uint32_t)d);
+                for (int u = 0; u < 4; ++u) {
+                    h[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
+                    hb += S * 8;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int d = base32 - (int)(h[u].x & 0xFFFFu);      // first owned position relative to the read start
+                    // pair of the read holding it, clamped into the zero pairs on either side
+                    const int q = max(-2, min(d >> 5, (int)(h[u].x >> 16)));
+                    const uint2 *wp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 8);
+                    const uint2 w0 = wp[0], w1 = wp[1];                  // {lo, hi} of pairs q and q + 1
+                    lo[half * 4 + u] = __builtin_amdgcn_alignbit(w1.x, w0.x, (uint32_t)d);   // v_alignbit uses bits [4:0] = d mod 32
+                    hi[half * 4 + u] = __builtin_amdgcn_alignbit(w1.y, w0.y, (uint32_t)d);
+                    both[half * 4 + u] = lo[half * 4 + u] & hi[half * 4 + u];
+                }
             }
-            add4(cnt[0], lo[0], lo[1], lo[2], lo[3], second);
-            add4(cnt[1], hi[0], hi[1], hi[2], hi[3], second);
-            add4(cnt[2], lo[0] & hi[0], lo[1] & hi[1], lo[2] & hi[2], lo[3] & hi[3], second);
-            second = !second;
+            add8(cnt[0], lo);
+            add8(cnt[1], hi);
+            add8(cnt[2], both);
         }
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
-    if (second) {
-#pragma unroll
-        for (int v = 0; v < NVEC; ++v) flush_pending(cnt[v]);
-    }
+#if TCMI_ABL & 8
+    if (cnt[0].p[0] != 0x12345678u) return;
+#endif
     // ---- planes -> byte counters -> LDS, layout [register j][lane] (conflict-free both ways) ---------
     uint32_t *s_part = s_seq;
     uint16_t (*s_fin)[MAXPOS] = reinterpret_cast<uint16_t (*)[MAXPOS]>(s_hdr);   // window counters of lo, hi, lo&hi
@@ -328,7 +318,8 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
 }
 
 #undef TCMI_ISSUE_STAGE
-#undef TCMI_CSA
+#undef TCMI_XOR3
+#undef TCMI_MAJ
 
 } // namespace
 

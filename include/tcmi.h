@@ -101,7 +101,7 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    take the fast kernel (default); 0 = they take the CIGAR-walk kernel
  *   "fast_format"    layout of the aligned reads on the device: 2 = 2-bit codes as two bit planes, 64 B per
  *                    150-bp read, bit-sliced counting (default); 1 = one-hot nibbles, 96 B per read
- *   "chunk_stages"   stages per fast-kernel chunk: 0 = as many as the format allows (default: 8 / 4), or 1..8
+ *   "chunk_stages"   stages per fast-kernel chunk: 0 = default (4), or 1..8 (format 1: at most 4)
  *   "host_threads"   threads tcmi_readset_upload packs with (default min(16, cores))
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
  *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches

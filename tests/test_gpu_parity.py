@@ -562,10 +562,15 @@ def test_graph_replay_equals_direct_launches(ctx):
             ctx.set_option("fuse_call", fuse)
             for graph in (1, 0):
                 ctx.set_option("use_graph", graph)
-                for rep in range(3):                                   # capture, then replays
-                    got = ctx.step(rs, L, 30, True, want_counts=False)
-                    assert all(np.array_equal(g, w) for g, w in zip(got, want)), (fuse, graph, rep)
+                for rec_mode in (1, 0, 2):                             # records: kernel stores to host / copy / side-stream copy
+                    ctx.set_option("records_to_host", rec_mode)
+                    for rep in range(3):                               # capture, then replays
+                        got = ctx.step(rs, L, 30, True, want_counts=False)
+                        assert all(np.array_equal(g, w) for g, w in zip(got, want)), (fuse, graph, rec_mode, rep)
+                    got = ctx.step(rs, L, 30, True, want_counts=True)
+                    assert all(np.array_equal(g, w) for g, w in zip(got[:3], want)), (fuse, graph, rec_mode)
     finally:
         ctx.set_option("fuse_call", 0)
         ctx.set_option("use_graph", 0)
+        ctx.set_option("records_to_host", 1)
     rs.free()

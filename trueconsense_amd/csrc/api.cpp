@@ -131,6 +131,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     free_ws(c);
     tcmi_drop_graphs(c);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
+    if (c->call_done) (void)hipEventDestroy(c->call_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TCMI_OK;
@@ -140,6 +142,7 @@ int tcmi_ctx_sync(tcmi_ctx *c)
 {
     if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
     TCMI_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->copy_stream) TCMI_HIP(c, hipStreamSynchronize(c->copy_stream));
     return TCMI_OK;
 }
 
@@ -155,7 +158,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "fuse_call")) { c->fuse_call = value != 0; tcmi_drop_graphs(c); }
-    else if (!std::strcmp(key, "records_to_host")) { c->records_to_host = value != 0; tcmi_drop_graphs(c); }
+    else if (!std::strcmp(key, "records_to_host")) { c->records_to_host = value < 0 ? 0 : value > 2 ? 2 : value; tcmi_drop_graphs(c); }
     else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
@@ -404,7 +407,7 @@ static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_
     if (ev_a) TCMI_HIP(ctx, hipEventRecord(ev_a, ctx->stream));
     // One launch for tally + call when nothing but the fast kernel adds into the matrix and the counts stay on
     // the device: the workgroup that completes a tile of the matrix calls it (tally_fast.hip, "fused call").
-    if (ctx->fuse_call && !want_counts && ctx->records_to_host && ctx->tally_variant == 0 && rs->g_reads == 0 &&
+    if (ctx->fuse_call && !want_counts && ctx->records_to_host == 1 && ctx->tally_variant == 0 && rs->g_reads == 0 &&
         std::max<int64_t>((L + TCMI_F_BLOCK - 1) / TCMI_F_BLOCK, rs->f_tiles) <= ctx->ws_tiles)
         return tcmi_launch_step_fused(ctx, rs, L, ld, ctx->d_counts, ctx->d_tile_done, ctx->ws_tiles, mincov, include_ambig,
                                       ctx->h_rec, ctx->h_rec + ld, ctx->h_rec + 2 * ld);
@@ -415,11 +418,23 @@ static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_
     // next step into this workspace needs no memset
     // The call records (3 bytes per position) go straight to the pinned host buffer: the kernel's own
     // stores cross PCIe, which saves the separate 90 KB copy kernel and one launch boundary per step.
-    uint8_t *rec = ctx->records_to_host ? ctx->h_rec : ctx->d_plain;
+    // Mode 2 keeps the kernel off PCIe: records into device memory, then a copy on the context's copy stream
+    // behind an event, beside the next step's tally (direct launches only; counts wanted -> mode 0).
+    const bool side_copy = ctx->records_to_host == 2 && !want_counts && !ctx->capturing;
+    uint8_t *rec = ctx->records_to_host == 1 || (ctx->records_to_host == 2 && ctx->capturing) ? ctx->h_rec : ctx->d_plain;
     rc = tcmi_launch_call(ctx, ctx->d_counts, L, ld, mincov, include_ambig, want_counts ? 0 : 1, rec, rec + ld, rec + 2 * ld,
                           nullptr, nullptr);
     if (rc) return rc;
-    if (!ctx->records_to_host)
+    if (side_copy) {
+        if (!ctx->copy_stream) {
+            TCMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            TCMI_HIP(ctx, hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming));
+        }
+        TCMI_HIP(ctx, hipEventRecord(ctx->call_done, ctx->stream));
+        TCMI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->call_done, 0));
+        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
+        ctx->step_on_copy_stream = true;
+    } else if (rec == ctx->d_plain)
         TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream));
     if (want_counts)
         TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -470,6 +485,7 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
             g.rs_uid = rs->uid; g.L = L; g.mincov = mincov; g.amb = include_ambig; g.counts = want_counts; g.memset_first = memset_first;
             const bool prof = ctx->prof;
             ctx->prof = false;                               // no pool events inside the capture
+            ctx->capturing = true;
             hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
             hipGraph_t graph = nullptr;
             if (e == hipSuccess) {
@@ -477,6 +493,7 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
                 e = hipStreamEndCapture(ctx->stream, &graph);
             }
             ctx->prof = prof;
+            ctx->capturing = false;
             if (e == hipSuccess && !rc) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
             if (e != hipSuccess || rc) {
@@ -499,7 +516,8 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
     ctx->counts_clean = !want_counts;
     // (recorded outside the graph: hipEventSynchronize does not wait for an event-record NODE of a
     // replayed graph on ROCm 7.0/7.2 — the pipeline test caught stale records when it was captured)
-    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->stream));
+    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->step_on_copy_stream ? ctx->copy_stream : ctx->stream));
+    ctx->step_on_copy_stream = false;
     ctx->step_L = L;
     ctx->step_counts = want_counts != 0;
     return TCMI_OK;

@@ -221,7 +221,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 4;
     };
     const int max_stages = fmt == 1 ? 4 : TCMI_F_MAXSTAGE;
-    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : max_stages;
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : 4;   // (format 2: 3..8 measured alike, 4 best for one BAM)
     std::vector<int32_t> f_pos((size_t)nf);
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);

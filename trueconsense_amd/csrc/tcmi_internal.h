@@ -132,7 +132,11 @@ struct tcmi_ctx {
     };
     std::vector<StepGraph> graphs;
     bool use_graph = false;         // direct launches queue with smaller gaps than graph replays (measured)
-    bool records_to_host = true;    // tcmi_step_begin: the call kernel stores its records in pinned host memory itself
+    int records_to_host = 1;        // tcmi_step_begin: 1 = the call kernel stores its records in pinned host memory itself,
+                                    // 0 = device buffer + copy on the stream, 2 = device buffer + copy on a side stream
+    hipStream_t copy_stream = nullptr;   // mode 2
+    hipEvent_t call_done = nullptr;
+    bool step_on_copy_stream = false, capturing = false;
     int step_graph = -1;            // graph used by the step in flight, -1 = direct launches
     int prof_every = 1;             // tcmi_step_begin: every n-th step is launched directly and bracketed with events
     int64_t step_tick = 0;
@@ -140,7 +144,7 @@ struct tcmi_ctx {
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int host_threads = 8;           // threads tcmi_readset_upload packs with
-    int chunk_stages = 0;           // stages per chunk of the fast kernels, 0 = as many as the format allows (4 / 8)
+    int chunk_stages = 0;           // stages per chunk of the fast kernels, 0 = default (4); format 2 takes up to 8
     int fast_format = 2;            // tcmi_readset_upload: layout of the aligned set (tcmi_readset::f_fmt)
     int fuse_call = 0;              // tcmi_step_begin: tally + call as one launch when the read set allows it (opt-in:
                                     // 2.5 % faster steps, but the call work lands in the tally kernel's time)

@@ -51,43 +51,61 @@ int64_t indel_after(const uint32_t *cg, int64_t n, int64_t k)
 }
 
 // Distinct tokens of one column in first-seen order.  A column holds a handful of distinct tokens and one of
-// them nearly always repeats, so a move-to-front probe of a short list beats hashing every token.
+// them nearly always repeats, so a move-to-front probe of a short list beats hashing every token.  Tokens are
+// PACKED into 64 bits where they fit (a base, a deletion of any length, an insertion of <= 12 bases): no string
+// is built per read; the text is produced once, for the modal token.
+//   bit 63 set | bits 0-7 first character | bits 8-9 kind (0 plain, 1 insertion, 2 deletion)
+//   insertion: bits 10-13 length, bit 14 reverse strand (only if an inserted base is '=': its text depends on the
+//              strand), bits 15-62 the inserted bases as BAM 4-bit codes;  deletion: bits 10-41 length
 struct Column {
-    struct Entry { std::string tok; int64_t count; };
+    struct Entry { uint64_t key; std::string tok; int64_t count; };   // key == 0: `tok` holds the text (long insertions)
     std::vector<Entry> seen;
     size_t last = 0;       // entry the previous token matched
     int64_t n = 0;
     int64_t depth = 0;     // reads overlapping the column before base-quality filtering
+    std::unordered_map<std::string, size_t> index;                 // only past 64 distinct tokens
+    std::unordered_map<uint64_t, size_t> kindex;
 
-    void add(const std::string &t)
+    void grow_index()
+    {
+        if (seen.size() != 65) return;                             // many distinct tokens (noisy inserts): hash them from here on
+        for (size_t e = 0; e < seen.size(); ++e) {
+            if (seen[e].key) kindex.emplace(seen[e].key, e);
+            else index.emplace(seen[e].tok, e);
+        }
+    }
+    void add_key(uint64_t key)
     {
         ++n;
-        if (last < seen.size() && seen[last].tok == t) {
-            ++seen[last].count;
-            return;
-        }
-        if (index.empty()) {
+        if (last < seen.size() && seen[last].key == key) { ++seen[last].count; return; }
+        if (seen.size() <= 64) {
             for (size_t e = 0; e < seen.size(); ++e)
-                if (seen[e].tok == t) {
-                    ++seen[e].count;
-                    last = e;
-                    return;
-                }
+                if (seen[e].key == key) { ++seen[e].count; last = e; return; }
+        } else {
+            auto it = kindex.find(key);
+            if (it != kindex.end()) { ++seen[it->second].count; last = it->second; return; }
+        }
+        seen.push_back(Entry{key, std::string(), 1});
+        last = seen.size() - 1;
+        if (seen.size() > 65) kindex.emplace(key, last);
+        grow_index();
+    }
+    void add_text(const std::string &t)
+    {
+        ++n;
+        if (last < seen.size() && !seen[last].key && seen[last].tok == t) { ++seen[last].count; return; }
+        if (seen.size() <= 64) {
+            for (size_t e = 0; e < seen.size(); ++e)
+                if (!seen[e].key && seen[e].tok == t) { ++seen[e].count; last = e; return; }
         } else {
             auto it = index.find(t);
-            if (it != index.end()) {
-                ++seen[it->second].count;
-                last = it->second;
-                return;
-            }
+            if (it != index.end()) { ++seen[it->second].count; last = it->second; return; }
         }
-        seen.push_back(Entry{t, 1});
+        seen.push_back(Entry{0, t, 1});
         last = seen.size() - 1;
-        if (!index.empty()) index.emplace(t, last);
-        else if (seen.size() > 64)                                 // many distinct tokens (noisy long inserts): hash them
-            for (size_t e = 0; e < seen.size(); ++e) index.emplace(seen[e].tok, e);
+        if (seen.size() > 65) index.emplace(t, last);
+        grow_index();
     }
-    std::unordered_map<std::string, size_t> index;                 // only past 64 distinct tokens
 };
 
 inline void append_number(std::string &s, int64_t v)
@@ -96,6 +114,28 @@ inline void append_number(std::string &s, int64_t v)
     int n = 0;
     do { d[n++] = (char)('0' + v % 10); v /= 10; } while (v);
     while (n) s.push_back(d[--n]);
+}
+
+std::string text_of(uint64_t key)
+{
+    std::string t(1, (char)(key & 0xFF));
+    const unsigned kind = (unsigned)(key >> 8) & 3u;
+    if (kind == 1) {
+        const int64_t len = (int64_t)(key >> 10) & 15;
+        const bool rev = (key >> 14) & 1;
+        t.push_back('+');
+        append_number(t, len);
+        for (int64_t i = 0; i < len; ++i) {
+            const char ch = NT16[(key >> (15 + 4 * i)) & 15];
+            t.push_back(ch == '=' ? (rev ? ',' : '.') : ch);
+        }
+    } else if (kind == 2) {
+        const int64_t len = (int64_t)((key >> 10) & 0xFFFFFFFFull);
+        t.push_back('-');
+        append_number(t, len);
+        t.append((size_t)len, 'N');
+    }
+    return t;
 }
 
 } // namespace
@@ -182,22 +222,33 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                         int q = 255;
                         if (r->qual) q = qpos < lq ? r->qual[my_qoff + qpos] : 0;
                         if (q < min_base_quality) break;                     // pileup_base_qual_skip
-                        tok.clear();
-                        if (is_match(op)) tok.push_back(base(qpos));
-                        else tok.push_back(op == 3 ? (rev ? '<' : '>') : '*');
-                        if (col == x + len - 1) {
-                            const int64_t indel = indel_after(cg, nc, k);
+                        const char first = is_match(op) ? base(qpos) : (op == 3 ? (rev ? '<' : '>') : '*');
+                        const int64_t indel = col == x + len - 1 ? indel_after(cg, nc, k) : 0;
+                        if (indel <= 12 && -indel <= 0xFFFFFFFFll) {
+                            uint64_t key = (1ull << 63) | (uint8_t)first;
                             if (indel > 0) {
-                                tok.push_back('+');
-                                append_number(tok, indel);
-                                for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
+                                key |= (1ull << 8) | ((uint64_t)indel << 10);
+                                bool any_eq = false;
+                                for (int64_t t = 1; t <= indel; ++t) {
+                                    const int64_t q2 = qpos + t;
+                                    // a base beyond SEQ reads as 'N' (code 15)
+                                    const unsigned nib = q2 >= lq ? 15u : ((q2 & 1) ? (s[q2 >> 1] & 0xFu) : (unsigned)(s[q2 >> 1] >> 4));
+                                    any_eq |= nib == 0;
+                                    key |= (uint64_t)nib << (15 + 4 * (t - 1));
+                                }
+                                if (any_eq && rev) key |= 1ull << 14;
                             } else if (indel < 0) {
-                                tok.push_back('-');
-                                append_number(tok, -indel);
-                                tok.append((size_t)(-indel), 'N');
+                                key |= (2ull << 8) | ((uint64_t)(-indel) << 10);
                             }
+                            C.add_key(key);
+                        } else {
+                            tok.clear();
+                            tok.push_back(first);
+                            tok.push_back('+');
+                            append_number(tok, indel);
+                            for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
+                            C.add_text(tok);
                         }
-                        C.add(tok);
                         break;
                     }
                     x += len;
@@ -211,16 +262,17 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         token_off[k] = off;
         n_tokens[k] = cols[(size_t)k].n;
         if (max_depth > 0 && cols[(size_t)k].depth > max_depth && depth_exceeded) *depth_exceeded = 1;
-        const std::string *best = nullptr;
+        const Column::Entry *best = nullptr;
         int64_t bc = 0;
         for (auto &e : cols[(size_t)k].seen)                     // first-seen order: ties go to the earliest
             if (e.count > bc) {
-                best = &e.tok; bc = e.count;
+                best = &e; bc = e.count;
             }
         if (best) {
-            if (off + (int64_t)best->size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");
-            std::memcpy(tokens + off, best->data(), best->size());
-            off += (int64_t)best->size();
+            const std::string text = best->key ? text_of(best->key) : best->tok;
+            if (off + (int64_t)text.size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");
+            std::memcpy(tokens + off, text.data(), text.size());
+            off += (int64_t)text.size();
         }
     }
     token_off[n_pos] = off;

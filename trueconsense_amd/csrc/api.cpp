@@ -70,6 +70,7 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
                          device, prop.gcnArchName);
     tcmi_ctx *c = new tcmi_ctx();
     c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (!own) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
@@ -155,6 +156,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
+    else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "fuse_call")) { c->fuse_call = value != 0; tcmi_drop_graphs(c); }

@@ -221,7 +221,16 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 4;
     };
     const int max_stages = fmt == 1 ? 4 : TCMI_F_MAXSTAGE;
-    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : 4;   // (format 2: 3..8 measured alike, 4 best for one BAM)
+    // Format 2, chunk_stages = 0: long chunks (up to 8 stages: the spread / reduce epilogue is paid once per chunk),
+    // but capped so that the launch has k * (4 workgroups per CU) chunks — with 2 315 chunks on 1 024 slots the third
+    // round of workgroups ran a quarter full.
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : fmt == 2 ? TCMI_F_MAXSTAGE : 4;
+    int64_t balanced_cap = INT64_MAX;
+    if (fmt == 2 && ctx->chunk_stages == 0 && ctx->balance_chunks && nf > 0) {
+        const int64_t slots = (int64_t)ctx->n_cu * 4, longest = (int64_t)TCMI_F_MAXSTAGE * 288;   // 288 reads per stage at 5 000x / 150 bp
+        const int64_t k = (nf + slots * longest - 1) / (slots * longest);
+        balanced_cap = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
+    }
     std::vector<int32_t> f_pos((size_t)nf);
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);
@@ -251,7 +260,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages
             if (fmt == 2) {                                                      // <= 255 reads per lane: 8 counter planes
                 const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
-                return std::max<int64_t>(sub, std::min<int64_t>(255 * S, n_stages * sub) / sub * sub);
+                const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(255 * S, n_stages * sub) / sub * sub);
+                return std::min(whole, balanced_cap);
             }
             return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, n_stages * sub) / sub * sub);   // <= 1024 reads
         };

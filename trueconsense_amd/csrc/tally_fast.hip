@@ -297,6 +297,7 @@ static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, 
     a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent;
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
     a.other_col = rs->f_fmt == 2 ? TCMI_A : TCMI_T;
+    a.pair_ok = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_counts) % 8 == 0);
     a.n_tail = (int32_t)((rs->f_events + FB - 1) / FB);
     int64_t grid = rs->f_chunks + a.n_tail;
     if (fused) {

@@ -30,6 +30,7 @@ struct FastArgs {
     int32_t n_tail, n_tiles, n_orphans;
     int32_t mincov, include_ambig;
     uint8_t *plain, *alt, *flags;
+    int32_t pair_ok;                // the matrix allows 64-bit adds over two adjacent positions (8-byte aligned, even ld)
     int32_t other_col;              // column the chunk blocks count class-less covered positions into (by subtraction)
 };
 

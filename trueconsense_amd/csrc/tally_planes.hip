@@ -27,7 +27,7 @@ namespace {
 
 #ifndef TCMI_ABL
 #define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
-                        // 8 no spread / final reduce / atomics
+                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once
 #endif
 constexpr int NPL = 8;                          // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
@@ -97,6 +97,9 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
         tally_tail_block<FUSED>(a, reinterpret_cast<int *>(s_hdr));
         return;
     }
+#if TCMI_ABL & 64
+    if (a.L != 0x7FFFFFF1) return;
+#endif
     const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
             const unsigned long long leads = __ballot(lead), valids = __ballot(valid);
             const unsigned long long above = lane == 63 ? 0ull : (leads >> (lane + 1)) << (lane + 1);
             const int next = above ? (__ffsll((long long)above) - 1) : __popcll(valids);
-            if (lead) {
+            if (lead && !(TCMI_ABL & 16)) {
                 const int run = next - lane;
                 atomicAdd(&s_cov[rel], run);
                 atomicAdd(&s_cov[rel + len], -run);
@@ -296,19 +299,48 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
         }
     }
     __syncthreads();
-    // ---- one coalesced global atomic per touched (class, position) -----------------------------------
-    for (int p = tid; p < npos; p += FB) {
-        const int gp = P0 + p;
-        if (gp >= a.L) continue;
-        const int cv = s_cov[p];
-        if (cv == 0) continue;
-        const int nT = s_fin[2][p], nC = s_fin[0][p] - nT, nG = s_fin[1][p] - nT;
-        const int nA = cv - nC - nG - nT;                       // includes the class-less positions, taken out by the tail blocks
-        atomicAdd(&a.counts[(int64_t)TCMI_COV * a.ld + gp], cv);
-        if (nA) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA);
-        if (nC) atomicAdd(&a.counts[(int64_t)TCMI_C * a.ld + gp], nC);
-        if (nG) atomicAdd(&a.counts[(int64_t)TCMI_G * a.ld + gp], nG);
-        if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
+    // ---- global atomics: coverage, C, G, T of TWO adjacent positions per 64-bit add (the columns never go
+    //      negative and never carry out of 32 bits), A one position at a time (the tail blocks subtract from it, so
+    //      it may be transiently negative and a carry would spill into the neighbour) ---------------------------
+    if (a.pair_ok) {
+        for (int p = 2 * tid; p < npos; p += 2 * FB) {
+            const int gp = P0 + p;                                  // even: P0 is a multiple of 8
+#if TCMI_ABL & 32
+            if (a.ld != 0x7FFFFFF1) continue;
+#endif
+            if (gp >= a.L) continue;
+            const bool two = gp + 1 < a.L;                          // (npos is a multiple of 8: p + 1 is inside the window)
+            const int cv0 = s_cov[p], cv1 = two ? s_cov[p + 1] : 0;
+            if ((cv0 | cv1) == 0) continue;
+            const int nT0 = s_fin[2][p], nC0 = s_fin[0][p] - nT0, nG0 = s_fin[1][p] - nT0;
+            const int nT1 = two ? s_fin[2][p + 1] : 0, nC1 = two ? s_fin[0][p + 1] - nT1 : 0, nG1 = two ? s_fin[1][p + 1] - nT1 : 0;
+            const int nA0 = cv0 - nC0 - nG0 - nT0, nA1 = cv1 - nC1 - nG1 - nT1;   // include the class-less positions (tail blocks)
+            auto add2 = [&](int col, int v0, int v1) {
+                if (v0 | v1)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&a.counts[(int64_t)col * a.ld + gp]),
+                              (unsigned long long)(uint32_t)v0 | ((unsigned long long)(uint32_t)v1 << 32));
+            };
+            add2(TCMI_COV, cv0, cv1);
+            add2(TCMI_C, nC0, nC1);
+            add2(TCMI_G, nG0, nG1);
+            add2(TCMI_T, nT0, nT1);
+            if (nA0) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA0);
+            if (nA1) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp + 1], nA1);
+        }
+    } else {
+        for (int p = tid; p < npos; p += FB) {
+            const int gp = P0 + p;
+            if (gp >= a.L) continue;
+            const int cv = s_cov[p];
+            if (cv == 0) continue;
+            const int nT = s_fin[2][p], nC = s_fin[0][p] - nT, nG = s_fin[1][p] - nT;
+            const int nA = cv - nC - nG - nT;                       // includes the class-less positions, taken out by the tail blocks
+            atomicAdd(&a.counts[(int64_t)TCMI_COV * a.ld + gp], cv);
+            if (nA) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA);
+            if (nC) atomicAdd(&a.counts[(int64_t)TCMI_C * a.ld + gp], nC);
+            if (nG) atomicAdd(&a.counts[(int64_t)TCMI_G * a.ld + gp], nG);
+            if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
+        }
     }
     if constexpr (FUSED) {
         __syncthreads();                                        // s_hdr held the window counters until here

@@ -102,6 +102,8 @@ struct tcmi_readset {
 
 struct tcmi_ctx {
     int device = -1;
+    int n_cu = 256;                  // compute units of the device
+    int balance_chunks = 1;          // format 2: size the chunks so that their number is a multiple of the resident workgroups
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin

@@ -134,7 +134,7 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
                                    "the contiguous read range of genome tile r; per step: tally, ONE all-reduce (sum) of the int32 "
                                    "[7][%d] matrix (%d bytes), call kernel, walk on rank 0" % (world, a.reads, ld, 28 * ld),
                        "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL all_reduce" if world > 1 else "none")},
-            "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "tally_fast_kernel" if "fast_format=1" in a.ctx_option else "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": tally_us},
             "consensus_len": len(cons), "coverage_sum": total_cov, "coverage_sum_expected": 150 * a.reads * world}))
     if dist is not None:
@@ -298,7 +298,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")      # PMC passes are separate runs (see profiles/README)
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch") * B      # measured per 1M-read BAM
+                key = "nibble_tally_hbm_bytes_per_launch" if "fast_format=1" in a.ctx_option else "tally_hbm_bytes_per_launch"
+                traffic = json.load(open(tp)).get(key) * B      # measured per 1M-read BAM
             except Exception:
                 traffic = None
         out = {
@@ -317,7 +318,7 @@ def main():
                        "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
                                   "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},
             "kernels_us": {"tally_general": 1e3 * gen_ms / max(1, gen_n), "tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
-            "roofline": {"kernel": "tally_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "tally_fast_kernel" if "fast_format=1" in a.ctx_option else "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_tally, "avg_launch_us": tally_us},
         }

@@ -106,10 +106,11 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
  *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches
  *                    (default: with two launches per step they queue with smaller gaps than graph replays)
+ *   "call_stream"    1 = direct launches put the call kernel on a second stream behind an event (default 0)
  *   "fuse_call"      1 = tcmi_step_begin without counts runs tally + call as ONE launch: the workgroup that
  *                    completes a 256-position tile of the matrix calls it (default 0)
  *   "records_to_host" 1 = in tcmi_step_begin the call kernel stores its records in pinned host memory
- *                    itself (default); 0 = device buffer + a separate D2H copy
+ *                    itself (default); 0 = device buffer + a D2H copy on the stream; 2 = + copy on a side stream
  *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin is launched directly with its
  *                    kernels bracketed by events, the others go out unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);

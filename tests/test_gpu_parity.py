@@ -562,8 +562,9 @@ def test_graph_replay_equals_direct_launches(ctx):
             ctx.set_option("fuse_call", fuse)
             for graph in (1, 0):
                 ctx.set_option("use_graph", graph)
-                for rec_mode in (1, 0, 2):                             # records: kernel stores to host / copy / side-stream copy
-                    ctx.set_option("records_to_host", rec_mode)
+                for rec_mode, side_call in ((1, 0), (0, 0), (2, 0), (1, 1), (2, 1)):   # records: kernel stores to host / copy / side-stream
+                    ctx.set_option("records_to_host", rec_mode)                        # copy; call kernel on its own stream
+                    ctx.set_option("call_stream", side_call)
                     for rep in range(3):                               # capture, then replays
                         got = ctx.step(rs, L, 30, True, want_counts=False)
                         assert all(np.array_equal(g, w) for g, w in zip(got, want)), (fuse, graph, rec_mode, rep)
@@ -573,4 +574,53 @@ def test_graph_replay_equals_direct_launches(ctx):
         ctx.set_option("fuse_call", 0)
         ctx.set_option("use_graph", 0)
         ctx.set_option("records_to_host", 1)
+        ctx.set_option("call_stream", 0)
     rs.free()
+
+
+def _uniform_reads(rng, starts, lengths, alphabet="ACGTN"):
+    """Flat arrays for reads with CIGAR <len>M at the given starts (already sorted), random bases."""
+    n = len(starts)
+    lengths = np.asarray(lengths, np.int64)
+    nb = (lengths + 1) // 2
+    seq_off = np.zeros(n + 1, np.uint64); seq_off[1:] = np.cumsum(nb)
+    codes = np.array([1, 2, 4, 8, 15], np.uint8)[:len(alphabet)]
+    seq = np.zeros(int(seq_off[-1]), np.uint8)
+    for i in range(n):
+        c = codes[rng.integers(0, len(codes), int(lengths[i]) + (int(lengths[i]) & 1))]
+        if lengths[i] & 1:
+            c[-1] = 0
+        seq[int(seq_off[i]):int(seq_off[i + 1])] = (c[0::2] << 4) | c[1::2]
+    return {"n_reads": n, "pos": np.asarray(starts, np.int32), "flag": np.zeros(n, np.uint16),
+            "l_qseq": lengths.astype(np.int32), "tid": np.zeros(n, np.int32),
+            "cigar_off": np.arange(n + 1, dtype=np.uint64), "cigar": (lengths.astype(np.uint32) << 4),
+            "seq_off": seq_off, "seq": seq, "qual": np.full(int(lengths.sum()), 30, np.uint8),
+            "qual_off": np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)}
+
+
+def test_chunk_geometry_extremes_both_formats(ctx):
+    """Shapes that push the chunker and the lane mapping of the two fast kernels to their limits: read lengths around
+    the 8- and 32-position word sizes, one-base reads, 600-base reads, tens of thousands of reads on one start
+    (narrow window, many depth slices, the 255-reads-per-lane bound), windows at the maximal width, reads that
+    start at position 0 and end on the last position."""
+    rng = np.random.default_rng(555)
+    cases = []
+    for length in (1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 150, 599, 600):
+        starts = np.sort(rng.integers(0, 40, 3000)).astype(np.int32)
+        cases.append(("len %d" % length, _uniform_reads(rng, starts, np.full(3000, length)), 40 + length))
+    cases.append(("60k reads on one start", _uniform_reads(rng, np.full(60_000, 77, np.int32), np.full(60_000, 150)), 300))
+    cases.append(("40k one-base reads on one position", _uniform_reads(rng, np.full(40_000, 5, np.int32), np.full(40_000, 1)), 10))
+    starts = np.sort(rng.integers(0, 5000, 20_000)).astype(np.int32)
+    cases.append(("mixed lengths 1..600", _uniform_reads(rng, starts, rng.integers(1, 601, 20_000)), 5600))
+    starts = np.sort(rng.integers(0, 200_000, 3000)).astype(np.int32)
+    cases.append(("sparse, every window at its widest", _uniform_reads(rng, starts, rng.integers(300, 601, 3000)), 200_600))
+    try:
+        for fmt in (2, 1):
+            ctx.set_option("fast_format", fmt)
+            for name, reads, L in cases:
+                want = c_oracle.tally(reads, L)
+                got = ctx.tally(reads, L=L)
+                assert np.array_equal(got, want), (fmt, name, np.argwhere(got != want)[:5])
+                assert int(got[:, 0].sum()) == int(reads["l_qseq"].sum()), (fmt, name)
+    finally:
+        ctx.set_option("fast_format", 2)

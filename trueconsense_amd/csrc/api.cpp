@@ -133,6 +133,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     tcmi_drop_graphs(c);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->call_done) (void)hipEventDestroy(c->call_done);
+    if (c->tally_done) (void)hipEventDestroy(c->tally_done);
+    if (c->call_stream && c->own_call_stream) (void)hipStreamDestroy(c->call_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -144,6 +146,7 @@ int tcmi_ctx_sync(tcmi_ctx *c)
     if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
     TCMI_HIP(c, hipStreamSynchronize(c->stream));
     if (c->copy_stream) TCMI_HIP(c, hipStreamSynchronize(c->copy_stream));
+    if (c->call_stream) TCMI_HIP(c, hipStreamSynchronize(c->call_stream));
     return TCMI_OK;
 }
 
@@ -156,6 +159,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
+    else if (!std::strcmp(key, "call_stream")) c->use_call_stream = value != 0;
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
@@ -416,30 +420,48 @@ static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_
     int rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 0);
     if (rc) return rc;
     if (ev_b) TCMI_HIP(ctx, hipEventRecord(ev_b, ctx->stream));
+    // The call kernel on a second stream behind an event (direct launches only): the stream of tallies is not
+    // held up by it, and the next tally — into another workspace — needs nothing from it.
+    hipStream_t main_stream = ctx->stream;
+    const bool side_call = ctx->use_call_stream && !ctx->capturing;
+    if (side_call) {
+        if (!ctx->call_stream) {
+            TCMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->call_stream, hipStreamNonBlocking));
+            ctx->own_call_stream = true;
+        }
+        if (!ctx->tally_done) TCMI_HIP(ctx, hipEventCreateWithFlags(&ctx->tally_done, hipEventDisableTiming));
+        TCMI_HIP(ctx, hipEventRecord(ctx->tally_done, main_stream));
+        TCMI_HIP(ctx, hipStreamWaitEvent(ctx->call_stream, ctx->tally_done, 0));
+        ctx->stream = ctx->call_stream;                          // everything below goes to the call stream
+        ctx->step_on_side_stream = ctx->call_stream;
+    }
     // when the counts are not wanted on the host, the call kernel zeroes them behind itself and the
     // next step into this workspace needs no memset
     // The call records (3 bytes per position) go straight to the pinned host buffer: the kernel's own
     // stores cross PCIe, which saves the separate 90 KB copy kernel and one launch boundary per step.
     // Mode 2 keeps the kernel off PCIe: records into device memory, then a copy on the context's copy stream
-    // behind an event, beside the next step's tally (direct launches only; counts wanted -> mode 0).
+    // behind an event (direct launches only; counts wanted -> mode 0).
     const bool side_copy = ctx->records_to_host == 2 && !want_counts && !ctx->capturing;
     uint8_t *rec = ctx->records_to_host == 1 || (ctx->records_to_host == 2 && ctx->capturing) ? ctx->h_rec : ctx->d_plain;
     rc = tcmi_launch_call(ctx, ctx->d_counts, L, ld, mincov, include_ambig, want_counts ? 0 : 1, rec, rec + ld, rec + 2 * ld,
                           nullptr, nullptr);
-    if (rc) return rc;
-    if (side_copy) {
+    hipError_t e = hipSuccess;
+    if (!rc && side_copy) {
         if (!ctx->copy_stream) {
-            TCMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-            TCMI_HIP(ctx, hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming));
+            e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming);
         }
-        TCMI_HIP(ctx, hipEventRecord(ctx->call_done, ctx->stream));
-        TCMI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->call_done, 0));
-        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
-        ctx->step_on_copy_stream = true;
-    } else if (rec == ctx->d_plain)
-        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream));
-    if (want_counts)
-        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (e == hipSuccess) e = hipEventRecord(ctx->call_done, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->call_done, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->copy_stream);
+        ctx->step_on_side_stream = ctx->copy_stream;
+    } else if (!rc && rec == ctx->d_plain)
+        e = hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess && want_counts)
+        e = hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "step launch failed: %s", hipGetErrorString(e));
     return TCMI_OK;
 }
 
@@ -518,8 +540,8 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
     ctx->counts_clean = !want_counts;
     // (recorded outside the graph: hipEventSynchronize does not wait for an event-record NODE of a
     // replayed graph on ROCm 7.0/7.2 — the pipeline test caught stale records when it was captured)
-    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->step_on_copy_stream ? ctx->copy_stream : ctx->stream));
-    ctx->step_on_copy_stream = false;
+    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->step_on_side_stream ? ctx->step_on_side_stream : ctx->stream));
+    ctx->step_on_side_stream = nullptr;
     ctx->step_L = L;
     ctx->step_counts = want_counts != 0;
     return TCMI_OK;

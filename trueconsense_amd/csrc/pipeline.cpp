@@ -164,6 +164,13 @@ int tcmi_pipeline_create(int device, int n_slots, int n_walkers, tcmi_pipeline *
             delete p;
             return rc;
         }
+        if (p->slots.empty()) {                                  // one call stream for all workspaces (option call_stream)
+            if (hipStreamCreateWithFlags(&c->call_stream, hipStreamNonBlocking) == hipSuccess) c->own_call_stream = true;
+            else c->call_stream = nullptr;
+        } else {
+            c->call_stream = p->slots[0]->call_stream;
+            c->own_call_stream = false;
+        }
         p->slots.push_back(c);
     }
     p->slot_busy.assign((size_t)n_slots, 0);

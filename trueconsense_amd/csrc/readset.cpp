@@ -227,7 +227,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : fmt == 2 ? TCMI_F_MAXSTAGE : 4;
     int64_t balanced_cap = INT64_MAX;
     if (fmt == 2 && ctx->chunk_stages == 0 && ctx->balance_chunks && nf > 0) {
-        const int64_t slots = (int64_t)ctx->n_cu * 4, longest = (int64_t)TCMI_F_MAXSTAGE * 288;   // 288 reads per stage at 5 000x / 150 bp
+        const int64_t slots = (int64_t)ctx->n_cu * 4, longest = (int64_t)TCMI_F_MAXSTAGE * 400;   // ~ 400 reads per stage at 5 000x / 150 bp
         const int64_t k = (nf + slots * longest - 1) / (slots * longest);
         balanced_cap = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
     }
@@ -244,10 +244,10 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
             if (fmt == 2) {
-                // lanes own 32 positions; an inner-loop body takes 8 reads per lane
+                // lanes own 32 positions; the inner loop takes bodies of 8 reads per lane and one of 4: fill the stage buffer
                 const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
                 const int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
-                int64_t sub = S * 8 * std::max<int64_t>(1, cap / (S * 8));
+                int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
                 if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
                 return sub;
             }

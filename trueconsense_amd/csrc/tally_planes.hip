@@ -69,6 +69,23 @@ __device__ inline void add8(Planes &c, const uint32_t (&x)[8])
     c.p[NPL - 1] ^= e;
 }
 
+// fold four bit vectors into the counter (the remainder of a stage)
+__device__ inline void add4(Planes &c, const uint32_t (&x)[4])
+{
+    const uint32_t s1 = TCMI_XOR3(c.p[0], x[0], x[1]), c1 = TCMI_MAJ(c.p[0], x[0], x[1]);
+    c.p[0] = TCMI_XOR3(s1, x[2], x[3]);
+    const uint32_t c2 = TCMI_MAJ(s1, x[2], x[3]);
+    uint32_t e = TCMI_MAJ(c.p[1], c1, c2);
+    c.p[1] = TCMI_XOR3(c.p[1], c1, c2);
+#pragma unroll
+    for (int k = 2; k < NPL - 1; ++k) {
+        const uint32_t t = c.p[k] & e;
+        c.p[k] ^= e;
+        e = t;
+    }
+    c.p[NPL - 1] ^= e;
+}
+
 // byte i of the result = count at bit position j + 8 i (planes [0, np) only; the others are known to be zero)
 template <int J>
 __device__ inline uint32_t spread(const Planes &c, int np)
@@ -208,37 +225,47 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
                 atomicAdd(&s_cov[rel + len], -run);
             }
         }
-        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free body of eight
-        //      reads (a stage holds S * 8 * m reads): indices past the stage are clamped onto the dummy header.
+        // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free bodies of eight
+        //      reads, then at most one body of four (a stage holds S * 4 * m reads); indices past the stage are
+        //      clamped onto the dummy header.
         const int Rs = (TCMI_ABL & 2) ? 0 : (ns + S - 1) / S;
         const int hbytes_end = ns * 8;
         int hb = s_eff * 8;                                      // byte offset of the lane's next header
-        for (int k = 0; k < Rs; k += 8) {
+#define TCMI_FETCH4(lo_, hi_, both_, at_)                                                                         \
+    do {                                                                                                          \
+        uint2 h_[4];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
+            h_[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end)); \
+            hb += S * 8;                                                                                          \
+        }                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
+            const int d_ = base32 - (int)(h_[u].x & 0xFFFFu);   /* first owned position relative to the read start */ \
+            /* pair of the read holding it, clamped into the zero pairs on either side */                          \
+            const int q_ = max(-2, min(d_ >> 5, (int)(h_[u].x >> 16)));                                           \
+            const uint2 *wp_ = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h_[u].y + q_ * 8); \
+            const uint2 w0_ = wp_[0], w1_ = wp_[1];             /* {lo, hi} of pairs q and q + 1 */                \
+            lo_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.x, w0_.x, (uint32_t)d_);   /* bits [4:0] = d mod 32 */   \
+            hi_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.y, w0_.y, (uint32_t)d_);                                \
+            both_[(at_) + u] = lo_[(at_) + u] & hi_[(at_) + u];                                                   \
+        }                                                                                                         \
+    } while (0)
+        int k = 0;
+        for (; Rs - k > 4; k += 8) {
             uint32_t lo[8], hi[8], both[8];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint2 h[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    h[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end));
-                    hb += S * 8;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int d = base32 - (int)(h[u].x & 0xFFFFu);      // first owned position relative to the read start
-                    // pair of the read holding it, clamped into the zero pairs on either side
-                    const int q = max(-2, min(d >> 5, (int)(h[u].x >> 16)));
-                    const uint2 *wp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h[u].y + q * 8);
-                    const uint2 w0 = wp[0], w1 = wp[1];                  // {lo, hi} of pairs q and q + 1
-                    lo[half * 4 + u] = __builtin_amdgcn_alignbit(w1.x, w0.x, (uint32_t)d);   // v_alignbit uses bits [4:0] = d mod 32
-                    hi[half * 4 + u] = __builtin_amdgcn_alignbit(w1.y, w0.y, (uint32_t)d);
-                    both[half * 4 + u] = lo[half * 4 + u] & hi[half * 4 + u];
-                }
-            }
+            TCMI_FETCH4(lo, hi, both, 0);
+            TCMI_FETCH4(lo, hi, both, 4);
             add8(cnt[0], lo);
             add8(cnt[1], hi);
             add8(cnt[2], both);
         }
+        if (k < Rs) {
+            uint32_t lo[4], hi[4], both[4];
+            TCMI_FETCH4(lo, hi, both, 0);
+            add4(cnt[0], lo);
+            add4(cnt[1], hi);
+            add4(cnt[2], both);
+        }
+#undef TCMI_FETCH4
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
 #if TCMI_ABL & 8

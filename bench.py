@@ -163,7 +163,7 @@ def main():
                          "one all-reduce (RCCL) of the count matrix per step, base calling on every rank")
     ap.add_argument("--also-single", action="store_true", help="afterwards also measure the same BAMs one per launch (adds a second launch shape)")
     ap.add_argument("--batch", type=int, default=4, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
-    ap.add_argument("--slots", type=int, default=4, help="workspaces of the native pipeline (steps queued ahead)")
+    ap.add_argument("--slots", type=int, default=6, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -313,7 +313,10 @@ def main():
                                    % (a.reads, a.reads * 150 // L, a.bams * B, B,
                                       "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
                        "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
-                       "step": "tally kernel + call kernel (zeroes the matrix behind itself, stores its records in pinned host memory)"
+                       "step": ("tally kernel + call kernel (zeroes the matrix behind itself, stores its records in pinned host memory)"
+                                if (a.serial or a.gpu_only or "defer_call=0" in a.ctx_option) else
+                                "ONE launch: the tally kernel, whose first blocks also call the matrix the previous step finished "
+                                "(position-wise call, records stored in pinned host memory, matrix left zeroed); the last step's call is launched on its own")
                                + ("" if a.gpu_only else " + host consensus walk per BAM"),
                        "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
                                   "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},

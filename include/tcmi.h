@@ -106,6 +106,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
  *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches
  *                    (default: with two launches per step they queue with smaller gaps than graph replays)
+ *   "defer_call"     (read from the pipeline's first workspace) 1 = tcmi_pipeline_run attaches the call of step k to
+ *                    the tally launch of step k + 1 — one launch per step (default); 0 = tally launch + call launch
  *   "call_stream"    1 = direct launches put the call kernel on a second stream behind an event (default 0)
  *   "fuse_call"      1 = tcmi_step_begin without counts runs tally + call as ONE launch: the workgroup that
  *                    completes a 256-position tile of the matrix calls it (default 0)

@@ -399,10 +399,14 @@ def test_batched_readset_and_pipeline(ctx):
         for k, i in enumerate(group):
             assert np.array_equal(counts[k * stride:k * stride + L], want_counts[i]), i
             assert not counts[k * stride + L:(k + 1) * stride].any()
-        out, status = pipe.run([rs, rs], L, 30, True, host_reads=[bams[i] for i in group] * 2, batch=len(group),
-                               pos_stride=stride)
-        assert not status.any()
-        assert out == [want_cons[i] for i in group] * 2
+        # the pipeline attaches the call of step k to the tally launch of step k + 1 (option defer_call, default);
+        # with it off every step is a tally launch and a call launch
+        for defer in (1, 0, 1):
+            pipe.ctx.set_option("defer_call", defer)
+            out, status = pipe.run([rs, rs, rs], L, 30, True, host_reads=[bams[i] for i in group] * 3, batch=len(group),
+                                   pos_stride=stride)
+            assert not status.any()
+            assert out == [want_cons[i] for i in group] * 3, defer
         rs.free()
     with pytest.raises(_ffi.TcmiError):
         pipe.ctx.upload_batch(bams[:2], 1024)                       # stride smaller than the reads' extent

@@ -159,6 +159,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "rounds_per_wg")) c->rounds_per_wg = value;
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
+    else if (!std::strcmp(key, "defer_call")) c->defer_call = value != 0;
     else if (!std::strcmp(key, "call_stream")) c->use_call_stream = value != 0;
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
@@ -480,6 +481,81 @@ void tcmi_drop_graphs(tcmi_ctx *ctx)
     ctx->graphs.clear();
 }
 
+} // extern "C"  (the next three functions are internal C++ linkage: tcmi_internal.h)
+
+// ---- ride-along call (used by the pipeline) ----------------------------------------------------------------------
+// A step without its call kernel: the tally is launched now; the call of this matrix is carried by the tally launch
+// of the NEXT step on the stream (`prev` of that call), or launched on its own by tcmi_step_flush.  One launch per
+// step instead of two, and the call's PCIe stores overlap with the next tally's streaming.
+static int launch_pending_call(tcmi_ctx *ctx)
+{
+    const int64_t ld = ctx->ws_ld;
+    int rc = tcmi_launch_call(ctx, ctx->d_counts, ctx->pend_L, ld, ctx->pend_mincov, ctx->pend_amb, 1, ctx->h_rec, ctx->h_rec + ld,
+                              ctx->h_rec + 2 * ld, nullptr, nullptr);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->stream));
+    ctx->call_pending = false;
+    ctx->counts_clean = true;
+    return TCMI_OK;
+}
+
+int tcmi_step_flush(tcmi_ctx *ctx)
+{
+    if (!ctx) return tcmi_fail(ctx, TCMI_E_ARG, "ctx is NULL");
+    if (!ctx->call_pending) return TCMI_OK;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_pending_call(ctx);
+}
+
+int tcmi_step_begin_deferred(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, tcmi_ctx *prev)
+{
+    if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || rs->max_end > L) return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld does not cover the reads (extent %lld)", (long long)L, (long long)rs->max_end);
+    if (rs->device != ctx->device) return tcmi_fail(ctx, TCMI_E_ARG, "read set lives on device %d, context on %d", rs->device, ctx->device);
+    if (ctx->step_L > 0 || ctx->call_pending) return tcmi_fail(ctx, TCMI_E_ARG, "tcmi_step_begin: the previous step of this context has not been ended");
+    int rc = ensure_ws(ctx, L);
+    if (rc) return rc;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (prev && (prev == ctx || !prev->call_pending)) prev = nullptr;
+    if (prev && prev->stream != ctx->stream) {                 // no stream order between the two: the call goes out on its own
+        rc = launch_pending_call(prev);
+        if (rc) return rc;
+        prev = nullptr;
+    }
+    if (!ctx->counts_clean) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ctx->ws_ld * TCMI_NCOL * 4, ctx->stream));
+    ctx->counts_clean = false;
+    ctx->step_graph = -1;
+    const bool sampled = ctx->prof && (ctx->step_tick++ % ctx->prof_every) == 0;
+    tcmi_ride ride = {};
+    if (prev) {
+        ride.counts = prev->d_counts; ride.ld = prev->ws_ld; ride.L = prev->pend_L; ride.mincov = prev->pend_mincov;
+        ride.amb = prev->pend_amb; ride.plain = prev->h_rec; ride.alt = prev->h_rec + prev->ws_ld; ride.flags = prev->h_rec + 2 * prev->ws_ld;
+        ctx->ride = &ride;
+    }
+    ctx->prof_mute = !sampled;
+    rc = tcmi_tally_dev(ctx, rs, L, ctx->ws_ld, ctx->d_counts, 0);
+    ctx->prof_mute = false;
+    ctx->ride = nullptr;
+    if (rc) return rc;
+    if (prev) {
+        if (ride.taken) {
+            TCMI_HIP(ctx, hipEventRecord(prev->step_done, ctx->stream));
+            prev->call_pending = false;
+            prev->counts_clean = true;
+        } else {                                               // this step had no fast-kernel launch to carry it
+            rc = launch_pending_call(prev);
+            if (rc) return rc;
+        }
+    }
+    ctx->call_pending = true;
+    ctx->pend_L = L; ctx->pend_mincov = mincov; ctx->pend_amb = include_ambig;
+    ctx->step_L = L;
+    ctx->step_counts = false;
+    return TCMI_OK;
+}
+
+extern "C" {
+
 int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, int want_counts)
 {
     if (!ctx || !rs) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
@@ -552,6 +628,10 @@ int tcmi_step_end(tcmi_ctx *ctx, const uint8_t **plain, const uint8_t **alt, con
 {
     if (!ctx) return tcmi_fail(ctx, TCMI_E_ARG, "ctx is NULL");
     if (ctx->step_L <= 0) return tcmi_fail(ctx, TCMI_E_ARG, "tcmi_step_end without tcmi_step_begin");
+    if (ctx->call_pending) {                                  // nobody carried this step's call: launch it now
+        const int rc = tcmi_step_flush(ctx);
+        if (rc) return rc;
+    }
     TCMI_HIP(ctx, hipEventSynchronize(ctx->step_done));      // only this step: the stream may be shared
     const int64_t ld = ctx->ws_ld;
     if (plain) *plain = ctx->h_rec;

@@ -223,6 +223,11 @@ int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_read
     const int n_slots = (int)p->slots.size();
     int64_t submitted = 0;
     int first_err = TCMI_OK;
+    // Ride-along call (option defer_call of slot 0): the call of step k is carried by the tally launch of step k + 1,
+    // so a step is ONE launch; the last step of the queue (or one nobody followed) launches its call on its own.
+    const bool defer = p->slots[0]->defer_call && !p->slots[0]->use_graph && !p->slots[0]->fuse_call &&
+                       p->slots[0]->records_to_host == 1 && !p->slots[0]->use_call_stream;
+    int pending_slot = -1;
     for (int64_t waited = 0; waited < n_items; ++waited) {
         // keep the stream fed: queue every step whose workspace is free
         while (submitted < n_items && submitted - waited < n_slots) {
@@ -235,7 +240,10 @@ int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_read
                 }
                 p->slot_busy[(size_t)slot] = 1;
             }
-            const int rc = tcmi_step_begin(p->slots[(size_t)slot], readsets[submitted], L_gpu, mincov, include_ambig, 0);
+            const int rc = defer ? tcmi_step_begin_deferred(p->slots[(size_t)slot], readsets[submitted], L_gpu, mincov, include_ambig,
+                                                            pending_slot >= 0 ? p->slots[(size_t)pending_slot] : nullptr)
+                                 : tcmi_step_begin(p->slots[(size_t)slot], readsets[submitted], L_gpu, mincov, include_ambig, 0);
+            if (defer && !rc) pending_slot = slot;
             if (rc) {
                 for (int b = 0; b < batch; ++b) { status[submitted * batch + b] = rc; out_len[submitted * batch + b] = 0; }
                 if (!first_err) { first_err = rc; p->err = tcmi_last_error(p->slots[(size_t)slot]); }
@@ -252,6 +260,7 @@ int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_read
             if (!queued) p->slot_busy[(size_t)slot] = 0;
         }
         if (!queued) continue;
+        if (slot == pending_slot) pending_slot = -1;             // nobody followed it: tcmi_step_end launches its call
         const int rc = tcmi_step_end(p->slots[(size_t)slot], nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc) {
             for (int b = 0; b < batch; ++b) { status[waited * batch + b] = rc; out_len[waited * batch + b] = 0; }

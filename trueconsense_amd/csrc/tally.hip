@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void tally_atomic_kernel(TallyArgs a)
 
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
-    if (rs->f_chunks > 0) {
+    if (rs->f_chunks > 0 || (ctx->ride && rs->g_reads == 0)) {   // (an empty fast launch still carries a ride-along call)
         const int rc = tcmi_launch_tally_fast(ctx, rs, L, ld, d_counts);
         if (rc) return rc;
     }

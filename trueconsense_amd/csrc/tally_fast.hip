@@ -61,11 +61,16 @@ __global__ __launch_bounds__(FB, FB == 512 ? 8 : 4) void tally_fast_kernel(FastA
     static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
 
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x >= a.n_chunks) {
-        tally_tail_block<FUSED>(a, reinterpret_cast<int *>(s_hdr));
+    if ((int)blockIdx.x < a.n_call2) {           // ride-along call of an earlier step's matrix (first in the grid: done early)
+        call_other_tile(a, (int)blockIdx.x);
         return;
     }
-    const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
+    const int bid = (int)blockIdx.x - a.n_call2;
+    if (bid >= a.n_chunks) {
+        tally_tail_block<FUSED>(a, bid, reinterpret_cast<int *>(s_hdr));
+        return;
+    }
+    const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
     const int npos = Wn * 8;
@@ -307,6 +312,13 @@ static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, 
         a.orphans = rs->d_forphan; a.n_tiles = (int32_t)rs->f_tiles; a.n_orphans = (int32_t)rs->f_orphans;
         a.mincov = mincov; a.include_ambig = include_ambig; a.plain = plain; a.alt = alt; a.flags = flags;
         grid += rs->f_orphans + std::max<int64_t>(0, tiles_L - rs->f_tiles);
+    }
+    if (ctx->ride && !fused && !ctx->ride->taken) {            // carry another workspace's call in this launch
+        tcmi_ride *r = ctx->ride;
+        a.counts2 = r->counts; a.ld2 = r->ld; a.L2 = (int32_t)r->L; a.n_call2 = (int32_t)((r->L + TILE - 1) / TILE);
+        a.mincov = r->mincov; a.include_ambig = r->amb; a.plain = r->plain; a.alt = r->alt; a.flags = r->flags;
+        grid += a.n_call2;
+        r->taken = true;
     }
     if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
     if (grid == 0) return TCMI_OK;

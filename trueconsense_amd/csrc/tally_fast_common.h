@@ -30,6 +30,10 @@ struct FastArgs {
     int32_t n_tail, n_tiles, n_orphans;
     int32_t mincov, include_ambig;
     uint8_t *plain, *alt, *flags;
+    // ride-along call (unfused launches): the first n_call2 blocks call a matrix that an EARLIER launch finished
+    int32_t *counts2;
+    int64_t ld2;
+    int32_t L2, n_call2;
     int32_t pair_ok;                // the matrix allows 64-bit adds over two adjacent positions (8-byte aligned, even ld)
     int32_t other_col;              // column the chunk blocks count class-less covered positions into (by subtraction)
 };
@@ -72,6 +76,28 @@ static __device__ inline void call_tile(const FastArgs &a, int t)
         a.flags[p] = rec.flags;
     }
     if (threadIdx.x == 0) __hip_atomic_store(&a.tile_done[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Ride-along call: block t calls tile t of ANOTHER matrix, complete since an earlier launch on the stream (plain
+// loads), with this launch's mincov / ambiguity switch, and leaves it zeroed.  The pipeline attaches the call of
+// step k to the tally launch of step k + 1 (another workspace): one launch per step, and the call's PCIe stores
+// overlap with the tally's streaming instead of sitting between two launches.
+static __device__ inline void call_other_tile(const FastArgs &a, int t)
+{
+    const int64_t p = (int64_t)t * TILE + threadIdx.x;
+    if (p >= a.L2) return;
+    int32_t v[TCMI_NCOL];
+#pragma unroll
+    for (int c = 0; c < TCMI_NCOL; ++c) {
+        int32_t *q = &a.counts2[(int64_t)c * a.ld2 + p];
+        v[c] = *q;
+        *q = 0;
+    }
+    const tcmi_calldev::Record rec = tcmi_calldev::call_position(v[TCMI_COV], v[TCMI_A], v[TCMI_T], v[TCMI_C], v[TCMI_G],
+                                                                 v[TCMI_X], v[TCMI_I], a.mincov, a.include_ambig);
+    a.plain[p] = rec.plain;
+    a.alt[p] = rec.alt;
+    a.flags[p] = rec.flags;
 }
 
 // Sign off `nt` tiles (tile index for slot k from `tile_of(k)`), then call those this workgroup completed.
@@ -124,11 +150,11 @@ static __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [4] */)
 // and wave: at an indel site thousands of reads carry the same event.  A covered position without an
 // A/C/G/T base was counted into column `other_col` by subtraction in the chunk blocks and is taken out here.
 template <bool FUSED>
-static __device__ inline void tally_tail_block(const FastArgs &a, int *s_last /* LDS [FB] */)
+static __device__ inline void tally_tail_block(const FastArgs &a, int bid /* block index behind the ride-along blocks */, int *s_last /* LDS [FB] */)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     {
-        const int64_t i = (int64_t)((int)blockIdx.x - a.n_chunks) * FB + tid;
+        const int64_t i = (int64_t)(bid - a.n_chunks) * FB + tid;
         const bool valid = i < a.n_events;
         const uint32_t key = valid ? a.events[i] : 0u;
         unsigned long long todo = __ballot(valid);
@@ -148,7 +174,7 @@ static __device__ inline void tally_tail_block(const FastArgs &a, int *s_last /*
             todo &= ~same;
         }
         if constexpr (FUSED) {
-            const int b = (int)blockIdx.x - a.n_chunks;
+            const int b = bid - a.n_chunks;
             if (b < a.n_tail) {
                 const int o = a.ev_tile_off[b];
                 sign_off_and_call(a, a.ev_tile_off[b + 1] - o, [&](int k) { return a.ev_tile[o + k]; },

@@ -29,6 +29,9 @@ namespace {
 #define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
                         // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once
 #endif
+#ifndef TCMI_P_WAVES
+#define TCMI_P_WAVES 4   // workgroups per CU the register budget is set for (5: 96 VGPRs, ten of them spilled; measured below)
+#endif
 constexpr int NPL = 8;                          // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
 constexpr int NREG = NVEC * 8;                  // byte-counter registers per lane after the spread
@@ -102,7 +105,7 @@ __device__ inline uint32_t spread(const Planes &c, int np)
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
+__global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged planes; later the slice partials
     __shared__ __attribute__((aligned(8))) uint2 s_hdr[HSLOTS];              // {pos - P0 | pairs << 16, byte offset in s_seq}
@@ -110,14 +113,19 @@ __global__ __launch_bounds__(FB, 4) void tally_planes_kernel(FastArgs a)
     __shared__ int s_scan[FB / 64];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x >= a.n_chunks) {
-        tally_tail_block<FUSED>(a, reinterpret_cast<int *>(s_hdr));
+    if ((int)blockIdx.x < a.n_call2) {           // ride-along call of an earlier step's matrix (first in the grid: done early)
+        call_other_tile(a, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.n_call2;
+    if (bid >= a.n_chunks) {
+        tally_tail_block<FUSED>(a, bid, reinterpret_cast<int *>(s_hdr));
         return;
     }
 #if TCMI_ABL & 64
     if (a.L != 0x7FFFFFF1) return;
 #endif
-    const tcmi_fast_chunk *chp = a.chunks + blockIdx.x;
+    const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
     const int npos = Wn * 8;

@@ -100,6 +100,10 @@ struct tcmi_readset {
     int64_t *d_round_seq = nullptr; // [n_rounds+1]
 };
 
+struct tcmi_ride {                  // a finished matrix waiting for its call (see tally_fast_common.h, call_other_tile)
+    int32_t *counts; int64_t ld, L; int32_t mincov; int amb; uint8_t *plain, *alt, *flags; bool taken;
+};
+
 struct tcmi_ctx {
     int device = -1;
     int n_cu = 256;                  // compute units of the device
@@ -146,6 +150,14 @@ struct tcmi_ctx {
     hipEvent_t tally_done = nullptr;
     hipStream_t copy_stream = nullptr;   // mode 2
     hipEvent_t call_done = nullptr;
+    // ride-along call (pipeline): the call of this context's step has not been launched yet; the next step on the
+    // stream (another workspace) carries it in its tally launch (tcmi_step_begin_deferred / tcmi_step_flush)
+    int defer_call = 1;             // pipeline: the call of step k rides in the tally launch of step k + 1
+    bool call_pending = false;
+    int64_t pend_L = 0;
+    int32_t pend_mincov = 0;
+    int pend_amb = 0;
+    struct tcmi_ride *ride = nullptr;            // set around a tally launch that may carry another context's call
     hipStream_t step_on_side_stream = nullptr;   // the step in flight ends on this stream (null: on `stream`)
     bool capturing = false;
     int step_graph = -1;            // graph used by the step in flight, -1 = direct launches
@@ -180,6 +192,9 @@ int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t 
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_step_fused(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts, int32_t *d_tile_done,
                            int64_t tile_cap, int32_t mincov, int include_ambig, uint8_t *plain, uint8_t *alt, uint8_t *flags);
+// pipeline-internal: a step whose call kernel rides in the NEXT step's tally launch (api.cpp)
+int tcmi_step_begin_deferred(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, tcmi_ctx *prev);
+int tcmi_step_flush(tcmi_ctx *ctx);
 int tcmi_launch_call(tcmi_ctx *ctx, int32_t *d_counts, int64_t L, int64_t ld, int32_t mincov,
                      int include_ambig, int clean, uint8_t *d_plain, uint8_t *d_alt, uint8_t *d_flags,
                      int32_t *d_events, int32_t *d_event_counts);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the pileup-tally + base-calling hot path on MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic input: `--batch` (default 4)
+A "step" = one pass of the hot path over one batch of synthetic input: `--batch` (default 8)
 independent BAMs of BASELINE configs[1] (1M reads x 29 903 bp each) whose reads are already resident in
 HBM as ONE read set (BAM b at positions shifted by b * 29 952), so one HIP tally launch and one HIP call
 launch process the batch; the call kernel stores the call records (3 bytes / position) in pinned host
@@ -162,8 +162,8 @@ def main():
                     help="BASELINE configs[4]: ONE BAM of gpus x --reads reads, each rank tallies its contiguous read range, "
                          "one all-reduce (RCCL) of the count matrix per step, base calling on every rank")
     ap.add_argument("--also-single", action="store_true", help="afterwards also measure the same BAMs one per launch (adds a second launch shape)")
-    ap.add_argument("--batch", type=int, default=4, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
-    ap.add_argument("--slots", type=int, default=6, help="workspaces of the native pipeline (steps queued ahead)")
+    ap.add_argument("--batch", type=int, default=8, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
+    ap.add_argument("--slots", type=int, default=12, help="workspaces of the native pipeline (steps queued ahead)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,19 +206,20 @@ def main():
     readsets, host_reads0, all_reads, group0 = [], None, [], []
     B = max(1, a.batch)
     pos_stride = (L + 255) // 256 * 256
-    for b in range(a.bams):
-        group = []
-        for k in range(B):
-            reads = sy.make_reads(ref, a.reads, seed=1000 * rank + b * B + k + 1,
-                                  indel_sites=sy.default_indel_sites(orfs) if a.indels else None)
+    # synthetic BAMs: seeded, generated on a few host threads (numpy releases the GIL), one group of B at a time
+    from concurrent.futures import ThreadPoolExecutor
+    gen_threads = max(1, min(8, B, (os.cpu_count() or 1) // max(1, world)))
+    sites = sy.default_indel_sites(orfs) if a.indels else None
+    with ThreadPoolExecutor(gen_threads) as ex:
+        for b in range(a.bams):
+            group = list(ex.map(lambda k: sy.make_reads(ref, a.reads, seed=1000 * rank + b * B + k + 1, indel_sites=sites), range(B)))
             if host_reads0 is None:
-                host_reads0 = reads
+                host_reads0 = group[0]
             if b == 0:
-                group0.append(reads)
-            group.append(reads)
-            all_reads.append(reads if a.indels else None)
-        readsets.append(ctx.upload(group[0]) if B == 1 else ctx.upload_batch(group, pos_stride))
-        del group
+                group0.extend(group)
+            all_reads.extend(group if a.indels else [None] * B)
+            readsets.append(ctx.upload(group[0]) if B == 1 else ctx.upload_batch(group, pos_stride))
+            del group
     alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
     alg_tally = alg_reads + 28 * L * B                          # + one write of the [L,7] int32 matrix per BAM
     pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
@@ -242,9 +243,19 @@ def main():
             hr = None
             if a.indels:
                 hr = [hreads[(i % len(rsets)) * B + k] for i in range(n) for k in range(B)]
-            out, _ = pipe.run([rsets[i % len(rsets)] for i in range(n)], L, a.mincov, True,
-                              host_reads=hr, extra=4096 if a.indels else 64, batch=B, pos_stride=pos_stride)
-            return out[-1]
+            # every consensus is written by the walkers into one preallocated host buffer (allocated and touched
+            # outside the timed region); no per-item Python objects inside it
+            stride = L + 1 + (4096 if a.indels else 64)
+            buf = out_buf[:n * B * stride]
+            out, lens, _ = pipe.run([rsets[i % len(rsets)] for i in range(n)], L, a.mincov, True,
+                                    host_reads=hr, extra=stride - L - 1, batch=B, pos_stride=pos_stride, out=buf)
+            last = n * B - 1
+            return out[last * stride:last * stride + int(lens[last])].tobytes()
+
+        out_buf = None
+        if not (a.serial or a.gpu_only):
+            out_buf = np.empty(max(n_steps, n_warm) * B * (L + 1 + (4096 if a.indels else 64)), np.uint8)
+            out_buf.fill(0)                                     # touch every page now
 
         def fence():
             ctx.sync()

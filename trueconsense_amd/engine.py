@@ -239,10 +239,13 @@ class Pipeline:
         p_ = np.ascontiguousarray(is_plus, np.uint8)
         check(lib().tcmi_pipeline_set_orfs(self.handle, len(s_), ptr(s_), ptr(e_), ptr(p_)))
 
-    def run(self, readsets, L, mincov, include_ambig, host_reads=None, extra=4096, batch=1, pos_stride=0):
+    def run(self, readsets, L, mincov, include_ambig, host_reads=None, extra=4096, batch=1, pos_stride=0, out=None):
         """-> (list of consensus bytes, int32 status array).  Raises on the first failed item.
         batch > 1: every read set holds `batch` BAMs (Context.upload_batch at `pos_stride`); the outputs
-        (and host_reads) are then per BAM, item-major."""
+        (and host_reads) are then per BAM, item-major.
+        out: a caller-owned uint8 array of >= n * (L + 1 + extra) bytes — the walkers write every consensus into it
+        at multiples of that stride and the call returns (out, lengths, status) without building Python objects
+        (a long queue otherwise spends its time in page faults of the fresh buffer and in 30 KB copies)."""
         n_items = len(readsets)
         rs = (C.c_void_p * n_items)(*[r.handle for r in readsets])
         n = n_items * int(batch)
@@ -261,13 +264,19 @@ class Pipeline:
             hr = (C.POINTER(_ffi.Reads) * n)(*ptrs)
             keep.append(by_id)
         stride = int(L) + 1 + int(extra)
-        out = np.empty(n * stride, np.uint8)
+        own = out is None
+        if own:
+            out = np.empty(n * stride, np.uint8)
+        elif out.dtype != np.uint8 or not out.flags.c_contiguous or out.size < n * stride:
+            raise ValueError("out must be a contiguous uint8 array of at least %d bytes" % (n * stride))
         lens = np.zeros(n, np.int64)
         status = np.zeros(n, np.int32)
         rc = lib().tcmi_pipeline_run_batched(self.handle, n_items, rs, int(batch), int(pos_stride), hr, int(L), int(mincov),
                                              int(bool(include_ambig)), ptr(out), stride, ptr(lens), ptr(status))
         self.last_status = status
         check(rc)
+        if not own:
+            return out, lens, status
         return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(n)], status
 
     def close(self):

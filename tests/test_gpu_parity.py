@@ -336,6 +336,25 @@ def test_self_cleaning_steps_and_pipeline(ctx):
     assert pipe.last_status[0] == _ffi.E_UNSUPPORTED
     out, _ = pipe.run([rss[1]], L, 30, True)                        # no candidates: fine without host reads
     assert out[0].decode() == want[1]
+    # the ride-along call must also work when a step has no fast-kernel launch to carry it: a read set that
+    # takes the CIGAR-walk kernel only, and one without reads (its consensus is all N)
+    pipe.ctx.set_option("tally_variant", 1)
+    rs_general = pipe.ctx.upload(sets[1])
+    pipe.ctx.set_option("tally_variant", 0)
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v) for k, v in sets[1].items()}
+    empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))
+    rs_empty = pipe.ctx.upload(empty)
+    p0, a0, f0, _ = pipe.ctx.step(rs_empty, L, 30, True, want_counts=False)
+    gff = {k: {"start": o["start"], "end": o["end"], "strand": "+"} for k, o in enumerate(orfs)}
+    want_empty = Sequences.consensus_from_records(p0, a0, f0, gff, {}, True)[0]
+    assert set(want_empty) == {"N"} and len(want_empty) == L
+    items = [rss[1], rs_general, rs_empty, rss[1], rs_empty, rs_general, rs_general, rss[1]]
+    exp = [want[1], want[1], want_empty, want[1], want_empty, want[1], want[1], want[1]]
+    for defer in (1, 0):
+        pipe.ctx.set_option("defer_call", defer)
+        out, status = pipe.run(items, L, 30, True)
+        assert not status.any() and [o.decode() for o in out] == exp, defer
+    pipe.ctx.set_option("defer_call", 1)
     pipe.close()
 
 

@@ -246,7 +246,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             if (fmt == 2) {
                 // lanes own 32 positions; the inner loop takes bodies of 8 reads per lane and one of 4: fill the stage buffer
                 const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
-                const int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
+                int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
+                if (ctx->stage_cap > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(ctx->stage_cap, S * 4));   // (experiments)
                 int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
                 if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
                 return sub;

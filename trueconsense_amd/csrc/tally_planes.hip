@@ -27,7 +27,10 @@ namespace {
 
 #ifndef TCMI_ABL
 #define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
-                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once
+                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once, 128 streaming only
+#endif
+#ifndef TCMI_P_BODY8
+#define TCMI_P_BODY8 1   // 0: four-read bodies only (fewer live registers, more carry ripples; measured below)
 #endif
 #ifndef TCMI_P_WAVES
 #define TCMI_P_WAVES 4   // workgroups per CU the register budget is set for (5: 96 VGPRs, ten of them spilled; measured below)
@@ -179,10 +182,23 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
 
+    uint32_t abl_acc = 0;
     for (int stage = 0; stage < n_stage; ++stage) {
         const int ns = min(sub_reads, n_reads - stage * sub_reads);
         const int mis = st_begin & 3;
         const int tw = st_end - st_begin + mis;
+#if TCMI_ABL & 128
+        {   // streaming only: consume the prefetched registers, issue the next stage, nothing else
+            abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ (uint32_t)h_pos0 ^ h_lo0 ^ (uint32_t)h_pos1 ^ h_lo1;
+            if (stage + 1 < n_stage) {
+                st_begin = st_end - 4;
+                st_end = st_end_next;
+                st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
+                TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
+            }
+            continue;
+        }
+#endif
         // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
         const bool valid0 = tid < ns, valid1 = tid + FB < ns;
         int rel0 = 0, len0 = 0, rel1 = 0, len1 = 0;
@@ -209,14 +225,15 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             if (!(TCMI_ABL & 4) && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
             if (!(TCMI_ABL & 4) && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
         }
-        __syncthreads();
-        // ---- B: issue the next stage's loads; they complete while C runs ----------------------------
+        // ---- B: issue the next stage's loads at once — in front of the barrier, so that this workgroup has loads in
+        //      flight while it waits there (the LDS stores above have read their registers); they complete while C runs
         if (stage + 1 < n_stage) {
             st_begin = st_end - 4;                               // the two zero pairs behind the last read come along
             st_end = st_end_next;
             st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
         }
+        __syncthreads();
         // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         }                                                                                                         \
     } while (0)
         int k = 0;
-        for (; Rs - k > 4; k += 8) {
+        for (; TCMI_P_BODY8 && Rs - k > 4; k += 8) {
             uint32_t lo[8], hi[8], both[8];
             TCMI_FETCH4(lo, hi, both, 0);
             TCMI_FETCH4(lo, hi, both, 4);
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             add8(cnt[1], hi);
             add8(cnt[2], both);
         }
-        if (k < Rs) {
+        for (; k < Rs; k += 4) {
             uint32_t lo[4], hi[4], both[4];
             TCMI_FETCH4(lo, hi, both, 0);
             add4(cnt[0], lo);
@@ -276,6 +293,10 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 #undef TCMI_FETCH4
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
+#if TCMI_ABL & 128
+    if (abl_acc == 0x12345678u) a.counts[tid] = 1;
+    return;
+#endif
 #if TCMI_ABL & 8
     if (cnt[0].p[0] != 0x12345678u) return;
 #endif

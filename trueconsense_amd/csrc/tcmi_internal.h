@@ -167,6 +167,7 @@ struct tcmi_ctx {
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int host_threads = 8;           // threads tcmi_readset_upload packs with
+    int stage_cap = 0;              // format 2: upper bound on the reads per stage (0 = fill the LDS buffer)
     int chunk_stages = 0;           // stages per chunk of the fast kernels, 0 = default (4); format 2 takes up to 8
     int fast_format = 2;            // tcmi_readset_upload: layout of the aligned set (tcmi_readset::f_fmt)
     int fuse_call = 0;              // tcmi_step_begin: tally + call as one launch when the read set allows it (opt-in:

@@ -216,9 +216,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     const int NW = 2, PAD = NW + 1;             // grid words per lane of tally_fast_kernel<2>
     // Layout of the base stream (tcmi_internal.h): format 1 = one-hot nibbles, format 2 = {lo, hi} plane pairs.
     const int fmt = ctx->fast_format == 1 ? 1 : 2;
-    const int64_t prefix = fmt == 1 ? PAD : 4;                                   // zero words in front of a chunk's first read
+    const int64_t prefix = fmt == 1 ? PAD : 2;                                   // zero words in front of a chunk's first read
     auto read_words = [&](int64_t len) -> int64_t {                              // words of one read, trailing zeros included
-        return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 4;
+        return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 2;
     };
     const int max_stages = fmt == 1 ? 4 : TCMI_F_MAXSTAGE;
     // Format 2, chunk_stages = 0: long chunks (up to 8 stages: the spread / reduce epilogue is paid once per chunk),

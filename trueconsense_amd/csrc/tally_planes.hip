@@ -4,12 +4,13 @@
 //
 // Data (tcmi_internal.h, format 2): per read 8 bytes of header and its aligned bases as codes
 // A=0 C=1 G=2 T=3 (anything else 0, listed as an OTHER event), 32 bases per pair of 32-bit words
-// {lo plane, hi plane}, followed by two zero pairs: 64 bytes for a 150-bp read instead of 96.
+// {lo plane, hi plane}, with one zero pair between reads: 56 bytes for a 150-bp read instead of 96.
 //
 // One workgroup per chunk (<= 8 stages of <= 438 reads), lane (g, s) owns 32 positions g of the
 // window and depth slice s of the reads.  Per read of the slice: one 64-bit LDS header, ONE
 // ds_read2_b64 (two pairs), two v_alignbit funnel shifts bring the read's planes onto the lane's
-// 32 positions; lo, hi and lo&hi (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders
+// 32 positions (a lane that straddles an end of the read sees the zero pair there; a lane wholly
+// outside the read is told so by its clamped pair index and takes zeros); lo, hi and lo&hi (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders
 // (sum and carry: one v_bitop3_b32 each) fold eight reads into the ones / twos / fours planes and an
 // eights carry that ripples through the upper planes (8 planes: <= 255 reads per lane and chunk).
 // ~19 VALU instructions per read and 32 positions (the nibble kernel: ~24 per 16).  At the end of the chunk the planes are spread into byte
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     const int Gn = (npos + 31) >> 5;            // lane groups of 32 positions
     const int S = FB / Gn;                      // depth slices
     const int s = tid / Gn, gi = tid - s * Gn;
-    const int base32 = gi * 32;                 // first owned position, relative to P0
+    const int base32p = gi * 32 + 32;           // first owned position relative to P0, + 32
     const int s_eff = s < S ? s : (1 << 20);    // lanes beyond the last slice only ever see the dummy read
     const int n_stage = (n_reads + sub_reads - 1) / sub_reads;
 
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
 
+#if TCMI_ABL & 128
     uint32_t abl_acc = 0;
+#endif
     for (int stage = 0; stage < n_stage; ++stage) {
         const int ns = min(sub_reads, n_reads - stage * sub_reads);
         const int mis = st_begin & 3;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         {   // streaming only: consume the prefetched registers, issue the next stage, nothing else
             abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ (uint32_t)h_pos0 ^ h_lo0 ^ (uint32_t)h_pos1 ^ h_lo1;
             if (stage + 1 < n_stage) {
-                st_begin = st_end - 4;
+                st_begin = st_end - 2;
                 st_end = st_end_next;
                 st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
                 TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
@@ -206,16 +209,16 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             rel0 = h_pos0 - P0;
             len0 = (int)(h_lo0 & 1023u);
             const int off = (int)(h_lo0 >> 10) - st_begin + mis;   // word index of the read in s_seq (even)
-            s_hdr[tid] = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)off * 4u);
+            s_hdr[tid] = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
         }
         if (valid1) {
             rel1 = h_pos1 - P0;
             len1 = (int)(h_lo1 & 1023u);
             const int off = (int)(h_lo1 >> 10) - st_begin + mis;
-            s_hdr[tid + FB] = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)off * 4u);
+            s_hdr[tid + FB] = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
         }
-        if (tid == 0)                                            // dummy: a read far to the right, no pairs; two zero pairs lie
-            s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)(mis + 4) * 4u);   // in front of the stage's first read
+        if (tid == 0)                                            // dummy: a read far to the right, no pairs: every lane is
+            s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)mis * 4u);      // outside it and gets zeros, whatever it loads
         {
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
             if (!(TCMI_ABL & 4) && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         // ---- B: issue the next stage's loads at once — in front of the barrier, so that this workgroup has loads in
         //      flight while it waits there (the LDS stores above have read their registers); they complete while C runs
         if (stage + 1 < n_stage) {
-            st_begin = st_end - 4;                               // the two zero pairs behind the last read come along
+            st_begin = st_end - 2;                               // the zero pair behind the last read comes along
             st_end = st_end_next;
             st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
@@ -264,13 +267,17 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             hb += S * 8;                                                                                          \
         }                                                                                                         \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
-            const int d_ = base32 - (int)(h_[u].x & 0xFFFFu);   /* first owned position relative to the read start */ \
-            /* pair of the read holding it, clamped into the zero pairs on either side */                          \
-            const int q_ = max(-2, min(d_ >> 5, (int)(h_[u].x >> 16)));                                           \
-            const uint2 *wp_ = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h_[u].y + q_ * 8); \
-            const uint2 w0_ = wp_[0], w1_ = wp_[1];             /* {lo, hi} of pairs q and q + 1 */                \
-            lo_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.x, w0_.x, (uint32_t)d_);   /* bits [4:0] = d mod 32 */   \
-            hi_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.y, w0_.y, (uint32_t)d_);                                \
+            /* d = first owned position relative to the read start; t = pair holding it, + 1 */                    \
+            const int dp_ = base32p - (int)(h_[u].x & 0xFFFFu);  /* d + 32 */                                       \
+            const int t_ = dp_ >> 5;                                                                              \
+            /* one zero pair lies on either side of a read: pairs t - 1 and t are loaded for 0 <= t <= pairs; a   \
+               lane further out (clamped index) is outside the read altogether and gets zeros */                   \
+            const int tc_ = max(0, min(t_, (int)(h_[u].x >> 16)));                                                \
+            const uint2 *wp_ = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h_[u].y + tc_ * 8); \
+            const uint2 w0_ = wp_[0], w1_ = wp_[1];             /* {lo, hi} of pairs t - 1 and t */                 \
+            const bool in_ = tc_ == t_;                                                                           \
+            lo_[(at_) + u] = in_ ? __builtin_amdgcn_alignbit(w1_.x, w0_.x, (uint32_t)dp_) : 0u;   /* bits [4:0] = d mod 32 */ \
+            hi_[(at_) + u] = in_ ? __builtin_amdgcn_alignbit(w1_.y, w0_.y, (uint32_t)dp_) : 0u;                    \
             both_[(at_) + u] = lo_[(at_) + u] & hi_[(at_) + u];                                                   \
         }                                                                                                         \
     } while (0)

@@ -21,22 +21,26 @@
 //    and clipped bases are dropped, and the tokens that are not plain bases ("*", "..+n..") become
 //    EVENT words (position | kind) that the tail blocks of the same launch count; a projected read
 //    spanning more than TCMI_F_SEG positions is cut into pieces (long reads), and the entries are then
-//    re-sorted by position.  Kept as
-//    8 bytes of header (pos; len | word offset << 10) + the aligned bases only, 8 bases per
-//    32-bit word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0 for
-//    anything else (N, IUPAC, '=', base beyond SEQ) — exactly what indexing.py:115-132
-//    distinguishes — followed by `pad` zero words, so that a lane may read the words just
-//    outside a read without a bounds test.  The reference positions of those "other" bases are
-//    kept in a side list (they count toward coverage but toward no class).
-//    Consecutive reads are grouped into CHUNKS (<= TCMI_F_CHUNK reads, window <= TCMI_F_MAXW
-//    grid words of 8 positions); one workgroup tallies one chunk in STAGES of <= sub_reads reads.
+//    re-sorted by position.  Kept as 8 bytes of header (pos; len | word offset << 10) + the aligned
+//    bases only, in one of two layouts (tcmi_readset::f_fmt, ctx option fast_format):
+//      format 2 (default, tally_planes.hip): codes A=0 C=1 G=2 T=3 (anything else 0), 32 bases per pair
+//        of words {lo plane, hi plane}, one zero pair in front of every read and behind the last of a
+//        chunk: 8 + 8*ceil(l/32) + 8 bytes, 56 for a 150-bp read;
+//      format 1 (tally_fast.hip): 8 bases per 32-bit word in linear nibble order, each nibble the
+//        one-hot class A=1 C=2 G=4 T=8 or 0, followed by `pad` zero words: 8 + 4*ceil(l/8) + 4*pad
+//        bytes, 96 for a 150-bp read at pad 3.
+//    "Anything else" (N, IUPAC, '=', base beyond SEQ, deleted / skipped positions) is exactly what
+//    indexing.py:115-132 puts in no class; those positions are listed as OTHER event words (they
+//    count toward coverage but toward no class).
+//    Consecutive reads are grouped into CHUNKS (window <= TCMI_F_MAXW grid words of 8 positions; format 1:
+//    <= TCMI_F_CHUNK reads; format 2: <= 255 reads per lane); one workgroup tallies one chunk in STAGES of
+//    <= sub_reads reads.
 //  * GENERAL set (CIGAR-walk kernel): what the fast path does not take (positions >= 2^29, reads
 //    with indels when option project_reads = 0, or everything when option tally_variant = 1),
 //    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
 //    offsets with a block scan), raw 4-bit codes.
 //
-// HBM traffic per read stays at or below the algorithmic 12 + 4*n_cigar + ceil(l/2) bytes
-// (aligned reads: 8 + 4*ceil(l/8) + 4*pad bytes, i.e. 96 vs 91 for a 150-bp read at pad 3).
+// The algorithmic bytes of SURVEY 8-d are 12 + 4*n_cigar + ceil(l/2) per read: 91 for a 150-bp read.
 #define TCMI_ROUND 256
 #ifndef TCMI_F_BLOCK
 #define TCMI_F_BLOCK 256           // lanes per workgroup of the fast kernel (256 or 512; 256 measured faster)

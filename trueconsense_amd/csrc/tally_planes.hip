@@ -41,7 +41,6 @@ constexpr int NVEC = 3;                         // lo, hi, lo & hi
 constexpr int NREG = NVEC * 8;                  // byte-counter registers per lane after the spread
 constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum
 constexpr int HSLOTS = 576;                     // header slots (TCMI_P_SUB + the dummy); the buffer later holds the window counters
-static_assert(FB == 256, "two header slots per lane cover a stage of up to 512 reads");
 static_assert(TCMI_P_SUB <= 2 * FB && TCMI_P_SUB < HSLOTS && HSLOTS * 8 >= NVEC * MAXPOS * 2, "s_hdr doubles as the 16-bit window counters");
 static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
 

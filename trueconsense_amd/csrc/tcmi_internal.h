@@ -50,9 +50,13 @@
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes in one piece
 #define TCMI_F_SEG 512             // projected reads longer than this are cut into pieces of this many positions
 #define TCMI_F_SUB 256             // max reads staged in LDS at a time
+#ifndef TCMI_F_SEQCAP
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
+#endif
 #define TCMI_F_MAXSTAGE 8          // stages per chunk (format 1 uses up to 4)
+#ifndef TCMI_P_SUB
 #define TCMI_P_SUB 512             // format 2: max reads staged in LDS at a time
+#endif
 // event word = reference position | kind; kinds may be combined
 #define TCMI_F_EVPOS   (1u << 29)  // positions must stay below this for the fast path
 #define TCMI_F_EV_OTHER (1u << 29) // a covered position whose token is no A/C/G/T base: was counted as T by subtraction

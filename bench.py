@@ -195,7 +195,8 @@ def main():
     L = len(ref)
     if a.split_bam:
         return run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs)
-    n_walkers = a.walkers or max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    # (configs[2] is bound by the host's insert-token sweeps: give it more walker threads)
+    n_walkers = a.walkers or max(1, min(14 if a.indels else 8, (os.cpu_count() or 1) // max(1, world)))
     pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
     ctx = pipe.ctx
     ctxs = [pipe.slot_context(k) for k in range(a.slots)]

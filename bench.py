@@ -216,8 +216,8 @@ def main():
             group = list(ex.map(lambda k: sy.make_reads(ref, a.reads, seed=1000 * rank + b * B + k + 1, indel_sites=sites), range(B)))
             if host_reads0 is None:
                 host_reads0 = group[0]
-            if b == 0:
-                group0.extend(group)
+            if b == 0 and a.also_single:
+                group0.extend(group)                            # (kept on the host only when they are needed again)
             all_reads.extend(group if a.indels else [None] * B)
             readsets.append(ctx.upload(group[0]) if B == 1 else ctx.upload_batch(group, pos_stride))
             del group

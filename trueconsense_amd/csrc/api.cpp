@@ -161,6 +161,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
     else if (!std::strcmp(key, "defer_call")) c->defer_call = value != 0;
     else if (!std::strcmp(key, "call_stream")) c->use_call_stream = value != 0;
+    else if (!std::strcmp(key, "wg_per_cu")) c->wg_per_cu = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "stage_cap")) c->stage_cap = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;

@@ -227,7 +227,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : fmt == 2 ? TCMI_F_MAXSTAGE : 4;
     int64_t balanced_cap = INT64_MAX;
     if (fmt == 2 && ctx->chunk_stages == 0 && ctx->balance_chunks && nf > 0) {
-        const int64_t slots = (int64_t)ctx->n_cu * 4, longest = (int64_t)TCMI_F_MAXSTAGE * 400;   // ~ 400 reads per stage at 5 000x / 150 bp
+        const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu, longest = (int64_t)TCMI_F_MAXSTAGE * 400;   // ~ 400 reads per stage at 5 000x / 150 bp
         const int64_t k = (nf + slots * longest - 1) / (slots * longest);
         balanced_cap = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
     }
@@ -259,9 +259,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             return sub;
         };
         auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages
-            if (fmt == 2) {                                                      // <= 255 reads per lane: 8 counter planes
+            if (fmt == 2) {                                                      // <= 2^planes - 1 reads per lane
                 const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
-                const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(255 * S, n_stages * sub) / sub * sub);
+                const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
                 return std::min(whole, balanced_cap);
             }
             return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, n_stages * sub) / sub * sub);   // <= 1024 reads

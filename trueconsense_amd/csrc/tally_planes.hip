@@ -33,10 +33,7 @@ namespace {
 #ifndef TCMI_P_BODY8
 #define TCMI_P_BODY8 1   // 0: four-read bodies only (fewer live registers, more carry ripples; measured below)
 #endif
-#ifndef TCMI_P_WAVES
-#define TCMI_P_WAVES 4   // workgroups per CU the register budget is set for (5: 96 VGPRs, ten of them spilled; measured below)
-#endif
-constexpr int NPL = 8;                          // counter planes per vector
+constexpr int NPL = TCMI_P_NPL;                 // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
 constexpr int NREG = NVEC * 8;                  // byte-counter registers per lane after the spread
 constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in the final prefix sum

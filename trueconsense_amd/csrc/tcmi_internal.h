@@ -54,6 +54,12 @@
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
 #endif
 #define TCMI_F_MAXSTAGE 8          // stages per chunk (format 1 uses up to 4)
+#ifndef TCMI_P_NPL
+#define TCMI_P_NPL 8               // format 2: counter planes per lane: a lane counts <= 2^NPL - 1 reads per chunk
+#endif
+#ifndef TCMI_P_WAVES
+#define TCMI_P_WAVES 4             // format 2: workgroups per CU the kernel's register budget is set for
+#endif
 #ifndef TCMI_P_SUB
 #define TCMI_P_SUB 512             // format 2: max reads staged in LDS at a time
 #endif
@@ -115,6 +121,7 @@ struct tcmi_ride {                  // a finished matrix waiting for its call (s
 struct tcmi_ctx {
     int device = -1;
     int n_cu = 256;                  // compute units of the device
+    int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the format-2 kernel (its register budget)
     int balance_chunks = 1;          // format 2: size the chunks so that their number is a multiple of the resident workgroups
     hipStream_t stream = nullptr;
     bool own_stream = true;

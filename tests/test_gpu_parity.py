@@ -647,3 +647,38 @@ def test_chunk_geometry_extremes_both_formats(ctx):
                 assert int(got[:, 0].sum()) == int(reads["l_qseq"].sum()), (fmt, name)
     finally:
         ctx.set_option("fast_format", 2)
+
+
+def test_pipeline_long_queue_every_item_right(ctx):
+    """A few hundred steps through the native pipeline (more items than workspaces, fewer walkers than jobs, the
+    ride-along call on and off, batched and single items, with and without accepted inserts): every consensus of the
+    queue must be the one its read set gives on its own."""
+    from trueconsense_amd.engine import Pipeline
+    ref, orfs = sy.make_reference(L=4000, cds=[(100, 1900), (2100, 3900)])
+    L, stride = len(ref), 4096
+    sites = [(600, "I", "ACG", 0.9), (1500, "D", 2, 0.9), (2500, "I", "T", 0.7)]
+    bams = [sy.make_reads(ref, 6000 + 500 * k, seed=900 + k, indel_sites=sites if k % 3 == 0 else None) for k in range(6)]
+    for slots, walkers in ((5, 3), (2, 6)):
+        pipe = Pipeline(0, slots=slots, walkers=walkers)
+        pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+        single = [pipe.ctx.upload(r) for r in bams]
+        want, _ = pipe.run(single, L, 30, True, host_reads=bams)
+        assert len(set(want)) >= 4 and any(len(w) > L for w in want)            # inserts were spliced in
+        rng = np.random.default_rng(slots)
+        order = [int(x) for x in rng.integers(0, 6, 240)]
+        for defer in (1, 0):
+            pipe.ctx.set_option("defer_call", defer)
+            out, status = pipe.run([single[i] for i in order], L, 30, True, host_reads=[bams[i] for i in order])
+            assert not status.any()
+            assert out == [want[i] for i in order], (slots, defer)
+        pairs = [(0, 1, 2), (3, 4, 5), (5, 0, 3)]
+        rss = [pipe.ctx.upload_batch([bams[i] for i in g], stride) for g in pairs]
+        order = [int(x) for x in rng.integers(0, 3, 90)]
+        pipe.ctx.set_option("defer_call", 1)
+        out, status = pipe.run([rss[j] for j in order], L, 30, True, host_reads=[bams[i] for j in order for i in pairs[j]],
+                               batch=3, pos_stride=stride)
+        assert not status.any()
+        assert out == [want[i] for j in order for i in pairs[j]], slots
+        for r in rss + single:
+            r.free()
+        pipe.close()

@@ -40,6 +40,7 @@ constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in 
 constexpr int HSLOTS = 576;                     // header slots (TCMI_P_SUB + the dummy); the buffer later holds the window counters
 static_assert(TCMI_P_SUB <= 2 * FB && TCMI_P_SUB < HSLOTS && HSLOTS * 8 >= NVEC * MAXPOS * 2, "s_hdr doubles as the 16-bit window counters");
 static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
+static_assert(NLD * FB * 4 <= TCMI_F_SEQCAP, "the unconditional stage stores must fit the stage buffer");
 
 // carry-save adder on bit vectors: sum and carry of three inputs (one v_bitop3_b32 each on gfx950;
 // truth table: bit i of the immediate = f(a = i >> 2 & 1, b = i >> 1 & 1, c = i & 1))
@@ -185,7 +186,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     for (int stage = 0; stage < n_stage; ++stage) {
         const int ns = min(sub_reads, n_reads - stage * sub_reads);
         const int mis = st_begin & 3;
-        const int tw = st_end - st_begin + mis;
 #if TCMI_ABL & 128
         {   // streaming only: consume the prefetched registers, issue the next stage, nothing else
             abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ (uint32_t)h_pos0 ^ h_lo0 ^ (uint32_t)h_pos1 ^ h_lo1;
@@ -215,14 +215,17 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         }
         if (tid == 0)                                            // dummy: a read far to the right, no pairs: every lane is
             s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)mis * 4u);      // outside it and gets zeros, whatever it loads
-        {
+        {   // all six stores, whatever the stage's length: the loads were clamped into the stage, the buffer holds
+            // 6 * 256 * 16 bytes, and nothing reads past the stage's last zero pair
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            if (!(TCMI_ABL & 4) && (0 * FB + tid) * 4 < tw) dst[0 * FB + tid] = pre0;
-            if (!(TCMI_ABL & 4) && (1 * FB + tid) * 4 < tw) dst[1 * FB + tid] = pre1;
-            if (!(TCMI_ABL & 4) && (2 * FB + tid) * 4 < tw) dst[2 * FB + tid] = pre2;
-            if (!(TCMI_ABL & 4) && (3 * FB + tid) * 4 < tw) dst[3 * FB + tid] = pre3;
-            if (!(TCMI_ABL & 4) && (4 * FB + tid) * 4 < tw) dst[4 * FB + tid] = pre4;
-            if (!(TCMI_ABL & 4) && (5 * FB + tid) * 4 < tw) dst[5 * FB + tid] = pre5;
+            if (!(TCMI_ABL & 4)) {
+                dst[0 * FB + tid] = pre0;
+                dst[1 * FB + tid] = pre1;
+                dst[2 * FB + tid] = pre2;
+                dst[3 * FB + tid] = pre3;
+                dst[4 * FB + tid] = pre4;
+                dst[5 * FB + tid] = pre5;
+            }
         }
         // ---- B: issue the next stage's loads at once — in front of the barrier, so that this workgroup has loads in
         //      flight while it waits there (the LDS stores above have read their registers); they complete while C runs

@@ -245,7 +245,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
             if (fmt == 2) {
                 // lanes own 32 positions; the inner loop takes bodies of 8 reads per lane and one of 4: fill the stage buffer
-                const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
+                const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
                 int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
                 if (ctx->stage_cap > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(ctx->stage_cap, S * 4));   // (experiments)
                 int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
@@ -260,7 +260,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         };
         auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages
             if (fmt == 2) {                                                      // <= 2^planes - 1 reads per lane
-                const int64_t S = TCMI_F_BLOCK / ((words * 8 + 31) / 32);
+                const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
                 const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
                 return std::min(whole, balanced_cap);
             }

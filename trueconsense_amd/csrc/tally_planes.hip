@@ -28,10 +28,22 @@ namespace {
 
 #ifndef TCMI_ABL
 #define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
-                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once, 128 streaming only
+                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once, 128 streaming only, 256 phase clocks
 #endif
 #ifndef TCMI_P_BODY8
 #define TCMI_P_BODY8 1   // 0: four-read bodies only (fewer live registers, more carry ripples; measured below)
+#endif
+#if TCMI_ABL & 256
+// phase clocks (diagnostic build): lane 0 of wave TCMI_DBG_WAVE of every chunk workgroup stamps the 100 MHz wall clock
+// at its phase boundaries; tools/phase_times.py reads them through tcmi_debug_phase_times
+#ifndef TCMI_DBG_WAVE
+#define TCMI_DBG_WAVE 0
+#endif
+constexpr int DBG_SLOTS = 64;
+__device__ unsigned long long tcmi_dbg[8192 * DBG_SLOTS];
+#define TCMI_STAMP() do { if (dbg_on && dbg_n < DBG_SLOTS) tcmi_dbg[(size_t)bid * DBG_SLOTS + dbg_n++] = wall_clock64(); } while (0)
+#else
+#define TCMI_STAMP() do { } while (0)
 #endif
 constexpr int NPL = TCMI_P_NPL;                 // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
@@ -40,6 +52,7 @@ constexpr int CPL = (MAXPOS + FB - 1) / FB;     // coverage entries per lane in 
 constexpr int HSLOTS = 576;                     // header slots (TCMI_P_SUB + the dummy); the buffer later holds the window counters
 static_assert(TCMI_P_SUB <= 2 * FB && TCMI_P_SUB < HSLOTS && HSLOTS * 8 >= NVEC * MAXPOS * 2, "s_hdr doubles as the 16-bit window counters");
 static_assert(NREG * FB <= TCMI_F_SEQCAP, "slice partials must fit the stage buffer");
+static_assert(4 * (FB / 2) <= HSLOTS - 3, "a lone four-read body of the widest slice layout must stay inside the header array");
 static_assert(NLD * FB * 4 <= TCMI_F_SEQCAP, "the unconditional stage stores must fit the stage buffer");
 
 // carry-save adder on bit vectors: sum and carry of three inputs (one v_bitop3_b32 each on gfx950;
@@ -126,18 +139,30 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 #if TCMI_ABL & 64
     if (a.L != 0x7FFFFFF1) return;
 #endif
+#if TCMI_ABL & 256
+    const bool dbg_on = tid == 64 * TCMI_DBG_WAVE && bid < 8192;
+    int dbg_n = 0;
+#endif
+    TCMI_STAMP();                                   // 0: start
     const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
     const int npos = Wn * 8;
-    const int Gn = (npos + 31) >> 5;            // lane groups of 32 positions
+    const int Gn = max(2, (npos + 31) >> 5);    // lane groups of 32 positions (at least two: S <= 128 keeps a body's four
+                                                // header slots of a lane inside the header array)
     const int S = FB / Gn;                      // depth slices
     const int s = tid / Gn, gi = tid - s * Gn;
     const int base32p = gi * 32 + 32;           // first owned position relative to P0, + 32
-    const int s_eff = s < S ? s : (1 << 20);    // lanes beyond the last slice only ever see the dummy read
     const int n_stage = (n_reads + sub_reads - 1) / sub_reads;
 
     for (int i = tid; i <= npos; i += FB) s_cov[i] = 0;
+    // the last three header slots: a dummy read far to the right (no pairs: every lane is outside it) for the lanes
+    // beyond the last depth slice and for the unused slots of a short stage, and 16 bytes of zeros that a lane outside
+    // a read loads instead of the read's pairs
+    if (tid < 3) s_hdr[HSLOTS - 3 + tid] = make_uint2(tid == 0 ? 0x7FFFu : 0u, 0u);
+    const int zero_off = (int)(reinterpret_cast<const char *>(&s_hdr[HSLOTS - 2]) - reinterpret_cast<const char *>(s_seq));
+    const int hb_first = s < S ? s * 8 : (HSLOTS - 3) * 8;       // byte offset of the lane's first header of a stage
+    const int hb_step = s < S ? S * 8 : 0;
     __syncthreads();                            // before any wave adds coverage runs into it
 
     Planes cnt[NVEC];
@@ -198,23 +223,35 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             continue;
         }
 #endif
+        TCMI_STAMP();                               // stage + 0: top of the stage
+#if TCMI_ABL & 256
+        __builtin_amdgcn_s_waitcnt(0);              // separate "the loads have arrived" from the stores
+        TCMI_STAMP();                               // stage + 1: loads arrived
+#endif
         // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
         const bool valid0 = tid < ns, valid1 = tid + FB < ns;
         int rel0 = 0, len0 = 0, rel1 = 0, len1 = 0;
-        if (valid0) {
-            rel0 = h_pos0 - P0;
-            len0 = (int)(h_lo0 & 1023u);
-            const int off = (int)(h_lo0 >> 10) - st_begin + mis;   // word index of the read in s_seq (even)
-            s_hdr[tid] = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
+        // header slots up to the end of the stage's last inner-loop body: real reads, then dummies
+        const int Rs = (ns + S - 1) / S;
+        const int k_end = Rs <= 4 ? 4 : Rs <= 8 ? 8 : (Rs + 3) & ~3;   // bodies: 8, 8, ..., then 4 (mirrors the loop below)
+        const int pad_end = k_end * S;
+        {
+            uint2 h0 = make_uint2(0x7FFFu, 0u), h1 = h0;
+            if (valid0) {
+                rel0 = h_pos0 - P0;
+                len0 = (int)(h_lo0 & 1023u);
+                const int off = (int)(h_lo0 >> 10) - st_begin + mis;   // word index of the read in s_seq (even)
+                h0 = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
+            }
+            if (valid1) {
+                rel1 = h_pos1 - P0;
+                len1 = (int)(h_lo1 & 1023u);
+                const int off = (int)(h_lo1 >> 10) - st_begin + mis;
+                h1 = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
+            }
+            if (tid < pad_end) s_hdr[tid] = h0;
+            if (tid + FB < pad_end) s_hdr[tid + FB] = h1;
         }
-        if (valid1) {
-            rel1 = h_pos1 - P0;
-            len1 = (int)(h_lo1 & 1023u);
-            const int off = (int)(h_lo1 >> 10) - st_begin + mis;
-            s_hdr[tid + FB] = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
-        }
-        if (tid == 0)                                            // dummy: a read far to the right, no pairs: every lane is
-            s_hdr[ns] = make_uint2(0x7FFFu, (uint32_t)mis * 4u);      // outside it and gets zeros, whatever it loads
         {   // all six stores, whatever the stage's length: the loads were clamped into the stage, the buffer holds
             // 6 * 256 * 16 bytes, and nothing reads past the stage's last zero pair
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
@@ -235,7 +272,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
         }
+        TCMI_STAMP();                               // stage + 2: stores and next issue done
         __syncthreads();
+        TCMI_STAMP();                               // stage + 3: past barrier 1
         // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -252,36 +291,36 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
                 atomicAdd(&s_cov[rel + len], -run);
             }
         }
+        TCMI_STAMP();                               // stage + 4: coverage runs done
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free bodies of eight
-        //      reads, then at most one body of four (a stage holds S * 4 * m reads); indices past the stage are
-        //      clamped onto the dummy header.
-        const int Rs = (TCMI_ABL & 2) ? 0 : (ns + S - 1) / S;
-        const int hbytes_end = ns * 8;
-        int hb = s_eff * 8;                                      // byte offset of the lane's next header
+        //      reads, then at most one body of four (a stage holds S * 4 * m reads); the slots past the stage's reads
+        //      hold dummy headers.
+        const int Rc = (TCMI_ABL & 2) ? 0 : Rs;
+        int hb = hb_first;                                       // byte offset of the lane's next header
 #define TCMI_FETCH4(lo_, hi_, both_, at_)                                                                         \
     do {                                                                                                          \
         uint2 h_[4];                                                                                              \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
-            h_[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + min(hb, hbytes_end)); \
-            hb += S * 8;                                                                                          \
+            h_[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_hdr) + hb);                 \
+            hb += hb_step;                                                                                        \
         }                                                                                                         \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
             /* d = first owned position relative to the read start; t = pair holding it, + 1 */                    \
             const int dp_ = base32p - (int)(h_[u].x & 0xFFFFu);  /* d + 32 */                                       \
             const int t_ = dp_ >> 5;                                                                              \
             /* one zero pair lies on either side of a read: pairs t - 1 and t are loaded for 0 <= t <= pairs; a   \
-               lane further out (clamped index) is outside the read altogether and gets zeros */                   \
+               lane further out (clamped index) is outside the read altogether and loads the 16 zero bytes */       \
             const int tc_ = max(0, min(t_, (int)(h_[u].x >> 16)));                                                \
-            const uint2 *wp_ = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + (int)h_[u].y + tc_ * 8); \
+            const int at_b_ = tc_ == t_ ? (int)h_[u].y + tc_ * 8 : zero_off;                                      \
+            const uint2 *wp_ = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_seq) + at_b_);    \
             const uint2 w0_ = wp_[0], w1_ = wp_[1];             /* {lo, hi} of pairs t - 1 and t */                 \
-            const bool in_ = tc_ == t_;                                                                           \
-            lo_[(at_) + u] = in_ ? __builtin_amdgcn_alignbit(w1_.x, w0_.x, (uint32_t)dp_) : 0u;   /* bits [4:0] = d mod 32 */ \
-            hi_[(at_) + u] = in_ ? __builtin_amdgcn_alignbit(w1_.y, w0_.y, (uint32_t)dp_) : 0u;                    \
+            lo_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.x, w0_.x, (uint32_t)dp_);   /* bits [4:0] = d mod 32 */  \
+            hi_[(at_) + u] = __builtin_amdgcn_alignbit(w1_.y, w0_.y, (uint32_t)dp_);                               \
             both_[(at_) + u] = lo_[(at_) + u] & hi_[(at_) + u];                                                   \
         }                                                                                                         \
     } while (0)
         int k = 0;
-        for (; TCMI_P_BODY8 && Rs - k > 4; k += 8) {
+        for (; TCMI_P_BODY8 && Rc - k > 4; k += 8) {
             uint32_t lo[8], hi[8], both[8];
             TCMI_FETCH4(lo, hi, both, 0);
             TCMI_FETCH4(lo, hi, both, 4);
@@ -289,7 +328,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             add8(cnt[1], hi);
             add8(cnt[2], both);
         }
-        for (; k < Rs; k += 4) {
+        for (; k < Rc; k += 4) {
             uint32_t lo[4], hi[4], both[4];
             TCMI_FETCH4(lo, hi, both, 0);
             add4(cnt[0], lo);
@@ -297,8 +336,10 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             add4(cnt[2], both);
         }
 #undef TCMI_FETCH4
+        TCMI_STAMP();                               // stage + 5: inner loop done
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
+    TCMI_STAMP();                                   // E0: stages done
 #if TCMI_ABL & 128
     if (abl_acc == 0x12345678u) a.counts[tid] = 1;
     return;
@@ -324,7 +365,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             s_part[(v * 8 + 7) * FB + tid] = spread<7>(cnt[v], np);
         }
     }
+    TCMI_STAMP();                                   // E1: spread + stores
     __syncthreads();
+    TCMI_STAMP();                                   // E2: barrier
     // ---- sum the slices; register j of group g holds 4 positions (j%8 + 8 i) of one vector ------------
     for (int item = tid; item < Gn * NREG; item += FB) {
         const int j = item / Gn, g = item - j * Gn;
@@ -346,6 +389,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         if (p + 16 < npos) f[16] = (uint16_t)(e >> 16);
         if (p + 24 < npos) f[24] = (uint16_t)(o >> 16);
     }
+    TCMI_STAMP();                                   // E3: slices summed
     // ---- coverage: inclusive prefix sum of the difference array, CPL entries per lane ----------------
     {
         const int i0 = tid * CPL;
@@ -361,6 +405,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         }
     }
     __syncthreads();
+    TCMI_STAMP();                                   // E4: coverage scan + barrier
     // ---- global atomics: coverage, C, G, T of TWO adjacent positions per 64-bit add (the columns never go
     //      negative and never carry out of 32 bits), A one position at a time (the tail blocks subtract from it, so
     //      it may be transiently negative and a carry would spill into the neighbour) ---------------------------
@@ -404,6 +449,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
         }
     }
+    TCMI_STAMP();                                   // E5: atomics issued
     if constexpr (FUSED) {
         __syncthreads();                                        // s_hdr held the window counters until here
         const int t0 = P0 / TILE;
@@ -412,10 +458,19 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 }
 
 #undef TCMI_ISSUE_STAGE
+#undef TCMI_STAMP
 #undef TCMI_XOR3
 #undef TCMI_MAJ
 
 } // namespace
+
+#if TCMI_ABL & 256
+extern "C" int tcmi_debug_phase_times(unsigned long long *out, int n_chunks)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tcmi_dbg), (size_t)std::min(n_chunks, 8192) * DBG_SLOTS * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 void tcmi_dispatch_tally_planes(const FastArgs &a, unsigned grid, hipStream_t stream, bool fused)
 {

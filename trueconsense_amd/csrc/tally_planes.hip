@@ -103,19 +103,36 @@ __device__ inline void add4(Planes &c, const uint32_t (&x)[4])
     c.p[NPL - 1] ^= e;
 }
 
-// byte i of the result = count at bit position j + 8 i (planes [0, np) only; the others are known to be zero)
-template <int J>
-__device__ inline uint32_t spread(const Planes &c, int np)
+// byte i of the result = count at bit position J + 8 i, from the planes [0, NP) (the others are known to be zero):
+// one shift and one v_and_or_b32 per plane
+template <int J, int NP>
+__device__ inline uint32_t spread(const Planes &c)
 {
     uint32_t r = 0;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        if (k >= 5 && k >= np) break;           // uniform: few reads per lane leave the top planes empty
+    for (int k = 0; k < NP; ++k) {
         const uint32_t m = 0x01010101u << k;
         const uint32_t v = J >= k ? (c.p[k] >> (J - k)) : (c.p[k] << (k - J));
-        r |= v & m;
+        r = __builtin_amdgcn_bitop3_b32(v, m, r, 0xEA);     // (v & m) | r
     }
     return r;
+}
+
+// the three bit-sliced counters of a lane -> 24 registers of four byte counters, stored [register][lane]
+template <int NP>
+__device__ inline void spread_all(const Planes (&cnt)[NVEC], uint32_t *s_part, int tid)
+{
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+        s_part[(v * 8 + 0) * FB + tid] = spread<0, NP>(cnt[v]);
+        s_part[(v * 8 + 1) * FB + tid] = spread<1, NP>(cnt[v]);
+        s_part[(v * 8 + 2) * FB + tid] = spread<2, NP>(cnt[v]);
+        s_part[(v * 8 + 3) * FB + tid] = spread<3, NP>(cnt[v]);
+        s_part[(v * 8 + 4) * FB + tid] = spread<4, NP>(cnt[v]);
+        s_part[(v * 8 + 5) * FB + tid] = spread<5, NP>(cnt[v]);
+        s_part[(v * 8 + 6) * FB + tid] = spread<6, NP>(cnt[v]);
+        s_part[(v * 8 + 7) * FB + tid] = spread<7, NP>(cnt[v]);
+    }
 }
 
 template <bool FUSED>
@@ -352,18 +369,12 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     uint16_t (*s_fin)[MAXPOS] = reinterpret_cast<uint16_t (*)[MAXPOS]>(s_hdr);   // window counters of lo, hi, lo&hi
     {
         const int per_lane = n_stage * ((sub_reads + S - 1) / S);                  // bound on the reads per lane (dummies count nothing)
-        const int np = 32 - __clz(per_lane);                                       // planes that can be non-zero
-#pragma unroll
-        for (int v = 0; v < NVEC; ++v) {
-            s_part[(v * 8 + 0) * FB + tid] = spread<0>(cnt[v], np);
-            s_part[(v * 8 + 1) * FB + tid] = spread<1>(cnt[v], np);
-            s_part[(v * 8 + 2) * FB + tid] = spread<2>(cnt[v], np);
-            s_part[(v * 8 + 3) * FB + tid] = spread<3>(cnt[v], np);
-            s_part[(v * 8 + 4) * FB + tid] = spread<4>(cnt[v], np);
-            s_part[(v * 8 + 5) * FB + tid] = spread<5>(cnt[v], np);
-            s_part[(v * 8 + 6) * FB + tid] = spread<6>(cnt[v], np);
-            s_part[(v * 8 + 7) * FB + tid] = spread<7>(cnt[v], np);
-        }
+        // planes that can be non-zero: one uniform branch, then straight-line code (few reads per lane leave the top
+        // planes empty)
+        if (per_lane < 32) spread_all<5>(cnt, s_part, tid);
+        else if (per_lane < 64) spread_all<6>(cnt, s_part, tid);
+        else if (per_lane < 128) spread_all<(NPL < 7 ? NPL : 7)>(cnt, s_part, tid);
+        else spread_all<NPL>(cnt, s_part, tid);
     }
     TCMI_STAMP();                                   // E1: spread + stores
     __syncthreads();

@@ -101,7 +101,11 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    take the fast kernel (default); 0 = they take the CIGAR-walk kernel
  *   "fast_format"    layout of the aligned reads on the device: 2 = 2-bit codes as two bit planes, 56 B per
  *                    150-bp read, bit-sliced counting (default); 1 = one-hot nibbles, 96 B per read
- *   "chunk_stages"   stages per fast-kernel chunk: 0 = default (4), or 1..8 (format 1: at most 4)
+ *   "chunk_stages"   stages per fast-kernel chunk: 0 = default (format 2: up to 8, capped by "balance_chunks"; format 1:
+ *                    4), or 1..8
+ *   "balance_chunks" format 2, chunk_stages = 0: size the chunks so that a launch has a multiple of
+ *                    (compute units x "wg_per_cu", default 4) of them (default 1)
+ *   "stage_cap"      format 2: upper bound on the reads per stage (0 = fill the LDS stage buffer; for experiments)
  *   "host_threads"   threads tcmi_readset_upload packs with (default min(16, cores))
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
  *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches

@@ -99,7 +99,7 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "tally_variant"  0 = reads take the fast kernel (default), 1 = every read takes the CIGAR-walk kernel
  *   "project_reads"  1 = reads with indels / ref-skips are projected onto the reference at upload and
  *                    take the fast kernel (default); 0 = they take the CIGAR-walk kernel
- *   "fast_format"    layout of the aligned reads on the device: 2 = 2-bit codes as two bit planes, 56 B per
+ *   "fast_format"    layout of the aligned reads on the device: 2 = 2-bit codes as two bit planes, 52 B per
  *                    150-bp read, bit-sliced counting (default); 1 = one-hot nibbles, 96 B per read
  *   "chunk_stages"   stages per fast-kernel chunk: 0 = default (format 2: up to 8, capped by "balance_chunks"; format 1:
  *                    4), or 1..8

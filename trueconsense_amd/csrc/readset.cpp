@@ -318,6 +318,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 const size_t c_end = ci + 1 < chunks.size() ? (size_t)chunks[ci + 1].word0 : f_seq_n;
                 std::memset(&f_seq[(size_t)c.word0], 0, (c_end - (size_t)c.word0) * 4);      // pads and alignment gaps stay zero
                 size_t cursor = (size_t)c.word0 + (size_t)prefix;
+                size_t stage_begin = (size_t)c.word0;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const tcmi_reads *r = s.r;
@@ -326,7 +327,13 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
                 const size_t base = cursor;
-                f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
+                // format 1: len | word offset from the chunk's first word << 10 (the position travels in f_pos);
+                // format 2: ONE packed word per read — position relative to the window | len << 10 | pair offset from
+                // the stage's first word << 20 (a stage starts on the zero pair in front of its first read)
+                if (fmt == 2)
+                    f_lenoff[(size_t)j] = (uint32_t)(rpos - c.P0) | ((uint32_t)s.len << 10) | ((uint32_t)((base - stage_begin) / 2) << 20);
+                else
+                    f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
                 cursor += (size_t)read_words(s.len);
                 if (fmt == 2) scratch.assign((size_t)nw + 1, 0u);
                 uint8_t *dst = reinterpret_cast<uint8_t *>(fmt == 2 ? scratch.data() : &f_seq[base]);
@@ -409,8 +416,10 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                         out[2 * q + 1] = hi;
                     }
                 }
-                if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads)
+                if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads) {
                     c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(cursor - (size_t)c.word0);
+                    stage_begin = cursor - 2;                        // format 2: the next stage starts on this read's zero pair
+                }
             }
             }
         };
@@ -493,7 +502,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     if (!rc && !ev_tile.empty()) rc = up((void **)&rs->d_fev_tile, ev_tile.data(), ev_tile.size() * 4);
     if (!rc && !orphans.empty()) rc = up((void **)&rs->d_forphan, orphans.data(), orphans.size() * 4);
     if (!rc && nf) {
-        rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);
+        if (fmt == 1) rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);   // (format 2 carries it in the packed header)
         if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fseq, f_seq.get(), f_seq_n * 4);

@@ -2,9 +2,9 @@
 // Counterpart of the per-token loop of indexing.py:102-132 for the tokens that are plain bases
 // (SURVEY §8-P2), like tally_fast.hip, with a denser layout and a cheaper inner loop:
 //
-// Data (tcmi_internal.h, format 2): per read 8 bytes of header and its aligned bases as codes
+// Data (tcmi_internal.h, format 2): per read ONE packed header word and its aligned bases as codes
 // A=0 C=1 G=2 T=3 (anything else 0, listed as an OTHER event), 32 bases per pair of 32-bit words
-// {lo plane, hi plane}, with one zero pair between reads: 56 bytes for a 150-bp read instead of 96.
+// {lo plane, hi plane}, with one zero pair between reads: 52 bytes for a 150-bp read instead of 96.
 //
 // One workgroup per chunk (<= 8 stages of <= 438 reads), lane (g, s) owns 32 positions g of the
 // window and depth slice s of the reads.  Per read of the slice: one 64-bit LDS header, ONE
@@ -190,24 +190,20 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     }
 
     // ---- prefetch registers: the next stage's headers (two slots per lane) and planes --------------
-    int h_pos0 = 0, h_pos1 = 0;
-    uint32_t h_lo0 = 0, h_lo1 = 0;
+    uint32_t h_lo0 = 0, h_lo1 = 0;              // packed headers: position - P0 | len << 10 | pair offset in the stage << 20
     uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};
     int st_begin = 0, st_end = chp->stage_end[0];   // word range of the stage (from word0)
     int st_end_next = chp->stage_end[1];            // fetched one stage ahead (a scalar load: its round trip hides under a stage)
     // Uniform base pointers + 32-bit lane offsets: the loads take the scalar-base form (no 64-bit address math
     // per lane).  Every lane loads (indices clamped into the stage): no exec-masked branch, so the loads stay in
     // flight across the inner loop.  (A macro, not a lambda: a closure kept the registers in scratch memory.)
-    const int32_t *pos_base = a.pos + read0;
     const uint32_t *lenoff_base = a.lenoff + read0;
     const uint32_t *seq_base = a.seq + word0;
 #define TCMI_ISSUE_STAGE(stage_, begin_, end_)                                                        \
     do {                                                                                              \
         const uint32_t r0_ = (uint32_t)min((stage_) * sub_reads + tid, n_reads - 1);                  \
         const uint32_t r1_ = (uint32_t)min((stage_) * sub_reads + FB + tid, n_reads - 1);             \
-        h_pos0 = pos_base[r0_];                                                                       \
         h_lo0 = lenoff_base[r0_];                                                                     \
-        h_pos1 = pos_base[r1_];                                                                       \
         h_lo1 = lenoff_base[r1_];                                                                     \
         const int mis_ = (begin_) & 3; /* keep the 16-byte loads aligned (word0 is a multiple of 4) */ \
         const uint4 *src_ = reinterpret_cast<const uint4 *>(seq_base + ((begin_) - mis_));            \
@@ -230,7 +226,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         const int mis = st_begin & 3;
 #if TCMI_ABL & 128
         {   // streaming only: consume the prefetched registers, issue the next stage, nothing else
-            abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ (uint32_t)h_pos0 ^ h_lo0 ^ (uint32_t)h_pos1 ^ h_lo1;
+            abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ h_lo0 ^ h_lo1;
             if (stage + 1 < n_stage) {
                 st_begin = st_end - 2;
                 st_end = st_end_next;
@@ -255,15 +251,15 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         {
             uint2 h0 = make_uint2(0x7FFFu, 0u), h1 = h0;
             if (valid0) {
-                rel0 = h_pos0 - P0;
-                len0 = (int)(h_lo0 & 1023u);
-                const int off = (int)(h_lo0 >> 10) - st_begin + mis;   // word index of the read in s_seq (even)
+                rel0 = (int)(h_lo0 & 1023u);
+                len0 = (int)((h_lo0 >> 10) & 1023u);
+                const int off = (int)(h_lo0 >> 20) * 2 + mis;          // word index of the read in s_seq (even)
                 h0 = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
             }
             if (valid1) {
-                rel1 = h_pos1 - P0;
-                len1 = (int)(h_lo1 & 1023u);
-                const int off = (int)(h_lo1 >> 10) - st_begin + mis;
+                rel1 = (int)(h_lo1 & 1023u);
+                len1 = (int)((h_lo1 >> 10) & 1023u);
+                const int off = (int)(h_lo1 >> 20) * 2 + mis;
                 h1 = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
             }
             if (tid < pad_end) s_hdr[tid] = h0;

@@ -21,14 +21,15 @@
 //    and clipped bases are dropped, and the tokens that are not plain bases ("*", "..+n..") become
 //    EVENT words (position | kind) that the tail blocks of the same launch count; a projected read
 //    spanning more than TCMI_F_SEG positions is cut into pieces (long reads), and the entries are then
-//    re-sorted by position.  Kept as 8 bytes of header (pos; len | word offset << 10) + the aligned
-//    bases only, in one of two layouts (tcmi_readset::f_fmt, ctx option fast_format):
-//      format 2 (default, tally_planes.hip): codes A=0 C=1 G=2 T=3 (anything else 0), 32 bases per pair
-//        of words {lo plane, hi plane}, one zero pair in front of every read and behind the last of a
-//        chunk: 8 + 8*ceil(l/32) + 8 bytes, 56 for a 150-bp read;
-//      format 1 (tally_fast.hip): 8 bases per 32-bit word in linear nibble order, each nibble the
-//        one-hot class A=1 C=2 G=4 T=8 or 0, followed by `pad` zero words: 8 + 4*ceil(l/8) + 4*pad
-//        bytes, 96 for a 150-bp read at pad 3.
+//    re-sorted by position.  Kept as a header + the aligned bases only, in one of two layouts
+//    (tcmi_readset::f_fmt, ctx option fast_format):
+//      format 2 (default, tally_planes.hip): ONE packed header word (position - window start | len << 10 |
+//        pair offset from the stage's first word << 20); codes A=0 C=1 G=2 T=3 (anything else 0), 32 bases
+//        per pair of words {lo plane, hi plane}, one zero pair in front of every read and behind the last
+//        of a chunk: 4 + 8*ceil(l/32) + 8 bytes, 52 for a 150-bp read;
+//      format 1 (tally_fast.hip): 8 bytes of header (pos; len | word offset << 10); 8 bases per 32-bit
+//        word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0, followed by
+//        `pad` zero words: 8 + 4*ceil(l/8) + 4*pad bytes, 96 for a 150-bp read at pad 3.
 //    "Anything else" (N, IUPAC, '=', base beyond SEQ, deleted / skipped positions) is exactly what
 //    indexing.py:115-132 puts in no class; those positions are listed as OTHER event words (they
 //    count toward coverage but toward no class).
@@ -92,8 +93,8 @@ struct tcmi_readset {
     int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
     int32_t f_nw = 2;           // grid words per lane the stream was padded for (pad = f_nw + 1)
     int32_t f_fmt = 2;          // base stream: 1 = one-hot nibbles (tally_fast.hip), 2 = two bit planes (tally_planes.hip)
-    int32_t *d_fpos = nullptr;  // [f_reads]
-    uint32_t *d_flenoff = nullptr; // [f_reads] len | (word offset from the chunk's word0) << 10
+    int32_t *d_fpos = nullptr;  // [f_reads] (format 1 only)
+    uint32_t *d_flenoff = nullptr; // [f_reads] format 1: len | (word offset from the chunk's word0) << 10; format 2: the packed header
     uint32_t *d_fseq = nullptr; // [f_words]
     uint32_t *d_fevent = nullptr;// [f_events] position | TCMI_F_EV_*: tokens that are not plain A/C/G/T bases
     tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]

@@ -131,7 +131,7 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_ftile_need, rs->d_fev_tile_off,
+    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_fcovrun, rs->d_ftile_need, rs->d_fev_tile_off,
                     rs->d_fev_tile, rs->d_forphan, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
@@ -234,6 +234,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     std::vector<int32_t> f_pos((size_t)nf);
     std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> f_lenoff((size_t)nf);
+    std::vector<uint32_t> f_covrun;             // format 2: coverage runs (tcmi_fast_chunk::run0 / n_runs)
     std::vector<tcmi_fast_chunk> chunks;
     std::unique_ptr<uint32_t[]> f_seq;          // not zero-filled on allocation: every packing thread clears its own chunks
     size_t f_seq_n = 0;
@@ -309,8 +310,10 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         }
         const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, (int64_t)chunks.size(), 64}));
         std::vector<std::vector<uint32_t>> ev_parts((size_t)n_threads);
+        std::vector<std::vector<uint32_t>> run_parts((size_t)n_threads);   // format 2: coverage runs, chunk by chunk
         auto pack_range = [&](int t) {
             std::vector<uint32_t> &ev = ev_parts[(size_t)t];
+            std::vector<uint32_t> &runs = run_parts[(size_t)t];
             std::vector<uint32_t> scratch;                                        // format 2: a read's nibbles before they become planes
             const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;
             for (size_t ci = c0; ci < c1; ++ci) {
@@ -319,6 +322,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 std::memset(&f_seq[(size_t)c.word0], 0, (c_end - (size_t)c.word0) * 4);      // pads and alignment gaps stay zero
                 size_t cursor = (size_t)c.word0 + (size_t)prefix;
                 size_t stage_begin = (size_t)c.word0;
+                c.run0 = (int64_t)runs.size();                   // (made global below, once the threads' parts are joined)
+                uint32_t run_key = 0xFFFFFFFFu;
             for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) {
                 const Sel &s = fsel[(size_t)j];
                 const tcmi_reads *r = s.r;
@@ -330,8 +335,14 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 // format 1: len | word offset from the chunk's first word << 10 (the position travels in f_pos);
                 // format 2: ONE packed word per read — position relative to the window | len << 10 | pair offset from
                 // the stage's first word << 20 (a stage starts on the zero pair in front of its first read)
-                if (fmt == 2)
+                if (fmt == 2) {
                     f_lenoff[(size_t)j] = (uint32_t)(rpos - c.P0) | ((uint32_t)s.len << 10) | ((uint32_t)((base - stage_begin) / 2) << 20);
+                    // coverage: reads of equal (position, length) follow each other in a sorted BAM — one run word per
+                    // group instead of per-read bookkeeping in the kernel
+                    const uint32_t key = (uint32_t)(rpos - c.P0) | ((uint32_t)s.len << 10);
+                    if (key == run_key && (runs.back() >> 20) < 4095u) runs.back() += 1u << 20;
+                    else { runs.push_back(key | (1u << 20)); run_key = key; }
+                }
                 else
                     f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
                 cursor += (size_t)read_words(s.len);
@@ -420,6 +431,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                     c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(cursor - (size_t)c.word0);
                     stage_begin = cursor - 2;                        // format 2: the next stage starts on this read's zero pair
                 }
+                if (j + 1 == c.read0 + c.n_reads) c.n_runs = (int32_t)((int64_t)runs.size() - c.run0);
             }
             }
         };
@@ -430,6 +442,11 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             for (auto &x : th) x.join();
         }
         for (auto &part : ev_parts) f_event.insert(f_event.end(), part.begin(), part.end());
+        for (int t = 0; t < n_threads; ++t) {                    // thread t packed the chunks [c0, c1): shift their run offsets
+            const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;
+            for (size_t ci = c0; ci < c1; ++ci) chunks[ci].run0 += (int64_t)f_covrun.size();
+            f_covrun.insert(f_covrun.end(), run_parts[(size_t)t].begin(), run_parts[(size_t)t].end());
+        }
     }
 
     const auto t2 = now();
@@ -507,6 +524,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fseq, f_seq.get(), f_seq_n * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
+        if (!rc && !f_covrun.empty()) rc = up((void **)&rs->d_fcovrun, f_covrun.data(), f_covrun.size() * 4);
     }
     if (!rc && ng) {
         rc = up((void **)&rs->d_pos, h_pos.data(), (size_t)ng * 4);

@@ -299,7 +299,7 @@ static int launch(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, 
                   int64_t tile_cap, int32_t mincov, int include_ambig, uint8_t *plain, uint8_t *alt, uint8_t *flags)
 {
     FastArgs a = {};
-    a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent;
+    a.pos = rs->d_fpos; a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent; a.covrun = rs->d_fcovrun;
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
     a.other_col = rs->f_fmt == 2 ? TCMI_A : TCMI_T;
     a.pair_ok = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_counts) % 8 == 0);

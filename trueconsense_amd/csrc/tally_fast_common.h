@@ -16,6 +16,7 @@ struct FastArgs {
     const uint32_t *seq;
     const tcmi_fast_chunk *chunks;
     const uint32_t *events;
+    const uint32_t *covrun;         // format 2: coverage runs (tcmi_fast_chunk::run0 / n_runs)
     int32_t *counts;
     int64_t ld;
     int64_t n_events;

@@ -17,7 +17,9 @@
 // counters once, the slices are summed through LDS, and per position
 //     C = n(lo) - n(lo&hi),  G = n(hi) - n(lo&hi),  T = n(lo&hi),  A = coverage - C - G - T
 // (covered positions without an A/C/G/T base land in A and are taken out by the tail blocks).
-// Staging, prefetch, coverage runs, final atomics and the fused call are those of tally_fast.hip.
+// Coverage comes from the packer's per-chunk list of runs of reads with equal (position, length): a (+n, -n)
+// pair per run in an LDS difference array, prefix-summed at the end.  Staging, prefetch, final atomics and the
+// fused call are those of tally_fast.hip.
 //
 // HBM-streaming integer work: no MFMA (BASELINE.json north_star).
 #include <algorithm>
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     __shared__ int32_t s_cov[MAXPOS + 8];                                     // coverage difference array
     __shared__ int s_scan[FB / 64];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.n_call2) {           // ride-along call of an earlier step's matrix (first in the grid: done early)
         call_other_tile(a, (int)blockIdx.x);
         return;
@@ -217,6 +219,18 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     } while (0)
     static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
+    // coverage: the packer lists the chunk's reads as runs of equal (position, length) — a few dozen words for a few
+    // thousand reads of a sorted BAM; each becomes a (+n, -n) pair in the difference array (prefix-summed at the end)
+    if (!(TCMI_ABL & 16)) {
+        const uint32_t *runs = a.covrun + chp->run0;
+        const int n_runs = chp->n_runs;
+        for (int i = tid; i < n_runs; i += FB) {
+            const uint32_t w = runs[i];
+            const int rel = (int)(w & 1023u), len = (int)((w >> 10) & 1023u), n = (int)(w >> 20);
+            atomicAdd(&s_cov[rel], n);
+            atomicAdd(&s_cov[rel + len], -n);
+        }
+    }
 
 #if TCMI_ABL & 128
     uint32_t abl_acc = 0;
@@ -243,7 +257,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 #endif
         // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
         const bool valid0 = tid < ns, valid1 = tid + FB < ns;
-        int rel0 = 0, len0 = 0, rel1 = 0, len1 = 0;
         // header slots up to the end of the stage's last inner-loop body: real reads, then dummies
         const int Rs = (ns + S - 1) / S;
         const int k_end = Rs <= 4 ? 4 : Rs <= 8 ? 8 : (Rs + 3) & ~3;   // bodies: 8, 8, ..., then 4 (mirrors the loop below)
@@ -251,14 +264,12 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         {
             uint2 h0 = make_uint2(0x7FFFu, 0u), h1 = h0;
             if (valid0) {
-                rel0 = (int)(h_lo0 & 1023u);
-                len0 = (int)((h_lo0 >> 10) & 1023u);
+                const int rel0 = (int)(h_lo0 & 1023u), len0 = (int)((h_lo0 >> 10) & 1023u);
                 const int off = (int)(h_lo0 >> 20) * 2 + mis;          // word index of the read in s_seq (even)
                 h0 = make_uint2((uint32_t)rel0 | ((uint32_t)(len0 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
             }
             if (valid1) {
-                rel1 = (int)(h_lo1 & 1023u);
-                len1 = (int)((h_lo1 >> 10) & 1023u);
+                const int rel1 = (int)(h_lo1 & 1023u), len1 = (int)((h_lo1 >> 10) & 1023u);
                 const int off = (int)(h_lo1 >> 20) * 2 + mis;
                 h1 = make_uint2((uint32_t)rel1 | ((uint32_t)(len1 + 31) >> 5) << 16, (uint32_t)(off - 2) * 4u);
             }
@@ -288,22 +299,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         TCMI_STAMP();                               // stage + 2: stores and next issue done
         __syncthreads();
         TCMI_STAMP();                               // stage + 3: past barrier 1
-        // coverage: one (+run, -run) pair per run of equal (pos, len) reads inside the wave
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bool valid = half ? valid1 : valid0;
-            const int rel = half ? rel1 : rel0, len = half ? len1 : len0;
-            const int prel = __shfl_up(rel, 1, 64), plen = __shfl_up(len, 1, 64);
-            const bool lead = valid && (lane == 0 || rel != prel || len != plen);
-            const unsigned long long leads = __ballot(lead), valids = __ballot(valid);
-            const unsigned long long above = lane == 63 ? 0ull : (leads >> (lane + 1)) << (lane + 1);
-            const int next = above ? (__ffsll((long long)above) - 1) : __popcll(valids);
-            if (lead && !(TCMI_ABL & 16)) {
-                const int run = next - lane;
-                atomicAdd(&s_cov[rel], run);
-                atomicAdd(&s_cov[rel + len], -run);
-            }
-        }
         TCMI_STAMP();                               // stage + 4: coverage runs done
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free bodies of eight
         //      reads, then at most one body of four (a stage holds S * 4 * m reads); the slots past the stage's reads

@@ -70,7 +70,7 @@
 #define TCMI_F_EV_X     (1u << 30) // token "*"
 #define TCMI_F_EV_I     (1u << 31) // token carries an insertion
 
-struct tcmi_fast_chunk {           // 64 bytes
+struct tcmi_fast_chunk {           // 80 bytes
     int64_t read0;                 // first read (index into f_pos / f_lenoff)
     int64_t word0;                 // first word of the chunk's base stream (multiple of 4)
     int32_t n_reads;
@@ -79,6 +79,11 @@ struct tcmi_fast_chunk {           // 64 bytes
     int32_t sub_reads;             // reads per stage (multiple of 64, <= TCMI_F_SUB)
     int32_t stage_end[TCMI_F_MAXSTAGE];   // word offset (from word0) one past stage i, trailing pad included;
                                           // stage i starts at stage_end[i-1] - pad (0 for i = 0)
+    // format 2: the chunk's coverage as runs of reads with equal (position, length), words of d_fcovrun:
+    // position - P0 | len << 10 | (reads in the run, <= 4095) << 20
+    int64_t run0;
+    int32_t n_runs;
+    int32_t reserved_;
 };
 
 struct tcmi_readset {
@@ -98,6 +103,7 @@ struct tcmi_readset {
     uint32_t *d_fseq = nullptr; // [f_words]
     uint32_t *d_fevent = nullptr;// [f_events] position | TCMI_F_EV_*: tokens that are not plain A/C/G/T bases
     tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]
+    uint32_t *d_fcovrun = nullptr;         // format 2: coverage runs of all chunks (tcmi_fast_chunk::run0 / n_runs)
     // fused call: tiles of TCMI_F_BLOCK positions; who adds into which (tally_fast.hip)
     int64_t f_tiles = 0, f_orphans = 0;
     int32_t *d_ftile_need = nullptr;   // [f_tiles] workgroups (chunks + tail blocks) adding into the tile

@@ -311,6 +311,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, (int64_t)chunks.size(), 64}));
         std::vector<std::vector<uint32_t>> ev_parts((size_t)n_threads);
         std::vector<std::vector<uint32_t>> run_parts((size_t)n_threads);   // format 2: coverage runs, chunk by chunk
+        std::atomic<bool> pack_overflow{false};
         auto pack_range = [&](int t) {
             std::vector<uint32_t> &ev = ev_parts[(size_t)t];
             std::vector<uint32_t> &runs = run_parts[(size_t)t];
@@ -336,6 +337,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 // format 2: ONE packed word per read — position relative to the window | len << 10 | pair offset from
                 // the stage's first word << 20 (a stage starts on the zero pair in front of its first read)
                 if (fmt == 2) {
+                    // (10 + 10 + 12 bits: the chunker keeps windows <= 768 positions, entries <= 600 positions and
+                    // stages <= 6144 words; checked, not assumed)
+                    if (rpos - c.P0 > 1023 || s.len > 1023 || (base - stage_begin) / 2 > 4095) pack_overflow.store(true);
                     f_lenoff[(size_t)j] = (uint32_t)(rpos - c.P0) | ((uint32_t)s.len << 10) | ((uint32_t)((base - stage_begin) / 2) << 20);
                     // coverage: reads of equal (position, length) follow each other in a sorted BAM — one run word per
                     // group instead of per-read bookkeeping in the kernel
@@ -441,6 +445,8 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             for (int t = 0; t < n_threads; ++t) th.emplace_back(pack_range, t);
             for (auto &x : th) x.join();
         }
+        if (pack_overflow.load())
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "internal: a packed read header field overflowed (window / length / stage offset)");
         for (auto &part : ev_parts) f_event.insert(f_event.end(), part.begin(), part.end());
         for (int t = 0; t < n_threads; ++t) {                    // thread t packed the chunks [c0, c1): shift their run offsets
             const size_t c0 = chunks.size() * (size_t)t / (size_t)n_threads, c1 = chunks.size() * (size_t)(t + 1) / (size_t)n_threads;

@@ -171,39 +171,72 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     std::vector<GSel> gsel;                 // general set
     int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
     bool any_cut = false;
-    for (int32_t bi = 0; bi < n_batch; ++bi) {
-    const tcmi_reads *r = batch[bi];
-    const int64_t off = (int64_t)bi * stride;
-    for (int64_t i = 0; i < r->n_reads; ++i) {
-        int64_t span;
-        if (!piles_up(r, i, &span)) continue;
-        const uint32_t *cg = r->cigar + r->cigar_off[i];
-        const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
-        if (nc > 65535)
-            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)", (long long)i, (long long)nc);
-        const int64_t lq = r->l_qseq[i];
-        if (lq < 0) return tcmi_fail(ctx, TCMI_E_ARG, "read %lld has negative l_qseq", (long long)i);
-        const int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
-        if (nbytes < (lq + 1) / 2)
-            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)", (long long)i, (long long)nbytes);
-        if (n_batch > 1 && r->pos[i] + span > stride)
-            return tcmi_fail(ctx, TCMI_E_ARG, "read %lld of BAM %d ends at %lld, beyond the batch stride %lld", (long long)i, bi,
-                             (long long)(r->pos[i] + span), (long long)stride);
-        if (span > INT32_MAX || off + r->pos[i] + span > INT32_MAX - 4096)
-            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31", (long long)i);
-        alg += 12 + 4 * nc + (lq + 1) / 2;
-        if (off + r->pos[i] + span > max_end) max_end = off + r->pos[i] + span;
-        int64_t y0, len;
-        if (use_fast && off + r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) fsel.push_back({r, i, off, y0, len, 0, false});
-        else if (use_fast && ctx->project_reads && off + r->pos[i] + span < TCMI_F_EVPOS) {
-            // any CIGAR, projected onto the reference; a long read in pieces (the count matrix is a sum over
-            // positions, so cutting a read changes nothing)
-            for (int64_t seg = 0; seg < span; seg += TCMI_F_SEG)
-                fsel.push_back({r, i, off, 0, std::min<int64_t>(TCMI_F_SEG, span - seg), seg, true});
-            if (span > TCMI_F_SEG) any_cut = true;
+    // every BAM's reads in `host_threads` contiguous slices, each into its own lists, joined in order afterwards
+    struct Part {
+        std::vector<Sel> fsel; std::vector<GSel> gsel;
+        int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0; bool any_cut = false;
+        int err = TCMI_OK; char msg[160] = {0};
+    };
+    const int n_cls = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, 64, n_reads_in / 65536 + 1}));
+    std::vector<Part> parts((size_t)n_batch * (size_t)n_cls);
+    auto classify = [&](int32_t bi, int t) {
+        Part &P = parts[(size_t)bi * (size_t)n_cls + (size_t)t];
+        const tcmi_reads *r = batch[bi];
+        const int64_t off = (int64_t)bi * stride;
+        const int64_t i0 = r->n_reads * t / n_cls, i1 = r->n_reads * (t + 1) / n_cls;
+        auto fail = [&](int code, const char *fmt, long long x, long long y, long long z) {
+            P.err = code;
+            std::snprintf(P.msg, sizeof P.msg, fmt, x, y, z);
+        };
+        for (int64_t i = i0; i < i1; ++i) {
+            int64_t span;
+            if (!piles_up(r, i, &span)) continue;
+            const uint32_t *cg = r->cigar + r->cigar_off[i];
+            const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+            if (nc > 65535) return fail(TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)%.0lld", i, nc, 0);
+            const int64_t lq = r->l_qseq[i];
+            if (lq < 0) return fail(TCMI_E_ARG, "read %lld has negative l_qseq%.0lld%.0lld", i, 0, 0);
+            const int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
+            if (nbytes < (lq + 1) / 2) return fail(TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)%.0lld", i, nbytes, 0);
+            if (n_batch > 1 && r->pos[i] + span > stride)
+                return fail(TCMI_E_ARG, "read %lld of a batched BAM ends at %lld, beyond the batch stride %lld", i, r->pos[i] + span, stride);
+            if (span > INT32_MAX || off + r->pos[i] + span > INT32_MAX - 4096)
+                return fail(TCMI_E_UNSUPPORTED, "read %lld ends beyond 2^31%.0lld%.0lld", i, 0, 0);
+            P.alg += 12 + 4 * nc + (lq + 1) / 2;
+            if (off + r->pos[i] + span > P.max_end) P.max_end = off + r->pos[i] + span;
+            int64_t y0, len;
+            if (use_fast && off + r->pos[i] + span < TCMI_F_EVPOS && aligned_shape(cg, nc, &y0, &len)) P.fsel.push_back({r, i, off, y0, len, 0, false});
+            else if (use_fast && ctx->project_reads && off + r->pos[i] + span < TCMI_F_EVPOS) {
+                // any CIGAR, projected onto the reference; a long read in pieces (the count matrix is a sum over
+                // positions, so cutting a read changes nothing)
+                for (int64_t seg = 0; seg < span; seg += TCMI_F_SEG)
+                    P.fsel.push_back({r, i, off, 0, std::min<int64_t>(TCMI_F_SEG, span - seg), seg, true});
+                if (span > TCMI_F_SEG) P.any_cut = true;
+            }
+            else { P.gsel.push_back({r, i, off}); P.g_cig += nc; P.g_seqw += (lq + 7) / 8; }
         }
-        else { gsel.push_back({r, i, off}); g_cig += nc; g_seqw += (lq + 7) / 8; }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_cls; ++t)
+            th.emplace_back([&, t] { for (int32_t bi = 0; bi < n_batch; ++bi) classify(bi, t); });
+        for (int32_t bi = 0; bi < n_batch; ++bi) classify(bi, 0);
+        for (auto &x : th) x.join();
     }
+    {
+        size_t nfs = 0, ngs = 0;
+        for (const Part &P : parts) {
+            if (P.err) return tcmi_fail(ctx, P.err, "%s", P.msg);
+            nfs += P.fsel.size(); ngs += P.gsel.size();
+        }
+        fsel.reserve(nfs); gsel.reserve(ngs);
+        for (Part &P : parts) {
+            fsel.insert(fsel.end(), P.fsel.begin(), P.fsel.end());
+            gsel.insert(gsel.end(), P.gsel.begin(), P.gsel.end());
+            g_cig += P.g_cig; g_seqw += P.g_seqw; alg += P.alg; max_end = std::max(max_end, P.max_end); any_cut |= P.any_cut;
+            std::vector<Sel>().swap(P.fsel);
+            std::vector<GSel>().swap(P.gsel);
+        }
     }
 
     if (any_cut)                                // pieces of long reads start further right than the reads that follow them

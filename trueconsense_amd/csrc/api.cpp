@@ -130,6 +130,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     free_ws(c);
+    tcmi_upload_scratch_free(c->upload_scratch);
+    c->upload_scratch = nullptr;
     tcmi_drop_graphs(c);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->call_done) (void)hipEventDestroy(c->call_done);

@@ -108,6 +108,41 @@ struct Up {
     }
 };
 
+// one entry of the aligned set: read i of BAM r (positions shifted by off); for a projected read the piece
+// [seg, seg + len) of its reference span
+struct Sel { const tcmi_reads *r; int64_t i, off, y0, len, seg; bool projected; };
+struct GSel { const tcmi_reads *r; int64_t i, off; };
+struct Part {                       // what one classification thread found in its slice of a BAM
+    std::vector<Sel> fsel; std::vector<GSel> gsel;
+    int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0; bool any_cut = false;
+    int err = TCMI_OK; char msg[160] = {0};
+};
+
+} // namespace
+
+// Host buffers of tcmi_readset_upload, kept per context between calls: an upload of 1 M reads walks through
+// ~200 MB of them, and a third of its time used to go into page faults of fresh allocations and their release.
+struct tcmi_upload_scratch {
+    std::vector<Sel> fsel;
+    std::vector<GSel> gsel;
+    std::vector<Part> parts;
+    std::vector<int32_t> f_pos;
+    std::vector<uint32_t> f_lenoff, f_event, f_covrun;
+    uint32_t *f_seq = nullptr;
+    size_t f_seq_cap = 0;
+    ~tcmi_upload_scratch() { delete[] f_seq; }
+    size_t bytes() const
+    {
+        size_t b = fsel.capacity() * sizeof(Sel) + gsel.capacity() * sizeof(GSel) + f_pos.capacity() * 4 + f_lenoff.capacity() * 4 +
+                   f_event.capacity() * 4 + f_covrun.capacity() * 4 + f_seq_cap * 4;
+        for (const Part &p : parts) b += p.fsel.capacity() * sizeof(Sel) + p.gsel.capacity() * sizeof(GSel);
+        return b;
+    }
+};
+
+void tcmi_upload_scratch_free(tcmi_upload_scratch *s) { delete s; }
+
+namespace {
 } // namespace
 
 extern "C" {
@@ -165,20 +200,23 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     // pass 1: select, classify, size
     // one entry of the aligned set: read i of BAM r (positions shifted by off); for a projected read the piece
     // [seg, seg + len) of its reference span (long reads are cut into pieces of <= TCMI_F_SEG positions)
-    struct Sel { const tcmi_reads *r; int64_t i, off, y0, len, seg; bool projected; };
-    struct GSel { const tcmi_reads *r; int64_t i, off; };
-    std::vector<Sel> fsel;                  // aligned set (len > 0)
-    std::vector<GSel> gsel;                 // general set
+    if (!ctx->upload_scratch) ctx->upload_scratch = new tcmi_upload_scratch();
+    tcmi_upload_scratch &SC = *ctx->upload_scratch;
+    struct Trim {                           // big batches do not keep their gigabytes around
+        tcmi_ctx *c;
+        ~Trim() { if (c->upload_scratch && c->upload_scratch->bytes() > ((size_t)768 << 20)) { tcmi_upload_scratch_free(c->upload_scratch); c->upload_scratch = nullptr; } }
+    } trim{ctx};
+    std::vector<Sel> &fsel = SC.fsel;       // aligned set (len > 0)
+    std::vector<GSel> &gsel = SC.gsel;      // general set
+    fsel.clear();
+    gsel.clear();
     int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0;
     bool any_cut = false;
     // every BAM's reads in `host_threads` contiguous slices, each into its own lists, joined in order afterwards
-    struct Part {
-        std::vector<Sel> fsel; std::vector<GSel> gsel;
-        int64_t g_cig = 0, g_seqw = 0, alg = 0, max_end = 0; bool any_cut = false;
-        int err = TCMI_OK; char msg[160] = {0};
-    };
     const int n_cls = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, 64, n_reads_in / 65536 + 1}));
-    std::vector<Part> parts((size_t)n_batch * (size_t)n_cls);
+    std::vector<Part> &parts = SC.parts;
+    parts.resize((size_t)n_batch * (size_t)n_cls);
+    for (Part &P : parts) { P.fsel.clear(); P.gsel.clear(); P.g_cig = P.g_seqw = P.alg = P.max_end = 0; P.any_cut = false; P.err = TCMI_OK; }
     auto classify = [&](int32_t bi, int t) {
         Part &P = parts[(size_t)bi * (size_t)n_cls + (size_t)t];
         const tcmi_reads *r = batch[bi];
@@ -234,8 +272,6 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             fsel.insert(fsel.end(), P.fsel.begin(), P.fsel.end());
             gsel.insert(gsel.end(), P.gsel.begin(), P.gsel.end());
             g_cig += P.g_cig; g_seqw += P.g_seqw; alg += P.alg; max_end = std::max(max_end, P.max_end); any_cut |= P.any_cut;
-            std::vector<Sel>().swap(P.fsel);
-            std::vector<GSel>().swap(P.gsel);
         }
     }
 
@@ -264,12 +300,16 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         const int64_t k = (nf + slots * longest - 1) / (slots * longest);
         balanced_cap = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
     }
-    std::vector<int32_t> f_pos((size_t)nf);
-    std::vector<uint32_t> f_event;              // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
-    std::vector<uint32_t> f_lenoff((size_t)nf);
-    std::vector<uint32_t> f_covrun;             // format 2: coverage runs (tcmi_fast_chunk::run0 / n_runs)
+    std::vector<int32_t> &f_pos = SC.f_pos;
+    std::vector<uint32_t> &f_event = SC.f_event;      // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
+    std::vector<uint32_t> &f_lenoff = SC.f_lenoff;
+    std::vector<uint32_t> &f_covrun = SC.f_covrun;    // format 2: coverage runs (tcmi_fast_chunk::run0 / n_runs)
+    f_pos.resize((size_t)nf);
+    f_lenoff.resize((size_t)nf);
+    f_event.clear();
+    f_covrun.clear();
     std::vector<tcmi_fast_chunk> chunks;
-    std::unique_ptr<uint32_t[]> f_seq;          // not zero-filled on allocation: every packing thread clears its own chunks
+    uint32_t *f_seq = nullptr;                  // (SC.f_seq) not zero-filled: every packing thread clears its own chunks
     size_t f_seq_n = 0;
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
@@ -338,7 +378,14 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 for (int64_t j = c.read0; j < c.read0 + c.n_reads; ++j) total += (size_t)read_words(fsel[(size_t)j].len);
             }
             total = (total + 3) & ~(size_t)3;
-            f_seq.reset(new uint32_t[total + 4]);
+            if (SC.f_seq_cap < total + 4) {
+                delete[] SC.f_seq;
+                SC.f_seq = nullptr;
+                SC.f_seq_cap = 0;
+                SC.f_seq = new uint32_t[total + 4 + total / 16];
+                SC.f_seq_cap = total + 4 + total / 16;
+            }
+            f_seq = SC.f_seq;
             f_seq_n = total;
         }
         const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ctx->host_threads, (int64_t)chunks.size(), 64}));
@@ -561,7 +608,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         if (fmt == 1) rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);   // (format 2 carries it in the packed header)
         if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
-        if (!rc) rc = up((void **)&rs->d_fseq, f_seq.get(), f_seq_n * 4);
+        if (!rc) rc = up((void **)&rs->d_fseq, f_seq, f_seq_n * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));
         if (!rc && !f_covrun.empty()) rc = up((void **)&rs->d_fcovrun, f_covrun.data(), f_covrun.size() * 4);
     }

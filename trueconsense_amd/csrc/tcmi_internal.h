@@ -125,8 +125,12 @@ struct tcmi_ride {                  // a finished matrix waiting for its call (s
     int32_t *counts; int64_t ld, L; int32_t mincov; int amb; uint8_t *plain, *alt, *flags; bool taken;
 };
 
+struct tcmi_upload_scratch;              // host buffers of tcmi_readset_upload, kept between calls (readset.cpp)
+void tcmi_upload_scratch_free(tcmi_upload_scratch *s);
+
 struct tcmi_ctx {
     int device = -1;
+    tcmi_upload_scratch *upload_scratch = nullptr;
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the format-2 kernel (its register budget)
     int balance_chunks = 1;          // format 2: size the chunks so that their number is a multiple of the resident workgroups

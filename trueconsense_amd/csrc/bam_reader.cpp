@@ -189,34 +189,29 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
 
     // ---- records: pass 1 walks the record lengths (sequential, light) and lays out the flat arrays,
     //      pass 2 fills them with `n_threads` workers over disjoint record ranges ----
-    const size_t rec0 = o;
     std::vector<size_t> rec_at;
     rec_at.reserve(N / 200 + 16);
-    while (o < N) {
+    std::vector<uint64_t> &qual_off = bam->qual_off;
+    bam->cigar_off.reserve(N / 200 + 16); bam->seq_off.reserve(N / 200 + 16); qual_off.reserve(N / 200 + 16);
+    uint64_t co = 0, so = 0, qo = 0;
+    while (o < N) {                                              // one walk: record starts and the offsets of the flat arrays
         if (!need(4)) return fail("truncated record length");
         const size_t bs = rd32(p + o);
         if (bs < 32 || !need(4 + bs)) return fail("truncated alignment record");
+        const uint8_t *r = p + o + 4;
+        const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
+        if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) return fail("alignment record fields overrun block_size");
         rec_at.push_back(o);
+        bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo);
+        co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
         o += 4 + bs;
     }
-    (void)rec0;
     const int64_t n = (int64_t)rec_at.size();
     bam->n = n;
+    bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo);
     bam->pos.resize((size_t)n); bam->l_qseq.resize((size_t)n); bam->tid.resize((size_t)n);
     bam->flag.resize((size_t)n); bam->mapq.resize((size_t)n);
-    bam->cigar_off.resize((size_t)n + 1); bam->seq_off.resize((size_t)n + 1);
-    std::vector<uint64_t> &qual_off = bam->qual_off;
-    qual_off.resize((size_t)n + 1);
     {
-        uint64_t co = 0, so = 0, qo = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const uint8_t *r = p + rec_at[(size_t)i] + 4;
-            const size_t bs = rd32(r - 4), l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
-            if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) { o = rec_at[(size_t)i]; return fail("alignment record fields overrun block_size"); }
-            bam->cigar_off[(size_t)i] = co; bam->seq_off[(size_t)i] = so; qual_off[(size_t)i] = qo;
-            co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
-        }
-        bam->cigar_off[(size_t)n] = co; bam->seq_off[(size_t)n] = so; qual_off[(size_t)n] = qo;
         bam->cigar.alloc((size_t)co + 1); bam->seq.alloc((size_t)so + 1); bam->qual.alloc((size_t)qo + 1);
         bam->cigar.data()[co] = 0; bam->seq.data()[so] = 0; bam->qual.data()[qo] = 0;
     }

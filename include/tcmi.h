@@ -95,30 +95,24 @@ int  tcmi_ctx_create_on_stream(int device, void *stream, tcmi_ctx **out);
 int  tcmi_ctx_destroy(tcmi_ctx *ctx);
 int  tcmi_ctx_sync(tcmi_ctx *ctx);                 /* wait for the context's stream               */
 void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launches go to          */
-/* tuning knobs (tcmi_readset_upload reads the packing ones, the launches the others):
- *   "tally_variant"  0 = reads take the fast kernel (default), 1 = every read takes the CIGAR-walk kernel
- *   "project_reads"  1 = reads with indels / ref-skips are projected onto the reference at upload and
- *                    take the fast kernel (default); 0 = they take the CIGAR-walk kernel
- *   "fast_format"    layout of the aligned reads on the device: 2 = 2-bit codes as two bit planes, 52 B per
- *                    150-bp read, bit-sliced counting (default); 1 = one-hot nibbles, 96 B per read
- *   "chunk_stages"   stages per fast-kernel chunk: 0 = default (format 2: up to 8, capped by "balance_chunks"; format 1:
- *                    4), or 1..8
- *   "balance_chunks" format 2, chunk_stages = 0: size the chunks so that a launch has a multiple of
+/* options (tcmi_readset_upload reads the packing ones, the launches the others):
+ *   "tally_variant"  0 = reads take the bit-plane kernel (default), 1 = every read takes the CIGAR-walk kernel
+ *                    (an independent implementation the tests cross-check with)
+ *   "project_reads"  1 = reads with indels / ref-skips are projected onto the reference when they are packed and
+ *                    take the bit-plane kernel (default); 0 = they take the CIGAR-walk kernel
+ *   "device_pack"    1 = tcmi_readset_upload copies the BAM-native arrays to the device and packs them there
+ *                    (pack_device.hip; default; needs reads sorted by position and entries of <= 512 positions,
+ *                    anything else takes the host packer); 0 = always pack on the host
+ *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
+ *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)
- *   "stage_cap"      format 2: upper bound on the reads per stage (0 = fill the LDS stage buffer; for experiments)
- *   "host_threads"   threads tcmi_readset_upload packs with (default min(16, cores))
+ *   "stage_cap"      upper bound on the reads per stage (0 = fill the LDS stage buffer; for experiments)
+ *   "host_threads"   threads the host packer uses (default min(16, cores))
  *   "rounds_per_wg"  CIGAR-walk kernel: rounds of 256 reads per workgroup (0 = auto)
- *   "use_graph"      1 = tcmi_step_begin replays the step as one hipGraph per read set; 0 = direct launches
- *                    (default: with two launches per step they queue with smaller gaps than graph replays)
  *   "defer_call"     (read from the pipeline's first workspace) 1 = tcmi_pipeline_run attaches the call of step k to
  *                    the tally launch of step k + 1 — one launch per step (default); 0 = tally launch + call launch
- *   "call_stream"    1 = direct launches put the call kernel on a second stream behind an event (default 0)
- *   "fuse_call"      1 = tcmi_step_begin without counts runs tally + call as ONE launch: the workgroup that
- *                    completes a 256-position tile of the matrix calls it (default 0)
- *   "records_to_host" 1 = in tcmi_step_begin the call kernel stores its records in pinned host memory
- *                    itself (default); 0 = device buffer + a D2H copy on the stream; 2 = + copy on a side stream
- *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin is launched directly with its
- *                    kernels bracketed by events, the others go out unmeasured (default 1) */
+ *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin has its kernels bracketed by events,
+ *                    the others go out unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

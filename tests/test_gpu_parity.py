@@ -109,10 +109,9 @@ def test_both_tally_kernels_agree(ctx):
     L = len(ref)
     want = c_oracle.tally(reads, L)
     want_x = c_oracle.tally(extra, L)
-    for variant, project, fmt in ((0, 1, 2), (0, 1, 1), (0, 0, 2), (0, 0, 1), (1, 1, 2)):
+    for variant, project in ((0, 1), (0, 0), (1, 1)):
         ctx.set_option("tally_variant", variant)
         ctx.set_option("project_reads", project)
-        ctx.set_option("fast_format", fmt)          # 2 = bit planes (default), 1 = one-hot nibbles
         rs = ctx.upload(reads)
         a, c, g = (C2.c_int64(0) for _ in range(3))
         _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
@@ -123,11 +122,10 @@ def test_both_tally_kernels_agree(ctx):
         else:
             assert a.value > 50_000 and g.value > 500 and a.value + g.value == rs.n_piled and c.value >= a.value // 4096
         rs.free()
-        assert np.array_equal(ctx.tally(reads, L=L), want), (variant, project, fmt)
-        assert np.array_equal(ctx.tally(extra, L=L), want_x), (variant, project, fmt)
+        assert np.array_equal(ctx.tally(reads, L=L), want), (variant, project)
+        assert np.array_equal(ctx.tally(extra, L=L), want_x), (variant, project)
     ctx.set_option("project_reads", 1)
     ctx.set_option("tally_variant", 0)
-    ctx.set_option("fast_format", 2)
     rs = ctx.upload(extra)
     a, c, g = (C2.c_int64(0) for _ in range(3))
     _ffi.check(_ffi.lib().tcmi_readset_sets(rs.handle, C2.byref(a), C2.byref(c), C2.byref(g)))
@@ -175,16 +173,11 @@ def test_full_size_1m_reads_exact_and_deterministic(ctx):
     assert np.array_equal(c1, want)
     wp, wa, wf = c_oracle.call(want, 30, True)
     assert np.array_equal(p1, wp) and np.array_equal(a1, wa) and np.array_equal(f1, wf)
-    # the one-launch step (the workgroup completing a tile calls it): 3 900 workgroups race to sign tiles off;
-    # every repetition must give the same records, and the matrix must be left zeroed each time
-    ctx.set_option("fuse_call", 1)
-    try:
-        for rep in range(25):
-            p3, a3, f3, _ = ctx.step(rs, L, 30, True, want_counts=False)
-            assert np.array_equal(p3, wp) and np.array_equal(a3, wa) and np.array_equal(f3, wf), rep
-        assert np.array_equal(ctx.step(rs, L, 30, True)[3], want)
-    finally:
-        ctx.set_option("fuse_call", 0)
+    # steps that leave the counts on the device: the call kernel zeroes the matrix behind itself
+    for rep in range(5):
+        p3, a3, f3, _ = ctx.step(rs, L, 30, True, want_counts=False)
+        assert np.array_equal(p3, wp) and np.array_equal(a3, wa) and np.array_equal(f3, wf), rep
+    assert np.array_equal(ctx.step(rs, L, 30, True)[3], want)
     rs.free()
 
 
@@ -369,15 +362,13 @@ def test_fuzz_random_cigars_all_paths(ctx):
         reads = fz.random_reads(rng, n, L, long_reads=long_reads, sort=sort)
         Lx = engine.reads_extent(reads, L)
         want = c_oracle.tally(reads, Lx)
-        for variant, project, fmt in ((0, 1, 2), (0, 1, 1), (0, 0, 2), (0, 0, 1), (1, 1, 2)):
+        for variant, project in ((0, 1), (0, 0), (1, 1)):
             ctx.set_option("tally_variant", variant)
             ctx.set_option("project_reads", project)
-            ctx.set_option("fast_format", fmt)
             got = ctx.tally(reads, L=Lx)
-            assert np.array_equal(got, want), (rep, variant, project, fmt, np.argwhere(got != want)[:5])
+            assert np.array_equal(got, want), (rep, variant, project, np.argwhere(got != want)[:5])
     ctx.set_option("tally_variant", 0)
     ctx.set_option("project_reads", 1)
-    ctx.set_option("fast_format", 2)
 
 
 def test_long_reference_sparse_reads(ctx):
@@ -525,82 +516,6 @@ def test_long_reads_take_the_fast_kernel_in_pieces(ctx):
     assert counts[:, 5].sum() > 1000 and counts[:, 6].sum() > 1000
 
 
-def test_fused_step_equals_two_launch_step(ctx):
-    """With option fuse_call, tcmi_step_begin without counts runs tally + call as ONE launch (the workgroup that
-    completes a tile of the matrix calls it).  Its records must equal the two-launch path and the oracle on dense, sparse, empty, batched
-    and long-read inputs, repeatedly on one workspace (the launch leaves matrix and sign-off counters zeroed)."""
-    from tests import fuzz_reads as fz
-    rng = np.random.default_rng(2024)
-    ref, orfs = sy.make_reference()
-    cases = []
-    cases.append(("dense+indels", sy.make_reads(ref, 120_000, seed=5, indel_sites=sy.default_indel_sites(orfs)), len(ref)))
-    cases.append(("few reads, long reference", sy.make_reads(ref, 300, seed=6), 400_000))
-    cases.append(("L just past the reads", sy.make_reads(ref, 5000, seed=8, start_range=(1000, 3000)), 3150))
-    fr = fz.random_reads(rng, 20_000, 9000, long_reads=True)
-    cases.append(("fuzz cigars, long reads", fr, int(engine.reads_extent(fr, 9000))))
-    empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v)
-             for k, v in sy.make_reads(ref, 10, seed=1).items()}
-    empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))
-    cases.append(("no reads", empty, 1000))
-    try:
-        for name, reads, L in cases:
-            rs = ctx.upload(reads)
-            want_counts = c_oracle.tally(reads, L)
-            want = c_oracle.call(want_counts, 30, True)
-            ctx.set_option("fuse_call", 0)
-            two = ctx.step(rs, L, 30, True, want_counts=False)
-            ctx.set_option("fuse_call", 1)
-            for rep in range(3):
-                one = ctx.step(rs, L, 30, True, want_counts=False)
-                for k in range(3):
-                    assert np.array_equal(one[k], two[k]), (name, rep, k)
-                    assert np.array_equal(one[k], want[k]), (name, rep, k)
-            p, a, f, counts = ctx.step(rs, L, 30, True, want_counts=True)      # the matrix was left zeroed
-            assert np.array_equal(counts, want_counts), name
-            rs.free()
-        # a batch: four BAMs at shifted positions, one launch
-        stride = 29952
-        group = [sy.make_reads(ref, 20_000 + 3000 * k, seed=60 + k) for k in range(4)]
-        rs = ctx.upload_batch(group, stride)
-        for rep in range(2):
-            p, a, f, _ = ctx.step(rs, 4 * stride, 30, True, want_counts=False)
-            for k, reads in enumerate(group):
-                w = c_oracle.call(c_oracle.tally(reads, len(ref)), 30, True)
-                for got, exp in zip((p, a, f), w):
-                    assert np.array_equal(got[k * stride:k * stride + len(ref)], exp), (rep, k)
-        rs.free()
-    finally:
-        ctx.set_option("fuse_call", 0)
-
-
-def test_graph_replay_equals_direct_launches(ctx):
-    """Option use_graph replays a step as one hipGraph per read set; direct launches are the default."""
-    ref, orfs = sy.make_reference()
-    reads = sy.make_reads(ref, 50_000, seed=15, indel_sites=sy.default_indel_sites(orfs))
-    L = len(ref)
-    rs = ctx.upload(reads)
-    want = c_oracle.call(c_oracle.tally(reads, L), 30, True)
-    try:
-        for fuse in (0, 1):
-            ctx.set_option("fuse_call", fuse)
-            for graph in (1, 0):
-                ctx.set_option("use_graph", graph)
-                for rec_mode, side_call in ((1, 0), (0, 0), (2, 0), (1, 1), (2, 1)):   # records: kernel stores to host / copy / side-stream
-                    ctx.set_option("records_to_host", rec_mode)                        # copy; call kernel on its own stream
-                    ctx.set_option("call_stream", side_call)
-                    for rep in range(3):                               # capture, then replays
-                        got = ctx.step(rs, L, 30, True, want_counts=False)
-                        assert all(np.array_equal(g, w) for g, w in zip(got, want)), (fuse, graph, rec_mode, rep)
-                    got = ctx.step(rs, L, 30, True, want_counts=True)
-                    assert all(np.array_equal(g, w) for g, w in zip(got[:3], want)), (fuse, graph, rec_mode)
-    finally:
-        ctx.set_option("fuse_call", 0)
-        ctx.set_option("use_graph", 0)
-        ctx.set_option("records_to_host", 1)
-        ctx.set_option("call_stream", 0)
-    rs.free()
-
-
 def _uniform_reads(rng, starts, lengths, alphabet="ACGTN"):
     """Flat arrays for reads with CIGAR <len>M at the given starts (already sorted), random bases."""
     n = len(starts)
@@ -621,8 +536,8 @@ def _uniform_reads(rng, starts, lengths, alphabet="ACGTN"):
             "qual_off": np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)}
 
 
-def test_chunk_geometry_extremes_both_formats(ctx):
-    """Shapes that push the chunker and the lane mapping of the two fast kernels to their limits: read lengths around
+def test_chunk_geometry_extremes(ctx):
+    """Shapes that push the chunker and the lane mapping of the bit-plane kernel to their limits: read lengths around
     the 8- and 32-position word sizes, one-base reads, 600-base reads, tens of thousands of reads on one start
     (narrow window, many depth slices, the 255-reads-per-lane bound), windows at the maximal width, reads that
     start at position 0 and end on the last position."""
@@ -637,16 +552,11 @@ def test_chunk_geometry_extremes_both_formats(ctx):
     cases.append(("mixed lengths 1..600", _uniform_reads(rng, starts, rng.integers(1, 601, 20_000)), 5600))
     starts = np.sort(rng.integers(0, 200_000, 3000)).astype(np.int32)
     cases.append(("sparse, every window at its widest", _uniform_reads(rng, starts, rng.integers(300, 601, 3000)), 200_600))
-    try:
-        for fmt in (2, 1):
-            ctx.set_option("fast_format", fmt)
-            for name, reads, L in cases:
-                want = c_oracle.tally(reads, L)
-                got = ctx.tally(reads, L=L)
-                assert np.array_equal(got, want), (fmt, name, np.argwhere(got != want)[:5])
-                assert int(got[:, 0].sum()) == int(reads["l_qseq"].sum()), (fmt, name)
-    finally:
-        ctx.set_option("fast_format", 2)
+    for name, reads, L in cases:
+        want = c_oracle.tally(reads, L)
+        got = ctx.tally(reads, L=L)
+        assert np.array_equal(got, want), (name, np.argwhere(got != want)[:5])
+        assert int(got[:, 0].sum()) == int(reads["l_qseq"].sum()), name
 
 
 def test_pipeline_long_queue_every_item_right(ctx):

@@ -95,8 +95,6 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     if (v && std::atoi(v) >= 1) c->host_threads = std::atoi(v);
     v = std::getenv("TCMI_CHUNK_STAGES");
     if (v && std::atoi(v) >= 1 && std::atoi(v) <= TCMI_F_MAXSTAGE) c->chunk_stages = std::atoi(v);
-    v = std::getenv("TCMI_FAST_FORMAT");
-    if (v) c->fast_format = std::atoi(v) == 1 ? 1 : 2;
 
     *out = c;
     return TCMI_OK;
@@ -104,14 +102,9 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
 
 extern "C" {
 
-void tcmi_drop_graphs(tcmi_ctx *ctx);
-
 static void free_ws(tcmi_ctx *c)
 {
     if (c->d_counts) (void)hipFree(c->d_counts);
-    if (c->d_tile_done) (void)hipFree(c->d_tile_done);
-    c->d_tile_done = nullptr;
-    c->ws_tiles = 0;
     if (c->d_plain) (void)hipFree(c->d_plain);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -132,12 +125,7 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     free_ws(c);
     tcmi_upload_scratch_free(c->upload_scratch);
     c->upload_scratch = nullptr;
-    tcmi_drop_graphs(c);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
-    if (c->call_done) (void)hipEventDestroy(c->call_done);
-    if (c->tally_done) (void)hipEventDestroy(c->tally_done);
-    if (c->call_stream && c->own_call_stream) (void)hipStreamDestroy(c->call_stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TCMI_OK;
@@ -147,8 +135,6 @@ int tcmi_ctx_sync(tcmi_ctx *c)
 {
     if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
     TCMI_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->copy_stream) TCMI_HIP(c, hipStreamSynchronize(c->copy_stream));
-    if (c->call_stream) TCMI_HIP(c, hipStreamSynchronize(c->call_stream));
     return TCMI_OK;
 }
 
@@ -162,15 +148,10 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "host_threads")) c->host_threads = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "chunk_stages")) c->chunk_stages = value < 0 ? 0 : value > TCMI_F_MAXSTAGE ? TCMI_F_MAXSTAGE : value;
     else if (!std::strcmp(key, "defer_call")) c->defer_call = value != 0;
-    else if (!std::strcmp(key, "call_stream")) c->use_call_stream = value != 0;
     else if (!std::strcmp(key, "wg_per_cu")) c->wg_per_cu = value < 1 ? 1 : value;
     else if (!std::strcmp(key, "stage_cap")) c->stage_cap = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
-    else if (!std::strcmp(key, "fast_format")) c->fast_format = value == 1 ? 1 : 2;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
-    else if (!std::strcmp(key, "fuse_call")) { c->fuse_call = value != 0; tcmi_drop_graphs(c); }
-    else if (!std::strcmp(key, "records_to_host")) { c->records_to_host = value < 0 ? 0 : value > 2 ? 2 : value; tcmi_drop_graphs(c); }
-    else if (!std::strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
@@ -290,13 +271,9 @@ static int ensure_ws(tcmi_ctx *ctx, int64_t L)
 {
     if (ctx->ws_L >= L && ctx->d_counts) return TCMI_OK;
     free_ws(ctx);
-    tcmi_drop_graphs(ctx);                                   // they hold the old workspace pointers
     ctx->counts_clean = false;
     int64_t ld = tcmi_round_up(L, 256);
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4));
-    ctx->ws_tiles = ld / TCMI_F_BLOCK + 16;
-    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_tile_done, (size_t)ctx->ws_tiles * 4));
-    TCMI_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)ctx->ws_tiles * 4, ctx->stream));
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_plain, (size_t)ld * 3));
     ctx->d_alt = ctx->d_plain + ld;
     ctx->d_flags = ctx->d_plain + 2 * ld;
@@ -409,80 +386,23 @@ int tcmi_call(tcmi_ctx *ctx, const int32_t *counts, int64_t L, int32_t mincov, i
     return rc;
 }
 
-// the launches of one step, on ctx->stream (directly, or while the stream is being captured)
+// The launches of one step on ctx->stream: [memset] tally, call.  When the counts are not wanted on the host the
+// call kernel zeroes them behind itself and the next step into this workspace needs no memset.  The call records
+// (3 bytes per position) go straight to the pinned host buffer: the kernel's own stores cross PCIe, which saves a
+// separate copy and one launch boundary per step.
 static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, int want_counts,
-                        bool memset_first, hipEvent_t ev_a, hipEvent_t ev_b)
+                        bool memset_first)
 {
     const int64_t ld = ctx->ws_ld;
     if (memset_first) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
-    if (ev_a) TCMI_HIP(ctx, hipEventRecord(ev_a, ctx->stream));
-    // One launch for tally + call when nothing but the fast kernel adds into the matrix and the counts stay on
-    // the device: the workgroup that completes a tile of the matrix calls it (tally_fast.hip, "fused call").
-    if (ctx->fuse_call && !want_counts && ctx->records_to_host == 1 && ctx->tally_variant == 0 && rs->g_reads == 0 &&
-        std::max<int64_t>((L + TCMI_F_BLOCK - 1) / TCMI_F_BLOCK, rs->f_tiles) <= ctx->ws_tiles)
-        return tcmi_launch_step_fused(ctx, rs, L, ld, ctx->d_counts, ctx->d_tile_done, ctx->ws_tiles, mincov, include_ambig,
-                                      ctx->h_rec, ctx->h_rec + ld, ctx->h_rec + 2 * ld);
     int rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 0);
     if (rc) return rc;
-    if (ev_b) TCMI_HIP(ctx, hipEventRecord(ev_b, ctx->stream));
-    // The call kernel on a second stream behind an event (direct launches only): the stream of tallies is not
-    // held up by it, and the next tally — into another workspace — needs nothing from it.
-    hipStream_t main_stream = ctx->stream;
-    const bool side_call = ctx->use_call_stream && !ctx->capturing;
-    if (side_call) {
-        if (!ctx->call_stream) {
-            TCMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->call_stream, hipStreamNonBlocking));
-            ctx->own_call_stream = true;
-        }
-        if (!ctx->tally_done) TCMI_HIP(ctx, hipEventCreateWithFlags(&ctx->tally_done, hipEventDisableTiming));
-        TCMI_HIP(ctx, hipEventRecord(ctx->tally_done, main_stream));
-        TCMI_HIP(ctx, hipStreamWaitEvent(ctx->call_stream, ctx->tally_done, 0));
-        ctx->stream = ctx->call_stream;                          // everything below goes to the call stream
-        ctx->step_on_side_stream = ctx->call_stream;
-    }
-    // when the counts are not wanted on the host, the call kernel zeroes them behind itself and the
-    // next step into this workspace needs no memset
-    // The call records (3 bytes per position) go straight to the pinned host buffer: the kernel's own
-    // stores cross PCIe, which saves the separate 90 KB copy kernel and one launch boundary per step.
-    // Mode 2 keeps the kernel off PCIe: records into device memory, then a copy on the context's copy stream
-    // behind an event (direct launches only; counts wanted -> mode 0).
-    const bool side_copy = ctx->records_to_host == 2 && !want_counts && !ctx->capturing;
-    uint8_t *rec = ctx->records_to_host == 1 || (ctx->records_to_host == 2 && ctx->capturing) ? ctx->h_rec : ctx->d_plain;
-    rc = tcmi_launch_call(ctx, ctx->d_counts, L, ld, mincov, include_ambig, want_counts ? 0 : 1, rec, rec + ld, rec + 2 * ld,
-                          nullptr, nullptr);
-    hipError_t e = hipSuccess;
-    if (!rc && side_copy) {
-        if (!ctx->copy_stream) {
-            e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming);
-        }
-        if (e == hipSuccess) e = hipEventRecord(ctx->call_done, ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->call_done, 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->copy_stream);
-        ctx->step_on_side_stream = ctx->copy_stream;
-    } else if (!rc && rec == ctx->d_plain)
-        e = hipMemcpyAsync(ctx->h_rec, ctx->d_plain, (size_t)ld * 3, hipMemcpyDeviceToHost, ctx->stream);
-    if (!rc && e == hipSuccess && want_counts)
-        e = hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream);
-    ctx->stream = main_stream;
+    rc = tcmi_launch_call(ctx, ctx->d_counts, L, ld, mincov, include_ambig, want_counts ? 0 : 1, ctx->h_rec, ctx->h_rec + ld,
+                          ctx->h_rec + 2 * ld, nullptr, nullptr);
     if (rc) return rc;
-    if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "step launch failed: %s", hipGetErrorString(e));
+    if (want_counts)
+        TCMI_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ld * TCMI_NCOL * 4, hipMemcpyDeviceToHost, ctx->stream));
     return TCMI_OK;
-}
-
-static void drop_graph(tcmi_ctx::StepGraph &g)
-{
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.ev_a) (void)hipEventDestroy(g.ev_a);
-    if (g.ev_b) (void)hipEventDestroy(g.ev_b);
-    g.exec = nullptr;
-    g.ev_a = g.ev_b = nullptr;
-}
-
-void tcmi_drop_graphs(tcmi_ctx *ctx)
-{
-    for (auto &g : ctx->graphs) drop_graph(g);
-    ctx->graphs.clear();
 }
 
 } // extern "C"  (the next three functions are internal C++ linkage: tcmi_internal.h)
@@ -528,7 +448,6 @@ int tcmi_step_begin_deferred(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, i
     }
     if (!ctx->counts_clean) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ctx->ws_ld * TCMI_NCOL * 4, ctx->stream));
     ctx->counts_clean = false;
-    ctx->step_graph = -1;
     const bool sampled = ctx->prof && (ctx->step_tick++ % ctx->prof_every) == 0;
     tcmi_ride ride = {};
     if (prev) {
@@ -571,57 +490,14 @@ int tcmi_step_begin(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mi
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     const bool memset_first = !ctx->counts_clean;
     ctx->counts_clean = false;
-    ctx->step_graph = -1;
-    // with profiling on, every prof_every-th step goes out as direct launches bracketed by events
+    // with profiling on, every prof_every-th step has its kernels bracketed by events
     const bool sampled = ctx->prof && (ctx->step_tick++ % ctx->prof_every) == 0;
-    if (ctx->use_graph && !sampled) {
-        // The step is launch-bound (five launches for ~40 us of GPU work): replay it as one hipGraph.
-        // Graphs are kept per (read set, parameters).
-        int hit = -1;
-        for (size_t k = 0; k < ctx->graphs.size(); ++k) {
-            const auto &g = ctx->graphs[k];
-            if (g.rs_uid == rs->uid && g.L == L && g.mincov == mincov && g.amb == include_ambig && g.counts == want_counts &&
-                g.memset_first == memset_first) { hit = (int)k; break; }
-        }
-        if (hit < 0) {
-            if (ctx->graphs.size() >= 32) { drop_graph(ctx->graphs.front()); ctx->graphs.erase(ctx->graphs.begin()); }
-            tcmi_ctx::StepGraph g;
-            g.rs_uid = rs->uid; g.L = L; g.mincov = mincov; g.amb = include_ambig; g.counts = want_counts; g.memset_first = memset_first;
-            const bool prof = ctx->prof;
-            ctx->prof = false;                               // no pool events inside the capture
-            ctx->capturing = true;
-            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
-            hipGraph_t graph = nullptr;
-            if (e == hipSuccess) {
-                rc = enqueue_step(ctx, rs, L, mincov, include_ambig, want_counts, memset_first, nullptr, nullptr);
-                e = hipStreamEndCapture(ctx->stream, &graph);
-            }
-            ctx->prof = prof;
-            ctx->capturing = false;
-            if (e == hipSuccess && !rc) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (e != hipSuccess || rc) {
-                drop_graph(g);
-                (void)hipGetLastError();
-                if (rc) return rc;
-                return tcmi_fail(ctx, TCMI_E_HIP, "hipGraph capture of the step failed: %s", hipGetErrorString(e));
-            }
-            ctx->graphs.push_back(g);
-            hit = (int)ctx->graphs.size() - 1;
-        }
-        TCMI_HIP(ctx, hipGraphLaunch(ctx->graphs[(size_t)hit].exec, ctx->stream));
-        ctx->step_graph = hit;
-    } else {
-        ctx->prof_mute = !sampled;
-        rc = enqueue_step(ctx, rs, L, mincov, include_ambig, want_counts, memset_first, nullptr, nullptr);
-        ctx->prof_mute = false;
-        if (rc) return rc;
-    }
+    ctx->prof_mute = !sampled;
+    rc = enqueue_step(ctx, rs, L, mincov, include_ambig, want_counts, memset_first);
+    ctx->prof_mute = false;
+    if (rc) return rc;
     ctx->counts_clean = !want_counts;
-    // (recorded outside the graph: hipEventSynchronize does not wait for an event-record NODE of a
-    // replayed graph on ROCm 7.0/7.2 — the pipeline test caught stale records when it was captured)
-    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->step_on_side_stream ? ctx->step_on_side_stream : ctx->stream));
-    ctx->step_on_side_stream = nullptr;
+    TCMI_HIP(ctx, hipEventRecord(ctx->step_done, ctx->stream));
     ctx->step_L = L;
     ctx->step_counts = want_counts != 0;
     return TCMI_OK;

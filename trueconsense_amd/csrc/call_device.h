@@ -1,5 +1,6 @@
 // call_device.h — the per-position call as a device function, shared by call.hip (one lane per position
-// of a finished matrix) and tally_fast.hip (the workgroup that completes a tile of the matrix calls it).
+// of a finished matrix) and tally_common.h (ride-along call: the first blocks of a tally launch call the matrix an
+// earlier launch finished).
 // What it replaces in the reference is listed in call.hip.
 #pragma once
 #include "tcmi_internal.h"

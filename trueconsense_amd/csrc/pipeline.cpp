@@ -154,22 +154,12 @@ int tcmi_pipeline_create(int device, int n_slots, int n_walkers, tcmi_pipeline *
     p->device = device;
     for (int s = 0; s < n_slots; ++s) {
         tcmi_ctx *c = nullptr;
-        // TCMI_PIPE_STREAMS (default 1): with 2, odd and even workspaces alternate between two streams, so the
-        // call kernel of one step can run beside the tally of the next
-        static const int n_streams = [] { const char *v = std::getenv("TCMI_PIPE_STREAMS"); return v && std::atoi(v) == 2 ? 2 : 1; }();
-        const int rc = s < n_streams ? tcmi_ctx_create(device, &c)
-                                     : tcmi_ctx_create_on_stream(device, tcmi_ctx_stream(p->slots[(size_t)(s % n_streams)]), &c);
+        // one stream for all workspaces: slot 0 owns it
+        const int rc = s == 0 ? tcmi_ctx_create(device, &c) : tcmi_ctx_create_on_stream(device, tcmi_ctx_stream(p->slots[0]), &c);
         if (rc) {
             for (size_t k = p->slots.size(); k-- > 0;) tcmi_ctx_destroy(p->slots[k]);
             delete p;
             return rc;
-        }
-        if (p->slots.empty()) {                                  // one call stream for all workspaces (option call_stream)
-            if (hipStreamCreateWithFlags(&c->call_stream, hipStreamNonBlocking) == hipSuccess) c->own_call_stream = true;
-            else c->call_stream = nullptr;
-        } else {
-            c->call_stream = p->slots[0]->call_stream;
-            c->own_call_stream = false;
         }
         p->slots.push_back(c);
     }
@@ -225,8 +215,7 @@ int tcmi_pipeline_run_batched(tcmi_pipeline *p, int64_t n_items, const tcmi_read
     int first_err = TCMI_OK;
     // Ride-along call (option defer_call of slot 0): the call of step k is carried by the tally launch of step k + 1,
     // so a step is ONE launch; the last step of the queue (or one nobody followed) launches its call on its own.
-    const bool defer = p->slots[0]->defer_call && !p->slots[0]->use_graph && !p->slots[0]->fuse_call &&
-                       p->slots[0]->records_to_host == 1 && !p->slots[0]->use_call_stream;
+    const bool defer = p->slots[0]->defer_call != 0;
     int pending_slot = -1;
     for (int64_t waited = 0; waited < n_items; ++waited) {
         // keep the stream fed: queue every step whose workspace is free

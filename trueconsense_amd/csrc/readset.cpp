@@ -126,14 +126,13 @@ struct tcmi_upload_scratch {
     std::vector<Sel> fsel;
     std::vector<GSel> gsel;
     std::vector<Part> parts;
-    std::vector<int32_t> f_pos;
     std::vector<uint32_t> f_lenoff, f_event, f_covrun;
     uint32_t *f_seq = nullptr;
     size_t f_seq_cap = 0;
     ~tcmi_upload_scratch() { delete[] f_seq; }
     size_t bytes() const
     {
-        size_t b = fsel.capacity() * sizeof(Sel) + gsel.capacity() * sizeof(GSel) + f_pos.capacity() * 4 + f_lenoff.capacity() * 4 +
+        size_t b = fsel.capacity() * sizeof(Sel) + gsel.capacity() * sizeof(GSel) + f_lenoff.capacity() * 4 +
                    f_event.capacity() * 4 + f_covrun.capacity() * 4 + f_seq_cap * 4;
         for (const Part &p : parts) b += p.fsel.capacity() * sizeof(Sel) + p.gsel.capacity() * sizeof(GSel);
         return b;
@@ -141,9 +140,6 @@ struct tcmi_upload_scratch {
 };
 
 void tcmi_upload_scratch_free(tcmi_upload_scratch *s) { delete s; }
-
-namespace {
-} // namespace
 
 extern "C" {
 
@@ -166,8 +162,7 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {rs->d_fpos, rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_fcovrun, rs->d_ftile_need, rs->d_fev_tile_off,
-                    rs->d_fev_tile, rs->d_forphan, rs->d_pos, rs->d_meta,
+    void *ptrs[] = {rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_fcovrun, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -282,29 +277,24 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     const auto t1 = now();
     // ---- aligned set: chunks, stages, padded one-hot bases, "other" positions ----------------
     const int64_t nf = (int64_t)fsel.size();
-    const int NW = 2, PAD = NW + 1;             // grid words per lane of tally_fast_kernel<2>
-    // Layout of the base stream (tcmi_internal.h): format 1 = one-hot nibbles, format 2 = {lo, hi} plane pairs.
-    const int fmt = ctx->fast_format == 1 ? 1 : 2;
-    const int64_t prefix = fmt == 1 ? PAD : 2;                                   // zero words in front of a chunk's first read
-    auto read_words = [&](int64_t len) -> int64_t {                              // words of one read, trailing zeros included
-        return fmt == 1 ? (len + 7) / 8 + PAD : 2 * ((len + 31) / 32) + 2;
+    // Layout of the base stream (tcmi_internal.h): {lo, hi} plane pairs.
+    const int64_t prefix = 2;                                                    // zero words in front of a chunk's first read
+    auto read_words = [&](int64_t len) -> int64_t {                              // words of one read, trailing zero pair included
+        return 2 * ((len + 31) / 32) + 2;
     };
-    const int max_stages = fmt == 1 ? 4 : TCMI_F_MAXSTAGE;
-    // Format 2, chunk_stages = 0: long chunks (up to 8 stages: the spread / reduce epilogue is paid once per chunk),
+    // chunk_stages = 0: long chunks (up to 8 stages: the spread / reduce epilogue is paid once per chunk),
     // but capped so that the launch has k * (4 workgroups per CU) chunks — with 2 315 chunks on 1 024 slots the third
     // round of workgroups ran a quarter full.
-    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, max_stages) : fmt == 2 ? TCMI_F_MAXSTAGE : 4;
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) : TCMI_F_MAXSTAGE;
     int64_t balanced_cap = INT64_MAX;
-    if (fmt == 2 && ctx->chunk_stages == 0 && ctx->balance_chunks && nf > 0) {
+    if (ctx->chunk_stages == 0 && ctx->balance_chunks && nf > 0) {
         const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu, longest = (int64_t)TCMI_F_MAXSTAGE * 400;   // ~ 400 reads per stage at 5 000x / 150 bp
         const int64_t k = (nf + slots * longest - 1) / (slots * longest);
         balanced_cap = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
     }
-    std::vector<int32_t> &f_pos = SC.f_pos;
     std::vector<uint32_t> &f_event = SC.f_event;      // position | TCMI_F_EV_* : tokens that are not plain A/C/G/T bases
     std::vector<uint32_t> &f_lenoff = SC.f_lenoff;
     std::vector<uint32_t> &f_covrun = SC.f_covrun;    // format 2: coverage runs (tcmi_fast_chunk::run0 / n_runs)
-    f_pos.resize((size_t)nf);
     f_lenoff.resize((size_t)nf);
     f_event.clear();
     f_covrun.clear();
@@ -313,32 +303,21 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     size_t f_seq_n = 0;
     {
         int64_t c_read0 = 0, c_lo = 0, c_hi = 0, c_maxnw = 0, c_n = 0;
-        // Stage size for a window of `words` grid words and reads of <= maxnw words: the kernel splits a
-        // stage over S = 256 / ceil(words / NW) depth slices and runs ceil(stage / S) inner-loop bodies per
-        // lane, unrolled by 4 and widened every 12: a stage of S * 12 reads (or a multiple) wastes none.
+        // Stage size for a window of `words` grid words and reads of <= maxnw grid words: lanes own 32 positions, the
+        // kernel splits a stage over S = 256 / ceil(window / 32) depth slices and its inner loop takes bodies of 8
+        // reads per lane and one of 4: a stage of S * 4 * m reads wastes none.  Fill the stage buffer.
         auto stage_reads = [&](int64_t words, int64_t maxnw) -> int64_t {
-            if (fmt == 2) {
-                // lanes own 32 positions; the inner loop takes bodies of 8 reads per lane and one of 4: fill the stage buffer
-                const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
-                int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
-                if (ctx->stage_cap > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(ctx->stage_cap, S * 4));   // (experiments)
-                int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
-                if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
-                return sub;
-            }
-            const int64_t S = TCMI_F_BLOCK / ((words + NW - 1) / NW);
-            const int64_t cap = std::min<int64_t>(TCMI_F_SUB, (TCMI_F_SEQCAP - 16 - PAD) / (maxnw + PAD));
-            int64_t sub = S * 12 * std::max<int64_t>(1, cap / (S * 12));
-            if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);            // window too wide for 12 per slice
+            const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
+            int64_t cap = std::min<int64_t>(TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - prefix) / read_words(maxnw * 8));
+            if (ctx->stage_cap > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(ctx->stage_cap, S * 4));   // (experiments)
+            int64_t sub = S * 4 * std::max<int64_t>(1, cap / (S * 4));
+            if (sub > cap) sub = std::max<int64_t>(S, cap / S * S);
             return sub;
         };
-        auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages
-            if (fmt == 2) {                                                      // <= 2^planes - 1 reads per lane
-                const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
-                const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
-                return std::min(whole, balanced_cap);
-            }
-            return std::max<int64_t>(sub, std::min<int64_t>(TCMI_F_CHUNK, n_stages * sub) / sub * sub);   // <= 1024 reads
+        auto chunk_reads = [&](int64_t sub, int64_t words) -> int64_t {          // whole stages, <= 2^planes - 1 reads per lane
+            const int64_t S = TCMI_F_BLOCK / std::max<int64_t>(2, (words * 8 + 31) / 32)   /* (the kernel keeps at least two lane groups) */;
+            const int64_t whole = std::max<int64_t>(sub, std::min<int64_t>(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
+            return std::min(whole, balanced_cap);
         };
         auto close = [&](int64_t next_read) {
             if (c_n == 0) return;
@@ -364,7 +343,6 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             }
             if (c_n == 0) { c_read0 = j; c_lo = lo; c_hi = e; c_maxnw = nw; }
             ++c_n;
-            f_pos[(size_t)j] = (int32_t)p;
         }
         close(nf);
         // the base stream, chunk by chunk: [pad] read [pad] read [pad] ... each chunk 16-byte aligned.
@@ -413,10 +391,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 const int64_t lq = r->l_qseq[s.i];
                 const int64_t nw = (s.len + 7) / 8;
                 const size_t base = cursor;
-                // format 1: len | word offset from the chunk's first word << 10 (the position travels in f_pos);
-                // format 2: ONE packed word per read — position relative to the window | len << 10 | pair offset from
+                // ONE packed word per read — position relative to the window | len << 10 | pair offset from
                 // the stage's first word << 20 (a stage starts on the zero pair in front of its first read)
-                if (fmt == 2) {
+                {
                     // (10 + 10 + 12 bits: the chunker keeps windows <= 768 positions, entries <= 600 positions and
                     // stages <= 6144 words; checked, not assumed)
                     if (rpos - c.P0 > 1023 || s.len > 1023 || (base - stage_begin) / 2 > 4095) pack_overflow.store(true);
@@ -427,11 +404,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                     if (key == run_key && (runs.back() >> 20) < 4095u) runs.back() += 1u << 20;
                     else { runs.push_back(key | (1u << 20)); run_key = key; }
                 }
-                else
-                    f_lenoff[(size_t)j] = (uint32_t)s.len | ((uint32_t)(base - (size_t)c.word0) << 10);
                 cursor += (size_t)read_words(s.len);
-                if (fmt == 2) scratch.assign((size_t)nw + 1, 0u);
-                uint8_t *dst = reinterpret_cast<uint8_t *>(fmt == 2 ? scratch.data() : &f_seq[base]);
+                scratch.assign((size_t)nw + 1, 0u);
+                uint8_t *dst = reinterpret_cast<uint8_t *>(scratch.data());
                 const int64_t have = std::max<int64_t>(0, std::min(s.len, lq - s.y0));   // bases present in SEQ
                 if (s.projected) {
                     // Walk the CIGAR once: matched bases land on their reference offset, D / N leave zero
@@ -479,7 +454,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                     }
                 }
                 // bases that are no A/C/G/T: rare, found a word at a time
-                const uint32_t *w = fmt == 2 ? scratch.data() : &f_seq[base];
+                const uint32_t *w = scratch.data();
                 for (int64_t k = 0; k < nw; ++k) {
                     const uint32_t v = w[k];
                     uint32_t nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;   // 1 per non-zero nibble
@@ -492,7 +467,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                         miss &= miss - 1;
                     }
                 }
-                if (fmt == 2) {
+                {
                     // one-hot nibbles -> codes A=0 C=1 G=2 T=3 (class-less = 0) as {lo plane, hi plane} per 32 bases
                     auto squeeze = [](uint32_t x) -> uint32_t {                 // bits 0,4,..,28 -> bits 0..7
                         x = (x | (x >> 3)) & 0x03030303u;
@@ -513,7 +488,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
                 }
                 if ((j - c.read0 + 1) % c.sub_reads == 0 || j + 1 == c.read0 + c.n_reads) {
                     c.stage_end[(j - c.read0) / c.sub_reads] = (int32_t)(cursor - (size_t)c.word0);
-                    stage_begin = cursor - 2;                        // format 2: the next stage starts on this read's zero pair
+                    stage_begin = cursor - 2;                        // the next stage starts on this read's zero pair
                 }
                 if (j + 1 == c.read0 + c.n_reads) c.n_runs = (int32_t)((int64_t)runs.size() - c.run0);
             }
@@ -571,42 +546,11 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     rs->uid = next_uid.fetch_add(1);
     rs->n_reads = n_reads_in; rs->n_piled = nf + ng; rs->alg_bytes = alg; rs->max_end = max_end; rs->device = ctx->device;
     rs->f_reads = nf; rs->f_chunks = (int64_t)chunks.size(); rs->f_words = (int64_t)f_seq_n;
-    rs->f_events = (int64_t)f_event.size(); rs->f_nw = NW; rs->f_fmt = fmt;
+    rs->f_events = (int64_t)f_event.size();
     rs->g_reads = ng; rs->n_rounds = n_rounds; rs->n_cigar = g_cig; rs->n_seqw = g_seqw;
-    // fused call (tally_fast.hip): who adds into which tile of TCMI_F_BLOCK positions
-    std::vector<int32_t> tile_need, ev_tile_off, ev_tile, orphans;
-    {
-        constexpr int64_t T = TCMI_F_BLOCK;
-        int64_t n_tiles = 0;
-        for (const auto &c : chunks) n_tiles = std::max<int64_t>(n_tiles, ((int64_t)c.P0 + (int64_t)c.Wn * 8 - 1) / T + 1);
-        for (uint32_t e : f_event) n_tiles = std::max<int64_t>(n_tiles, (int64_t)(e & (TCMI_F_EVPOS - 1u)) / T + 1);
-        tile_need.assign((size_t)n_tiles, 0);
-        for (const auto &c : chunks)
-            for (int64_t t = c.P0 / T; t <= ((int64_t)c.P0 + (int64_t)c.Wn * 8 - 1) / T; ++t) ++tile_need[(size_t)t];
-        const size_t n_tail = (f_event.size() + (size_t)T - 1) / (size_t)T;
-        ev_tile_off.assign(n_tail + 1, 0);
-        for (size_t b = 0; b < n_tail; ++b) {
-            const size_t first = ev_tile.size();
-            for (size_t i = b * (size_t)T; i < std::min(f_event.size(), (b + 1) * (size_t)T); ++i) {
-                const int32_t t = (int32_t)((f_event[i] & (TCMI_F_EVPOS - 1u)) / (uint32_t)T);
-                if (std::find(ev_tile.begin() + (std::ptrdiff_t)first, ev_tile.end(), t) == ev_tile.end()) ev_tile.push_back(t);
-            }
-            for (size_t k = first; k < ev_tile.size(); ++k) ++tile_need[(size_t)ev_tile[k]];
-            ev_tile_off[b + 1] = (int32_t)ev_tile.size();
-        }
-        for (int64_t t = 0; t < n_tiles; ++t)
-            if (tile_need[(size_t)t] == 0) orphans.push_back((int32_t)t);
-        rs->f_tiles = n_tiles;
-        rs->f_orphans = (int64_t)orphans.size();
-    }
     Up up{ctx, rs};
-    if (!tile_need.empty()) rc = up((void **)&rs->d_ftile_need, tile_need.data(), tile_need.size() * 4);
-    if (!rc) rc = up((void **)&rs->d_fev_tile_off, ev_tile_off.data(), ev_tile_off.size() * 4);
-    if (!rc && !ev_tile.empty()) rc = up((void **)&rs->d_fev_tile, ev_tile.data(), ev_tile.size() * 4);
-    if (!rc && !orphans.empty()) rc = up((void **)&rs->d_forphan, orphans.data(), orphans.size() * 4);
     if (!rc && nf) {
-        if (fmt == 1) rc = up((void **)&rs->d_fpos, f_pos.data(), (size_t)nf * 4);   // (format 2 carries it in the packed header)
-        if (!rc) rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
+        rc = up((void **)&rs->d_flenoff, f_lenoff.data(), (size_t)nf * 4);
         if (!rc && !f_event.empty()) rc = up((void **)&rs->d_fevent, f_event.data(), f_event.size() * 4);
         if (!rc) rc = up((void **)&rs->d_fseq, f_seq, f_seq_n * 4);
         if (!rc) rc = up((void **)&rs->d_fchunk, chunks.data(), chunks.size() * sizeof(tcmi_fast_chunk));

@@ -1,51 +1,36 @@
 // tally_planes.hip — stage A for ALIGNED reads on gfx950, bases as 2-bit codes in two bit planes.
 // Counterpart of the per-token loop of indexing.py:102-132 for the tokens that are plain bases
-// (SURVEY §8-P2), like tally_fast.hip, with a denser layout and a cheaper inner loop:
+// (SURVEY §8-P2).
 //
-// Data (tcmi_internal.h, format 2): per read ONE packed header word and its aligned bases as codes
+// Data (tcmi_internal.h): per read ONE packed header word and its aligned bases as codes
 // A=0 C=1 G=2 T=3 (anything else 0, listed as an OTHER event), 32 bases per pair of 32-bit words
-// {lo plane, hi plane}, with one zero pair between reads: 52 bytes for a 150-bp read instead of 96.
+// {lo plane, hi plane}, with one zero pair between reads: 52 bytes for a 150-bp read.  The layout is
+// produced on the device by pack_device.hip (default) or on the host by readset.cpp.
 //
-// One workgroup per chunk (<= 8 stages of <= 438 reads), lane (g, s) owns 32 positions g of the
+// One workgroup per chunk (<= 8 stages of <= 510 reads), lane (g, s) owns 32 positions g of the
 // window and depth slice s of the reads.  Per read of the slice: one 64-bit LDS header, ONE
 // ds_read2_b64 (two pairs), two v_alignbit funnel shifts bring the read's planes onto the lane's
 // 32 positions (a lane that straddles an end of the read sees the zero pair there; a lane wholly
-// outside the read is told so by its clamped pair index and takes zeros); lo, hi and lo&hi (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders
-// (sum and carry: one v_bitop3_b32 each) fold eight reads into the ones / twos / fours planes and an
-// eights carry that ripples through the upper planes (8 planes: <= 255 reads per lane and chunk).
-// ~19 VALU instructions per read and 32 positions (the nibble kernel: ~24 per 16).  At the end of the chunk the planes are spread into byte
-// counters once, the slices are summed through LDS, and per position
+// outside the read is told so by its clamped pair index and takes zeros); lo, hi and lo&hi
+// (= C|T, G|T, T) are then COUNTED BIT-SLICED: carry-save adders (sum and carry: one v_bitop3_b32
+// each) fold eight reads into the ones / twos / fours planes and an eights carry that ripples through
+// the upper planes (8 planes: <= 255 reads per lane and chunk).  ~19 VALU instructions per read and
+// 32 positions.  At the end of the chunk the planes are spread into byte counters once, the slices
+// are summed through LDS, and per position
 //     C = n(lo) - n(lo&hi),  G = n(hi) - n(lo&hi),  T = n(lo&hi),  A = coverage - C - G - T
 // (covered positions without an A/C/G/T base land in A and are taken out by the tail blocks).
-// Coverage comes from the packer's per-chunk list of runs of reads with equal (position, length): a (+n, -n)
-// pair per run in an LDS difference array, prefix-summed at the end.  Staging, prefetch, final atomics and the
-// fused call are those of tally_fast.hip.
+// Coverage comes from the packer's per-chunk list of runs of reads with equal (position, length):
+// a (+n, -n) pair per run in an LDS difference array, prefix-summed at the end.
 //
 // HBM-streaming integer work: no MFMA (BASELINE.json north_star).
 #include <algorithm>
 
-#include "tally_fast_common.h"
+#include "tally_common.h"
 
 namespace {
 
-#ifndef TCMI_ABL
-#define TCMI_ABL 0      // diagnostic builds only (tools/build_variant.sh), bit mask: 2 no inner loop, 4 no global loads / staging,
-                        // 8 no spread / final reduce / atomics, 16 no coverage runs, 64 chunk blocks return at once, 128 streaming only, 256 phase clocks
-#endif
 #ifndef TCMI_P_BODY8
-#define TCMI_P_BODY8 1   // 0: four-read bodies only (fewer live registers, more carry ripples; measured below)
-#endif
-#if TCMI_ABL & 256
-// phase clocks (diagnostic build): lane 0 of wave TCMI_DBG_WAVE of every chunk workgroup stamps the 100 MHz wall clock
-// at its phase boundaries; tools/phase_times.py reads them through tcmi_debug_phase_times
-#ifndef TCMI_DBG_WAVE
-#define TCMI_DBG_WAVE 0
-#endif
-constexpr int DBG_SLOTS = 64;
-__device__ unsigned long long tcmi_dbg[8192 * DBG_SLOTS];
-#define TCMI_STAMP() do { if (dbg_on && dbg_n < DBG_SLOTS) tcmi_dbg[(size_t)bid * DBG_SLOTS + dbg_n++] = wall_clock64(); } while (0)
-#else
-#define TCMI_STAMP() do { } while (0)
+#define TCMI_P_BODY8 1   // 0: four-read bodies only (fewer live registers, more carry ripples)
 #endif
 constexpr int NPL = TCMI_P_NPL;                 // counter planes per vector
 constexpr int NVEC = 3;                         // lo, hi, lo & hi
@@ -137,7 +122,6 @@ __device__ inline void spread_all(const Planes (&cnt)[NVEC], uint32_t *s_part, i
     }
 }
 
-template <bool FUSED>
 __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_seq[TCMI_F_SEQCAP];   // staged planes; later the slice partials
@@ -152,17 +136,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     }
     const int bid = (int)blockIdx.x - a.n_call2;
     if (bid >= a.n_chunks) {
-        tally_tail_block<FUSED>(a, bid, reinterpret_cast<int *>(s_hdr));
+        tally_tail_block(a, bid);
         return;
     }
-#if TCMI_ABL & 64
-    if (a.L != 0x7FFFFFF1) return;
-#endif
-#if TCMI_ABL & 256
-    const bool dbg_on = tid == 64 * TCMI_DBG_WAVE && bid < 8192;
-    int dbg_n = 0;
-#endif
-    TCMI_STAMP();                                   // 0: start
     const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
@@ -221,7 +197,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     TCMI_ISSUE_STAGE(0, st_begin, st_end);
     // coverage: the packer lists the chunk's reads as runs of equal (position, length) — a few dozen words for a few
     // thousand reads of a sorted BAM; each becomes a (+n, -n) pair in the difference array (prefix-summed at the end)
-    if (!(TCMI_ABL & 16)) {
+    {
         const uint32_t *runs = a.covrun + chp->run0;
         const int n_runs = chp->n_runs;
         for (int i = tid; i < n_runs; i += FB) {
@@ -232,29 +208,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         }
     }
 
-#if TCMI_ABL & 128
-    uint32_t abl_acc = 0;
-#endif
     for (int stage = 0; stage < n_stage; ++stage) {
         const int ns = min(sub_reads, n_reads - stage * sub_reads);
         const int mis = st_begin & 3;
-#if TCMI_ABL & 128
-        {   // streaming only: consume the prefetched registers, issue the next stage, nothing else
-            abl_acc ^= pre0.x ^ pre1.y ^ pre2.z ^ pre3.w ^ pre4.x ^ pre5.y ^ h_lo0 ^ h_lo1;
-            if (stage + 1 < n_stage) {
-                st_begin = st_end - 2;
-                st_end = st_end_next;
-                st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
-                TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
-            }
-            continue;
-        }
-#endif
-        TCMI_STAMP();                               // stage + 0: top of the stage
-#if TCMI_ABL & 256
-        __builtin_amdgcn_s_waitcnt(0);              // separate "the loads have arrived" from the stores
-        TCMI_STAMP();                               // stage + 1: loads arrived
-#endif
         // ---- A: headers, coverage runs and planes of this stage -> LDS ------------------------------
         const bool valid0 = tid < ns, valid1 = tid + FB < ns;
         // header slots up to the end of the stage's last inner-loop body: real reads, then dummies
@@ -279,7 +235,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         {   // all six stores, whatever the stage's length: the loads were clamped into the stage, the buffer holds
             // 6 * 256 * 16 bytes, and nothing reads past the stage's last zero pair
             uint4 *dst = reinterpret_cast<uint4 *>(s_seq);
-            if (!(TCMI_ABL & 4)) {
+            {
                 dst[0 * FB + tid] = pre0;
                 dst[1 * FB + tid] = pre1;
                 dst[2 * FB + tid] = pre2;
@@ -296,14 +252,11 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
         }
-        TCMI_STAMP();                               // stage + 2: stores and next issue done
         __syncthreads();
-        TCMI_STAMP();                               // stage + 3: past barrier 1
-        TCMI_STAMP();                               // stage + 4: coverage runs done
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free bodies of eight
         //      reads, then at most one body of four (a stage holds S * 4 * m reads); the slots past the stage's reads
         //      hold dummy headers.
-        const int Rc = (TCMI_ABL & 2) ? 0 : Rs;
+        const int Rc = Rs;
         int hb = hb_first;                                       // byte offset of the lane's next header
 #define TCMI_FETCH4(lo_, hi_, both_, at_)                                                                         \
     do {                                                                                                          \
@@ -344,17 +297,8 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             add4(cnt[2], both);
         }
 #undef TCMI_FETCH4
-        TCMI_STAMP();                               // stage + 5: inner loop done
         __syncthreads();                                        // every lane is done with this stage's LDS
     }
-    TCMI_STAMP();                                   // E0: stages done
-#if TCMI_ABL & 128
-    if (abl_acc == 0x12345678u) a.counts[tid] = 1;
-    return;
-#endif
-#if TCMI_ABL & 8
-    if (cnt[0].p[0] != 0x12345678u) return;
-#endif
     // ---- planes -> byte counters -> LDS, layout [register j][lane] (conflict-free both ways) ---------
     uint32_t *s_part = s_seq;
     uint16_t (*s_fin)[MAXPOS] = reinterpret_cast<uint16_t (*)[MAXPOS]>(s_hdr);   // window counters of lo, hi, lo&hi
@@ -367,9 +311,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         else if (per_lane < 128) spread_all<(NPL < 7 ? NPL : 7)>(cnt, s_part, tid);
         else spread_all<NPL>(cnt, s_part, tid);
     }
-    TCMI_STAMP();                                   // E1: spread + stores
     __syncthreads();
-    TCMI_STAMP();                                   // E2: barrier
     // ---- sum the slices; register j of group g holds 4 positions (j%8 + 8 i) of one vector ------------
     for (int item = tid; item < Gn * NREG; item += FB) {
         const int j = item / Gn, g = item - j * Gn;
@@ -391,7 +333,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         if (p + 16 < npos) f[16] = (uint16_t)(e >> 16);
         if (p + 24 < npos) f[24] = (uint16_t)(o >> 16);
     }
-    TCMI_STAMP();                                   // E3: slices summed
     // ---- coverage: inclusive prefix sum of the difference array, CPL entries per lane ----------------
     {
         const int i0 = tid * CPL;
@@ -407,16 +348,12 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         }
     }
     __syncthreads();
-    TCMI_STAMP();                                   // E4: coverage scan + barrier
     // ---- global atomics: coverage, C, G, T of TWO adjacent positions per 64-bit add (the columns never go
     //      negative and never carry out of 32 bits), A one position at a time (the tail blocks subtract from it, so
     //      it may be transiently negative and a carry would spill into the neighbour) ---------------------------
     if (a.pair_ok) {
         for (int p = 2 * tid; p < npos; p += 2 * FB) {
             const int gp = P0 + p;                                  // even: P0 is a multiple of 8
-#if TCMI_ABL & 32
-            if (a.ld != 0x7FFFFFF1) continue;
-#endif
             if (gp >= a.L) continue;
             const bool two = gp + 1 < a.L;                          // (npos is a multiple of 8: p + 1 is inside the window)
             const int cv0 = s_cov[p], cv1 = two ? s_cov[p + 1] : 0;
@@ -451,31 +388,38 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
         }
     }
-    TCMI_STAMP();                                   // E5: atomics issued
-    if constexpr (FUSED) {
-        __syncthreads();                                        // s_hdr held the window counters until here
-        const int t0 = P0 / TILE;
-        sign_off_and_call(a, (P0 + npos - 1) / TILE - t0 + 1, [&](int k) { return t0 + k; }, reinterpret_cast<int *>(s_hdr));
-    }
 }
 
 #undef TCMI_ISSUE_STAGE
-#undef TCMI_STAMP
 #undef TCMI_XOR3
 #undef TCMI_MAJ
 
 } // namespace
 
-#if TCMI_ABL & 256
-extern "C" int tcmi_debug_phase_times(unsigned long long *out, int n_chunks)
-{
-    (void)hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tcmi_dbg), (size_t)std::min(n_chunks, 8192) * DBG_SLOTS * 8, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
-void tcmi_dispatch_tally_planes(const FastArgs &a, unsigned grid, hipStream_t stream, bool fused)
+
+// Launch over the aligned set of a read set: [ride-along call blocks][one block per chunk][tail blocks: event words].
+int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
-    if (fused) hipLaunchKernelGGL((tally_planes_kernel<true>), dim3(grid), dim3(FB), 0, stream, a);
-    else hipLaunchKernelGGL((tally_planes_kernel<false>), dim3(grid), dim3(FB), 0, stream, a);
+    FastArgs a = {};
+    a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent; a.covrun = rs->d_fcovrun;
+    a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
+    a.pair_ok = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_counts) % 8 == 0);
+    int64_t grid = rs->f_chunks + (rs->f_events + FB - 1) / FB;
+    if (ctx->ride && !ctx->ride->taken) {                     // carry another workspace's call in this launch
+        tcmi_ride *r = ctx->ride;
+        a.counts2 = r->counts; a.ld2 = r->ld; a.L2 = (int32_t)r->L; a.n_call2 = (int32_t)((r->L + TILE - 1) / TILE);
+        a.mincov = r->mincov; a.include_ambig = r->amb; a.plain = r->plain; a.alt = r->alt; a.flags = r->flags;
+        grid += a.n_call2;
+        r->taken = true;
+    }
+    if (grid > INT32_MAX) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many chunks");
+    if (grid == 0) return TCMI_OK;
+    a.n_chunks = (int32_t)rs->f_chunks;
+    tcmi_prof_begin(ctx, TCMI_K_TALLY);
+    (void)hipGetLastError();                                   // drop any stale error of this thread
+    hipLaunchKernelGGL(tally_planes_kernel, dim3((unsigned)grid), dim3(FB), 0, ctx->stream, a);
+    tcmi_prof_end(ctx, TCMI_K_TALLY);
+    TCMI_HIP(ctx, hipGetLastError());
+    return TCMI_OK;
 }

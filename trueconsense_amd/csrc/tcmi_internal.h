@@ -11,58 +11,51 @@
 #include "../../include/tcmi.h"
 
 // ---- device read layout -------------------------------------------------------------
-// Only reads that pile up (mapped, tid >= 0, pos >= 0, reference span > 0)
-// are kept, split in two sets at upload time:
+// Only reads that pile up (mapped, tid == 0, pos >= 0, reference span > 0)
+// are kept, in two sets:
 //
-//  * ALIGNED set (fast kernel).  A read
-//    whose CIGAR is one run of match ops (M / = / X, optionally flanked by S / H clips) is taken
-//    as it is; any other CIGAR is PROJECTED onto the reference while it is packed: matched bases
-//    land on their reference offset, deleted / skipped positions become empty nibbles, inserted
-//    and clipped bases are dropped, and the tokens that are not plain bases ("*", "..+n..") become
-//    EVENT words (position | kind) that the tail blocks of the same launch count; a projected read
-//    spanning more than TCMI_F_SEG positions is cut into pieces (long reads), and the entries are then
-//    re-sorted by position.  Kept as a header + the aligned bases only, in one of two layouts
-//    (tcmi_readset::f_fmt, ctx option fast_format):
-//      format 2 (default, tally_planes.hip): ONE packed header word (position - window start | len << 10 |
-//        pair offset from the stage's first word << 20); codes A=0 C=1 G=2 T=3 (anything else 0), 32 bases
-//        per pair of words {lo plane, hi plane}, one zero pair in front of every read and behind the last
-//        of a chunk: 4 + 8*ceil(l/32) + 8 bytes, 52 for a 150-bp read;
-//      format 1 (tally_fast.hip): 8 bytes of header (pos; len | word offset << 10); 8 bases per 32-bit
-//        word in linear nibble order, each nibble the one-hot class A=1 C=2 G=4 T=8 or 0, followed by
-//        `pad` zero words: 8 + 4*ceil(l/8) + 4*pad bytes, 96 for a 150-bp read at pad 3.
+//  * ALIGNED set (tally_planes.hip) — every read of every BASELINE config.  A read whose CIGAR is one run
+//    of match ops (M / = / X, optionally flanked by S / H clips) is taken as it is; any other CIGAR is
+//    PROJECTED onto the reference while it is packed: matched bases land on their reference offset,
+//    deleted / skipped positions stay empty, inserted and clipped bases are dropped, and the tokens that
+//    are not plain bases ("*", "..+n..") become EVENT words (position | kind) that the tail blocks of the
+//    same launch count.  Per entry ONE packed header word (position - window start | len << 10 | pair
+//    offset from the stage's first word << 20) and the bases as codes A=0 C=1 G=2 T=3 (anything else 0),
+//    32 bases per pair of words {lo plane, hi plane}, one zero pair in front of every read and behind the
+//    last of a chunk: 4 + 8*ceil(l/32) + 8 bytes, 52 for a 150-bp read.
 //    "Anything else" (N, IUPAC, '=', base beyond SEQ, deleted / skipped positions) is exactly what
 //    indexing.py:115-132 puts in no class; those positions are listed as OTHER event words (they
 //    count toward coverage but toward no class).
-//    Consecutive reads are grouped into CHUNKS (window <= TCMI_F_MAXW grid words of 8 positions; format 1:
-//    <= TCMI_F_CHUNK reads; format 2: <= 255 reads per lane); one workgroup tallies one chunk in STAGES of
-//    <= sub_reads reads.
-//  * GENERAL set (CIGAR-walk kernel): what the fast path does not take (positions >= 2^29, reads
-//    with indels when option project_reads = 0, or everything when option tally_variant = 1),
-//    in ROUNDS of TCMI_ROUND reads with per-round offset tables (the kernel rebuilds per-read
-//    offsets with a block scan), raw 4-bit codes.
+//    Consecutive reads are grouped into CHUNKS (window <= TCMI_F_MAXW grid words of 8 positions,
+//    <= 255 reads per lane); one workgroup tallies one chunk in STAGES of <= sub_reads reads.
+//    Packed on the DEVICE from the BAM-native arrays (pack_device.hip: sorted input, entries of
+//    <= TCMI_D_MAXLEN positions) or on the HOST (readset.cpp: anything, long reads in pieces of
+//    TCMI_F_SEG positions, re-sorted).
+//  * GENERAL set (CIGAR-walk kernel, tally.hip): what the aligned path does not take (positions >= 2^29,
+//    reads with indels under option project_reads = 0, or everything under option tally_variant = 1;
+//    the tests use these to cross-check independent implementations), in ROUNDS of TCMI_ROUND reads with
+//    per-round offset tables, raw 4-bit codes.
 //
 // The algorithmic bytes of SURVEY 8-d are 12 + 4*n_cigar + ceil(l/2) per read: 91 for a 150-bp read.
 #define TCMI_ROUND 256
 #ifndef TCMI_F_BLOCK
 #define TCMI_F_BLOCK 256           // lanes per workgroup of the fast kernel (256 or 512; 256 measured faster)
 #endif
-#define TCMI_F_CHUNK 1024          // max reads per chunk
 #define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes in one piece
 #define TCMI_F_SEG 512             // projected reads longer than this are cut into pieces of this many positions
-#define TCMI_F_SUB 256             // max reads staged in LDS at a time
 #ifndef TCMI_F_SEQCAP
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
 #endif
-#define TCMI_F_MAXSTAGE 8          // stages per chunk (format 1 uses up to 4)
+#define TCMI_F_MAXSTAGE 8          // stages per chunk
 #ifndef TCMI_P_NPL
-#define TCMI_P_NPL 8               // format 2: counter planes per lane: a lane counts <= 2^NPL - 1 reads per chunk
+#define TCMI_P_NPL 8               // counter planes per lane: a lane counts <= 2^NPL - 1 reads per chunk
 #endif
 #ifndef TCMI_P_WAVES
-#define TCMI_P_WAVES 4             // format 2: workgroups per CU the kernel's register budget is set for
+#define TCMI_P_WAVES 4             // workgroups per CU the kernel's register budget is set for
 #endif
 #ifndef TCMI_P_SUB
-#define TCMI_P_SUB 512             // format 2: max reads staged in LDS at a time
+#define TCMI_P_SUB 512             // max reads staged in LDS at a time
 #endif
 // event word = reference position | kind; kinds may be combined
 #define TCMI_F_EVPOS   (1u << 29)  // positions must stay below this for the fast path
@@ -76,10 +69,10 @@ struct tcmi_fast_chunk {           // 80 bytes
     int32_t n_reads;
     int32_t P0;                    // window start, multiple of 8
     int32_t Wn;                    // window length in grid words
-    int32_t sub_reads;             // reads per stage (multiple of 64, <= TCMI_F_SUB)
+    int32_t sub_reads;             // reads per stage (<= TCMI_P_SUB)
     int32_t stage_end[TCMI_F_MAXSTAGE];   // word offset (from word0) one past stage i, trailing pad included;
                                           // stage i starts at stage_end[i-1] - pad (0 for i = 0)
-    // format 2: the chunk's coverage as runs of reads with equal (position, length), words of d_fcovrun:
+    // the chunk's coverage as runs of reads with equal (position, length), words of d_fcovrun:
     // position - P0 | len << 10 | (reads in the run, <= 4095) << 20
     int64_t run0;
     int32_t n_runs;
@@ -96,20 +89,11 @@ struct tcmi_readset {
     int device = -1;
     // aligned set
     int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
-    int32_t f_nw = 2;           // grid words per lane the stream was padded for (pad = f_nw + 1)
-    int32_t f_fmt = 2;          // base stream: 1 = one-hot nibbles (tally_fast.hip), 2 = two bit planes (tally_planes.hip)
-    int32_t *d_fpos = nullptr;  // [f_reads] (format 1 only)
-    uint32_t *d_flenoff = nullptr; // [f_reads] format 1: len | (word offset from the chunk's word0) << 10; format 2: the packed header
+    uint32_t *d_flenoff = nullptr; // [f_reads] the packed header words
     uint32_t *d_fseq = nullptr; // [f_words]
     uint32_t *d_fevent = nullptr;// [f_events] position | TCMI_F_EV_*: tokens that are not plain A/C/G/T bases
     tcmi_fast_chunk *d_fchunk = nullptr;   // [f_chunks]
-    uint32_t *d_fcovrun = nullptr;         // format 2: coverage runs of all chunks (tcmi_fast_chunk::run0 / n_runs)
-    // fused call: tiles of TCMI_F_BLOCK positions; who adds into which (tally_fast.hip)
-    int64_t f_tiles = 0, f_orphans = 0;
-    int32_t *d_ftile_need = nullptr;   // [f_tiles] workgroups (chunks + tail blocks) adding into the tile
-    int32_t *d_fev_tile_off = nullptr; // [tail blocks + 1]
-    int32_t *d_fev_tile = nullptr;     // distinct tiles per tail block
-    int32_t *d_forphan = nullptr;      // [f_orphans] tiles < f_tiles with need 0
+    uint32_t *d_fcovrun = nullptr;         // coverage runs of all chunks (tcmi_fast_chunk::run0 / n_runs)
     // general set
     int64_t g_reads = 0, n_rounds = 0, n_cigar = 0, n_seqw = 0;
     int32_t *d_pos = nullptr;   // [g_reads]
@@ -121,7 +105,7 @@ struct tcmi_readset {
     int64_t *d_round_seq = nullptr; // [n_rounds+1]
 };
 
-struct tcmi_ride {                  // a finished matrix waiting for its call (see tally_fast_common.h, call_other_tile)
+struct tcmi_ride {                  // a finished matrix waiting for its call (see tally_common.h, call_other_tile)
     int32_t *counts; int64_t ld, L; int32_t mincov; int amb; uint8_t *plain, *alt, *flags; bool taken;
 };
 
@@ -132,8 +116,8 @@ struct tcmi_ctx {
     int device = -1;
     tcmi_upload_scratch *upload_scratch = nullptr;
     int n_cu = 256;                  // compute units of the device
-    int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the format-2 kernel (its register budget)
-    int balance_chunks = 1;          // format 2: size the chunks so that their number is a multiple of the resident workgroups
+    int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)
+    int balance_chunks = 1;          // size the chunks so that their number is a multiple of the resident workgroups
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin
@@ -149,33 +133,12 @@ struct tcmi_ctx {
     // workspace of tcmi_step / host-buffer conveniences
     int64_t ws_L = 0, ws_ld = 0;
     int32_t *d_counts = nullptr;
-    int32_t *d_tile_done = nullptr; // [ws_tiles] sign-off counters of the fused step, zero between launches
-    int64_t ws_tiles = 0;
     uint8_t *d_plain = nullptr, *d_alt = nullptr, *d_flags = nullptr;
     uint8_t *h_rec = nullptr;       // pinned: plain | alt | flags, each ws_ld bytes
     int32_t *h_counts = nullptr;    // pinned [7][ws_ld]
     int64_t step_L = 0;             // > 0 between tcmi_step_begin and tcmi_step_end
     bool step_counts = false;
     bool counts_clean = false;      // the workspace matrix was left zeroed by the last call kernel
-    // hipGraph replay of whole steps (tcmi_step_begin)
-    struct StepGraph {
-        uint64_t rs_uid = 0; int64_t L = 0; int32_t mincov = 0; int amb = 0, counts = 0; bool memset_first = false;
-        hipGraphExec_t exec = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    };
-    std::vector<StepGraph> graphs;
-    bool use_graph = false;         // direct launches queue with smaller gaps than graph replays (measured)
-    int records_to_host = 1;        // tcmi_step_begin: 1 = the call kernel stores its records in pinned host memory itself,
-                                    // 0 = device buffer + copy on the stream, 2 = device buffer + copy on a side stream
-    // "call_stream" = 1: the call kernel of a step goes to a second stream behind an event, so the next step's
-    // tally (another workspace) starts as soon as this one's tally ends instead of after its call kernel.
-    // Measured: 80.0 vs 81.4 us per step, but the kernels then share the GPU (tally 71 us, call 29 us by their
-    // events), so off by default: clean per-kernel times are worth more than 2 %.
-    int use_call_stream = 0;
-    hipStream_t call_stream = nullptr;
-    bool own_call_stream = false;
-    hipEvent_t tally_done = nullptr;
-    hipStream_t copy_stream = nullptr;   // mode 2
-    hipEvent_t call_done = nullptr;
     // ride-along call (pipeline): the call of this context's step has not been launched yet; the next step on the
     // stream (another workspace) carries it in its tally launch (tcmi_step_begin_deferred / tcmi_step_flush)
     int defer_call = 1;             // pipeline: the call of step k rides in the tally launch of step k + 1
@@ -184,20 +147,14 @@ struct tcmi_ctx {
     int32_t pend_mincov = 0;
     int pend_amb = 0;
     struct tcmi_ride *ride = nullptr;            // set around a tally launch that may carry another context's call
-    hipStream_t step_on_side_stream = nullptr;   // the step in flight ends on this stream (null: on `stream`)
-    bool capturing = false;
-    int step_graph = -1;            // graph used by the step in flight, -1 = direct launches
     int prof_every = 1;             // tcmi_step_begin: every n-th step is launched directly and bracketed with events
     int64_t step_tick = 0;
     bool prof_open = false, prof_mute = false;
     int tally_variant = 0;          // 0 = aligned reads through the fast kernel; 1 = every read through the CIGAR-walk kernel
     int rounds_per_wg = 0;          // 0 = auto
     int host_threads = 8;           // threads tcmi_readset_upload packs with
-    int stage_cap = 0;              // format 2: upper bound on the reads per stage (0 = fill the LDS buffer)
-    int chunk_stages = 0;           // stages per chunk of the fast kernels, 0 = default (4); format 2 takes up to 8
-    int fast_format = 2;            // tcmi_readset_upload: layout of the aligned set (tcmi_readset::f_fmt)
-    int fuse_call = 0;              // tcmi_step_begin: tally + call as one launch when the read set allows it (opt-in:
-                                    // 2.5 % faster steps, but the call work lands in the tally kernel's time)
+    int stage_cap = 0;              // upper bound on the reads per stage (0 = fill the LDS buffer)
+    int chunk_stages = 0;           // stages per chunk, 0 = default (up to 8)
     int project_reads = 1;          // reads with indels / skips go to the fast kernel projected onto the reference
 };
 
@@ -217,8 +174,6 @@ void tcmi_prof_end(tcmi_ctx *ctx, int k);
 // kernels (tally.hip / call.hip)
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
-int tcmi_launch_step_fused(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts, int32_t *d_tile_done,
-                           int64_t tile_cap, int32_t mincov, int include_ambig, uint8_t *plain, uint8_t *alt, uint8_t *flags);
 // pipeline-internal: a step whose call kernel rides in the NEXT step's tally launch (api.cpp)
 int tcmi_step_begin_deferred(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, tcmi_ctx *prev);
 int tcmi_step_flush(tcmi_ctx *ctx);

@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the pileup-tally + base-calling hot path on MI355X.
+"""bench.py — BAM file -> consensus FASTA throughput of the pileup-tally + base-calling path on MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic input: `--batch` (default 8)
-independent BAMs of BASELINE configs[1] (1M reads x 29 903 bp each) whose reads are already resident in
-HBM as ONE read set (BAM b at positions shifted by b * 29 952), so one HIP tally launch and one HIP call
-launch process the batch; the call kernel stores the call records (3 bytes / position) in pinned host
-memory and zeroes the count matrix behind itself; native host threads walk each BAM's records to its
-consensus sequence (the FASTA content).  Metric: reference positions per second (BASELINE.json), whole job.
-`--also-single` measures the same BAMs one per launch afterwards ("single_bam_per_launch"); `--batch 1`
-makes that the primary measurement.
+Headline (`value`): reference positions per second, whole job, measured from BAM FILES on disk to FASTA text:
+a "step" is one BAM of BASELINE configs[1] (1M synthetic 150-bp reads over a 29 903-bp reference) through
+decode (file read, BGZF inflate, records) -> upload (H2D + pack) -> HIP tally + call -> host consensus walk ->
+FASTA text, with the stages of consecutive BAMs overlapped (trueconsense_amd.engine.FileRunner).  The synthetic
+BAM files are written before the clock starts.  `--steps K --warmup W`: W untimed BAMs, then exactly K timed ones.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--reads R] [--no-cpu-baseline]
+Secondary blocks of the same JSON line:
+  e2e_single_bam   one BAM at a time, nothing overlapped: per-stage latency (configs[1] as written)
+  resident         reads already packed in HBM, 8 BAMs per launch: the kernel rate (what round 1 called the headline)
+  roofline         the dominant HIP kernel against the 8 TB/s HBM roofline, on the bytes it really moves
+  cpu_baseline     the same stages on this box's host cores: C restatement of decode + tally + call (oracle/),
+                   1 thread and N threads, plus the host walk
+  fasta_bit_exact  one consensus of the timed path compared with the oracle chain (outside the clock)
 
-N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank
-processes its own independent BAMs (BASELINE config 4: many-BAM shard, no data-path
-collective; weak scaling) and the only collective is the timing barrier / max-reduce.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--files F] [--indels] [--split-bam]
+
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank processes its own BAM files
+(BASELINE configs[3]: many-BAM shard, no data-path collective; weak scaling); the only collectives are the timing
+barrier and the max-reduce of the elapsed time.  `--split-bam` measures configs[4] instead (one BAM over N ranks,
+one reduce of the count matrix per step).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,52 +39,112 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 
 
-def cpu_baseline(reads, L, mincov, orfs):
-    """The oracle timed on this box's host cores (1 thread): the scalar C restatement on the
-    full workload, and the Python-loop restatement (the reference's own structure: per-token
-    Python loop + O(L^2) ORF pass) on a small sample."""
+# ----------------------------------------------------------------------------------------------- inputs
+def write_inputs(tmp, ref, orfs, n_files, n_reads, rank, indels, level):
+    """Seeded synthetic BAM files of configs[1] (or [2] with --indels).  -> (paths, reads of file 0)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.io import bamwriter
+    sites = sy.default_indel_sites(orfs) if indels else None
+    first = {}
+
+    def one(k):
+        reads = sy.make_reads(ref, n_reads, seed=1000 * rank + k + 1, indel_sites=sites)
+        path = os.path.join(tmp, "r%d_%d.bam" % (rank, k))
+        if indels:
+            bamwriter.write_bam(path, reads, "MN908947.3", len(ref), level=level)
+        else:
+            bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n_reads, -1), 150,
+                                     "MN908947.3", len(ref), level=level)
+        if k == 0:
+            first["reads"] = reads
+        return path
+
+    with ThreadPoolExecutor(max(1, min(8, n_files, (os.cpu_count() or 1)))) as ex:
+        paths = list(ex.map(one, range(n_files)))
+    return paths, first["reads"]
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(paths, L, mincov, orfs, n_threads, budget_s=12.0):
+    """The same stages on the host: oracle/bam_oracle.c (sequential gunzip + record walk), oracle/tally_oracle.c
+    (scalar tally + call) and the product's own host walk (it is host code on both sides), per BAM file.
+    Once on one thread, then `n_threads` threads each working through the files for about `budget_s` seconds."""
+    import threading
     import numpy as np
     from oracle import c_oracle
     from oracle import tc_oracle as orc
-    c_oracle.tally(reads, L)                                  # warm (page-in)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 8.0:
-        counts = c_oracle.tally(reads, L)
-        c_oracle.call(counts, mincov, True)
+    from trueconsense_amd.engine import Walker
+    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+
+    def one(path, stages=None):
+        t0 = time.perf_counter()
+        reads = c_oracle.read_bam(path)
+        t1 = time.perf_counter()
+        counts = c_oracle.tally(reads, max(L, c_oracle.extent(reads, L)))
+        t2 = time.perf_counter()
+        plain, alt, flags = c_oracle.call(counts, mincov, True)
+        cons = walker(plain[:L], alt[:L], flags[:L])[0]
+        t3 = time.perf_counter()
+        if stages is not None:
+            stages.append((t1 - t0, t2 - t1, t3 - t2))
+        return cons
+
+    one(paths[0])                                                # warm (page cache, lazy binding)
+    st = []
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 4.0 and reps < 8):
+        one(paths[reps % len(paths)], st)
         reps += 1
-        if reps >= 40:
-            break
-    c_s = (time.perf_counter() - t0) / reps
-    # Python-loop port on the first 3 000 reads (about 450 k pileup tokens)
+    s1 = (time.perf_counter() - t0) / reps
+    done = [0] * n_threads
+    stop = time.perf_counter() + budget_s
+
+    def work(t):
+        k = t
+        while time.perf_counter() < stop:
+            one(paths[k % len(paths)])
+            k += n_threads
+            done[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    tn0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dtn = time.perf_counter() - tn0
+    total = sum(done)
+    # the reference's own loop structure (per-token Python loop) on a small sample, for scale
+    reads = c_oracle.read_bam(paths[0])
     n_s = min(3000, int(reads["n_reads"]))
-    nb = len(reads["seq"]) // int(reads["n_reads"])
     sub = {"n_reads": n_s, "pos": reads["pos"][:n_s], "flag": reads["flag"][:n_s], "l_qseq": reads["l_qseq"][:n_s],
            "cigar_off": reads["cigar_off"][:n_s + 1], "cigar": reads["cigar"], "seq_off": reads["seq_off"][:n_s + 1],
-           "seq": reads["seq"][:n_s * nb]}
-    t0 = time.perf_counter()
+           "seq": reads["seq"]}
+    tp = time.perf_counter()
     cols = orc.pileup_columns(sub)
     for toks in cols.values():
         orc.tally_tokens(toks)
-    py_tok_s = (time.perf_counter() - t0) / max(1, sum(len(v) for v in cols.values()))
-    t0 = time.perf_counter()
-    Ls = 3000
-    orc.build_consensus(mincov, counts[:Ls].astype(np.int64), [{"start": 266, "end": 2900, "strand": "+"}], True, None, True)
-    py_walk_s = time.perf_counter() - t0
-    tokens = float(np.sum(reads["l_qseq"]))
-    return {"value": L / c_s, "unit": "positions/s", "cores": 1, "kind": "port",
-            "sample": "oracle/tally_oracle.c (scalar C, -O2) tally+call over the full %d-read workload, %d repetitions"
-                      % (int(reads["n_reads"]), reps),
-            "seconds_per_bam": c_s,
-            "python_port": {"tally_seconds_per_bam_extrapolated": py_tok_s * tokens,
-                            "ns_per_token": py_tok_s * 1e9,
-                            "walk_seconds_first_3000_positions": py_walk_s,
-                            "sample": "oracle/tc_oracle.py per-token loop on the first %d reads; literal O(L^2) "
-                                      "BuildConsensus restatement on 3 000 positions" % n_s}}
+    py_tok_s = (time.perf_counter() - tp) / max(1, sum(len(v) for v in cols.values()))
+    return {"value": L * total / dtn, "unit": "positions/s", "cores": n_threads, "kind": "port",
+            "sample": "BAM file -> consensus per file: oracle/bam_oracle.c (gunzip + records) + oracle/tally_oracle.c "
+                      "(scalar tally + call, -O2) + host walk; %d threads each looping over the %d bench files for %.0f s "
+                      "(%d BAMs done)" % (n_threads, len(paths), budget_s, total),
+            "seconds_per_bam_per_thread": dtn * n_threads / max(1, total),
+            "one_thread": {"value": L / s1, "unit": "positions/s", "cores": 1, "seconds_per_bam": s1, "bams": reps,
+                           "stage_seconds": {"decode": float(np.mean([a for a, _, _ in st])),
+                                             "tally": float(np.mean([b for _, b, _ in st])),
+                                             "call_walk": float(np.mean([c for _, _, c in st]))}},
+            "python_loop_ns_per_token": py_tok_s * 1e9,
+            "python_loop_tally_seconds_per_bam_extrapolated": py_tok_s * float(np.sum(reads["l_qseq"])),
+            "cores_on_box": os.cpu_count()}
 
 
+# ----------------------------------------------------------------------------------------------- configs[4]
 def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
-    """BASELINE configs[4]: one BAM split into `world` contiguous read ranges (genome tiles)."""
-    import numpy as np
+    """BASELINE configs[4]: one BAM split into `world` contiguous read ranges (genome tiles); per step every rank
+    tallies its range, ONE reduce (sum) of the int32 [7][ld] matrix to rank 0, which calls and walks."""
     from trueconsense_amd import _ffi
     from trueconsense_amd import distributed as td
     from trueconsense_amd import synthetic as sy
@@ -87,17 +156,18 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)     # tally, collective and call on torch's stream
     rs = ctx.upload(reads)
     counts = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
-    rec = torch.zeros((3, ld), dtype=torch.uint8, device="cuda")
+    rec = torch.zeros((3, ld), dtype=torch.uint8).pin_memory()                     # the call kernel stores across PCIe
     walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    rec_np = rec.numpy()
 
     def step():
         counts.zero_()
         ctx.tally_dev(rs, L, ld, counts.data_ptr(), zero=False)
-        td.allreduce_counts(counts)                              # ONE exchange: int32 sum of 7 x ld over the ranks
-        ctx.call_dev(counts.data_ptr(), L, ld, a.mincov, True, rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr())
+        td.reduce_counts(counts, dst=0)                              # ONE exchange: int32 sum of 7 x ld, to rank 0 only
         if rank == 0:
-            h = rec.cpu().numpy()
-            return walker(h[0, :L], h[1, :L], h[2, :L])[0]
+            ctx.call_dev(counts.data_ptr(), L, ld, a.mincov, True, rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr())
+            torch.cuda.current_stream().synchronize()
+            return walker(rec_np[0, :L], rec_np[1, :L], rec_np[2, :L])[0]
         return None
 
     def fence():
@@ -122,48 +192,54 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
         dt = float(t.item())
     if rank == 0:
         tally_us = 1e3 * tally_ms / max(1, tally_n)
+        real = rs.device_bytes + 28 * L
         alg = rs.algorithmic_bytes + 28 * L
-        achieved = alg / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
+        achieved = real / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
         total_cov = int(counts[0, :L].sum().item())
         print(json.dumps({
-            "metric": "reference positions/sec (ONE BAM of %d reads split over %d GPU(s), BAM -> consensus)" % (a.reads * world, world),
+            "metric": "reference positions/sec (ONE BAM of %d reads split over %d GPU(s), reads resident in HBM -> consensus)" % (a.reads * world, world),
             "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, one BAM of %d x %d synthetic 150-bp reads, rank r holds "
-                                   "the contiguous read range of genome tile r; per step: tally, ONE all-reduce (sum) of the int32 "
-                                   "[7][%d] matrix (%d bytes), call kernel, walk on rank 0" % (world, a.reads, ld, 28 * ld),
-                       "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL all_reduce" if world > 1 else "none")},
-            "roofline": {"kernel": "tally_fast_kernel" if "fast_format=1" in a.ctx_option else "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": tally_us},
+                                   "the contiguous read range of genome tile r; per step: tally, ONE reduce (sum) of the int32 "
+                                   "[7][%d] matrix (%d bytes) to rank 0, call kernel + walk on rank 0" % (world, a.reads, ld, 28 * ld),
+                       "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL reduce" if world > 1 else "none")},
+            "roofline": {"kernel": "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": real,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": tally_us},
             "consensus_len": len(cons), "coverage_sum": total_cov, "coverage_sum_expected": 150 * a.reads * world}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=32, help="timed BAM files (each one BAM file -> FASTA)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--reads", type=int, default=1_000_000)
-    ap.add_argument("--bams", type=int, default=2, help="distinct resident read sets (each --batch BAMs) cycled through per rank")
+    ap.add_argument("--files", type=int, default=8, help="distinct synthetic BAM files per rank, cycled through")
+    ap.add_argument("--level", type=int, default=6, help="zlib level the synthetic BAMs are written with (samtools' default is 6)")
     ap.add_argument("--mincov", type=int, default=30)
+    ap.add_argument("--decoders", type=int, default=0, help="BAMs being decoded at a time (0 = auto)")
+    ap.add_argument("--decode-threads", type=int, default=0, help="native threads per BAM decode (0 = auto)")
+    ap.add_argument("--walkers", type=int, default=2)
+    ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-only", action="store_true", help="leave the host consensus walk out of the step")
-    ap.add_argument("--walkers", type=int, default=0, help="host threads for the consensus walks (0 = auto: min(8, cores/ranks))")
-    ap.add_argument("--serial", action="store_true", help="no overlap: finish each BAM (GPU + walk) before starting the next")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (diagnostic)")
-    ap.add_argument("--profile-every", type=int, default=8, help="with kernel events on, every n-th step per workspace is launched directly and bracketed with HIP events")
-    ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries (general kernel + insert sweep)")
-    ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option on every workspace (diagnostic)")
+    ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident kernel-rate leg")
+    ap.add_argument("--only-resident", action="store_true", help="only the HBM-resident leg (short runs under rocprofv3)")
+    ap.add_argument("--resident-batch", type=int, default=8, help="BAMs per launch of the resident leg")
+    ap.add_argument("--resident-steps", type=int, default=200)
+    ap.add_argument("--slots", type=int, default=12, help="workspaces of the native pipeline in the resident leg")
+    ap.add_argument("--profile-every", type=int, default=8)
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option (diagnostic)")
+    ap.add_argument("--tmp", default=None, help="directory for the synthetic BAM files (default: /dev/shm or $TMPDIR)")
     ap.add_argument("--split-bam", action="store_true",
                     help="BASELINE configs[4]: ONE BAM of gpus x --reads reads, each rank tallies its contiguous read range, "
-                         "one all-reduce (RCCL) of the count matrix per step, base calling on every rank")
-    ap.add_argument("--also-single", action="store_true", help="afterwards also measure the same BAMs one per launch (adds a second launch shape)")
-    ap.add_argument("--batch", type=int, default=8, help="BAMs per step and launch: their reads are uploaded as one read set at shifted positions")
-    ap.add_argument("--slots", type=int, default=12, help="workspaces of the native pipeline (steps queued ahead)")
+                         "one reduce (RCCL) of the count matrix per step, base calling on rank 0")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,165 +265,216 @@ def main():
 
     from trueconsense_amd import _ffi
     from trueconsense_amd import synthetic as sy
-    from trueconsense_amd.engine import Pipeline, Walker
+    from trueconsense_amd.engine import Context, FileRunner, Pipeline
 
     ref, orfs = sy.make_reference()
     L = len(ref)
     if a.split_bam:
         return run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs)
-    # (configs[2] is bound by the host's insert-token sweeps: give it more walker threads)
-    n_walkers = a.walkers or max(1, min(14 if a.indels else 8, (os.cpu_count() or 1) // max(1, world)))
-    pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)   # one stream, `slots` workspaces, native walker threads
-    ctx = pipe.ctx
+
+    cores = max(1, (os.cpu_count() or 1) // max(1, world if not rehearse else 1))
+    cores = min(cores, 16)                                       # the box's CPU share per GPU
+    decoders = a.decoders or (2 if cores >= 8 else 1)
+    decode_threads = a.decode_threads or max(1, cores // decoders)
+
+    if a.only_resident:
+        ctx = Context(local_rank)
+        res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, lambda: (ctx.sync(), torch.cuda.synchronize()))
+        res["resident"].update(metric="reference positions/sec (reads resident in HBM -> consensus)", n_gpus=world)
+        print(json.dumps(res))
+        return
+    # ---- inputs: BAM files on disk, written outside the clock ------------------------------------------
+    base = a.tmp or ("/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (4 << 30) else tempfile.gettempdir())
+    tmp = tempfile.mkdtemp(prefix="tcmi_bench_", dir=base)
+    try:
+        t_gen = time.perf_counter()
+        paths, reads0 = write_inputs(tmp, ref, orfs, a.files, a.reads, rank, a.indels, a.level)
+        t_gen = time.perf_counter() - t_gen
+        out = run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, Context, FileRunner, Pipeline,
+                        ref, orfs, L, paths, reads0, decoders, decode_threads, cores, t_gen)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, Context, FileRunner, Pipeline, ref, orfs, L,
+              paths, reads0, decoders, decode_threads, cores, t_gen):
+    ctx = Context(local_rank)
+    for kv in a.ctx_option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gff_rows = [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs]
+    file_of = lambda i: paths[i % len(paths)]
+
+    # ---- headline: BAM files -> FASTA text, stages overlapped ------------------------------------------
+    runner = FileRunner(ctx, gff_rows, a.mincov, True, decoders=decoders, decode_threads=decode_threads, walkers=a.walkers)
+    if a.warmup > 0:
+        runner.run([file_of(i) for i in range(a.warmup)], ref_len=L)
+    runner.seconds = {k: 0.0 for k in runner.seconds}
+    runner.bytes = {k: 0 for k in runner.bytes}
+    fence()
+    t0 = time.perf_counter()
+    fastas = runner.run([file_of(i) for i in range(a.steps)], names=["S%d" % (i % len(paths)) for i in range(a.steps)], ref_len=L)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if not a.no_resident:
+            resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
+        return None
+
+    out = {
+        "metric": "reference positions/sec (BAM file -> consensus FASTA, 1M reads x 29 903 bp per BAM)",
+        "value": L * a.steps * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic", "bams_per_min": 60.0 * a.steps * world / dt,
+        "config": {"workload": "BASELINE configs[%d]: 29 903-bp reference, %d synthetic 150-bp reads per BAM (~%dx coverage)%s, "
+                               "%d distinct BAM files per GPU (zlib level %d, written before the clock starts) cycled through; "
+                               "a step = one BAM FILE -> FASTA text%s"
+                               % (2 if a.indels else 1, a.reads, a.reads * 150 // L,
+                                  ", indel carriers at CDS boundaries" if a.indels else "", len(paths), a.level,
+                                  "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
+                   "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
+                   "stages": "decode (file read + BGZF inflate + records, host: %d BAMs in flight x %d threads) -> upload "
+                             "(H2D + pack) -> HIP tally + call (records to pinned host memory) -> host walk + FASTA text "
+                             "(%d threads); stages of consecutive BAMs overlap" % (decoders, decode_threads, a.walkers),
+                   "bam_file_bytes": runner.bytes["file"] // max(1, a.steps), "bam_inflated_bytes": runner.bytes["inflated"] // max(1, a.steps),
+                   "device_bytes_per_bam": runner.bytes["device"] // max(1, a.steps),
+                   "input_generation_seconds_outside_clock": t_gen},
+        "e2e_stage_busy_seconds_per_bam": {k: v / a.steps for k, v in runner.seconds.items()},
+    }
+
+    # ---- one BAM at a time, nothing overlapped ---------------------------------------------------------
+    single = FileRunner(ctx, gff_rows, a.mincov, True, decoders=1, decode_threads=min(16, cores), walkers=1)
+    lat = []
+    for i in range(3):
+        single.seconds = {k: 0.0 for k in single.seconds}
+        t1 = time.perf_counter()
+        single.run([file_of(i)], ref_len=L)
+        lat.append((time.perf_counter() - t1, dict(single.seconds)))
+    best = min(lat, key=lambda x: x[0])
+    out["e2e_single_bam"] = {"seconds": best[0], "positions_per_s": L / best[0], "stage_seconds": best[1],
+                             "decode_threads": min(16, cores), "runs": [x[0] for x in lat]}
+
+    # ---- bit-exactness of what was timed, against the oracle chain (outside the clock) -----------------
+    out.update(check_fasta(a, np, fastas[0], reads0, ref, orfs, L))
+
+    # ---- secondary: reads resident in HBM, the kernel rate and its roofline ----------------------------
+    if not a.no_resident:
+        res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
+        out["resident"] = res["resident"]
+        out["roofline"] = res["roofline"]
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(paths, L, a.mincov, orfs, n_threads=cores)
+    return out
+
+
+def check_fasta(a, np, fasta_text, reads0, ref, orfs, L):
+    """FASTA text of bench file 0 from the timed path vs the oracle chain on the same reads: scalar C tally + call
+    (oracle/tally_oracle.c), reference-pinned list_inserts / build_consensus (oracle/tc_oracle.py)."""
+    from oracle import c_oracle
+    from oracle import tc_oracle as orc
+    counts = c_oracle.tally(reads0, L)
+    has, ins = orc.list_inserts(counts, a.mincov, lambda p: orc.region_tokens(reads0, p))
+    want, _ = orc.build_consensus(a.mincov, counts.astype(np.int64), [dict(o) for o in orfs], True, ins if has else None, True)
+    want_text = orc.fasta_text("S0", a.mincov, want)
+    return {"fasta_bit_exact": bool(fasta_text == want_text), "fasta_sha256": hashlib.sha256(fasta_text.encode()).hexdigest()[:16],
+            "consensus_len": len(fasta_text.split("\n")[1])}
+
+
+def resident_leg(a, ctx0, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence):
+    """Reads of `--resident-batch` BAMs already packed in HBM as ONE read set (BAM b at positions shifted by
+    b * 29 952): per step one tally launch (whose first blocks call the previous step's matrix) + host walks, through
+    the native pipeline; repeated until at least one second has been timed.  HIP events around every
+    `--profile-every`-th launch give the kernel time for the roofline block."""
+    from concurrent.futures import ThreadPoolExecutor
+    B = max(1, a.resident_batch)
+    pos_stride = (L + 255) // 256 * 256
+    n_walkers = max(1, min(8, (os.cpu_count() or 1)))
+    pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)
     ctxs = [pipe.slot_context(k) for k in range(a.slots)]
     for kv in a.ctx_option:
         k, v = kv.split("=")
         for c in ctxs:
             c.set_option(k, int(v))
-    readsets, host_reads0, all_reads, group0 = [], None, [], []
-    B = max(1, a.batch)
-    pos_stride = (L + 255) // 256 * 256
-    # synthetic BAMs: seeded, generated on a few host threads (numpy releases the GIL), one group of B at a time
-    from concurrent.futures import ThreadPoolExecutor
-    gen_threads = max(1, min(8, B, (os.cpu_count() or 1) // max(1, world)))
     sites = sy.default_indel_sites(orfs) if a.indels else None
-    with ThreadPoolExecutor(gen_threads) as ex:
-        for b in range(a.bams):
-            group = list(ex.map(lambda k: sy.make_reads(ref, a.reads, seed=1000 * rank + b * B + k + 1, indel_sites=sites), range(B)))
-            if host_reads0 is None:
-                host_reads0 = group[0]
-            if b == 0 and a.also_single:
-                group0.extend(group)                            # (kept on the host only when they are needed again)
-            all_reads.extend(group if a.indels else [None] * B)
-            readsets.append(ctx.upload(group[0]) if B == 1 else ctx.upload_batch(group, pos_stride))
+    readsets, hreads = [], []
+    with ThreadPoolExecutor(min(8, B)) as ex:
+        for b in range(2):
+            group = list(ex.map(lambda k: sy.make_reads(ref, a.reads, seed=5000 + 1000 * rank + b * B + k, indel_sites=sites), range(B)))
+            readsets.append(pipe.ctx.upload(group[0]) if B == 1 else pipe.ctx.upload_batch(group, pos_stride))
+            hreads.extend(group if a.indels else [None] * B)
             del group
-    alg_reads = readsets[0].algorithmic_bytes                   # 91 B per 150M read
-    alg_tally = alg_reads + 28 * L * B                          # + one write of the [L,7] int32 matrix per BAM
     pipe.set_orfs([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
-    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    n = a.resident_steps
+    stride = L + 1 + (4096 if a.indels else 64)
+    buf = np.empty(n * B * stride, np.uint8)
+    buf.fill(0)
+    hr = [hreads[(i % 2) * B + k] for i in range(n) for k in range(B)] if a.indels else None
 
-    def measure(rsets, B, n_steps, n_warm, hreads):
-        """n_steps steps of B BAMs each over the read sets `rsets`; -> (seconds, last consensus, kernel times)."""
-        def run(n):
-            if n <= 0:
-                return None
-            if a.serial or a.gpu_only:
-                cons = None
-                for i in range(n):
-                    Lg = L if B == 1 else B * pos_stride
-                    plain, alt, flags, _ = ctx.step(rsets[i % len(rsets)], Lg, a.mincov, True, want_counts=False)
-                    if not a.gpu_only:
-                        for k in range(B):
-                            o = k * pos_stride
-                            cons = walker(plain[o:o + L], alt[o:o + L], flags[o:o + L])[0]
-                return cons
-            hr = None
-            if a.indels:
-                hr = [hreads[(i % len(rsets)) * B + k] for i in range(n) for k in range(B)]
-            # every consensus is written by the walkers into one preallocated host buffer (allocated and touched
-            # outside the timed region); no per-item Python objects inside it
-            stride = L + 1 + (4096 if a.indels else 64)
-            buf = out_buf[:n * B * stride]
-            out, lens, _ = pipe.run([rsets[i % len(rsets)] for i in range(n)], L, a.mincov, True,
-                                    host_reads=hr, extra=stride - L - 1, batch=B, pos_stride=pos_stride, out=buf)
-            last = n * B - 1
-            return out[last * stride:last * stride + int(lens[last])].tobytes()
+    def run():
+        pipe.run([readsets[i % 2] for i in range(n)], L, a.mincov, True, host_reads=hr, extra=stride - L - 1, batch=B,
+                 pos_stride=pos_stride, out=buf)
 
-        out_buf = None
-        if not (a.serial or a.gpu_only):
-            out_buf = np.empty(max(n_steps, n_warm) * B * (L + 1 + (4096 if a.indels else 64)), np.uint8)
-            out_buf.fill(0)                                     # touch every page now
-
-        def fence():
-            ctx.sync()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        run(n_warm)
-        for c in ([] if a.no_kernel_events else ctxs):
-            c.set_option("profile_every", a.profile_every)
-            c.profile(True)                                     # HIP events around the kernels, on the pipeline's stream
-        fence()
-        t0 = time.perf_counter()
-        cons = run(n_steps)
-        fence()
-        dt = time.perf_counter() - t0
-        k = {"tally_ms": 0.0, "tally_n": 0, "call_ms": 0.0, "call_n": 0, "gen_ms": 0.0, "gen_n": 0}
-        for c in ctxs:
-            for name, kid in (("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL), ("gen", _ffi.K_TALLY_GENERAL)):
-                m, n = c.profile_get(kid)
-                k[name + "_ms"] += m
-                k[name + "_n"] += n
-            c.profile(False)
-        return dt, cons, k
-
-    dt, cons, k = measure(readsets, B, a.steps, a.warmup, all_reads)
-    tally_ms, tally_n, call_ms, call_n, gen_ms, gen_n, zero_ms = (k["tally_ms"], k["tally_n"], k["call_ms"], k["call_n"],
-                                                                  k["gen_ms"], k["gen_n"], 0.0)
-    single = None
-    if a.also_single and world == 1 and B > 1 and not a.indels and not (a.serial or a.gpu_only):
-        # the same BAMs one per launch (plain BASELINE configs[1] shape), for comparison
-        srs = [ctx.upload(r) for r in group0]
-        dt1, _, k1 = measure(srs, 1, max(100, a.steps), a.warmup, None)
-        us1 = 1e3 * k1["tally_ms"] / max(1, k1["tally_n"])
-        alg1 = srs[0].algorithmic_bytes + 28 * L
-        single = {"value": L * max(100, a.steps) / dt1, "unit": "positions/s", "ms_per_step": 1e3 * dt1 / max(100, a.steps),
-                  "tally_us": us1, "roofline_frac": (alg1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS) if us1 > 0 else None,
-                  "algorithmic_bytes_per_launch": alg1}
-        for r in srs:
-            r.free()
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        tally_us = 1e3 * tally_ms / max(1, tally_n)
-        achieved = alg_tally / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")      # PMC passes are separate runs (see profiles/README)
-        if os.path.exists(tp):
-            try:
-                key = "nibble_tally_hbm_bytes_per_launch" if "fast_format=1" in a.ctx_option else "tally_hbm_bytes_per_launch"
-                traffic = json.load(open(tp)).get(key) * B      # measured per 1M-read BAM
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "reference positions/sec (1M reads x 29 903 bp per BAM, reads resident in HBM, BAM -> consensus)",
-            "value": L * a.steps * B * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "bams_per_min": 60.0 * a.steps * B * world / dt,
-            "config": {"workload": "BASELINE configs[1]: 29 903-bp reference, %d synthetic 150-bp reads per BAM "
-                                   "(~%dx coverage), %d distinct BAMs resident per GPU, %d BAM(s) per step and launch%s"
-                                   % (a.reads, a.reads * 150 // L, a.bams * B, B,
-                                      "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
-                       "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
-                       "step": ("tally kernel + call kernel (zeroes the matrix behind itself, stores its records in pinned host memory)"
-                                if (a.serial or a.gpu_only or "defer_call=0" in a.ctx_option) else
-                                "ONE launch: the tally kernel, whose first blocks also call the matrix the previous step finished "
-                                "(position-wise call, records stored in pinned host memory, matrix left zeroed); the last step's call is launched on its own")
-                               + ("" if a.gpu_only else " + host consensus walk per BAM"),
-                       "overlap": "serial (Python loop)" if (a.serial or a.gpu_only) else
-                                  "native pipeline: one stream, %d workspaces queued ahead; walks on %d host threads" % (a.slots, n_walkers)},
-            "kernels_us": {"tally_general": 1e3 * gen_ms / max(1, gen_n), "tally": tally_us, "call": 1e3 * call_ms / max(1, call_n), "zero": 1e3 * zero_ms / max(1, tally_n)},
-            "roofline": {"kernel": "tally_fast_kernel" if "fast_format=1" in a.ctx_option else "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_tally, "avg_launch_us": tally_us},
-        }
-        if not a.gpu_only:
-            out["consensus_len"] = len(cons) if cons is not None else 0
-        if single is not None:
-            out["single_bam_per_launch"] = single
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_reads0, L, a.mincov, orfs)
-            out["cpu_baseline"]["cores_on_box"] = os.cpu_count()
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    run()                                                        # warm
+    for c in ctxs:
+        c.set_option("profile_every", a.profile_every)
+        c.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    repeats = 0
+    while repeats < 1 or time.perf_counter() - t0 < 1.0:
+        run()
+        repeats += 1
+    fence()
+    dt = time.perf_counter() - t0
+    tally_ms = tally_n = 0
+    for c in ctxs:
+        m, k = c.profile_get(_ffi.K_TALLY)
+        tally_ms += m
+        tally_n += k
+        c.profile(False)
+    tally_us = 1e3 * tally_ms / max(1, tally_n)
+    real = readsets[0].device_bytes + 28 * L * B                 # what one launch reads (packed reads) + one write of the matrices
+    alg = readsets[0].algorithmic_bytes + 28 * L * B             # SURVEY §8-d: the BAM-form bytes (91 B per 150M read)
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch") * B
+            traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run (per 1M-read BAM x batch), not measured in this run"
+        except Exception:
+            traffic = None
+    achieved = real / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0
+    res = {"resident": {"value": L * n * repeats * B / dt, "unit": "positions/s", "ms_per_step": 1e3 * dt / (n * repeats),
+                        "steps": n, "repeats": repeats, "bams_per_step": B, "seconds": dt,
+                        "note": "reads already packed in HBM; pack + H2D + decode are NOT in this figure"},
+           "roofline": {"kernel": "tally_planes_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                        "bytes_per_launch": real, "bytes_note": "device bytes of the packed read set (read once) + 28 B x positions (count matrix)",
+                        "avg_launch_us": tally_us, "launches_timed": tally_n,
+                        "algorithmic": {"bytes_per_launch": alg, "achieved": alg / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0,
+                                        "frac": (alg / (tally_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tally_us > 0 else 0.0,
+                                        "note": "SURVEY 8-d bytes (12 + 4 n_cigar + l/2 per read): the kernel reads the packed 2-bit planes, fewer bytes than this"}}}
+    for r in readsets:
+        r.free()
+    pipe.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -10,8 +10,8 @@ _SO = os.path.join(_HERE, "_build", "libtcoracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "tally_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("tally_oracle.c", "bam_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
@@ -26,6 +26,16 @@ def lib():
         _lib.orc_tally.restype = C.c_int64
         _lib.orc_extent.restype = C.c_int64
         _lib.orc_call.restype = None
+        _lib.orc_bam_load.restype = C.c_int
+        _lib.orc_bam_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        _lib.orc_bam_dims.restype = None
+        _lib.orc_bam_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        _lib.orc_bam_ref0.restype = C.c_char_p
+        _lib.orc_bam_ref0.argtypes = [C.c_void_p]
+        _lib.orc_bam_fill.restype = None
+        _lib.orc_bam_fill.argtypes = [C.c_void_p] * 12
+        _lib.orc_bam_free.restype = None
+        _lib.orc_bam_free.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -58,3 +68,30 @@ def call(counts, mincov, include_ambig):
     lib().orc_call(_p(counts, C.c_int32), C.c_int64(L), C.c_int32(mincov), C.c_int(bool(include_ambig)),
                    _p(plain, C.c_uint8), _p(alt, C.c_uint8), _p(flags, C.c_uint8))
     return plain, alt, flags
+
+
+def read_bam(path):
+    """BAM file -> dict of flat arrays in the tcmi_reads layout (oracle/bam_oracle.c: sequential gunzip of the
+    multi-member stream + one record walk, one thread), plus 'ref0_name', 'ref0_len', 'n_ref', 'inflated_bytes'."""
+    h = C.c_void_p()
+    rc = lib().orc_bam_load(str(path).encode(), C.byref(h))
+    if rc:
+        raise ValueError("bam_oracle: cannot decode %s (code %d)" % (path, rc))
+    try:
+        n, nc, ns, nq, lr, infl = (C.c_int64(0) for _ in range(6))
+        nref = C.c_int32(0)
+        lib().orc_bam_dims(h, C.byref(n), C.byref(nc), C.byref(ns), C.byref(nq), C.byref(nref), C.byref(lr), C.byref(infl))
+        n_ = n.value
+        r = {"n_reads": n_, "pos": np.empty(n_, np.int32), "flag": np.empty(n_, np.uint16), "l_qseq": np.empty(n_, np.int32),
+             "tid": np.empty(n_, np.int32), "mapq": np.empty(n_, np.uint8), "cigar_off": np.empty(n_ + 1, np.uint64),
+             "cigar": np.empty(max(1, nc.value), np.uint32), "seq_off": np.empty(n_ + 1, np.uint64),
+             "seq": np.empty(max(1, ns.value), np.uint8), "qual_off": np.empty(n_ + 1, np.uint64),
+             "qual": np.empty(max(1, nq.value), np.uint8)}
+        lib().orc_bam_fill(h, *[r[k].ctypes.data_as(C.c_void_p) for k in
+                                ("pos", "flag", "l_qseq", "tid", "mapq", "cigar_off", "cigar", "seq_off", "seq", "qual_off", "qual")])
+        r["cigar"], r["seq"], r["qual"] = r["cigar"][:nc.value], r["seq"][:ns.value], r["qual"][:nq.value]
+        r.update(ref0_name=(lib().orc_bam_ref0(h) or b"").decode(), ref0_len=lr.value, n_ref=nref.value,
+                 inflated_bytes=infl.value)
+        return r
+    finally:
+        lib().orc_bam_free(h)

@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -112,6 +114,12 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
 {
     if (!path || !out) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
     *out = nullptr;
+    const bool timing = std::getenv("TCMI_BAM_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = now();
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return tcmi_fail(nullptr, TCMI_E_IO, "cannot open %s", path);
     std::vector<uint8_t> file;
@@ -125,6 +133,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         std::fclose(fp);
         if (got != (size_t)sz) return tcmi_fail(nullptr, TCMI_E_IO, "short read on %s", path);
     }
+    const auto t_read = now();
     std::vector<Block> blocks;
     size_t total = 0;
     int rc = scan_blocks(file, blocks, &total);
@@ -155,6 +164,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
     if (bad.load() >= 0)
         return tcmi_fail(nullptr, TCMI_E_FORMAT, "BGZF block %lld failed to inflate or its CRC32 does not match", bad.load());
 
+    const auto t_inflate = now();
     // ---- BAM header (SAM spec §4.2) ----
     const uint8_t *p = raw.data();
     const size_t N = total;
@@ -206,6 +216,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
         o += 4 + bs;
     }
+    const auto t_walk = now();
     const int64_t n = (int64_t)rec_at.size();
     bam->n = n;
     bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo);
@@ -271,6 +282,9 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
             if (u) bam->sorted = 0;
         for (int64_t sp : spans) bam->max_span = std::max(bam->max_span, sp);
     }
+    if (timing)
+        std::fprintf(stderr, "[tcmi bam] read %.1f ms, inflate %.1f ms (%d threads, %zu blocks), record walk %.1f ms, fill %.1f ms\n",
+                     ms(t_start, t_read), ms(t_read, t_inflate), n_threads, blocks.size(), ms(t_inflate, t_walk), ms(t_walk, now()));
     *out = bam;
     return TCMI_OK;
 }

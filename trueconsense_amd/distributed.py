@@ -5,8 +5,9 @@ Two shard shapes (BASELINE.json configs[3] and [4]):
 * many BAMs  — independent objects: rank r takes BAMs r, r+world, ...; NO data-path collective.
 * one BAM    — the tally is a commutative integer sum: the coordinate-sorted reads are cut into
                `world` contiguous ranges, every rank tallies its range into a full-length
-               int32 [7][ld] matrix in HBM and ONE all-reduce (sum) of that matrix (837 284 B at
-               L = 29 903) makes it whole on every rank; base calling then runs on one GPU.
+               int32 [7][ld] matrix in HBM and ONE exchange of that matrix (837 284 B at L = 29 903):
+               a reduce to the rank that calls and walks (reduce_counts), or an all-reduce when every
+               rank wants the whole matrix (allreduce_counts).
 """
 from __future__ import annotations
 
@@ -60,6 +61,23 @@ def allreduce_counts(t, group=None):
         t.copy_(h)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def reduce_counts(t, dst=0, group=None):
+    """Sum of the [7][ld] int32 matrix over the ranks, delivered to rank `dst` only (the call kernel and the walk
+    run on one GPU, so nobody else needs the whole matrix: SURVEY §8-e).  RCCL reduce under "nccl"; staged
+    through the host under gloo.  The other ranks' tensors are left as they were."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            t.copy_(h)
+    else:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return t
 
 

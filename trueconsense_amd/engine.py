@@ -407,3 +407,78 @@ class BamFile:
             self.close()
         except Exception:
             pass
+
+
+class FileRunner:
+    """BAM files -> consensus FASTA text (TrueConsense.py:212-264 for many inputs; BASELINE configs[1] / [3]).
+
+    Stages per BAM: decode (tcmi_bam_load: file read, BGZF inflate, records -> flat arrays; `decode_threads` native
+    threads each, `decoders` BAMs in flight) -> upload (H2D + pack) -> step (HIP tally + call, records to pinned host
+    memory) -> walk (insert tokens, sequential consensus walk, FASTA text; `walkers` threads).  The GPU stages run on
+    the calling thread; decode and walk overlap with them.  `seconds` accumulates each stage's busy time."""
+
+    def __init__(self, ctx, gff_rows, mincov, include_ambig=True, decoders=2, decode_threads=8, walkers=2):
+        self.ctx, self.mincov, self.amb = ctx, int(mincov), bool(include_ambig)
+        self.gff = {k: dict(r) for k, r in enumerate(gff_rows)}
+        self.decoders, self.decode_threads, self.walkers = int(decoders), int(decode_threads), int(walkers)
+        self.seconds = {"decode": 0.0, "upload": 0.0, "step": 0.0, "walk": 0.0}
+        self.bytes = {"file": 0, "inflated": 0, "device": 0}
+
+    def _load(self, path):
+        import time
+        t = time.perf_counter()
+        bam = BamFile(path, threads=self.decode_threads)
+        return bam, time.perf_counter() - t
+
+    def _walk(self, bam, name, plain, alt, flags):
+        import time
+        from .Events import inserts_from_flags
+        from .Sequences import consensus_from_records
+        t = time.perf_counter()
+        _, ins = inserts_from_flags(flags, bam)
+        cons = consensus_from_records(plain, alt, flags, self.gff, ins, True)[0]
+        text = ">%s mincov=%d\n%s\n" % (name, self.mincov, cons)          # Outputs.py:182-183
+        bam.close()
+        return text, time.perf_counter() - t
+
+    def run(self, paths, names=None, ref_len=0):
+        """-> list of FASTA texts, in input order."""
+        import time
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(paths)
+        names = names or ["S%d" % i for i in range(n)]
+        out = [None] * n
+        with ThreadPoolExecutor(self.decoders) as dec, ThreadPoolExecutor(self.walkers) as wk:
+            loads, walks = deque(), deque()
+            nxt = 0
+            while nxt < n and len(loads) < self.decoders + 1:
+                loads.append(dec.submit(self._load, paths[nxt]))
+                nxt += 1
+            for i in range(n):
+                bam, dt = loads.popleft().result()
+                self.seconds["decode"] += dt
+                if nxt < n:
+                    loads.append(dec.submit(self._load, paths[nxt]))
+                    nxt += 1
+                t0 = time.perf_counter()
+                rs = self.ctx.upload(bam)
+                t1 = time.perf_counter()
+                L = max(int(ref_len), rs.max_end, 1)
+                plain, alt, flags, _ = self.ctx.step(rs, L, self.mincov, self.amb, want_counts=False)
+                t2 = time.perf_counter()
+                self.seconds["upload"] += t1 - t0
+                self.seconds["step"] += t2 - t1
+                self.bytes["file"] += bam.file_bytes
+                self.bytes["inflated"] += bam.inflated_bytes
+                self.bytes["device"] += rs.device_bytes
+                rs.free()
+                walks.append((i, wk.submit(self._walk, bam, names[i], plain, alt, flags)))
+                while len(walks) > self.walkers + 1:                     # bound the decoded BAMs kept alive
+                    k, f = walks.popleft()
+                    out[k], dw = f.result()
+                    self.seconds["walk"] += dw
+            for k, f in walks:
+                out[k], dw = f.result()
+                self.seconds["walk"] += dw
+        return out

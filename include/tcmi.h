@@ -116,8 +116,10 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
-enum { TCMI_K_TALLY = 0 /* aligned-read (fast) tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZERO = 2,
-       TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */, TCMI_K_NKERNELS = 4 };
+enum { TCMI_K_TALLY = 0 /* bit-plane tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZERO = 2,
+       TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */,
+       TCMI_K_PACK_CLASSIFY = 4 /* device packer: classify + scan */, TCMI_K_PACK = 5 /* device packer: scatter + pack */,
+       TCMI_K_INFLATE = 6 /* device BGZF inflate */, TCMI_K_RECORDS = 7 /* device BAM record walk */, TCMI_K_NKERNELS = 8 };
 int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
 int  tcmi_profile_reset(tcmi_ctx *ctx);
 int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
@@ -129,8 +131,9 @@ int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *laun
  * piled-up read) — the reference keeps columns beyond the FASTA length (indexing.py:137-151). */
 int tcmi_reads_extent(const tcmi_reads *reads, int64_t ref_len, int64_t *out_L);
 
-/* Copy reads into HBM in the kernel's layout (SoA headers, CIGAR stream, 4-bit SEQ
- * stream in linear nibble order padded to 4 bytes per read).                     */
+/* Reads -> HBM in the tally kernel's layout.  By default the BAM-native arrays are copied to the device as they are
+ * and packed there by HIP kernels (CIGAR projection, token classification, coverage runs, 4-bit -> bit planes);
+ * inputs the device packer does not take (see option "device_pack") are packed on the host.                        */
 int tcmi_readset_upload(tcmi_ctx *ctx, const tcmi_reads *reads, tcmi_readset **out);
 /* Several BAMs in ONE read set (BASELINE configs[3], many independent BAMs): BAM b's positions are
  * shifted by b * stride (a multiple of 256, >= the extent of every BAM), so one tally launch and one
@@ -141,9 +144,12 @@ int tcmi_readset_upload_batch(tcmi_ctx *ctx, const tcmi_reads *const *reads, int
 int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs);
 int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled,
                       int64_t *algorithmic_bytes, int64_t *device_bytes, int64_t *max_end);
-/* how the reads were split: aligned (single match op -> fast kernel) vs general (CIGAR walk) */
+/* how the reads were split: aligned set (bit-plane kernel; entries, chunks) vs general set (CIGAR-walk kernel) */
 int tcmi_readset_sets(const tcmi_readset *rs, int64_t *aligned_reads, int64_t *aligned_chunks,
                       int64_t *general_reads);
+
+/* *packed_on_device = 1 when the HIP packer (pack_device.hip) built the read set, 0 when the host packer did */
+int tcmi_readset_origin(const tcmi_readset *rs, int32_t *packed_on_device);
 
 /* Device-resident tally.  d_counts: device int32 [7][ld] (plane order TCMI_COV..TCMI_I,
  * plane p at d_counts + p*ld, ld >= L).  Zeroes the planes first when `zero` != 0,

@@ -133,6 +133,39 @@ def test_both_tally_kernels_agree(ctx):
     rs.free()
 
 
+def test_device_packer_against_host_packer_and_oracle(ctx):
+    """The default upload copies the BAM-native arrays to the device and packs them with HIP kernels (CIGAR projection,
+    token classes, coverage runs, 4-bit -> bit planes); option device_pack = 0 packs on the host.  Both must give the
+    oracle's matrix, and the read sets must say who packed them: the device takes what is sorted or not as long as no
+    entry exceeds 512 positions; long reads and far positions go to the host packer."""
+    from tests import fuzz_reads as fz
+    rng = np.random.default_rng(99)
+    ref, orfs = sy.make_reference()
+    cases = [("150M + indel carriers", sy.make_reads(ref, 150_000, seed=41, indel_sites=sy.default_indel_sites(orfs)), len(ref), True),
+             ("every CIGAR op, odd SEQ content", fz.random_reads(rng, 20_000, 3000, long_reads=False, sort=True), None, True),
+             ("unsorted (chunk budget runs out: host packer)", fz.random_reads(rng, 3000, 1500, long_reads=False, sort=False), None, False),
+             ("long reads", fz.random_reads(rng, 2000, 20_000, long_reads=True, sort=True), None, False),
+             ("mixed lengths 1..512", _uniform_reads(rng, np.sort(rng.integers(0, 5000, 20_000)).astype(np.int32), rng.integers(1, 513, 20_000)), 5600, True),
+             ("60k reads on one start", _uniform_reads(rng, np.full(60_000, 77, np.int32), np.full(60_000, 150)), 300, True),
+             ("513-base reads", _uniform_reads(rng, np.sort(rng.integers(0, 900, 500)).astype(np.int32), np.full(500, 513)), 1500, False)]
+    seen = {}
+    try:
+        for name, reads, L, on_device in cases:
+            L = L or engine.reads_extent(reads, 0)
+            want = c_oracle.tally(reads, L)
+            for dp in (1, 0):
+                ctx.set_option("device_pack", dp)
+                rs = ctx.upload(reads)
+                assert rs.packed_on_device == bool(dp and on_device), (name, dp)
+                got = ctx.step(rs, L, 30, True)[3]
+                assert np.array_equal(got, want), (name, dp, np.argwhere(got != want)[:5])
+                seen.setdefault(name, []).append((rs.n_piled, rs.algorithmic_bytes, rs.max_end))
+                rs.free()
+    finally:
+        ctx.set_option("device_pack", 1)
+    assert all(a == b for a, b in seen.values()), seen              # kept reads, algorithmic bytes, extent: same from both packers
+
+
 def test_tally_accumulate_split_readsets(ctx):
     """cfg 5 shape: one BAM split into contiguous read ranges, partial matrices summed."""
     ref, _ = sy.make_reference(L=8000, cds=[(10, 900)])
@@ -163,6 +196,7 @@ def test_full_size_1m_reads_exact_and_deterministic(ctx):
     reads = sy.make_reads(ref, 1_000_000, seed=2)
     L = len(ref)
     rs = ctx.upload(reads)
+    assert rs.packed_on_device
     assert rs.n_piled == 1_000_000 and rs.algorithmic_bytes == 91 * 1_000_000
     p1, a1, f1, c1 = ctx.step(rs, L, 30, True)
     p2, a2, f2, c2 = ctx.step(rs, L, 30, True)

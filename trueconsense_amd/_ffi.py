@@ -18,7 +18,7 @@ TCMI_OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_FORMAT, E_IO, E_KEYERROR, E_ZERODIV, E_UNSUPPORTED = range(-1, -10, -1)
 COLS = ("coverage", "A", "T", "C", "G", "X", "I")        # indexing.py:134
 F_LOWCOV, F_PRIMX, F_MINDEL, F_INSCAND, F_COVGT, F_COVZERO, F_AMBIG = 1, 2, 4, 8, 16, 32, 64
-K_TALLY, K_CALL, K_ZERO, K_TALLY_GENERAL = 0, 1, 2, 3
+K_TALLY, K_CALL, K_ZERO, K_TALLY_GENERAL, K_PACK_CLASSIFY, K_PACK, K_INFLATE, K_RECORDS = range(8)
 
 
 class TcmiError(RuntimeError):
@@ -59,6 +59,7 @@ _SIGS = {
     "tcmi_readset_free": (_int, [_vp, _vp]),
     "tcmi_readset_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "tcmi_readset_sets": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64)]),
+    "tcmi_readset_origin": (_int, [_vp, _P(_i32)]),
     "tcmi_tally_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _int]),
     "tcmi_tally": (_int, [_vp, _P(Reads), _i64, _vp]),
     "tcmi_counts_download": (_int, [_vp, _vp, _i64, _i64, _vp]),

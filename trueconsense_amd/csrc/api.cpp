@@ -125,6 +125,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     free_ws(c);
     tcmi_upload_scratch_free(c->upload_scratch);
     c->upload_scratch = nullptr;
+    tcmi_dev_arena_free(c->dev_arena);
+    c->dev_arena = nullptr;
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -152,6 +154,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "stage_cap")) c->stage_cap = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
+    else if (!std::strcmp(key, "device_pack")) c->device_pack = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);

@@ -1,0 +1,671 @@
+// pack_device.hip — DEVICE: BAM-native reads -> the bit-plane layout tally_planes.hip consumes.
+//
+// What the reference does per pileup token in Python (indexing.py:100-139: pileup membership, the token of every
+// covered position, parse_query_sequences' classification) is decided here per READ by HIP kernels, straight from
+// the arrays a BAM holds (SAM spec §4.2: pos, flag, l_seq, CIGAR words, 4-bit SEQ) — either as the flat arrays of
+// struct tcmi_reads copied to the device as they are, or from the inflated BAM byte stream itself (bam_device.hip):
+//
+//   pk_classify   one lane per read: does it pile up, reference span, CIGAR shape ([H][S]M[S][H] reads
+//                 are taken as they are, anything else is projected onto the reference), words it will occupy;
+//                 per-workgroup sums for the scan
+//   pk_scan       exclusive scan of the per-workgroup sums (one workgroup)
+//   pk_scatter    compacted index of every kept read + its word offset (block scan + the scanned sums)
+//   pk_pack       one workgroup per run of consecutive kept reads: cuts it into chunks (window <= 768 positions,
+//                 <= 255 reads per lane, <= 8 stages that fill the tally kernel's LDS stage buffer), writes the chunk
+//                 records, ONE packed header word per read, the coverage runs (reads of equal position and length),
+//                 and per read the bases as {lo, hi} bit planes: 4-bit codes are classified eight at a time with
+//                 SWAR bit tricks (one-hot test, C|T and G|T planes, 3-step bit squeeze), CIGAR ops are walked by the
+//                 read's lane (M/=/X copy bit fields, D -> X events, insertions -> I events on the base before,
+//                 every covered position without an A/C/G/T base -> OTHER event)
+//
+// HBM-streaming byte / bit work: no MFMA.  Input 91 B + 20 B of offsets per 150-bp read, output 52 B.
+#include <algorithm>
+#include <cstring>
+
+#include "tally_common.h"
+
+namespace {
+
+constexpr int PB = 256;                          // lanes per workgroup of every kernel here
+constexpr int PK_CMAX = 3328;                    // most reads one pk_pack workgroup takes
+constexpr uint32_t NIB = 0x11111111u;
+
+struct PackSrc {
+    // mode 0: flat arrays (struct tcmi_reads on the device)
+    const int32_t *pos; const uint16_t *flag; const int32_t *l_qseq; const int32_t *tid;
+    const uint64_t *cigar_off; const uint32_t *cigar; const uint64_t *seq_off; const uint8_t *seq;
+    // mode 1: the inflated BAM stream and the offset of every record's block_size field
+    const uint8_t *stream; const uint64_t *rec_off;
+    int64_t n;
+    int32_t mode, pos_shift;
+};
+
+struct ReadView {
+    int32_t tid, pos, l_seq;
+    uint32_t flag, n_cigar;
+    const uint8_t *cigar;       // n_cigar little-endian words, not necessarily aligned
+    const uint8_t *seq;         // ceil(l_seq / 2) bytes
+    bool bad;                   // inconsistent offsets / lengths
+};
+
+__device__ inline uint32_t ld_u32(const uint8_t *p)
+{
+    // aligned dword loads + funnel shift (the record fields of a BAM stream sit at any byte offset)
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3) * 8u;
+    const uint32_t lo = q[0];
+    if (sh == 0) return lo;
+    return __builtin_amdgcn_alignbit(q[1], lo, sh);
+}
+
+__device__ inline ReadView view(const PackSrc &s, int64_t i)
+{
+    ReadView v;
+    v.bad = false;
+    if (s.mode == 0) {
+        v.tid = s.tid ? s.tid[i] : 0;
+        v.pos = s.pos[i];
+        v.l_seq = s.l_qseq[i];
+        v.flag = s.flag[i];
+        const uint64_t c0 = s.cigar_off[i], c1 = s.cigar_off[i + 1], q0 = s.seq_off[i], q1 = s.seq_off[i + 1];
+        v.bad = c1 < c0 || c1 - c0 > 65535u || q1 < q0 || v.l_seq < 0 || (int64_t)(q1 - q0) < ((int64_t)v.l_seq + 1) / 2;
+        v.n_cigar = v.bad ? 0u : (uint32_t)(c1 - c0);
+        v.cigar = reinterpret_cast<const uint8_t *>(s.cigar + c0);
+        v.seq = s.seq + q0;
+    } else {
+        const uint8_t *r = s.stream + s.rec_off[i] + 4;        // behind block_size
+        v.tid = (int32_t)ld_u32(r);
+        v.pos = (int32_t)ld_u32(r + 4);
+        const uint32_t w2 = ld_u32(r + 8), w3 = ld_u32(r + 12);
+        const uint32_t l_name = w2 & 0xFFu;
+        v.n_cigar = w3 & 0xFFFFu;
+        v.flag = w3 >> 16;
+        v.l_seq = (int32_t)ld_u32(r + 16);
+        v.cigar = r + 32 + l_name;
+        v.seq = v.cigar + 4 * (size_t)v.n_cigar;
+        v.bad = v.l_seq < 0;                                    // (the record walk has checked the fields against block_size)
+    }
+    return v;
+}
+
+__device__ inline bool consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+__device__ inline bool is_match(uint32_t op) { return op == 0 || op == 7 || op == 8; }
+
+// per-read word of pk_classify: len (10 bits, <= TCMI_D_MAXLEN) | projected << 10 | kept << 11 | y0 << 12
+constexpr uint32_t INFO_PROJ = 1u << 10, INFO_KEPT = 1u << 11;
+// flags raised for the host
+enum { PKF_LONG = 1, PKF_FARPOS = 2, PKF_BADREAD = 4, PKF_EVENT_OVF = 8, PKF_CHUNK_OVF = 16, PKF_HEADER_OVF = 32, PKF_WORD_OVF = 64,
+       PKF_MULTIREF = 128 };
+
+struct PackTotals {                 // device scalars, copied back to the host
+    unsigned long long alg_bytes;
+    unsigned long long n_kept, n_words;
+    int32_t max_end;
+    uint32_t flags;
+    uint32_t n_chunks, n_events, n_runs;
+    uint32_t word_cursor;
+    uint32_t pad_[2];
+};
+
+__device__ inline uint32_t words_of(uint32_t len) { return 2u * ((len + 31u) >> 5) + 2u; }
+
+// inclusive scan of a pair over the workgroup (PB lanes)
+__device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ox = (uint32_t)__shfl_up((int)v.x, d, 64), oy = (uint32_t)__shfl_up((int)v.y, d, 64);
+        if (lane >= d) { v.x += ox; v.y += oy; }
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = v;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < PB / 64; ++w)
+        if (w < wave) { v.x += wave_tot[w].x; v.y += wave_tot[w].y; }
+    return v;
+}
+
+// ---- 1: classify ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *blk_sum, PackTotals *tot)
+{
+    __shared__ uint2 s_w[PB / 64];
+    const int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x;
+    uint32_t word = 0, nwords = 0;
+    if (i < s.n) {
+        const ReadView v = view(s, i);
+        bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
+        if (v.bad && !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
+        if (!(v.flag & 0x4u) && v.tid > 0) atomicOr(&tot->flags, (uint32_t)PKF_MULTIREF);   // (the host packer words the error)
+        if (kept) {
+            // one walk over the CIGAR: reference span, and is it [H]*[S]* (M|=|X)+ [S]*[H]* ?
+            int64_t span = 0, m = 0, y0 = 0;
+            int ph = 0;                     // 0 start / leading H, 1 leading S, 2 match run, 3 trailing S, 4 trailing H
+            bool simple = true;
+            for (uint32_t k = 0; k < v.n_cigar; ++k) {
+                const uint32_t c = ld_u32(v.cigar + 4 * (size_t)k), op = c & 0xFu, len = c >> 4;
+                if (consumes_ref(op)) span += len;
+                if (op == 5) { if (ph >= 2) ph = 4; else if (ph == 1) simple = false; }
+                else if (op == 4) { if (ph <= 1) { ph = 1; y0 += len; } else if (ph <= 3) ph = 3; else simple = false; }
+                else if (is_match(op)) { if (ph <= 2) { ph = 2; m += len; } else simple = false; }
+                else simple = false;
+            }
+            simple = simple && ph >= 2 && m > 0 && y0 < (1 << 20);
+            kept = span > 0;
+            if (kept) {
+                const int64_t end = (int64_t)v.pos + s.pos_shift + span;
+                const int64_t len = simple ? m : span;
+                if (end >= (int64_t)TCMI_F_EVPOS) { atomicOr(&tot->flags, (uint32_t)PKF_FARPOS); kept = false; }
+                else if (len > TCMI_D_MAXLEN) { atomicOr(&tot->flags, (uint32_t)PKF_LONG); kept = false; }
+                else {
+                    word = (uint32_t)len | (simple ? 0u : INFO_PROJ) | INFO_KEPT | (simple ? (uint32_t)y0 << 12 : 0u);
+                    nwords = words_of((uint32_t)len);
+                    atomicAdd(&tot->alg_bytes, (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2));
+                    atomicMax(&tot->max_end, (int32_t)end);
+                }
+            }
+        }
+        info[i] = word;
+    }
+    const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
+    if (threadIdx.x == PB - 1) blk_sum[blockIdx.x] = incl;
+}
+
+// ---- 2: exclusive scan of the workgroup sums (one workgroup, any number of entries) ---------------------------------
+__global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, int64_t n_blk, PackTotals *tot)
+{
+    __shared__ unsigned long long s_x[1024], s_y[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n_blk + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blk);
+    unsigned long long sx = 0, sy = 0;
+    for (int64_t b = b0; b < b1; ++b) { sx += blk_sum[b].x; sy += blk_sum[b].y; }
+    s_x[t] = sx; s_y[t] = sy;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                    // Hillis-Steele over the 1024 partials
+        const unsigned long long ax = t >= d ? s_x[t - d] : 0, ay = t >= d ? s_y[t - d] : 0;
+        __syncthreads();
+        s_x[t] += ax; s_y[t] += ay;
+        __syncthreads();
+    }
+    unsigned long long bx = s_x[t] - sx, by = s_y[t] - sy;  // exclusive base of this lane's range
+    for (int64_t b = b0; b < b1; ++b) {
+        const uint2 v = blk_sum[b];
+        blk_sum[b] = make_uint2((uint32_t)bx, (uint32_t)by);
+        bx += v.x; by += v.y;
+    }
+    if (t == 1023) { tot->n_kept = s_x[1023]; tot->n_words = s_y[1023]; }
+}
+
+// ---- 3: scatter: compacted index + word offset of every kept read -----------------------------------------------------
+__global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info, const uint2 *blk_base, uint32_t *c_idx,
+                                                 int32_t *c_pos, uint32_t *c_info, uint32_t *c_woff)
+{
+    __shared__ uint2 s_w[PB / 64];
+    const int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x;
+    const uint32_t w = i < s.n ? info[i] : 0u;
+    const uint2 mine = make_uint2(w ? 1u : 0u, w ? words_of(w & 1023u) : 0u);
+    const uint2 incl = block_scan2(mine, s_w);
+    if (w) {
+        const uint2 base = blk_base[blockIdx.x];
+        const uint32_t j = base.x + incl.x - 1u;
+        c_idx[j] = (uint32_t)i;
+        c_pos[j] = (s.mode == 0 ? s.pos[i] : (int32_t)ld_u32(s.stream + s.rec_off[i] + 8)) + s.pos_shift;
+        c_info[j] = w;
+        c_woff[j] = base.y + incl.y - mine.y;
+    }
+}
+
+// ---- 4: pack ------------------------------------------------------------------------------------------------------------
+struct PackOut {
+    uint32_t *lenoff;               // [n_kept]
+    uint32_t *seq;                  // [word_cap]
+    tcmi_fast_chunk *chunks;        // [chunk_cap]
+    uint32_t *covrun;               // [n_kept]: the runs of a chunk start at its first read's index
+    uint32_t *events;               // [event_cap]
+    uint32_t word_cap, chunk_cap, event_cap;
+};
+
+__device__ inline void push_event(const PackOut &o, PackTotals *tot, uint32_t w)
+{
+    const uint32_t slot = atomicAdd(&tot->n_events, 1u);
+    if (slot < o.event_cap) o.events[slot] = w;
+}
+
+// eight 4-bit BAM codes (base k in nibble k) -> one bit per base: C|T, G|T, "is one of A C G T"
+__device__ inline void classify8(uint32_t n, uint32_t &lo, uint32_t &hi, uint32_t &ok)
+{
+    const uint32_t x0 = n & NIB, x1 = (n >> 1) & NIB, x2 = (n >> 2) & NIB, x3 = (n >> 3) & NIB;
+    const uint32_t s01 = x0 ^ x1, c01 = x0 & x1, s23 = x2 ^ x3, c23 = x2 & x3;
+    ok = (s01 ^ s23) & ~(c01 | c23);                            // exactly one bit set: A=1 C=2 G=4 T=8
+    lo = (x1 | x3) & ok;
+    hi = (x2 | x3) & ok;
+}
+__device__ inline uint32_t squeeze8(uint32_t t)                 // bits 0,4,..,28 -> bits 0..7
+{
+    t = (t | (t >> 3)) & 0x03030303u;
+    t = (t | (t >> 6)) & 0x000F000Fu;
+    return (t | (t >> 12)) & 0xFFu;
+}
+
+// bases [yy, yy + nb) of a read (nb <= 32) as bit planes; bases at or beyond l_seq are "not A/C/G/T"
+__device__ inline void fetch32(const uint8_t *seq, int32_t l_seq, int32_t yy, int nb, uint32_t &lo, uint32_t &hi, uint32_t &ok)
+{
+    lo = hi = ok = 0;
+    const int have = min(nb, l_seq - yy);
+    if (have <= 0) return;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(seq + (yy >> 1));
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3) * 8u;
+    uint32_t d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = q[k];
+    uint32_t w[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t b = sh ? __builtin_amdgcn_alignbit(d[k + 1], d[k], sh) : d[k];
+        w[k] = ((b & 0x0F0F0F0Fu) << 4) | ((b >> 4) & 0x0F0F0F0Fu);   // BAM keeps the first base of a byte in the high nibble
+    }
+    const bool odd = yy & 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t n = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 4) : w[k];
+        uint32_t l, h, v;
+        classify8(n, l, h, v);
+        lo |= squeeze8(l) << (8 * k);
+        hi |= squeeze8(h) << (8 * k);
+        ok |= squeeze8(v) << (8 * k);
+    }
+    const uint32_t mask = have >= 32 ? 0xFFFFFFFFu : ((1u << have) - 1u);
+    lo &= mask; hi &= mask; ok &= mask;
+}
+
+// htslib resolve_cigar2's peek at the last reference base of op k: is an insertion reported there?
+__device__ inline bool ins_after(const uint8_t *cg, uint32_t n, uint32_t k)
+{
+    if (k + 1 >= n) return false;
+    const uint32_t c2 = ld_u32(cg + 4 * (size_t)(k + 1)), op2 = c2 & 0xFu;
+    uint32_t tot = 0;
+    if (op2 == 1) {
+        tot = c2 >> 4;
+        for (uint32_t j = k + 2; j < n; ++j) {
+            const uint32_t c = ld_u32(cg + 4 * (size_t)j), o = c & 0xFu;
+            if (o == 1) tot += c >> 4;
+            else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        for (uint32_t j = k + 2; j < n; ++j) {
+            const uint32_t c = ld_u32(cg + 4 * (size_t)j), o = c & 0xFu;
+            if (o == 1) tot += c >> 4;
+            else if (consumes_ref(o)) break;
+        }
+    }
+    return tot > 0;
+}
+
+// one read -> its plane pairs (out: 2 * ceil(len / 32) words, then the zero pair) and its event words
+__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, int32_t gpos,
+                                 uint32_t *out)
+{
+    const ReadView v = view(src, i);
+    const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
+    if (!(info & INFO_PROJ)) {
+        const int y0 = (int)(info >> 12);
+        for (int q = 0; q < npair; ++q) {
+            const int nb = min(32, len - 32 * q);
+            uint32_t lo, hi, ok;
+            fetch32(v.seq, v.l_seq, y0 + 32 * q, nb, lo, hi, ok);
+            *reinterpret_cast<uint2 *>(out + 2 * q) = make_uint2(lo, hi);
+            uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
+            while (miss) {
+                const int b = __builtin_ctz(miss);
+                push_event(o, tot, (uint32_t)(gpos + 32 * q + b) | TCMI_F_EV_OTHER);
+                miss &= miss - 1;
+            }
+        }
+    } else {
+        // Walk the CIGAR: matched bases land on their reference offset (bit-field copies into the pair being built), D / N
+        // leave empty positions, and the tokens that are not plain bases become events: X for a deleted base
+        // whose token is exactly "*", I on the last reference base before an insertion (also "*+..": I but not X).
+        int q_cur = 0;
+        uint32_t lo = 0, hi = 0, ok = 0;
+        auto flush_to = [&](int q_new) {            // store the pairs [q_cur, q_new), all but the first of them empty
+            while (q_cur < q_new && q_cur < npair) {
+                const int nb = min(32, len - 32 * q_cur);
+                *reinterpret_cast<uint2 *>(out + 2 * q_cur) = make_uint2(lo, hi);
+                uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
+                while (miss) {
+                    const int b = __builtin_ctz(miss);
+                    push_event(o, tot, (uint32_t)(gpos + 32 * q_cur + b) | TCMI_F_EV_OTHER);
+                    miss &= miss - 1;
+                }
+                lo = hi = ok = 0;
+                ++q_cur;
+            }
+        };
+        int x = 0, y = 0;
+        for (uint32_t k = 0; k < v.n_cigar && x < len; ++k) {
+            const uint32_t c = ld_u32(v.cigar + 4 * (size_t)k), op = c & 0xFu;
+            const int oplen = (int)(c >> 4);
+            if (consumes_ref(op)) {
+                const bool ins = oplen > 0 && ins_after(v.cigar, v.n_cigar, k);
+                if (is_match(op)) {
+                    int t = 0;
+                    while (t < oplen) {
+                        const int q = (x + t) >> 5, b0 = (x + t) & 31, nb = min(32 - b0, oplen - t);
+                        flush_to(q);
+                        uint32_t l, h, g;
+                        fetch32(v.seq, v.l_seq, y + t, nb, l, h, g);
+                        lo |= l << b0; hi |= h << b0; ok |= g << b0;
+                        t += nb;
+                    }
+                } else if (op == 2) {
+                    const int nx = ins ? oplen - 1 : oplen;
+                    for (int t = 0; t < nx; ++t) push_event(o, tot, (uint32_t)(gpos + x + t) | TCMI_F_EV_X);
+                }
+                if (ins) push_event(o, tot, (uint32_t)(gpos + x + oplen - 1) | TCMI_F_EV_I);
+                x += oplen;
+            }
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += oplen;
+        }
+        flush_to(npair);
+    }
+    *reinterpret_cast<uint2 *>(out + 2 * npair) = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint32_t *c_idx, const int32_t *c_pos, const uint32_t *c_info,
+                                              const uint32_t *c_woff, uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages,
+                                              int stage_cap, PackTotals *tot)
+{
+    __shared__ int32_t s_pos[PK_CMAX];
+    __shared__ uint32_t s_woff[PK_CMAX + 1];
+    __shared__ uint16_t s_len[PK_CMAX];
+    __shared__ uint16_t s_run[PK_CMAX + 1];     // chunk-relative index of every run's first read
+    __shared__ int s_red[3][PB / 64];
+    __shared__ int s_scan[PB / 64];
+    __shared__ uint32_t s_slot[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
+    const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
+    for (int t = tid; t < n; t += PB) {
+        s_pos[t] = c_pos[r0 + t];
+        s_len[t] = (uint16_t)(c_info[r0 + t] & 1023u);
+        s_woff[t] = c_woff[r0 + t];
+    }
+    if (tid == 0) s_woff[n] = r0 + n < n_kept ? c_woff[r0 + n] : n_words;
+    __syncthreads();
+
+    int cur = 0;
+    while (cur < n) {                                            // uniform: one chunk per turn
+        const int P0 = s_pos[cur] & ~7;
+        // the chunk's reads: the longest prefix of [cur, n) inside a window of MAXPOS positions that starts at P0
+        int viol = n;
+        for (int t = cur + 1 + tid; t < n; t += PB) {
+            const int rel = s_pos[t] - P0;
+            if (rel < 0 || rel + (int)s_len[t] > MAXPOS) { viol = t; break; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) viol = min(viol, __shfl_xor(viol, d, 64));
+        if (lane == 0) s_red[0][wave] = viol;
+        __syncthreads();
+        int e1 = s_red[0][0];
+#pragma unroll
+        for (int w = 1; w < PB / 64; ++w) e1 = min(e1, s_red[0][w]);
+        int mend = 0, mlen = 0;
+        for (int t = cur + tid; t < e1; t += PB) {
+            mend = max(mend, s_pos[t] - P0 + (int)s_len[t]);
+            mlen = max(mlen, (int)s_len[t]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mend = max(mend, __shfl_xor(mend, d, 64)); mlen = max(mlen, __shfl_xor(mlen, d, 64)); }
+        if (lane == 0) { s_red[1][wave] = mend; s_red[2][wave] = mlen; }
+        __syncthreads();
+        mend = s_red[1][0]; mlen = s_red[2][0];
+#pragma unroll
+        for (int w = 1; w < PB / 64; ++w) { mend = max(mend, s_red[1][w]); mlen = max(mlen, s_red[2][w]); }
+        // stage and chunk sizes exactly as the tally kernel will derive them from (Wn, sub_reads): readset.cpp's rules
+        const int Wn = (mend + 7) >> 3;
+        const int S = FB / max(2, (Wn * 8 + 31) >> 5);
+        int cap = min((int)TCMI_P_SUB, (TCMI_F_SEQCAP - 16 - 2) / (int)words_of((uint32_t)mlen));
+        if (stage_cap > 0) cap = min(cap, max(stage_cap, S * 4));
+        int sub = S * 4 * max(1, cap / (S * 4));
+        if (sub > cap) sub = max(S, cap / S * S);
+        const int whole = max(sub, min(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
+        const int nc = min(e1 - cur, whole);
+        const uint32_t words_c = s_woff[cur + nc] - s_woff[cur];
+        if (tid == 0) {
+            s_slot[0] = atomicAdd(&tot->n_chunks, 1u);
+            s_slot[1] = atomicAdd(&tot->word_cursor, (2u + words_c + 3u) & ~3u);
+        }
+        // ---- coverage runs: reads of equal (position, length) follow each other in a sorted BAM ---------------------
+        int n_runs = 0;
+        for (int t0 = 0; t0 < nc; t0 += PB) {
+            const int t = t0 + tid;
+            bool start = false;
+            if (t < nc) {
+                const int j = cur + t;
+                start = t == 0 || (t & 2047) == 0 || s_pos[j] != s_pos[j - 1] || s_len[j] != s_len[j - 1];
+            }
+            const int incl = block_scan_incl(start ? 1 : 0, s_scan);    // (two barriers inside: s_slot is visible after them)
+            if (start) s_run[n_runs + incl - 1] = (uint16_t)t;
+            __syncthreads();
+            n_runs += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+            __syncthreads();
+        }
+        static_assert(PB / 64 == 4, "run count sums four wave totals");
+        if (tid == 0) s_run[n_runs] = (uint16_t)nc;
+        __syncthreads();
+        const uint32_t ci = s_slot[0], w0 = s_slot[1];
+        const bool fits = ci < o.chunk_cap && (unsigned long long)w0 + ((2u + words_c + 3u) & ~3u) <= o.word_cap;
+        if (!fits && tid == 0) atomicOr(&tot->flags, (uint32_t)(ci >= o.chunk_cap ? PKF_CHUNK_OVF : PKF_WORD_OVF));
+        if (fits) {
+            const uint32_t g0 = r0 + (uint32_t)cur;             // compacted index of the chunk's first read
+            for (int k = tid; k < n_runs; k += PB) {
+                const int t = s_run[k], cnt = (int)s_run[k + 1] - t, j = cur + t;
+                o.covrun[g0 + k] = (uint32_t)(s_pos[j] - P0) | ((uint32_t)s_len[j] << 10) | ((uint32_t)cnt << 20);
+            }
+            if (tid == 0) {
+                tcmi_fast_chunk c;
+                c.read0 = g0; c.word0 = w0; c.n_reads = nc; c.P0 = P0; c.Wn = Wn; c.sub_reads = sub;
+                for (int st = 0; st < TCMI_F_MAXSTAGE; ++st) {
+                    const int last = min(nc, (st + 1) * sub);
+                    c.stage_end[st] = st * sub < nc ? (int32_t)(2u + s_woff[cur + last] - s_woff[cur]) : 0;
+                }
+                c.run0 = g0; c.n_runs = n_runs; c.reserved_ = 0;
+                o.chunks[ci] = c;
+                atomicAdd(&tot->n_runs, (uint32_t)n_runs);
+                o.seq[w0] = 0u; o.seq[w0 + 1] = 0u;              // the zero pair in front of the first read
+                for (uint32_t g = 2u + words_c; g < ((2u + words_c + 3u) & ~3u); ++g) o.seq[w0 + g] = 0u;
+            }
+            // ---- per read: header word, planes, events ---------------------------------------------------------------
+            for (int t = tid; t < nc; t += PB) {
+                const int j = cur + t, st = t / sub;
+                const uint32_t base = 2u + s_woff[j] - s_woff[cur];                          // words from word0
+                const uint32_t sb = st == 0 ? 0u : s_woff[cur + st * sub] - s_woff[cur];     // the stage starts on the zero pair in front of its first read
+                const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
+                if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
+                o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
+                pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], s_pos[j], o.seq + w0 + base);
+            }
+        }
+        cur += nc;
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct tcmi_dev_arena {             // grow-only device scratch of a context (freed with it): the packers' temporaries
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+static int arena_reserve(tcmi_ctx *ctx, size_t bytes)
+{
+    if (!ctx->dev_arena) ctx->dev_arena = new tcmi_dev_arena();
+    tcmi_dev_arena &A = *ctx->dev_arena;
+    A.used = 0;
+    if (A.cap >= bytes) return TCMI_OK;
+    if (A.base) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(A.base); A.base = nullptr; A.cap = 0; }
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    if (hipMalloc((void **)&A.base, want) != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) for the pack scratch failed", want);
+    A.cap = want;
+    return TCMI_OK;
+}
+
+static void *arena_take(tcmi_ctx *ctx, size_t bytes)
+{
+    tcmi_dev_arena &A = *ctx->dev_arena;
+    const size_t at = (A.used + 255) & ~(size_t)255;
+    A.used = at + bytes;
+    return A.base + at;
+}
+
+void tcmi_dev_arena_free(tcmi_dev_arena *a)
+{
+    if (!a) return;
+    if (a->base) (void)hipFree(a->base);
+    delete a;
+}
+
+void *tcmi_arena_reserve_take(tcmi_ctx *ctx, size_t total, size_t first)   // (bam_device.hip shares the arena)
+{
+    if (arena_reserve(ctx, total)) return nullptr;
+    return arena_take(ctx, first);
+}
+void *tcmi_arena_take(tcmi_ctx *ctx, size_t bytes) { return arena_take(ctx, bytes); }
+
+// Pack `n` reads described by `src` (device pointers) into a read set.  Returns TCMI_E_UNSUPPORTED (with `*why` set) when
+// the input needs the host packer: entries longer than TCMI_D_MAXLEN, positions beyond 2^29, malformed reads (the host
+// packer words the error).  The arena must already hold the source arrays; this takes its temporaries behind them.
+int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint32_t *why)
+{
+    PackSrc src = *static_cast<const PackSrc *>(src_);
+    *why = 0;
+    const int64_t n = src.n;
+    if (n > 0xFFFFFFF0ll) { *why = PKF_LONG; return TCMI_E_UNSUPPORTED; }
+    const int64_t n_blk = (n + PB - 1) / PB;
+    uint32_t *info = (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4);
+    uint2 *blk_sum = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
+    PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
+    PackTotals tot;
+    std::memset(&tot, 0, sizeof tot);
+    TCMI_HIP(ctx, hipMemsetAsync(d_tot, 0, sizeof(PackTotals), ctx->stream));
+    if (n > 0) {
+        (void)hipGetLastError();
+        tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
+        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, d_tot);
+        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, n_blk, d_tot);
+        tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
+        TCMI_HIP(ctx, hipGetLastError());
+    }
+    TCMI_HIP(ctx, hipMemcpyAsync(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (tot.flags) { *why = tot.flags; return TCMI_E_UNSUPPORTED; }
+    const int64_t nf = (int64_t)tot.n_kept;
+    rs->n_piled = nf; rs->f_reads = nf; rs->alg_bytes = (int64_t)tot.alg_bytes; rs->max_end = tot.max_end;
+    rs->packed_on_device = 1;
+    if (nf == 0) return TCMI_OK;
+    if (tot.n_words > 0xF0000000ull) { *why = PKF_WORD_OVF; return TCMI_E_UNSUPPORTED; }
+
+    // chunk size: as readset.cpp — long chunks, but a multiple of the resident workgroups of them
+    int64_t C = 2048;
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) : TCMI_F_MAXSTAGE;
+    if (ctx->chunk_stages == 0 && ctx->balance_chunks) {
+        const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu, longest = (int64_t)TCMI_F_MAXSTAGE * 400;
+        const int64_t k = (nf + slots * longest - 1) / (slots * longest);
+        C = std::max<int64_t>(64, (nf + k * slots - 1) / (k * slots));
+    }
+    C = std::min<int64_t>(C, PK_CMAX);
+    const int64_t n_wg = (nf + C - 1) / C;
+    // every workgroup opens at least one chunk; more when a window or a lane's 255-read budget runs out
+    const uint32_t chunk_cap = (uint32_t)std::min<int64_t>(nf, 4 * n_wg + (int64_t)tot.max_end / 128 + 64);
+    const uint32_t word_cap = (uint32_t)std::min<unsigned long long>(0xFFFFFFF0ull, tot.n_words + 8ull * chunk_cap + 16);
+
+    uint32_t *c_idx = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
+    int32_t *c_pos = (int32_t *)arena_take(ctx, (size_t)nf * 4);
+    uint32_t *c_info = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
+    uint32_t *c_woff = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
+    if (ctx->dev_arena->used > ctx->dev_arena->cap) { return tcmi_fail(ctx, TCMI_E_NOMEM, "internal: pack scratch under-reserved"); }
+
+    uint32_t event_cap = (uint32_t)std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(1 << 20, nf / 2));
+    for (int attempt = 0;; ++attempt) {
+        PackOut o = {};
+        // one allocation for everything the tally kernel reads: headers | planes | chunk records | runs | events
+        const size_t b_len = ((size_t)nf * 4 + 255) & ~(size_t)255, b_seq = ((size_t)word_cap * 4 + 255) & ~(size_t)255,
+                     b_chk = ((size_t)chunk_cap * sizeof(tcmi_fast_chunk) + 255) & ~(size_t)255, b_run = b_len,
+                     b_ev = ((size_t)event_cap * 4 + 255) & ~(size_t)255;
+        char *blob = nullptr;
+        if (hipMalloc((void **)&blob, b_len + b_seq + b_chk + b_run + b_ev + 256) != hipSuccess) {
+            return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) for the packed read set failed", b_len + b_seq + b_chk + b_run + b_ev);
+        }
+        rs->d_blob = blob;
+        o.lenoff = (uint32_t *)blob;
+        o.seq = (uint32_t *)(blob + b_len);
+        o.chunks = (tcmi_fast_chunk *)(blob + b_len + b_seq);
+        o.covrun = (uint32_t *)(blob + b_len + b_seq + b_chk);
+        o.events = (uint32_t *)(blob + b_len + b_seq + b_chk + b_run);
+        o.word_cap = word_cap; o.chunk_cap = chunk_cap; o.event_cap = event_cap;
+        TCMI_HIP(ctx, hipMemsetAsync(blob + b_len + b_seq + b_chk + b_run + b_ev, 0, 256, ctx->stream));   // slack behind the last array
+        TCMI_HIP(ctx, hipMemsetAsync(&d_tot->n_chunks, 0, 4 * sizeof(uint32_t), ctx->stream));              // n_chunks, n_events, n_runs, word_cursor
+        (void)hipGetLastError();
+        tcmi_prof_begin(ctx, TCMI_K_PACK);
+        if (attempt == 0)
+            hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, c_idx, c_pos, c_info, c_woff);
+        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, (uint32_t)nf,
+                           (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot);
+        tcmi_prof_end(ctx, TCMI_K_PACK);
+        TCMI_HIP(ctx, hipGetLastError());
+        TCMI_HIP(ctx, hipMemcpyAsync(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+        TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (tot.n_events > event_cap && attempt == 0) {          // rare: a read set full of N / indel tokens — once more with room for all
+            (void)hipFree(blob);
+            rs->d_blob = nullptr;
+            event_cap = tot.n_events + 1024;
+            continue;
+        }
+        if (tot.flags || tot.n_events > event_cap) {
+            *why = tot.flags ? tot.flags : (uint32_t)PKF_EVENT_OVF;
+            return TCMI_E_UNSUPPORTED;
+        }
+        rs->d_flenoff = o.lenoff; rs->d_fseq = o.seq; rs->d_fchunk = o.chunks; rs->d_fcovrun = o.covrun; rs->d_fevent = o.events;
+        rs->f_chunks = tot.n_chunks; rs->f_words = tot.word_cursor; rs->f_events = tot.n_events;
+        rs->dev_bytes = nf * 4 + (int64_t)tot.word_cursor * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) +
+                        (int64_t)tot.n_runs * 4 + (int64_t)tot.n_events * 4;
+        return TCMI_OK;
+    }
+}
+
+// the flat arrays of struct tcmi_reads -> device (one arena block) -> tcmi_pack_on_device
+int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why)
+{
+    *why = 0;
+    const int64_t n = r->n_reads;
+    const size_t n_cig = n ? (size_t)r->cigar_off[n] : 0, n_seq = n ? (size_t)r->seq_off[n] : 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz[8] = {al((size_t)n * 4), al((size_t)n * 2), al((size_t)n * 4), r->tid ? al((size_t)n * 4) : 0, al((size_t)(n + 1) * 8),
+                          al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 64)};
+    size_t src_bytes = 0;
+    for (size_t b : sz) src_bytes += b + 256;
+    const size_t tmp_bytes = al((size_t)n * 4) * 5 + al((size_t)((n + PB - 1) / PB + 1) * 8) + 4096 + 8 * 256;
+    int rc = arena_reserve(ctx, src_bytes + tmp_bytes);
+    if (rc) return rc;
+    PackSrc s = {};
+    s.mode = 0; s.n = n; s.pos_shift = 0;
+    struct Item { const void *h; size_t bytes, room; const void **d; };
+    const Item items[8] = {{r->pos, (size_t)n * 4, sz[0], (const void **)&s.pos}, {r->flag, (size_t)n * 2, sz[1], (const void **)&s.flag},
+                           {r->l_qseq, (size_t)n * 4, sz[2], (const void **)&s.l_qseq}, {r->tid, (size_t)n * 4, sz[3], (const void **)&s.tid},
+                           {r->cigar_off, (size_t)(n + 1) * 8, sz[4], (const void **)&s.cigar_off}, {r->cigar, n_cig * 4, sz[5], (const void **)&s.cigar},
+                           {r->seq_off, (size_t)(n + 1) * 8, sz[6], (const void **)&s.seq_off}, {r->seq, n_seq, sz[7], (const void **)&s.seq}};
+    for (const Item &it : items) {
+        if (!it.h || it.room == 0) { *it.d = nullptr; continue; }
+        char *d = (char *)arena_take(ctx, it.room);
+        *it.d = d;
+        if (it.bytes) TCMI_HIP(ctx, hipMemcpyAsync(d, it.h, it.bytes, hipMemcpyHostToDevice, ctx->stream));
+        TCMI_HIP(ctx, hipMemsetAsync(d + it.bytes, 0, it.room - it.bytes, ctx->stream));   // the 24-byte window loads of fetch32 may run past the last read
+    }
+    if (n == 0) { rs->packed_on_device = 1; return TCMI_OK; }
+    return tcmi_pack_on_device(ctx, &s, rs, why);
+}

@@ -23,10 +23,14 @@ int64_t ref_span(const uint32_t *cg, int64_t n)
     return s;
 }
 
+// Reads on a second or later reference: the reference implementation piles them up keyed by position only, so they
+// collide with the first reference's columns and its BuildIndex fails (indexing.py:137-151).  They never
+// pile up here, and an upload that meets a mapped one fails with TCMI_E_UNSUPPORTED instead of tallying it onto
+// reference 0's coordinates.
 inline bool piles_up(const tcmi_reads *r, int64_t i, int64_t *span)
 {
     if (r->flag[i] & 0x4) return false;
-    if (r->tid && r->tid[i] < 0) return false;
+    if (r->tid && r->tid[i] != 0) return false;
     if (r->pos[i] < 0) return false;
     *span = ref_span(r->cigar + r->cigar_off[i], (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]));
     return *span > 0;
@@ -162,6 +166,10 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (rs->d_blob) {                                            // device-packed: one allocation holds the aligned set
+        (void)hipFree(rs->d_blob);
+        rs->d_flenoff = nullptr; rs->d_fseq = nullptr; rs->d_fevent = nullptr; rs->d_fchunk = nullptr; rs->d_fcovrun = nullptr;
+    }
     void *ptrs[] = {rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_fcovrun, rs->d_pos, rs->d_meta,
                     rs->d_lseq, rs->d_cigar, rs->d_seq, rs->d_round_cig, rs->d_round_seq};
     for (void *p : ptrs)
@@ -191,6 +199,29 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
+    static std::atomic<uint64_t> next_uid{1};
+
+    // ---- default: the BAM-native arrays go to the device as they are and HIP kernels pack them (pack_device.hip) ----
+    if (ctx->device_pack && use_fast && ctx->project_reads && n_batch == 1) {
+        const tcmi_reads *r = batch[0];
+        bool multi_ref = false;
+        tcmi_readset *rs = new tcmi_readset();
+        rs->uid = next_uid.fetch_add(1);
+        rs->n_reads = r->n_reads;
+        rs->device = ctx->device;
+        uint32_t why = 0;
+        rc = tcmi_upload_and_pack_on_device(ctx, r, rs, &why);
+        if (rc == TCMI_OK) {
+            if (timing) std::fprintf(stderr, "[tcmi upload] device pack: %.1f ms (%.1f MB on the device)\n", ms(t0, now()), rs->dev_bytes / 1e6);
+            *out = rs;
+            return TCMI_OK;
+        }
+        tcmi_readset_free(ctx, rs);
+        if (rc != TCMI_E_UNSUPPORTED) return rc;
+        (void)multi_ref;
+        if (timing) std::fprintf(stderr, "[tcmi upload] device pack declined (flags 0x%x): host packer\n", why);
+        rc = TCMI_OK;
+    }
 
     // pass 1: select, classify, size
     // one entry of the aligned set: read i of BAM r (positions shifted by off); for a projected read the piece
@@ -223,6 +254,9 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
         };
         for (int64_t i = i0; i < i1; ++i) {
             int64_t span;
+            if (r->tid && r->tid[i] > 0 && !(r->flag[i] & 0x4))
+                return fail(TCMI_E_UNSUPPORTED, "read %lld is mapped to reference %lld: only single-reference alignments are supported "
+                                                "(the reference implementation keys columns by position only and fails on these)%.0lld", i, r->tid[i], 0);
             if (!piles_up(r, i, &span)) continue;
             const uint32_t *cg = r->cigar + r->cigar_off[i];
             const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
@@ -540,7 +574,6 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
     h_rc[(size_t)n_rounds] = co;
     h_rs[(size_t)n_rounds] = so;
 
-    static std::atomic<uint64_t> next_uid{1};
     const auto t3 = now();
     tcmi_readset *rs = new tcmi_readset();
     rs->uid = next_uid.fetch_add(1);
@@ -594,6 +627,13 @@ int tcmi_readset_info(const tcmi_readset *rs, int64_t *n_reads, int64_t *n_piled
     if (alg) *alg = rs->alg_bytes;
     if (dev) *dev = rs->dev_bytes;
     if (max_end) *max_end = rs->max_end;
+    return TCMI_OK;
+}
+
+int tcmi_readset_origin(const tcmi_readset *rs, int32_t *packed_on_device)
+{
+    if (!rs || !packed_on_device) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    *packed_on_device = rs->packed_on_device;
     return TCMI_OK;
 }
 

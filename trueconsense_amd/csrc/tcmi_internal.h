@@ -44,6 +44,7 @@
 #define TCMI_F_MAXW 96             // max grid words (8 positions each) in a chunk window
 #define TCMI_F_MAXSPAN 600         // longest aligned read the fast kernel takes in one piece
 #define TCMI_F_SEG 512             // projected reads longer than this are cut into pieces of this many positions
+#define TCMI_D_MAXLEN 512          // longest entry the device packer takes (a window holds MAXW * 8 = 768 positions)
 #ifndef TCMI_F_SEQCAP
 #define TCMI_F_SEQCAP 6144         // LDS words for staged bases
 #endif
@@ -87,6 +88,8 @@ struct tcmi_readset {
     int64_t dev_bytes = 0;
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
     int device = -1;
+    int packed_on_device = 0;   // 1: pack_device.hip built the aligned set (everything below lives in d_blob)
+    char *d_blob = nullptr;     // one allocation holding d_flenoff | d_fseq | d_fchunk | d_fcovrun | d_fevent
     // aligned set
     int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
     uint32_t *d_flenoff = nullptr; // [f_reads] the packed header words
@@ -111,10 +114,14 @@ struct tcmi_ride {                  // a finished matrix waiting for its call (s
 
 struct tcmi_upload_scratch;              // host buffers of tcmi_readset_upload, kept between calls (readset.cpp)
 void tcmi_upload_scratch_free(tcmi_upload_scratch *s);
+struct tcmi_dev_arena;                   // grow-only device scratch of the device packer / BAM decoder (pack_device.hip)
+void tcmi_dev_arena_free(tcmi_dev_arena *a);
 
 struct tcmi_ctx {
     int device = -1;
     tcmi_upload_scratch *upload_scratch = nullptr;
+    tcmi_dev_arena *dev_arena = nullptr;
+    int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)
     int balance_chunks = 1;          // size the chunks so that their number is a multiple of the resident workgroups
@@ -128,8 +135,8 @@ struct tcmi_ctx {
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
-    double prof_ms[TCMI_K_NKERNELS] = {0, 0, 0, 0};
-    int64_t prof_n[TCMI_K_NKERNELS] = {0, 0, 0, 0};
+    double prof_ms[TCMI_K_NKERNELS] = {};
+    int64_t prof_n[TCMI_K_NKERNELS] = {};
     // workspace of tcmi_step / host-buffer conveniences
     int64_t ws_L = 0, ws_ld = 0;
     int32_t *d_counts = nullptr;
@@ -171,6 +178,12 @@ int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...);
 void tcmi_prof_begin(tcmi_ctx *ctx, int k);
 void tcmi_prof_end(tcmi_ctx *ctx, int k);
 
+// device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
+// input needs the host packer
+int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);
+int tcmi_pack_on_device(tcmi_ctx *ctx, const void *pack_src, tcmi_readset *rs, uint32_t *why);
+void *tcmi_arena_reserve_take(tcmi_ctx *ctx, size_t total, size_t first);
+void *tcmi_arena_take(tcmi_ctx *ctx, size_t bytes);
 // kernels (tally.hip / call.hip)
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);

@@ -23,6 +23,9 @@ class ReadSet:
         v = [C.c_int64(0) for _ in range(5)]
         check(lib().tcmi_readset_info(handle, *[C.byref(x) for x in v]))
         self.n_reads, self.n_piled, self.algorithmic_bytes, self.device_bytes, self.max_end = (x.value for x in v)
+        o = C.c_int32(0)
+        check(lib().tcmi_readset_origin(handle, C.byref(o)))
+        self.packed_on_device = bool(o.value)       # pack_device.hip built it (else the host packer)
 
     def free(self):
         if self.handle:

@@ -324,11 +324,17 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
         runner.run([file_of(i) for i in range(a.warmup)], ref_len=L)
     runner.seconds = {k: 0.0 for k in runner.seconds}
     runner.bytes = {k: 0 for k in runner.bytes}
+    ctx.profile(True)                                            # HIP events around every kernel of the cold path
     fence()
     t0 = time.perf_counter()
     fastas = runner.run([file_of(i) for i in range(a.steps)], names=["S%d" % (i % len(paths)) for i in range(a.steps)], ref_len=L)
     fence()
     dt = time.perf_counter() - t0
+    cold = {}
+    for name, kid in (("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK), ("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL)):
+        m, k = ctx.profile_get(kid)
+        cold[name] = {"us_per_bam": 1e3 * m / max(1, a.steps), "launches": k}
+    ctx.profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -357,6 +363,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
                    "device_bytes_per_bam": runner.bytes["device"] // max(1, a.steps),
                    "input_generation_seconds_outside_clock": t_gen},
         "e2e_stage_busy_seconds_per_bam": {k: v / a.steps for k, v in runner.seconds.items()},
+        "cold_kernels": cold,
     }
 
     # ---- one BAM at a time, nothing overlapped ---------------------------------------------------------

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     __shared__ uint2 s_w[PB / 64];
     const int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x;
     uint32_t word = 0, nwords = 0;
+    unsigned long long my_alg = 0;
+    int32_t my_end = 0;
     if (i < s.n) {
         const ReadView v = view(s, i);
         bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
                 else {
                     word = (uint32_t)len | (simple ? 0u : INFO_PROJ) | INFO_KEPT | (simple ? (uint32_t)y0 << 12 : 0u);
                     nwords = words_of((uint32_t)len);
-                    atomicAdd(&tot->alg_bytes, (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2));
-                    atomicMax(&tot->max_end, (int32_t)end);
+                    my_alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
+                    my_end = (int32_t)end;
                 }
             }
         }
@@ -171,6 +173,16 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     }
     const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
     if (threadIdx.x == PB - 1) blk_sum[blockIdx.x] = incl;
+    // algorithmic bytes and extent: one atomic per wave, not per read
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_alg += (unsigned long long)__shfl_xor((long long)my_alg, d, 64);
+        my_end = max(my_end, __shfl_xor(my_end, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && my_alg) {
+        atomicAdd(&tot->alg_bytes, my_alg);
+        atomicMax(&tot->max_end, my_end);
+    }
 }
 
 // ---- 2: exclusive scan of the workgroup sums (one workgroup, any number of entries) ---------------------------------

@@ -15,8 +15,8 @@
  * aborts across this boundary.
  *
  * Threading: one context per device/stream; contexts are independent; a single
- * context is not thread-safe.  Host-only entry points (tcmi_consensus_walk,
- * tcmi_bam_*, tcmi_pack_*) are re-entrant and need no GPU.
+ * context is not thread-safe.  Host-only entry points (tcmi_consensus_walk, tcmi_modal_tokens,
+ * tcmi_bam_*) are re-entrant and need no GPU; tcmi_bamfile_read needs the HIP runtime (pinned memory).
  */
 #ifndef TCMI_H
 #define TCMI_H
@@ -272,6 +272,24 @@ int  tcmi_bam_header(const tcmi_bam *bam, int32_t *n_ref, const char **ref0_name
 int  tcmi_bam_info(const tcmi_bam *bam, int64_t *n_reads, int32_t *sorted, int64_t *file_bytes,
                    int64_t *inflated_bytes, int64_t *n_blocks, int64_t *n_cigar, int64_t *n_qual);
 const char *tcmi_bam_text(const tcmi_bam *bam);    /* SAM header text, owned by bam                */
+
+/* ---- BAM decoded ON THE DEVICE (the default file path; the host reader above stays for files it does not take) ----
+ * tcmi_bamfile_read: HOST — file bytes into pinned memory, BGZF block table, BAM header (only the leading blocks the
+ * header occupies are inflated on the host).  tcmi_readset_from_bamfile: the compressed bytes cross PCIe, HIP kernels
+ * inflate every BGZF block (one wavefront per block), follow the record chain, and pack the reads for the tally —
+ * the host never sees a decoded read.  Returns TCMI_E_UNSUPPORTED for files that need the host reader
+ * (records straddling BGZF blocks — htslib never writes those —, reads spanning more than 512 positions, positions
+ * beyond 2^29): fall back to tcmi_bam_load + tcmi_readset_upload.                                                  */
+typedef struct tcmi_bamfile tcmi_bamfile;
+int  tcmi_bamfile_read(const char *path, tcmi_bamfile **out);
+int  tcmi_bamfile_free(tcmi_bamfile *f);
+int  tcmi_bamfile_info(const tcmi_bamfile *f, int64_t *file_bytes, int64_t *inflated_bytes, int64_t *n_blocks, int32_t *n_ref,
+                       const char **ref0_name, int64_t *ref0_len);
+const char *tcmi_bamfile_text(const tcmi_bamfile *f);
+int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads);
+/* for tests and tools: the device-inflated stream and the record offsets copied back to the host */
+int  tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *stream, int64_t stream_cap,
+                                 uint64_t *rec_off, int64_t rec_cap, int64_t *n_rec);
 
 #ifdef __cplusplus
 }

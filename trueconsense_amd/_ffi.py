@@ -84,6 +84,12 @@ _SIGS = {
     "tcmi_bam_header": (_int, [_vp, _P(_i32), _P(C.c_char_p), _P(_i64)]),
     "tcmi_bam_info": (_int, [_vp, _P(_i64), _P(_i32), _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "tcmi_bam_text": (C.c_char_p, [_vp]),
+    "tcmi_bamfile_read": (_int, [C.c_char_p, _P(_vp)]),
+    "tcmi_bamfile_free": (_int, [_vp]),
+    "tcmi_bamfile_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i32), _P(C.c_char_p), _P(_i64)]),
+    "tcmi_bamfile_text": (C.c_char_p, [_vp]),
+    "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
+    "tcmi_bamfile_decode_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _P(_i64)]),
 }
 
 _lib = None

@@ -1,0 +1,714 @@
+// bam_device.hip — DEVICE: a BAM file's BGZF blocks -> the inflated BAM byte stream + the offset of every alignment
+// record, in HBM, without the host ever decoding the file (pysam / htslib's role for indexing.py:19,96-100; wire format
+// SAM spec §4.1 BGZF, §4.2 BAM, RFC 1951 DEFLATE).
+//
+// The host only reads the file, walks the gzip member headers (18 bytes per block) and inflates the first block(s) far
+// enough to parse the BAM header; the compressed bytes (a few MB .. tens of MB) cross PCIe once.
+//
+//   bgzf_inflate   ONE WAVEFRONT PER BGZF BLOCK (blocks are independent deflate streams of <= 64 KiB).  All decoder state
+//                  is wave-uniform: the bit buffer, the Huffman root tables (10 / 9 bits, in LDS, built in parallel from
+//                  the canonical code: every lane decodes its table indices bit by bit), the output position.  Literals
+//                  and LZ77 matches go through a 32 KiB LDS ring (the deflate window); a match is copied by all 64 lanes
+//                  at once; finished 4 KiB segments are flushed to HBM with 16-byte stores.  While it inflates, the wave
+//                  also follows the chain of BAM records through its block (block_size fields, read from the ring as soon
+//                  as they are complete) and lists the record starts: htslib-written BAMs start every BGZF block on a
+//                  record boundary, which the chain check (`overshoot` of a block = 0) verifies; files that do not are
+//                  left to the host reader.
+//   rec_compact    per-block record lists -> one dense array of record offsets (block scan + copy)
+//
+// Serial-latency-bound bit / byte work, not HBM-bound and not a contraction: no MFMA.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tcmi_internal.h"
+
+namespace {
+
+constexpr int WIN = 32768, WMASK = WIN - 1;     // LDS ring = the deflate window
+constexpr int SEG = 4096;                       // flush granularity
+constexpr int LL_ROOT = 10, D_ROOT = 9, CL_ROOT = 7;
+constexpr int MAX_REC_PER_BLOCK = 65536 / 36 + 2;   // a record is at least 36 bytes (block_size + 32 fixed + 1 name byte ..)
+
+struct BlockDesc {
+    uint64_t cin;        // first byte of the deflate payload in the file
+    uint64_t uout;       // first byte of its output in the inflated stream
+    uint32_t clen;       // payload bytes
+    uint32_t ulen;       // ISIZE
+    int32_t entry;       // offset of the first record start inside this block (>= 0), or -1: no record walk (header blocks)
+    uint32_t pad_;
+};
+
+// status word of a block
+enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_BAD_LENGTH = 2, ST_BAD_RECORD = 3 };
+
+__constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InflateArgs {
+    const uint32_t *__restrict__ file32;     // the file as 4-byte words (16-byte aligned base, >= 64 bytes of slack behind it)
+    const BlockDesc *blocks;
+    uint8_t *out;               // inflated stream
+    uint32_t *rec_slot;         // [n_blocks][MAX_REC_PER_BLOCK]: record starts relative to the block's first byte
+    uint32_t *n_rec;            // [n_blocks]
+    int32_t *overshoot;         // [n_blocks]: bytes by which the block's last record runs into the next block
+    uint32_t *status;           // [n_blocks]
+    int32_t n_blocks;
+};
+
+struct Bits {                   // wave-uniform bit reader over the file's dwords
+    const uint32_t *__restrict__ w;
+    uint64_t idx;               // next dword to load
+    uint64_t bb;
+    int bc;
+};
+
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ inline void refill(Bits &b)
+{
+    if (b.bc <= 32) {
+        b.bb |= (uint64_t)b.w[b.idx] << b.bc;
+        ++b.idx;
+        b.bc += 32;
+    }
+}
+__device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
+{
+    const uint32_t v = (uint32_t)b.bb & ((1u << n) - 1u);
+    b.bb >>= n;
+    b.bc -= n;
+    return v;
+}
+
+// canonical Huffman decode of the bits in `v` (first stream bit = bit 0), at most `maxlen` bits: puff.c's loop
+__device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint32_t v, int maxlen, int *nbits)
+{
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= maxlen; ++len) {
+        code |= (int)(v & 1u);
+        v >>= 1;
+        const int c = cnt[len];
+        if (code - c < first) { *nbits = len; return sym[index + (code - first)]; }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    *nbits = 0;
+    return -1;
+}
+
+// lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table (entry = nbits | symbol << 4; 0 = not in
+// the root: longer than `root` bits or no such code).  Returns false for an over-subscribed code.
+__device__ inline bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, uint16_t *tab, int root)
+{
+    const int lane = threadIdx.x;
+    __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
+    if (lane < 16) cnt[lane] = 0;
+    __syncthreads();
+    // histogram of the code lengths: one ballot per length and group of 64 symbols (uniform results)
+    for (int g = 0; g < n; g += 64) {
+        const int l = g + lane < n ? lens[g + lane] : 0;
+        for (int len = 1; len <= 15; ++len) {
+            const unsigned long long m = __ballot(l == len);
+            if (lane == 0 && m) cnt[len] += (uint16_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    // offsets of each length in the sorted symbol array; over-subscription check
+    int left = 1, off = 0;
+    bool ok = true;
+    for (int len = 1; len <= 15; ++len) {
+        const int c = cnt[len];
+        left = (left << 1) - c;
+        if (left < 0) ok = false;
+        if (lane == 0) nxt[len] = (uint16_t)off;
+        off += c;
+    }
+    __syncthreads();
+    // rank of every symbol among those of its length, in symbol order -> its slot in the sorted array
+    for (int g = 0; g < n; g += 64) {
+        const int l = g + lane < n ? lens[g + lane] : 0;
+        for (int len = 1; len <= 15; ++len) {
+            const unsigned long long m = __ballot(l == len);
+            if (!m) continue;
+            const int base = nxt[len];
+            __syncthreads();
+            if (l == len) sym[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(g + lane);
+            if (lane == 0) nxt[len] = (uint16_t)(base + __popcll(m));
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // root table: every lane decodes its indices
+    for (int i = lane; i < (1 << root); i += 64) {
+        int nb;
+        const int s = slow_decode(cnt, sym, (uint32_t)i, root, &nb);
+        tab[i] = s >= 0 ? (uint16_t)(nb | (s << 4)) : (uint16_t)0;
+    }
+    __syncthreads();
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN];
+    __shared__ uint16_t s_ll[1 << LL_ROOT];
+    __shared__ uint16_t s_dt[1 << D_ROOT];
+    __shared__ uint16_t s_cl[1 << CL_ROOT];
+    __shared__ uint8_t s_lens[320];             // literal/length code lengths [0, 288), distance code lengths [288, 320)
+    __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
+    __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
+    __shared__ uint8_t s_cll[19];
+
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    if (blk >= a.n_blocks) return;
+    const BlockDesc d = a.blocks[blk];
+    const uint32_t ulen = d.ulen;
+    uint8_t *out = a.out + d.uout;
+    uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
+
+    Bits b;
+    b.w = a.file32;
+    b.idx = d.cin >> 2;
+    b.bb = 0;
+    b.bc = 0;
+    {   // the payload starts at any byte: drop the bytes in front of it from the first dword
+        const int skip = (int)(d.cin & 3) * 8;
+        b.bb = (uint64_t)(b.w[b.idx] >> skip);
+        b.bc = 32 - skip;
+        ++b.idx;
+    }
+    const uint64_t idx_end = ((d.cin + d.clen + 3) >> 2) + 2;      // reading further than this means a corrupt stream
+
+    uint32_t op = 0;                    // bytes produced
+    uint32_t flushed = 0;               // bytes already written to HBM (multiple of SEG)
+    uint32_t err = ST_OK;
+    // the chain of BAM records through this block
+    uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFFFu;
+    uint32_t n_rec = 0;
+
+    auto flush_segments = [&]() {
+        while (op - flushed >= SEG) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & WMASK));
+            uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);          // uout is a multiple of 16 (host pads blocks)
+#pragma unroll
+            for (int k = 0; k < SEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+            flushed += SEG;
+        }
+    };
+    auto follow_records = [&]() {       // list every record start whose block_size field is complete
+        while (next_rec != 0xFFFFFFFFu && next_rec + 4 <= op && next_rec < ulen) {
+            const uint32_t bs = (uint32_t)s_win[next_rec & WMASK] | ((uint32_t)s_win[(next_rec + 1) & WMASK] << 8) |
+                                ((uint32_t)s_win[(next_rec + 2) & WMASK] << 16) | ((uint32_t)s_win[(next_rec + 3) & WMASK] << 24);
+            const uint32_t ubs = uni(bs);
+            if (ubs < 32u || ubs > (1u << 28) || n_rec >= (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFFFu; break; }
+            if (lane == 0) slots[n_rec] = next_rec;
+            ++n_rec;
+            next_rec += 4u + ubs;
+        }
+    };
+
+    bool last = false;
+    while (!last && err == ST_OK) {
+        if (b.idx > idx_end) { err = ST_BAD_STREAM; break; }
+        refill(b);
+        last = take(b, 1) != 0;
+        const uint32_t type = take(b, 2);
+        if (type == 0) {
+            // ---- stored block: byte-align, LEN / NLEN, LEN raw bytes ---------------------------------------------
+            take(b, b.bc & 7);
+            refill(b);
+            const uint32_t len = take(b, 16);
+            refill(b);
+            const uint32_t nlen = take(b, 16);
+            if ((len ^ nlen) != 0xFFFFu || op + len > ulen) { err = ST_BAD_STREAM; break; }
+            // byte address of the raw data: what the bit buffer holds beyond it is dropped
+            const uint64_t at = b.idx * 4 - (uint64_t)(b.bc >> 3);
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(b.w) + at;
+            uint32_t done = 0;
+            while (done < len) {
+                const uint32_t n = min(len - done, (uint32_t)SEG - (op & (SEG - 1)));
+                for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & WMASK] = src[done + i];
+                op += n;
+                done += n;
+                follow_records();
+                flush_segments();
+            }
+            const uint64_t nat = at + len;
+            b.idx = nat >> 2;
+            const int skip = (int)(nat & 3) * 8;
+            b.bb = (uint64_t)(b.w[b.idx] >> skip);
+            b.bc = 32 - skip;
+            ++b.idx;
+            continue;
+        }
+        if (type == 3) { err = ST_BAD_STREAM; break; }
+        // ---- code lengths of this block ----------------------------------------------------------------------------
+        int nlen = 288, ndist = 32;
+        if (type == 1) {
+            __syncthreads();
+            for (int i = lane; i < 320; i += 64) s_lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+        } else {
+            refill(b);
+            nlen = (int)take(b, 5) + 257;
+            ndist = (int)take(b, 5) + 1;
+            const int ncode = (int)take(b, 4) + 4;
+            if (nlen > 286 || ndist > 30) { err = ST_BAD_STREAM; break; }
+            __syncthreads();
+            if (lane < 19) s_cll[lane] = 0;
+            __syncthreads();
+            for (int i = 0; i < ncode; ++i) {
+                refill(b);
+                const uint32_t v = take(b, 3);
+                if (lane == 0) s_cll[CL_ORDER[i]] = (uint8_t)v;
+            }
+            if (!build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT)) { err = ST_BAD_STREAM; break; }
+            for (int i = lane; i < 320; i += 64) s_lens[i] = 0;
+            __syncthreads();
+            int got = 0, prev = 0;
+            while (got < nlen + ndist) {
+                refill(b);
+                const uint32_t e = uni(s_cl[(uint32_t)b.bb & ((1u << CL_ROOT) - 1u)]);
+                const int nb = (int)(e & 15u), sym = (int)(e >> 4);
+                if (nb == 0) { err = ST_BAD_STREAM; break; }
+                take(b, nb);
+                int rep = 1, val = sym;
+                if (sym == 16) { if (got == 0) { err = ST_BAD_STREAM; break; } rep = 3 + (int)take(b, 2); val = prev; }
+                else if (sym == 17) { rep = 3 + (int)take(b, 3); val = 0; }
+                else if (sym == 18) { rep = 11 + (int)take(b, 7); val = 0; }
+                if (got + rep > nlen + ndist) { err = ST_BAD_STREAM; break; }
+                // literal/length lengths go to [0, nlen), distance lengths to [288, 288 + ndist)
+                if (val != 0 && lane < rep) {
+                    const int k = got + lane;
+                    s_lens[k < nlen ? k : 288 + (k - nlen)] = (uint8_t)val;
+                }
+                got += rep;
+                prev = val;
+            }
+            if (err != ST_OK) break;
+            __syncthreads();
+            if (uni(s_lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
+        }
+        if (!build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT)) { err = ST_BAD_STREAM; break; }
+        if (!build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT)) { err = ST_BAD_STREAM; break; }
+
+        // ---- symbols -------------------------------------------------------------------------------------------------
+        for (;;) {
+            refill(b);
+            if (b.idx > idx_end) { err = ST_BAD_STREAM; break; }
+            uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
+            int nb = (int)(e & 15u), sym = (int)(e >> 4);
+            if (nb == 0) {                      // a code longer than the root table
+                sym = slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15, &nb);
+                sym = (int)uni((uint32_t)sym);
+                nb = (int)uni((uint32_t)nb);
+                if (sym < 0) { err = ST_BAD_STREAM; break; }
+            }
+            take(b, nb);
+            if (sym < 256) {
+                if (op >= ulen) { err = ST_BAD_LENGTH; break; }
+                if (lane == 0) s_win[op & WMASK] = (uint8_t)sym;
+                ++op;
+            } else if (sym == 256) {
+                break;
+            } else {
+                const int s = sym - 257;
+                if (s > 28) { err = ST_BAD_STREAM; break; }
+                int len;
+                if (s < 8) len = 3 + s;
+                else if (s == 28) len = 258;
+                else { const int eb = (s >> 2) - 1; len = 3 + ((4 + (s & 3)) << eb) + (int)take(b, eb); }
+                refill(b);
+                e = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
+                nb = (int)(e & 15u);
+                int ds = (int)(e >> 4);
+                if (nb == 0) {
+                    ds = slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15, &nb);
+                    ds = (int)uni((uint32_t)ds);
+                    nb = (int)uni((uint32_t)nb);
+                    if (ds < 0) { err = ST_BAD_STREAM; break; }
+                }
+                take(b, nb);
+                if (ds > 29) { err = ST_BAD_STREAM; break; }
+                uint32_t dist;
+                if (ds < 4) dist = 1u + (uint32_t)ds;
+                else {
+                    const int eb = (ds >> 1) - 1;
+                    refill(b);
+                    dist = 1u + ((2u + (uint32_t)(ds & 1)) << eb) + take(b, eb);
+                }
+                if (dist > op || op + (uint32_t)len > ulen) { err = dist > op ? ST_BAD_STREAM : ST_BAD_LENGTH; break; }
+                // the match: all lanes copy; with dist < len the pattern of the last `dist` bytes repeats
+                if (dist >= (uint32_t)len) {
+                    for (int i = lane; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op - dist + i) & WMASK];
+                } else {
+                    const float inv = 1.0f / (float)dist;
+                    for (int i = lane; i < len; i += 64) {
+                        int qd = (int)((float)i * inv);
+                        int r = i - qd * (int)dist;
+                        if (r < 0) r += (int)dist;
+                        if (r >= (int)dist) r -= (int)dist;
+                        s_win[(op + i) & WMASK] = s_win[(op - dist + r) & WMASK];
+                    }
+                }
+                op += (uint32_t)len;
+            }
+            if (next_rec + 4 <= op) follow_records();
+            if (op - flushed >= SEG) flush_segments();
+        }
+    }
+    if (err == ST_OK && op != ulen) err = ST_BAD_LENGTH;
+    // the tail: whole 16-byte pieces, then bytes
+    if (err == ST_OK) {
+        follow_records();
+        flush_segments();
+        const uint32_t rest = op - flushed;
+        for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & WMASK];
+    }
+    if (lane == 0) {
+        a.status[blk] = err;
+        a.n_rec[blk] = n_rec;
+        // a block that is walked must end on a record boundary, or say by how much its last record runs over
+        a.overshoot[blk] = d.entry >= 0 && next_rec != 0xFFFFFFFFu ? (int32_t)(next_rec - ulen) : 0;
+    }
+}
+
+// per-block record lists -> dense offsets into the stream; base[b] = exclusive scan of n_rec (done by one workgroup first)
+__global__ __launch_bounds__(1024) void rec_scan(const uint32_t *n_rec, uint64_t *base, int32_t n_blocks, unsigned long long *total)
+{
+    __shared__ unsigned long long s[1024];
+    const int t = threadIdx.x;
+    const int per = (n_blocks + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blocks);
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += n_rec[b];
+    s[t] = sum;
+    __syncthreads();
+    for (int dd = 1; dd < 1024; dd <<= 1) {
+        const unsigned long long x = t >= dd ? s[t - dd] : 0;
+        __syncthreads();
+        s[t] += x;
+        __syncthreads();
+    }
+    unsigned long long run = s[t] - sum;
+    for (int b = b0; b < b1; ++b) { base[b] = run; run += n_rec[b]; }
+    if (t == 1023) *total = s[1023];
+}
+
+__global__ __launch_bounds__(256) void rec_compact(const BlockDesc *blocks, const uint32_t *rec_slot, const uint32_t *n_rec,
+                                                   const uint64_t *base, uint64_t *rec_off)
+{
+    const int blk = blockIdx.x;
+    const uint32_t n = n_rec[blk];
+    const uint64_t b0 = base[blk], u0 = blocks[blk].uout;
+    const uint32_t *src = rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) rec_off[b0 + i] = u0 + src[i];
+}
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+} // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct tcmi_bamfile {                           // a BAM file's bytes in pinned host memory + what the host parsed of it
+    uint8_t *bytes = nullptr;                   // hipHostMalloc
+    size_t n_bytes = 0, cap = 0;
+    std::vector<BlockDesc> blocks;
+    size_t inflated = 0;                        // bytes of the stream as laid out on the device (blocks padded to 16 bytes)
+    std::string text;
+    std::vector<std::string> ref_name;
+    std::vector<int64_t> ref_len;
+    std::string path;
+};
+
+extern "C" {
+
+int tcmi_bamfile_free(tcmi_bamfile *f)
+{
+    if (!f) return TCMI_OK;
+    if (f->bytes) (void)hipHostFree(f->bytes);
+    delete f;
+    return TCMI_OK;
+}
+
+// Read the file into pinned memory, walk the BGZF block headers (RFC 1952 + the BC subfield) and parse the BAM header
+// (inflating, with zlib on this thread, only as many leading blocks as the header occupies).
+int tcmi_bamfile_read(const char *path, tcmi_bamfile **out)
+{
+    if (!path || !out) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    *out = nullptr;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return tcmi_fail(nullptr, TCMI_E_IO, "cannot open %s", path);
+    std::fseek(fp, 0, SEEK_END);
+    const long sz = std::ftell(fp);
+    std::fseek(fp, 0, SEEK_SET);
+    if (sz < 0) { std::fclose(fp); return tcmi_fail(nullptr, TCMI_E_IO, "cannot size %s", path); }
+    tcmi_bamfile *f = new tcmi_bamfile();
+    f->path = path;
+    f->n_bytes = (size_t)sz;
+    f->cap = ((size_t)sz + 256 + 15) & ~(size_t)15;
+    if (hipHostMalloc((void **)&f->bytes, f->cap, hipHostMallocDefault) != hipSuccess) {
+        std::fclose(fp);
+        delete f;
+        (void)hipGetLastError();
+        return tcmi_fail(nullptr, TCMI_E_NOMEM, "hipHostMalloc(%zu) for %s failed (is a GPU present?)", (size_t)sz + 256, path);
+    }
+    const size_t got = sz ? std::fread(f->bytes, 1, (size_t)sz, fp) : 0;
+    std::fclose(fp);
+    std::memset(f->bytes + f->n_bytes, 0, f->cap - f->n_bytes);
+    auto bail = [&](int code, const char *what, size_t at) {
+        tcmi_bamfile_free(f);
+        return tcmi_fail(nullptr, code, "%s: %s at byte %zu", path, what, at);
+    };
+    if (got != (size_t)sz) return bail(TCMI_E_IO, "short read", got);
+    // ---- block headers ----
+    size_t off = 0, uout = 0;
+    while (off < f->n_bytes) {
+        if (f->n_bytes - off < 18) return bail(TCMI_E_FORMAT, "truncated BGZF block header", off);
+        const uint8_t *h = f->bytes + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return bail(TCMI_E_FORMAT, "not a BGZF block (is the file a BAM?)", off);
+        const size_t xlen = rd16(h + 10);
+        if (f->n_bytes - off < 12 + xlen) return bail(TCMI_E_FORMAT, "truncated BGZF extra field", off);
+        size_t bsize = 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *s = h + 12 + x;
+            const size_t slen = rd16(s + 2);
+            if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (size_t)rd16(s + 4) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || f->n_bytes - off < bsize) return bail(TCMI_E_FORMAT, "bad BGZF block size", off);
+        BlockDesc b;
+        b.cin = off + 12 + xlen;
+        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
+        b.ulen = rd32(h + bsize - 4);
+        b.uout = uout;
+        b.entry = 0;
+        b.pad_ = 0;
+        if (b.ulen > 65536) return bail(TCMI_E_FORMAT, "BGZF block inflates to more than 64 KiB", off);
+        uout += ((size_t)b.ulen + 15) & ~(size_t)15;            // every block's output starts 16-byte aligned on the device
+        off += bsize;
+        f->blocks.push_back(b);
+    }
+    f->inflated = uout;
+    // ---- BAM header: inflate leading blocks on this thread until it is complete ----
+    std::vector<uint8_t> head;
+    size_t nb = 0;
+    auto more = [&]() -> bool {
+        if (nb >= f->blocks.size()) return false;
+        const BlockDesc &b = f->blocks[nb];
+        const size_t at = head.size();
+        head.resize(at + b.ulen);
+        if (b.ulen) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = f->bytes + b.cin; zs.avail_in = b.clen;
+            zs.next_out = head.data() + at; zs.avail_out = b.ulen;
+            const int rc = inflate(&zs, Z_FINISH);
+            const bool ok = rc == Z_STREAM_END && zs.total_out == b.ulen;
+            inflateEnd(&zs);
+            if (!ok) return false;
+        }
+        ++nb;
+        return true;
+    };
+    auto need = [&](size_t k) { while (head.size() < k) if (!more()) return false; return true; };
+    if (!need(12) || std::memcmp(head.data(), "BAM\1", 4) != 0) return bail(TCMI_E_FORMAT, "BAM magic missing", 0);
+    const size_t l_text = rd32(head.data() + 4);
+    if (!need(12 + l_text)) return bail(TCMI_E_FORMAT, "truncated header text", 8);
+    f->text.assign((const char *)head.data() + 8, l_text);
+    size_t o = 8 + l_text;
+    const size_t n_ref = rd32(head.data() + o);
+    o += 4;
+    for (size_t r = 0; r < n_ref; ++r) {
+        if (!need(o + 4)) return bail(TCMI_E_FORMAT, "truncated reference list", o);
+        const size_t l_name = rd32(head.data() + o);
+        o += 4;
+        if (!need(o + l_name + 4)) return bail(TCMI_E_FORMAT, "truncated reference name", o);
+        f->ref_name.emplace_back((const char *)head.data() + o, l_name ? l_name - 1 : 0);
+        o += l_name;
+        f->ref_len.push_back((int64_t)rd32(head.data() + o));
+        o += 4;
+    }
+    // records start `o` bytes into the stream: in block k at offset o - (inflated bytes of the blocks before it)
+    size_t before = 0;
+    size_t k = 0;
+    for (; k < f->blocks.size(); ++k) {
+        if (o < before + f->blocks[k].ulen) break;
+        f->blocks[k].entry = -1;                                  // header only (or empty)
+        before += f->blocks[k].ulen;
+    }
+    if (k < f->blocks.size()) f->blocks[k].entry = (int32_t)(o - before);
+    *out = f;
+    return TCMI_OK;
+}
+
+int tcmi_bamfile_info(const tcmi_bamfile *f, int64_t *file_bytes, int64_t *inflated_bytes, int64_t *n_blocks, int32_t *n_ref,
+                      const char **ref0_name, int64_t *ref0_len)
+{
+    if (!f) return tcmi_fail(nullptr, TCMI_E_ARG, "bamfile is NULL");
+    if (file_bytes) *file_bytes = (int64_t)f->n_bytes;
+    if (inflated_bytes) { int64_t s = 0; for (const auto &b : f->blocks) s += b.ulen; *inflated_bytes = s; }
+    if (n_blocks) *n_blocks = (int64_t)f->blocks.size();
+    if (n_ref) *n_ref = (int32_t)f->ref_name.size();
+    if (ref0_name) *ref0_name = f->ref_name.empty() ? "" : f->ref_name[0].c_str();
+    if (ref0_len) *ref0_len = f->ref_len.empty() ? 0 : f->ref_len[0];
+    return TCMI_OK;
+}
+
+const char *tcmi_bamfile_text(const tcmi_bamfile *f) { return f ? f->text.c_str() : ""; }
+
+} // extern "C"
+
+// ---- device decode: H2D of the compressed file, bgzf_inflate, chain check, dense record offsets (all in the context's arena) ----
+namespace {
+struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; };
+
+int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
+{
+    const size_t nb = f->blocks.size();
+    if (nb == 0) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: no BGZF blocks", f->path.c_str());
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // bounds on the records for the arena: a record takes at least 36 bytes of the stream; reserve for records of >= 64 bytes
+    // (block_size + 32 fixed bytes + name + CIGAR + SEQ + QUAL of a 15-base read) — the arena cannot grow under live data
+    const size_t max_rec = f->inflated / 36 + 16;
+    const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
+    const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 64),
+                 b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 3 + al(nb * 8) + 256;
+    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 5 + al((guess_rec / 256 + 2) * 8) + 8192 + 16 * 256;
+    if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
+    uint8_t *d_file = (uint8_t *)tcmi_arena_take(ctx, b_file);
+    BlockDesc *d_desc = (BlockDesc *)tcmi_arena_take(ctx, b_desc);
+    uint8_t *d_out = (uint8_t *)tcmi_arena_take(ctx, b_out);
+    uint32_t *d_slot = (uint32_t *)tcmi_arena_take(ctx, b_slot);
+    uint32_t *d_nrec = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    int32_t *d_over = (int32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    uint32_t *d_stat = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    uint64_t *d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
+    unsigned long long *d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
+
+    TCMI_HIP(ctx, hipMemcpyAsync(d_file, f->bytes, f->cap, hipMemcpyHostToDevice, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(d_desc, f->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    InflateArgs a;
+    a.file32 = reinterpret_cast<const uint32_t *>(d_file);
+    a.blocks = d_desc; a.out = d_out; a.rec_slot = d_slot; a.n_rec = d_nrec; a.overshoot = d_over; a.status = d_stat;
+    a.n_blocks = (int32_t)nb;
+    (void)hipGetLastError();
+    tcmi_prof_begin(ctx, TCMI_K_INFLATE);
+    hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    tcmi_prof_end(ctx, TCMI_K_INFLATE);
+    TCMI_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, d_total);
+    TCMI_HIP(ctx, hipGetLastError());
+    // the verdict of every block comes back to the host: a few bytes per block
+    std::vector<uint32_t> stat(nb);
+    std::vector<int32_t> over(nb);
+    unsigned long long total = 0;
+    TCMI_HIP(ctx, hipMemcpyAsync(stat.data(), d_stat, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(over.data(), d_over, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t b = 0; b < nb; ++b)
+        if (stat[b] == ST_BAD_STREAM || stat[b] == ST_BAD_LENGTH)
+            return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: BGZF block %zu failed to inflate (deflate stream or ISIZE damaged)", f->path.c_str(), b);
+    // The record chain: every block was walked from offset 0 on the assumption that its predecessor ends on a record
+    // boundary.  In block order that assumption holds by induction up to the first block that runs over, so a bad
+    // record before that point is real, and anything after it is not to be trusted.
+    for (size_t b = 0; b < nb; ++b) {
+        if (stat[b] == ST_BAD_RECORD)
+            return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: alignment record with an impossible block_size in BGZF block %zu", f->path.c_str(), b);
+        if (over[b] != 0)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: a record straddles BGZF blocks %zu / %zu (the file was not written the htslib way): host reader",
+                             f->path.c_str(), b, b + 1);
+    }
+    if (total > max_rec) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: impossible record count", f->path.c_str());
+    const size_t n = (size_t)total;
+    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 5 + al((n / 256 + 2) * 8) + 8192 + 16 * 256;
+    if (need_rest > b_rest)
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: %zu very short records need more device scratch than was reserved: host reader", f->path.c_str(), n);
+    uint64_t *d_rec = (uint64_t *)tcmi_arena_take(ctx, al(n * 8 + 8));
+    tcmi_prof_begin(ctx, TCMI_K_RECORDS);
+    if (n) hipLaunchKernelGGL(rec_compact, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_desc, d_slot, d_nrec, d_base, d_rec);
+    tcmi_prof_end(ctx, TCMI_K_RECORDS);
+    TCMI_HIP(ctx, hipGetLastError());
+    D->d_out = d_out; D->d_rec = d_rec; D->d_desc = d_desc; D->n = n;
+    return TCMI_OK;
+}
+} // namespace
+
+extern "C" {
+
+// BAM bytes -> read set in HBM, everything on the device: H2D of the compressed file, bgzf_inflate, record index,
+// pack_device.hip.  TCMI_E_UNSUPPORTED when the file needs the host reader (records that straddle BGZF blocks, entries
+// longer than 512 positions, ...): the caller falls back to tcmi_bam_load + tcmi_readset_upload.
+int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads_out)
+{
+    if (!ctx || !f || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    *out = nullptr;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceBam D;
+    int rc = decode_on_device(ctx, f, &D);
+    if (rc) return rc;
+    if (n_reads_out) *n_reads_out = (int64_t)D.n;
+    tcmi_pack_src s = {};
+    s.stream = D.d_out; s.rec_off = D.d_rec; s.n = (int64_t)D.n; s.mode = 1; s.pos_shift = 0;
+    static std::atomic<uint64_t> next_uid{1ull << 40};
+    tcmi_readset *rs = new tcmi_readset();
+    rs->uid = next_uid.fetch_add(1);
+    rs->n_reads = (int64_t)D.n;
+    rs->device = ctx->device;
+    uint32_t why = 0;
+    rc = D.n ? tcmi_pack_on_device(ctx, &s, rs, &why) : TCMI_OK;
+    if (rc == TCMI_OK) {
+        rs->packed_on_device = 2;               // decoded AND packed on the device
+        *out = rs;
+        return TCMI_OK;
+    }
+    tcmi_readset_free(ctx, rs);
+    if (rc == TCMI_E_UNSUPPORTED)
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the device packer declined (flags 0x%x: long reads, far positions, a second reference or malformed reads): host reader",
+                         f->path.c_str(), why);
+    return rc;
+}
+
+// For tests and tools: the device-inflated stream (contiguous, as the file inflates) and the record offsets, back on the host.
+// stream_cap >= inflated bytes (tcmi_bamfile_info); rec_cap entries of rec_off.
+int tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *stream, int64_t stream_cap, uint64_t *rec_off,
+                                int64_t rec_cap, int64_t *n_rec)
+{
+    if (!ctx || !f || !stream || !n_rec) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceBam D;
+    int rc = decode_on_device(ctx, f, &D);
+    if (rc) return rc;
+    *n_rec = (int64_t)D.n;
+    if ((int64_t)D.n > rec_cap && rec_off) return tcmi_fail(ctx, TCMI_E_ARG, "rec_off holds %lld entries, the file has %zu records", (long long)rec_cap, D.n);
+    int64_t at = 0;
+    std::vector<uint64_t> rec(D.n);
+    if (D.n) TCMI_HIP(ctx, hipMemcpyAsync(rec.data(), D.d_rec, D.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (const BlockDesc &b : f->blocks) {      // the device keeps every block's output 16-byte aligned: close the gaps
+        if (at + (int64_t)b.ulen > stream_cap) return tcmi_fail(ctx, TCMI_E_ARG, "stream buffer too small");
+        if (b.ulen) TCMI_HIP(ctx, hipMemcpyAsync(stream + at, D.d_out + b.uout, b.ulen, hipMemcpyDeviceToHost, ctx->stream));
+        at += b.ulen;
+    }
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rec_off) {
+        // device offsets are in the padded layout: map them back to offsets in the contiguous stream
+        size_t k = 0;
+        int64_t contiguous = 0;
+        for (size_t i = 0; i < D.n; ++i) {
+            while (k + 1 < f->blocks.size() && rec[i] >= f->blocks[k].uout + (((uint64_t)f->blocks[k].ulen + 15) & ~15ull)) { contiguous += f->blocks[k].ulen; ++k; }
+            rec_off[i] = (uint64_t)contiguous + (rec[i] - f->blocks[k].uout);
+        }
+    }
+    return TCMI_OK;
+}
+
+} // extern "C"

@@ -30,15 +30,7 @@ constexpr int PB = 256;                          // lanes per workgroup of every
 constexpr int PK_CMAX = 3328;                    // most reads one pk_pack workgroup takes
 constexpr uint32_t NIB = 0x11111111u;
 
-struct PackSrc {
-    // mode 0: flat arrays (struct tcmi_reads on the device)
-    const int32_t *pos; const uint16_t *flag; const int32_t *l_qseq; const int32_t *tid;
-    const uint64_t *cigar_off; const uint32_t *cigar; const uint64_t *seq_off; const uint8_t *seq;
-    // mode 1: the inflated BAM stream and the offset of every record's block_size field
-    const uint8_t *stream; const uint64_t *rec_off;
-    int64_t n;
-    int32_t mode, pos_shift;
-};
+using PackSrc = tcmi_pack_src;
 
 struct ReadView {
     int32_t tid, pos, l_seq;

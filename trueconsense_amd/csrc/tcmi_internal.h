@@ -178,6 +178,16 @@ int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...);
 void tcmi_prof_begin(tcmi_ctx *ctx, int k);
 void tcmi_prof_end(tcmi_ctx *ctx, int k);
 
+// what the device packer reads (device pointers)
+struct tcmi_pack_src {
+    // mode 0: flat arrays (struct tcmi_reads on the device)
+    const int32_t *pos; const uint16_t *flag; const int32_t *l_qseq; const int32_t *tid;
+    const uint64_t *cigar_off; const uint32_t *cigar; const uint64_t *seq_off; const uint8_t *seq;
+    // mode 1: the inflated BAM stream and the offset of every record's block_size field (bam_device.hip)
+    const uint8_t *stream; const uint64_t *rec_off;
+    int64_t n;
+    int32_t mode, pos_shift;
+};
 // device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);

@@ -110,6 +110,13 @@ class Context:
         check(lib().tcmi_readset_upload_batch(self.handle, arr, len(structs), int(stride), C.byref(h)), self.handle)
         return ReadSet(self, h, (keep, structs))
 
+    def upload_bamfile(self, dbam):
+        """DeviceBam -> ReadSet: BGZF inflate, record index and packing all on the device."""
+        h, n = C.c_void_p(), C.c_int64(0)
+        check(lib().tcmi_readset_from_bamfile(self.handle, dbam.handle, C.byref(h), C.byref(n)), self.handle)
+        rs = ReadSet(self, h, None)
+        return rs
+
     def tally(self, reads, L=None, ref_len=0):
         """reads -> int32 [L,7] (coverage,A,T,C,G,X,I); L defaults to max(ref_len, read extent)."""
         r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)
@@ -412,6 +419,46 @@ class BamFile:
             pass
 
 
+class DeviceBam:
+    """A BAM file headed for the device decoder (tcmi_bamfile): the HOST side only reads the bytes into pinned memory,
+    walks the BGZF block headers and parses the BAM header; Context.upload_bamfile() inflates, indexes and packs it with
+    HIP kernels.  Raises TcmiError(E_UNSUPPORTED) there when the file needs the host reader (BamFile)."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        check(lib().tcmi_bamfile_read(str(path).encode(), C.byref(h)))
+        self.handle = h
+        self.filename = str(path)
+        fb, ib, nb, ln = (C.c_int64(0) for _ in range(4))
+        n_ref, name = C.c_int32(0), C.c_char_p()
+        check(lib().tcmi_bamfile_info(h, C.byref(fb), C.byref(ib), C.byref(nb), C.byref(n_ref), C.byref(name), C.byref(ln)))
+        self.file_bytes, self.inflated_bytes, self.n_blocks = fb.value, ib.value, nb.value
+        self.nreferences = n_ref.value
+        self.references = ((name.value or b"").decode(),) if n_ref.value else ()
+        self.lengths = (ln.value,) if n_ref.value else ()
+        self.text = (lib().tcmi_bamfile_text(h) or b"").decode("utf-8", "replace")
+
+    def decode_to_host(self, ctx):
+        """(for tests / tools) -> (inflated stream uint8, record offsets uint64), both produced by the device."""
+        stream = np.empty(max(1, self.inflated_bytes), np.uint8)
+        cap = self.inflated_bytes // 36 + 16
+        rec = np.empty(cap, np.uint64)
+        n = C.c_int64(0)
+        check(lib().tcmi_bamfile_decode_to_host(ctx.handle, self.handle, ptr(stream), stream.size, ptr(rec), cap, C.byref(n)), ctx.handle)
+        return stream[:self.inflated_bytes], rec[:n.value].copy()
+
+    def close(self):
+        if self.handle:
+            lib().tcmi_bamfile_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FileRunner:
     """BAM files -> consensus FASTA text (TrueConsense.py:212-264 for many inputs; BASELINE configs[1] / [3]).
 
@@ -424,24 +471,33 @@ class FileRunner:
         self.ctx, self.mincov, self.amb = ctx, int(mincov), bool(include_ambig)
         self.gff = {k: dict(r) for k, r in enumerate(gff_rows)}
         self.decoders, self.decode_threads, self.walkers = int(decoders), int(decode_threads), int(walkers)
+        self.device_decode = True       # BGZF inflate + record index on the GPU; files it does not take go to the host reader
         self.seconds = {"decode": 0.0, "upload": 0.0, "step": 0.0, "walk": 0.0}
         self.bytes = {"file": 0, "inflated": 0, "device": 0}
+        self.decoded_on = {"device": 0, "host": 0}
 
     def _load(self, path):
+        """Host stage of the decode: for the device decoder only the file read + BGZF block table + BAM header."""
         import time
         t = time.perf_counter()
-        bam = BamFile(path, threads=self.decode_threads)
+        bam = DeviceBam(path) if self.device_decode else BamFile(path, threads=self.decode_threads)
         return bam, time.perf_counter() - t
 
     def _walk(self, bam, name, plain, alt, flags):
         import time
-        from .Events import inserts_from_flags
+        from .Events import candidates_from_flags, inserts_from_flags
         from .Sequences import consensus_from_records
         t = time.perf_counter()
-        _, ins = inserts_from_flags(flags, bam)
+        if isinstance(bam, DeviceBam):
+            # the decoded reads never reached the host: decode here only if an insert candidate needs its tokens
+            path = bam.filename
+            bam.close()
+            bam = BamFile(path, threads=self.decode_threads) if candidates_from_flags(flags) else None
+        _, ins = inserts_from_flags(flags, bam) if bam is not None else (False, None)
         cons = consensus_from_records(plain, alt, flags, self.gff, ins, True)[0]
         text = ">%s mincov=%d\n%s\n" % (name, self.mincov, cons)          # Outputs.py:182-183
-        bam.close()
+        if bam is not None:
+            bam.close()
         return text, time.perf_counter() - t
 
     def run(self, paths, names=None, ref_len=0):
@@ -465,7 +521,21 @@ class FileRunner:
                     loads.append(dec.submit(self._load, paths[nxt]))
                     nxt += 1
                 t0 = time.perf_counter()
-                rs = self.ctx.upload(bam)
+                if isinstance(bam, DeviceBam):
+                    try:
+                        rs = self.ctx.upload_bamfile(bam)
+                        self.decoded_on["device"] += 1
+                    except _ffi.TcmiError as e:
+                        if e.code != _ffi.E_UNSUPPORTED:
+                            raise
+                        path = bam.filename
+                        bam.close()
+                        bam = BamFile(path, threads=self.decode_threads)      # the host reader takes it
+                        rs = self.ctx.upload(bam)
+                        self.decoded_on["host"] += 1
+                else:
+                    rs = self.ctx.upload(bam)
+                    self.decoded_on["host"] += 1
                 t1 = time.perf_counter()
                 L = max(int(ref_len), rs.max_end, 1)
                 plain, alt, flags, _ = self.ctx.step(rs, L, self.mincov, self.amb, want_counts=False)

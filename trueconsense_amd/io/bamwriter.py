@@ -26,8 +26,12 @@ def _reg2bin(beg, end):
     return 0
 
 
-def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, block=0xFF00):
-    """reads: dict with n_reads,pos,flag,l_qseq,cigar_off,cigar,seq_off,seq[,qual,qual_off,tid,mapq]."""
+def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, block=0xFF00, split_records=False, refs=None):
+    """reads: dict with n_reads,pos,flag,l_qseq,cigar_off,cigar,seq_off,seq[,qual,qual_off,tid,mapq].
+    Blocks are cut the way htslib cuts them (bgzf_flush_try): the header gets blocks of its own and a record that does not
+    fit into the current block starts the next one, so every BGZF block begins on a record boundary (only a record larger
+    than a block spans several).  split_records=True fills every block to the brim instead (records straddle blocks, as
+    some other writers do).  refs: [(name, length), ...] for more than one @SQ."""
     n = int(reads["n_reads"])
     pos, flag, lq = reads["pos"], reads["flag"], reads["l_qseq"]
     co, cg, so, sq = reads["cigar_off"], reads["cigar"], reads["seq_off"], reads["seq"]
@@ -36,16 +40,21 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
     if qual is not None and qoff is None:
         qoff = np.concatenate(([0], np.cumsum(np.asarray(lq, np.int64))))
     tid = reads.get("tid")
-    text = sam_text if sam_text is not None else "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (ref_name, ref_len)
-    tb, nb = text.encode(), ref_name.encode() + b"\0"
-    out = bytearray(b"BAM\1" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", 1) +
-                    struct.pack("<i", len(nb)) + nb + struct.pack("<i", ref_len))
+    refs = refs or [(ref_name, ref_len)]
+    text = sam_text if sam_text is not None else "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    tb = text.encode()
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(refs)))
+    for name, ln in refs:
+        nb = name.encode() + b"\0"
+        out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
     with open(path, "wb") as fh:
         def flush(final=False):
             nonlocal out
             while len(out) >= block or (final and out):
                 fh.write(_bgzf_block(bytes(out[:block]), level))
                 out = out[block:]
+        if not split_records:
+            flush(final=True)                       # the header never shares a block with records
         cg_b = np.ascontiguousarray(cg, "<u4").tobytes()
         sq_b = np.ascontiguousarray(sq, np.uint8).tobytes()
         q_b = np.ascontiguousarray(qual, np.uint8).tobytes() if qual is not None else None
@@ -65,9 +74,16 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
             rec = (struct.pack("<iiBBHHHIiii", t, p, len(name), 60, _reg2bin(max(p, 0), max(p, 0) + max(span, 1)), nc,
                                int(flag[i]), l, -1, -1, 0) + name + cg_b[4 * c0:4 * c1] +
                    sq_b[s0:s0 + (l + 1) // 2] + q)
-            out += struct.pack("<i", len(rec)) + rec
-            if len(out) >= 4 * block:
-                flush()
+            if split_records:
+                out += struct.pack("<i", len(rec)) + rec
+                if len(out) >= 4 * block:
+                    flush()
+            else:
+                if out and len(out) + 4 + len(rec) > block:
+                    flush(final=True)
+                out += struct.pack("<i", len(rec)) + rec
+                if len(out) >= block:               # a record larger than a block: spans several, the next record starts afresh
+                    flush(final=True)
         flush(final=True)
         fh.write(_EOF)
 
@@ -116,9 +132,13 @@ def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_le
     tb, nmb = text.encode(), ref_name.encode() + b"\0"
     head = (b"BAM\1" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", 1) + struct.pack("<i", len(nmb)) + nmb +
             struct.pack("<i", ref_len))
-    payload = head + rec.tobytes()
     block = 0xFF00
+    per = max(1, block // (4 + rec_len))            # whole records per block, as htslib cuts them
     with open(path, "wb") as fh:
-        for o in range(0, len(payload), block):
-            fh.write(_bgzf_block(payload[o:o + block], level))
+        for o in range(0, len(head), block):
+            fh.write(_bgzf_block(head[o:o + block], level))
+        flat = rec.reshape(-1)
+        step = per * (4 + rec_len)
+        for o in range(0, flat.size, step):
+            fh.write(_bgzf_block(flat[o:o + step].tobytes(), level))
         fh.write(_EOF)

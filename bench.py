@@ -227,7 +227,9 @@ def main():
     ap.add_argument("--decoders", type=int, default=0, help="BAMs being decoded at a time (0 = auto)")
     ap.add_argument("--decode-threads", type=int, default=0, help="native threads per BAM decode (0 = auto)")
     ap.add_argument("--walkers", type=int, default=2)
+    ap.add_argument("--gpu-streams", type=int, default=2, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
+    ap.add_argument("--host-decode", action="store_true", help="decode the BAMs on the host (tcmi_bam_load) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident kernel-rate leg")
     ap.add_argument("--only-resident", action="store_true", help="only the HBM-resident leg (short runs under rocprofv3)")
@@ -319,22 +321,30 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     file_of = lambda i: paths[i % len(paths)]
 
     # ---- headline: BAM files -> FASTA text, stages overlapped ------------------------------------------
-    runner = FileRunner(ctx, gff_rows, a.mincov, True, decoders=decoders, decode_threads=decode_threads, walkers=a.walkers)
+    runner = FileRunner(ctx, gff_rows, a.mincov, True, decoders=decoders, decode_threads=decode_threads, walkers=a.walkers,
+                        gpu_streams=a.gpu_streams)
+    runner.device_decode = not a.host_decode
     if a.warmup > 0:
         runner.run([file_of(i) for i in range(a.warmup)], ref_len=L)
     runner.seconds = {k: 0.0 for k in runner.seconds}
-    runner.bytes = {k: 0 for k in runner.bytes}
-    ctx.profile(True)                                            # HIP events around every kernel of the cold path
+    runner.decoded_on = {k: 0 for k in runner.decoded_on}
+    for c in runner.contexts:
+        c.profile(True)                                          # HIP events around every kernel of the cold path
     fence()
     t0 = time.perf_counter()
     fastas = runner.run([file_of(i) for i in range(a.steps)], names=["S%d" % (i % len(paths)) for i in range(a.steps)], ref_len=L)
     fence()
     dt = time.perf_counter() - t0
     cold = {}
-    for name, kid in (("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK), ("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL)):
-        m, k = ctx.profile_get(kid)
+    for name, kid in (("inflate", _ffi.K_INFLATE), ("records", _ffi.K_RECORDS), ("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK),
+                      ("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL)):
+        m = k = 0
+        for c in runner.contexts:
+            mm, kk = c.profile_get(kid)
+            m, k = m + mm, k + kk
         cold[name] = {"us_per_bam": 1e3 * m / max(1, a.steps), "launches": k}
-    ctx.profile(False)
+    for c in runner.contexts:
+        c.profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,19 +366,22 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
                                   ", indel carriers at CDS boundaries" if a.indels else "", len(paths), a.level,
                                   "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
                    "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
-                   "stages": "decode (file read + BGZF inflate + records, host: %d BAMs in flight x %d threads) -> upload "
-                             "(H2D + pack) -> HIP tally + call (records to pinned host memory) -> host walk + FASTA text "
-                             "(%d threads); stages of consecutive BAMs overlap" % (decoders, decode_threads, a.walkers),
-                   "bam_file_bytes": runner.bytes["file"] // max(1, a.steps), "bam_inflated_bytes": runner.bytes["inflated"] // max(1, a.steps),
-                   "device_bytes_per_bam": runner.bytes["device"] // max(1, a.steps),
+                   "stages": "read (file bytes into pinned memory, BGZF block table, BAM header; host, %d files in flight) -> "
+                             "upload (H2D of the COMPRESSED file, HIP: BGZF inflate + record chain + CIGAR projection / "
+                             "classification / bit-plane pack) -> HIP tally + call (records to pinned host memory) -> host walk + "
+                             "FASTA text (%d threads); stages of consecutive BAMs overlap; decoded on: %s"
+                             % (decoders, a.walkers, json.dumps(runner.decoded_on)),
+                   "bam_file_bytes": os.path.getsize(paths[0]),
                    "input_generation_seconds_outside_clock": t_gen},
         "e2e_stage_busy_seconds_per_bam": {k: v / a.steps for k, v in runner.seconds.items()},
         "cold_kernels": cold,
     }
 
     # ---- one BAM at a time, nothing overlapped ---------------------------------------------------------
-    single = FileRunner(ctx, gff_rows, a.mincov, True, decoders=1, decode_threads=min(16, cores), walkers=1)
+    single = FileRunner(ctx, gff_rows, a.mincov, True, decoders=1, decode_threads=min(16, cores), walkers=1, gpu_streams=1)
+    single.device_decode = not a.host_decode
     lat = []
+    single.run([file_of(0)], ref_len=L)                          # (its context's workspace and arena are allocated on first use)
     for i in range(3):
         single.seconds = {k: 0.0 for k in single.seconds}
         t1 = time.perf_counter()

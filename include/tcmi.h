@@ -291,6 +291,22 @@ int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readse
 int  tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *stream, int64_t stream_cap,
                                  uint64_t *rec_off, int64_t rec_cap, int64_t *n_rec);
 
+/* ---- BAM files -> FASTA text: native runner of the whole path for many inputs (TrueConsense.py:212-264 per file;
+ * BASELINE configs[1] / [3]).  Three stages on their own threads, consecutive BAMs overlapping: read (host: file bytes,
+ * block table, header), gpu (one thread per context: device decode + pack + tally + call; the host reader for files
+ * the device decoder declines), walk (host: insert tokens if a candidate exists, consensus walk, FASTA text).
+ *   out_text        n * stride bytes; text i (">name mincov=N\n<consensus>\n", Outputs.py:182-183) at out_text + i*stride
+ *   stage_seconds   [4] busy seconds summed over the items: read, decode + pack, step, walk (may be NULL)
+ *   decoded_on      [2] items decoded on the device / by the host reader (may be NULL)                                */
+typedef struct tcmi_filerunner tcmi_filerunner;
+int tcmi_filerunner_create(int device, int n_readers, int n_gpu, int n_walkers, int host_decode_threads, tcmi_filerunner **out);
+int tcmi_filerunner_destroy(tcmi_filerunner *r);
+int tcmi_filerunner_set_orfs(tcmi_filerunner *r, int32_t n_orf, const int64_t *start, const int64_t *end, const uint8_t *is_plus);
+tcmi_ctx *tcmi_filerunner_ctx(tcmi_filerunner *r, int k);
+int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
+                        int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
+                        int32_t *status, double *stage_seconds, int64_t *decoded_on);
+
 #ifdef __cplusplus
 }
 #endif

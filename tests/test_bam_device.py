@@ -79,6 +79,17 @@ def test_device_inflate_and_record_index_match_zlib(ctx, tmp_path):
     p = str(tmp_path / "fuzz.bam")
     bamwriter.write_bam(p, fuzz, "ref", 3000, level=4)
     check_decode(ctx, p).close()
+    # matches that reach back 10 - 30 KB (beyond the kernel's LDS ring): groups of reads with random qualities, repeated
+    grp = sy.make_reads(ref, 40, seed=6)
+    k = 50
+    far = {"n_reads": 40 * k, "pos": np.tile(grp["pos"], k), "flag": np.tile(grp["flag"], k), "l_qseq": np.tile(grp["l_qseq"], k),
+           "tid": np.zeros(40 * k, np.int32), "cigar_off": np.arange(40 * k + 1, dtype=np.uint64), "cigar": np.tile(grp["cigar"], k),
+           "seq_off": np.arange(40 * k + 1, dtype=np.uint64) * np.uint64(75), "seq": np.tile(grp["seq"], k),
+           "qual": np.tile(rng.integers(0, 42, 40 * 150).astype(np.uint8), k)}
+    for level in (6, 9):
+        p = str(tmp_path / ("far%d.bam" % level))
+        bamwriter.write_bam(p, far, "MN908947.3", len(ref), level=level)
+        check_decode(ctx, p).close()
     # no reads at all; one read
     empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v) for k, v in reads.items()}
     empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))

@@ -90,6 +90,11 @@ _SIGS = {
     "tcmi_bamfile_text": (C.c_char_p, [_vp]),
     "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
     "tcmi_bamfile_decode_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _P(_i64)]),
+    "tcmi_filerunner_create": (_int, [_int, _int, _int, _int, _int, _P(_vp)]),
+    "tcmi_filerunner_destroy": (_int, [_vp]),
+    "tcmi_filerunner_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "tcmi_filerunner_ctx": (_vp, [_vp, _int]),
+    "tcmi_filerunner_run": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -127,6 +127,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     c->upload_scratch = nullptr;
     tcmi_dev_arena_free(c->dev_arena);
     c->dev_arena = nullptr;
+    for (auto &b : c->blob_pool) (void)hipFree(b.p);
+    c->blob_pool.clear();
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -8,8 +8,10 @@
 //   bgzf_inflate   ONE WAVEFRONT PER BGZF BLOCK (blocks are independent deflate streams of <= 64 KiB).  All decoder state
 //                  is wave-uniform: the bit buffer, the Huffman root tables (10 / 9 bits, in LDS, built in parallel from
 //                  the canonical code: every lane decodes its table indices bit by bit), the output position.  Literals
-//                  and LZ77 matches go through a 32 KiB LDS ring (the deflate window); a match is copied by all 64 lanes
-//                  at once; finished 4 KiB segments are flushed to HBM with 16-byte stores.  While it inflates, the wave
+//                  and LZ77 matches go through an 8 KiB LDS ring of the most recent output (a match is copied by all 64
+//                  lanes at once; the rare match that reaches further back — the deflate window is 32 KiB — reads what was
+//                  already flushed); finished 2 KiB segments are flushed to HBM with 16-byte stores.  14 KiB of LDS per
+//                  wavefront: ten blocks in flight per CU hide each other's LDS / decode latencies.  While it inflates, the wave
 //                  also follows the chain of BAM records through its block (block_size fields, read from the ring as soon
 //                  as they are complete) and lists the record starts: htslib-written BAMs start every BGZF block on a
 //                  record boundary, which the chain check (`overshoot` of a block = 0) verifies; files that do not are
@@ -21,8 +23,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,8 +35,14 @@
 
 namespace {
 
-constexpr int WIN = 32768, WMASK = WIN - 1;     // LDS ring = the deflate window
-constexpr int SEG = 4096;                       // flush granularity
+#ifndef TCMI_INFLATE_WIN
+#define TCMI_INFLATE_WIN 8192
+#endif
+constexpr int WIN = TCMI_INFLATE_WIN, WMASK = WIN - 1;   // LDS ring: the most recent output.  The deflate window is 32 KiB: a match that
+                                                         // reaches further back than the ring reads what was already flushed to HBM
+constexpr int SEG = 2048;                       // flush granularity
+constexpr int NEAR = WIN - 264;                 // matches up to this distance are copied LDS -> LDS
+static_assert(SEG <= WIN - 528 && (WIN & (WIN - 1)) == 0 && WIN % SEG == 0, "a far match must find its source flushed");
 constexpr int LL_ROOT = 10, D_ROOT = 9, CL_ROOT = 7;
 constexpr int MAX_REC_PER_BLOCK = 65536 / 36 + 2;   // a record is at least 36 bytes (block_size + 32 fixed + 1 name byte ..)
 
@@ -60,19 +71,41 @@ struct InflateArgs {
     int32_t n_blocks;
 };
 
-struct Bits {                   // wave-uniform bit reader over the file's dwords
+#ifndef TCMI_INFLATE_INRING
+#define TCMI_INFLATE_INRING 512
+#endif
+constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input staged in LDS (two halves)
+
+struct Bits {                   // wave-uniform bit reader over the file's dwords, staged through an LDS ring
     const uint32_t *__restrict__ w;
-    uint64_t idx;               // next dword to load
+    uint32_t *ring;             // LDS [IN_RING]: dword k of the file sits in ring[k % IN_RING] while idx - IN_RING/2 <= k < hi
+    uint64_t idx;               // next dword to consume
+    uint64_t hi;                // dwords below this are in the ring
     uint64_t bb;
     int bc;
 };
+
+// one coalesced load (16 bytes per lane) refills the half of the ring that has been consumed
+__device__ inline void stage_input(Bits &b)
+{
+    constexpr int LANES = IN_RING / 2 / 4;      // lanes that carry 16 bytes each
+    const bool mine = (int)threadIdx.x < LANES;
+    uint4 v = {};
+    if (mine) v = reinterpret_cast<const uint4 *>(b.w + b.hi)[threadIdx.x];
+    __syncthreads();
+    if (mine) *reinterpret_cast<uint4 *>(b.ring + ((b.hi + 4 * threadIdx.x) & (IN_RING - 1))) = v;    // (hi is a multiple of 4: no uint4 wraps)
+    __syncthreads();
+    b.hi += IN_RING / 2;
+}
+static_assert(IN_RING / 2 / 4 <= 64 && IN_RING >= 64, "a half of the input ring is one load per lane");
 
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ inline void refill(Bits &b)
 {
     if (b.bc <= 32) {
-        b.bb |= (uint64_t)b.w[b.idx] << b.bc;
+        if (b.idx + IN_RING / 2 >= b.hi) stage_input(b);
+        b.bb |= (uint64_t)uni(b.ring[b.idx & (IN_RING - 1)]) << b.bc;
         ++b.idx;
         b.bc += 32;
     }
@@ -165,6 +198,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
     __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
     __shared__ uint8_t s_cll[19];
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[IN_RING];
 
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -176,15 +210,18 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 
     Bits b;
     b.w = a.file32;
-    b.idx = d.cin >> 2;
-    b.bb = 0;
-    b.bc = 0;
-    {   // the payload starts at any byte: drop the bytes in front of it from the first dword
-        const int skip = (int)(d.cin & 3) * 8;
-        b.bb = (uint64_t)(b.w[b.idx] >> skip);
+    b.ring = s_in;
+    auto seek = [&](uint64_t byte) {     // start reading bits at this byte of the file
+        b.idx = byte >> 2;
+        b.hi = b.idx & ~(uint64_t)3;     // (16-byte aligned loads)
+        stage_input(b);
+        stage_input(b);
+        const int skip = (int)(byte & 3) * 8;
+        b.bb = (uint64_t)(uni(b.ring[b.idx & (IN_RING - 1)]) >> skip);
         b.bc = 32 - skip;
         ++b.idx;
-    }
+    };
+    seek(d.cin);
     const uint64_t idx_end = ((d.cin + d.clen + 3) >> 2) + 2;      // reading further than this means a corrupt stream
 
     uint32_t op = 0;                    // bytes produced
@@ -241,12 +278,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 follow_records();
                 flush_segments();
             }
-            const uint64_t nat = at + len;
-            b.idx = nat >> 2;
-            const int skip = (int)(nat & 3) * 8;
-            b.bb = (uint64_t)(b.w[b.idx] >> skip);
-            b.bc = 32 - skip;
-            ++b.idx;
+            seek(at + len);
             continue;
         }
         if (type == 3) { err = ST_BAD_STREAM; break; }
@@ -346,7 +378,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 }
                 if (dist > op || op + (uint32_t)len > ulen) { err = dist > op ? ST_BAD_STREAM : ST_BAD_LENGTH; break; }
                 // the match: all lanes copy; with dist < len the pattern of the last `dist` bytes repeats
-                if (dist >= (uint32_t)len) {
+                if (dist > (uint32_t)NEAR) {
+                    // beyond the LDS ring: the source lies in a segment that is complete and was flushed right after the
+                    // symbol that completed it (same wavefront: its stores are ordered before this load)
+                    const uint8_t *src = out + (op - dist);
+                    for (int i = lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
+                } else if (dist >= (uint32_t)len) {
                     for (int i = lane; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op - dist + i) & WMASK];
                 } else {
                     const float inv = 1.0f / (float)dist;
@@ -419,7 +456,8 @@ inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct tcmi_bamfile {                           // a BAM file's bytes in pinned host memory + what the host parsed of it
     uint8_t *bytes = nullptr;                   // hipHostMalloc
-    size_t n_bytes = 0, cap = 0;
+    size_t n_bytes = 0, cap = 0;                // cap: bytes that go to the device (file + zeroed slack)
+    size_t pool_cap = 0;                        // bytes of the pinned allocation
     std::vector<BlockDesc> blocks;
     size_t inflated = 0;                        // bytes of the stream as laid out on the device (blocks padded to 16 bytes)
     std::string text;
@@ -428,12 +466,48 @@ struct tcmi_bamfile {                           // a BAM file's bytes in pinned 
     std::string path;
 };
 
+namespace {
+// pinned file buffers are kept for the next file: hipHostMalloc / hipHostFree cost about as much as reading 8 MB
+struct PinnedPool {
+    std::mutex mu;
+    struct Buf { uint8_t *p; size_t cap; };
+    std::vector<Buf> free_;
+    uint8_t *take(size_t want, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < free_.size(); ++k)
+                if (free_[k].cap >= want && free_[k].cap <= 2 * want + (1 << 20)) {
+                    uint8_t *p = free_[k].p;
+                    *cap = free_[k].cap;
+                    free_.erase(free_.begin() + (long)k);
+                    return p;
+                }
+        }
+        uint8_t *p = nullptr;
+        const size_t c = want + want / 8;
+        if (hipHostMalloc((void **)&p, c, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *cap = c;
+        return p;
+    }
+    void give(uint8_t *p, size_t cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_.size() < 8) { free_.push_back({p, cap}); return; }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool(); return *p; }   // (never destroyed: the HIP runtime may be gone by then)
+} // namespace
+
 extern "C" {
 
 int tcmi_bamfile_free(tcmi_bamfile *f)
 {
     if (!f) return TCMI_OK;
-    if (f->bytes) (void)hipHostFree(f->bytes);
+    if (f->bytes) pinned_pool().give(f->bytes, f->pool_cap);
     delete f;
     return TCMI_OK;
 }
@@ -453,12 +527,12 @@ int tcmi_bamfile_read(const char *path, tcmi_bamfile **out)
     tcmi_bamfile *f = new tcmi_bamfile();
     f->path = path;
     f->n_bytes = (size_t)sz;
-    f->cap = ((size_t)sz + 256 + 15) & ~(size_t)15;
-    if (hipHostMalloc((void **)&f->bytes, f->cap, hipHostMallocDefault) != hipSuccess) {
+    f->cap = ((size_t)sz + 4096 + 15) & ~(size_t)15;            // slack: the inflate kernel stages its input 1 KiB at a time
+    f->bytes = pinned_pool().take(f->cap, &f->pool_cap);
+    if (!f->bytes) {
         std::fclose(fp);
         delete f;
-        (void)hipGetLastError();
-        return tcmi_fail(nullptr, TCMI_E_NOMEM, "hipHostMalloc(%zu) for %s failed (is a GPU present?)", (size_t)sz + 256, path);
+        return tcmi_fail(nullptr, TCMI_E_NOMEM, "hipHostMalloc(%zu) for %s failed (is a GPU present?)", (size_t)sz + 4096, path);
     }
     const size_t got = sz ? std::fread(f->bytes, 1, (size_t)sz, fp) : 0;
     std::fclose(fp);
@@ -582,7 +656,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
     const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 64),
                  b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 3 + al(nb * 8) + 256;
-    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 5 + al((guess_rec / 256 + 2) * 8) + 8192 + 16 * 256;
+    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 5 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 16 * 256;
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
     uint8_t *d_file = (uint8_t *)tcmi_arena_take(ctx, b_file);
     BlockDesc *d_desc = (BlockDesc *)tcmi_arena_take(ctx, b_desc);
@@ -630,7 +704,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     }
     if (total > max_rec) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: impossible record count", f->path.c_str());
     const size_t n = (size_t)total;
-    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 5 + al((n / 256 + 2) * 8) + 8192 + 16 * 256;
+    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 5 + al((n / 256 + 2) * 8) * 3 + 8192 + 16 * 256;
     if (need_rest > b_rest)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: %zu very short records need more device scratch than was reserved: host reader", f->path.c_str(), n);
     uint64_t *d_rec = (uint64_t *)tcmi_arena_take(ctx, al(n * 8 + 8));
@@ -653,9 +727,12 @@ int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset
     if (!ctx || !f || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     *out = nullptr;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    static const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     DeviceBam D;
     int rc = decode_on_device(ctx, f, &D);
     if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     if (n_reads_out) *n_reads_out = (int64_t)D.n;
     tcmi_pack_src s = {};
     s.stream = D.d_out; s.rec_off = D.d_rec; s.n = (int64_t)D.n; s.mode = 1; s.pos_shift = 0;
@@ -669,6 +746,11 @@ int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset
     if (rc == TCMI_OK) {
         rs->packed_on_device = 2;               // decoded AND packed on the device
         *out = rs;
+        if (timing) {
+            const auto t2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[tcmi bamfile] decode on device %.2f ms, pack %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
         return TCMI_OK;
     }
     tcmi_readset_free(ctx, rs);

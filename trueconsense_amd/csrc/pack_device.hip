@@ -121,9 +121,12 @@ __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */
 }
 
 // ---- 1: classify ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *blk_sum, PackTotals *tot)
+__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *blk_sum, unsigned long long *blk_alg, int32_t *blk_end,
+                                                  PackTotals *tot)
 {
     __shared__ uint2 s_w[PB / 64];
+    __shared__ unsigned long long s_alg[PB / 64];
+    __shared__ int32_t s_end[PB / 64];
     const int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x;
     uint32_t word = 0, nwords = 0;
     unsigned long long my_alg = 0;
@@ -165,26 +168,36 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     }
     const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
     if (threadIdx.x == PB - 1) blk_sum[blockIdx.x] = incl;
-    // algorithmic bytes and extent: one atomic per wave, not per read
+    // algorithmic bytes and extent: per-workgroup partials that pk_scan folds (same-address atomics serialise in L2:
+    // 31 000 of them cost 0.39 ms)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         my_alg += (unsigned long long)__shfl_xor((long long)my_alg, d, 64);
         my_end = max(my_end, __shfl_xor(my_end, d, 64));
     }
-    if ((threadIdx.x & 63) == 0 && my_alg) {
-        atomicAdd(&tot->alg_bytes, my_alg);
-        atomicMax(&tot->max_end, my_end);
+    if ((threadIdx.x & 63) == 0) { s_alg[threadIdx.x >> 6] = my_alg; s_end[threadIdx.x >> 6] = my_end; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        int32_t e = 0;
+        for (int w = 0; w < PB / 64; ++w) { a += s_alg[w]; e = max(e, s_end[w]); }
+        blk_alg[blockIdx.x] = a;
+        blk_end[blockIdx.x] = e;
     }
 }
 
 // ---- 2: exclusive scan of the workgroup sums (one workgroup, any number of entries) ---------------------------------
-__global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, int64_t n_blk, PackTotals *tot)
+__global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned long long *blk_alg, const int32_t *blk_end, int64_t n_blk,
+                                                PackTotals *tot)
 {
     __shared__ unsigned long long s_x[1024], s_y[1024];
     const int t = threadIdx.x;
     const int64_t per = (n_blk + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blk);
-    unsigned long long sx = 0, sy = 0;
-    for (int64_t b = b0; b < b1; ++b) { sx += blk_sum[b].x; sy += blk_sum[b].y; }
+    unsigned long long sx = 0, sy = 0, alg = 0;
+    int32_t mend = 0;
+    for (int64_t b = b0; b < b1; ++b) { sx += blk_sum[b].x; sy += blk_sum[b].y; alg += blk_alg[b]; mend = max(mend, blk_end[b]); }
+    if (alg) atomicAdd(&tot->alg_bytes, alg);                  // (at most 1024 of these)
+    if (mend) atomicMax(&tot->max_end, mend);
     s_x[t] = sx; s_y[t] = sy;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                    // Hillis-Steele over the 1024 partials
@@ -553,6 +566,8 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     const int64_t n_blk = (n + PB - 1) / PB;
     uint32_t *info = (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4);
     uint2 *blk_sum = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
+    unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
+    int32_t *blk_end = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 4);
     PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
     PackTotals tot;
     std::memset(&tot, 0, sizeof tot);
@@ -560,8 +575,8 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     if (n > 0) {
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
-        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, d_tot);
-        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, n_blk, d_tot);
+        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, blk_alg, blk_end, d_tot);
+        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, blk_alg, blk_end, n_blk, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
         TCMI_HIP(ctx, hipGetLastError());
     }
@@ -602,8 +617,18 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
                      b_chk = ((size_t)chunk_cap * sizeof(tcmi_fast_chunk) + 255) & ~(size_t)255, b_run = b_len,
                      b_ev = ((size_t)event_cap * 4 + 255) & ~(size_t)255;
         char *blob = nullptr;
-        if (hipMalloc((void **)&blob, b_len + b_seq + b_chk + b_run + b_ev + 256) != hipSuccess) {
-            return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) for the packed read set failed", b_len + b_seq + b_chk + b_run + b_ev);
+        const size_t want = b_len + b_seq + b_chk + b_run + b_ev + 256;
+        for (size_t k = 0; k < ctx->blob_pool.size(); ++k)       // a freed read set of about this size?
+            if (ctx->blob_pool[k].bytes >= want && ctx->blob_pool[k].bytes <= want + want / 2 + (1 << 20)) {
+                blob = ctx->blob_pool[k].p;
+                rs->blob_bytes = ctx->blob_pool[k].bytes;
+                ctx->blob_pool.erase(ctx->blob_pool.begin() + (long)k);
+                break;
+            }
+        if (!blob) {
+            rs->blob_bytes = want + want / 16;
+            if (hipMalloc((void **)&blob, rs->blob_bytes) != hipSuccess)
+                return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc(%zu) for the packed read set failed", rs->blob_bytes);
         }
         rs->d_blob = blob;
         o.lenoff = (uint32_t *)blob;
@@ -627,6 +652,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         if (tot.n_events > event_cap && attempt == 0) {          // rare: a read set full of N / indel tokens — once more with room for all
             (void)hipFree(blob);
             rs->d_blob = nullptr;
+            rs->blob_bytes = 0;
             event_cap = tot.n_events + 1024;
             continue;
         }
@@ -653,7 +679,7 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
                           al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 64)};
     size_t src_bytes = 0;
     for (size_t b : sz) src_bytes += b + 256;
-    const size_t tmp_bytes = al((size_t)n * 4) * 5 + al((size_t)((n + PB - 1) / PB + 1) * 8) + 4096 + 8 * 256;
+    const size_t tmp_bytes = al((size_t)n * 4) * 5 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 12 * 256;
     int rc = arena_reserve(ctx, src_bytes + tmp_bytes);
     if (rc) return rc;
     PackSrc s = {};

@@ -6,7 +6,10 @@
 // finished records into consensus sequences: insert candidates -> modal tokens (Events.py:5-82),
 // then the sequential walk of Sequences.BuildConsensus (Sequences.py:179-322, consensus_walk.cpp).
 // No Python in the loop, so no GIL between the walkers.
+#include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -65,13 +68,11 @@ bool parse_token(const char *t, int64_t n, int *size_digit, const char **bases, 
     return false;
 }
 
-int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
+// call records of one BAM -> consensus: insert candidates -> modal tokens (Events.py:5-82), then the sequential walk
+int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags, int64_t L, const tcmi_reads *reads, bool reads_known,
+                 const std::vector<int64_t> &orf_start, const std::vector<int64_t> &orf_end, const std::vector<uint8_t> &orf_plus,
+                 char *out, int64_t cap, int64_t *out_len, long long item)
 {
-    const int64_t item = item_in * p->batch + b;               // output index
-    const int64_t shift = (int64_t)b * p->pos_stride;           // BAM b's slice of every record plane
-    tcmi_ctx *c = p->slots[(size_t)slot];
-    const int64_t L = p->L, ld = c->ws_ld;
-    const uint8_t *plain = c->h_rec + shift, *alt = c->h_rec + ld + shift, *flags = c->h_rec + 2 * ld + shift;
     // insert candidates (Events.py:29-36 evaluated by the call kernel) -> accepted inserts
     std::vector<int64_t> cand;
     for (int64_t i = 0; i < L; ++i)
@@ -79,11 +80,9 @@ int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
     std::vector<int64_t> ins_pos, ins_off(1, 0);
     std::vector<int32_t> ins_shift;
     std::string ins_seq;
-    const tcmi_reads *reads = p->host_reads ? p->host_reads[item] : nullptr;
-    if (!cand.empty() && !reads)
+    if (!cand.empty() && !reads_known)
         return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED,
-                         "item %lld has %zu insert candidates but no host reads were given to resolve their tokens",
-                         (long long)item, cand.size());
+                         "item %lld has %zu insert candidates but no host reads were given to resolve their tokens", item, cand.size());
     if (!cand.empty()) {
         std::vector<int64_t> off(cand.size() + 1), cnt(cand.size());
         std::vector<char> toks(1 << 16);
@@ -111,12 +110,23 @@ int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
             ins_off.push_back((int64_t)ins_seq.size());
         }
     }
-    const int32_t n_orf = (int32_t)p->orf_start.size();
+    const int32_t n_orf = (int32_t)orf_start.size();
     std::vector<int64_t> ns((size_t)n_orf), ne((size_t)n_orf);
     int64_t err_pos = 0;
-    return tcmi_consensus_walk(plain, alt, flags, L, n_orf, p->orf_start.data(), p->orf_end.data(), p->orf_plus.data(),
+    return tcmi_consensus_walk(plain, alt, flags, L, n_orf, orf_start.data(), orf_end.data(), orf_plus.data(),
                                (int32_t)ins_pos.size(), ins_pos.data(), ins_shift.data(), ins_seq.c_str(), ins_off.data(), 1,
-                               p->out + item * p->stride, p->stride, &p->out_len[item], ns.data(), ne.data(), &err_pos);
+                               out, cap, out_len, ns.data(), ne.data(), &err_pos);
+}
+
+int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
+{
+    const int64_t item = item_in * p->batch + b;               // output index
+    const int64_t shift = (int64_t)b * p->pos_stride;           // BAM b's slice of every record plane
+    tcmi_ctx *c = p->slots[(size_t)slot];
+    const int64_t L = p->L, ld = c->ws_ld;
+    const tcmi_reads *reads = p->host_reads ? p->host_reads[item] : nullptr;
+    return walk_records(c->h_rec + shift, c->h_rec + ld + shift, c->h_rec + 2 * ld + shift, L, reads, reads != nullptr, p->orf_start,
+                        p->orf_end, p->orf_plus, p->out + item * p->stride, p->stride, &p->out_len[item], (long long)item);
 }
 
 void worker_main(tcmi_pipeline *p)
@@ -282,6 +292,241 @@ int tcmi_pipeline_run(tcmi_pipeline *p, int64_t n_items, const tcmi_readset *con
 {
     return tcmi_pipeline_run_batched(p, n_items, readsets, 1, 0, host_reads, L, mincov, include_ambig, out_cons, stride,
                                      out_len, status);
+}
+
+} // extern "C"
+
+
+// ---- BAM FILES -> FASTA text: the whole command line of the reference (TrueConsense.py:212-264) for many inputs -------------
+// Three stages on their own threads, consecutive BAMs overlapping:
+//   read   HOST: file bytes into pinned memory + BGZF block table + BAM header (tcmi_bamfile_read)
+//   gpu    one thread per context (stream + device arena): H2D of the compressed bytes, HIP inflate / record chain / pack,
+//          tally + call, call records into the item's buffer; a file the device decoder declines is decoded by the host
+//          reader (tcmi_bam_load) and packed from its flat arrays
+//   walk   HOST: insert tokens when a candidate exists (decodes the BAM on the host then: the decoded reads never left the
+//          device), the sequential consensus walk, ">name mincov=N\n<consensus>\n" (Outputs.py:182-183)
+struct tcmi_filerunner {
+    int device = 0, n_readers = 2, n_walkers = 2, host_threads = 8;
+    std::vector<tcmi_ctx *> ctxs;
+    std::vector<int64_t> orf_start, orf_end;
+    std::vector<uint8_t> orf_plus;
+};
+
+namespace {
+
+struct FileItem {
+    tcmi_bamfile *file = nullptr;       // after the read stage
+    std::vector<uint8_t> rec;           // plain | alt | flags, L each, after the gpu stage
+    int64_t L = 0;
+    int state = 0;                      // 0 nothing, 1 read, 2 records ready, 3 done
+    int rc = TCMI_OK;
+    std::string err;
+    bool on_device = false;
+};
+
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace
+
+extern "C" {
+
+int tcmi_filerunner_create(int device, int n_readers, int n_gpu, int n_walkers, int host_decode_threads, tcmi_filerunner **out)
+{
+    if (!out || n_readers < 1 || n_readers > 64 || n_gpu < 1 || n_gpu > 16 || n_walkers < 1 || n_walkers > 64)
+        return tcmi_fail(nullptr, TCMI_E_ARG, "need 1..64 readers, 1..16 gpu contexts, 1..64 walkers");
+    *out = nullptr;
+    tcmi_filerunner *r = new tcmi_filerunner();
+    r->device = device; r->n_readers = n_readers; r->n_walkers = n_walkers; r->host_threads = host_decode_threads > 0 ? host_decode_threads : 8;
+    for (int k = 0; k < n_gpu; ++k) {
+        tcmi_ctx *c = nullptr;
+        const int rc = tcmi_ctx_create(device, &c);
+        if (rc) {
+            for (auto *x : r->ctxs) tcmi_ctx_destroy(x);
+            delete r;
+            return rc;
+        }
+        r->ctxs.push_back(c);
+    }
+    *out = r;
+    return TCMI_OK;
+}
+
+int tcmi_filerunner_destroy(tcmi_filerunner *r)
+{
+    if (!r) return TCMI_OK;
+    for (auto *c : r->ctxs) tcmi_ctx_destroy(c);
+    delete r;
+    return TCMI_OK;
+}
+
+int tcmi_filerunner_set_orfs(tcmi_filerunner *r, int32_t n_orf, const int64_t *start, const int64_t *end, const uint8_t *is_plus)
+{
+    if (!r || n_orf < 0 || (n_orf > 0 && (!start || !end || !is_plus))) return tcmi_fail(nullptr, TCMI_E_ARG, "bad argument");
+    r->orf_start.assign(start, start + n_orf);
+    r->orf_end.assign(end, end + n_orf);
+    r->orf_plus.assign(is_plus, is_plus + n_orf);
+    return TCMI_OK;
+}
+
+tcmi_ctx *tcmi_filerunner_ctx(tcmi_filerunner *r, int k) { return (r && k >= 0 && k < (int)r->ctxs.size()) ? r->ctxs[(size_t)k] : nullptr; }
+
+// out_text: n * stride bytes, text i at out_text + i * stride, out_len[i] bytes (stride >= ref_len + inserted bases + name + 32)
+// stage_seconds[4]: busy seconds summed over the items: read, upload (decode + pack), step, walk
+// decoded_on[2]: items decoded on the device / by the host reader
+int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
+                        int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
+                        int32_t *status, double *stage_seconds, int64_t *decoded_on)
+{
+    if (!r || n < 0 || (n > 0 && (!paths || !out_text || !out_len || !status))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    std::vector<FileItem> items((size_t)n);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int64_t> next_read{0}, next_gpu{0}, next_walk{0};
+    int64_t n_done = 0;                                         // (under mu) items finished: bounds how far the readers run ahead
+    const int64_t window = (int64_t)r->n_readers + (int64_t)r->ctxs.size() + r->n_walkers + 2;
+    double sec[4] = {0, 0, 0, 0};
+    int64_t on[2] = {0, 0};
+
+    auto reader = [&]() {
+        for (;;) {
+            const int64_t i = next_read.fetch_add(1);
+            if (i >= n) return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return i < n_done + window; });
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            FileItem &it = items[(size_t)i];
+            if (device_decode) {
+                it.rc = tcmi_bamfile_read(paths[i], &it.file);
+                if (it.rc) it.err = tcmi_last_error(nullptr);
+            }
+            const double dt = seconds_since(t0);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                it.state = 1;
+                sec[0] += dt;
+            }
+            cv.notify_all();
+        }
+    };
+    auto gpu = [&](tcmi_ctx *ctx) {
+        for (;;) {
+            const int64_t i = next_gpu.fetch_add(1);
+            if (i >= n) return;
+            FileItem &it = items[(size_t)i];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return it.state >= 1; });
+            }
+            double t_up = 0, t_step = 0;
+            if (!it.rc) {
+                const auto t0 = std::chrono::steady_clock::now();
+                tcmi_readset *rs = nullptr;
+                tcmi_bam *hb = nullptr;
+                int rc = TCMI_E_UNSUPPORTED;
+                if (it.file) {
+                    rc = tcmi_readset_from_bamfile(ctx, it.file, &rs, nullptr);
+                    it.on_device = rc == TCMI_OK;
+                }
+                if (rc == TCMI_E_UNSUPPORTED) {                  // the host reader takes it
+                    rc = tcmi_bam_load(paths[i], r->host_threads, &hb);
+                    if (!rc) {
+                        tcmi_reads reads;
+                        tcmi_bam_reads(hb, &reads);
+                        rc = tcmi_readset_upload(ctx, &reads, &rs);
+                    }
+                }
+                t_up = seconds_since(t0);
+                const auto t1 = std::chrono::steady_clock::now();
+                if (!rc) {
+                    int64_t max_end = 0;
+                    tcmi_readset_info(rs, nullptr, nullptr, nullptr, nullptr, &max_end);
+                    const int64_t L = std::max<int64_t>({ref_len, max_end, 1});
+                    const uint8_t *pl, *al, *fl;
+                    int64_t ld = 0;
+                    rc = tcmi_step(ctx, rs, L, mincov, include_ambig, &pl, &al, &fl, nullptr, &ld);
+                    if (!rc) {
+                        it.L = L;
+                        it.rec.resize((size_t)L * 3);
+                        std::memcpy(it.rec.data(), pl, (size_t)L);
+                        std::memcpy(it.rec.data() + L, al, (size_t)L);
+                        std::memcpy(it.rec.data() + 2 * L, fl, (size_t)L);
+                    }
+                }
+                t_step = seconds_since(t1);
+                if (rc) { it.rc = rc; it.err = tcmi_last_error(ctx); }
+                if (rs) tcmi_readset_free(ctx, rs);
+                if (hb) tcmi_bam_free(hb);
+            }
+            if (it.file) { tcmi_bamfile_free(it.file); it.file = nullptr; }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                it.state = 2;
+                sec[1] += t_up; sec[2] += t_step;
+                if (!it.rc) on[it.on_device ? 0 : 1] += 1;
+            }
+            cv.notify_all();
+        }
+    };
+    auto walker = [&]() {
+        for (;;) {
+            const int64_t i = next_walk.fetch_add(1);
+            if (i >= n) return;
+            FileItem &it = items[(size_t)i];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return it.state >= 2; });
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            out_len[i] = 0;
+            if (!it.rc) {
+                const int64_t L = it.L;
+                const uint8_t *pl = it.rec.data(), *al = pl + L, *fl = pl + 2 * L;
+                bool cand = false;
+                for (int64_t k = 0; k < L && !cand; ++k) cand = (fl[k] & TCMI_F_INSCAND) != 0;
+                tcmi_bam *hb = nullptr;
+                tcmi_reads reads;
+                int rc = TCMI_OK;
+                if (cand) {                                      // insert tokens need the reads on the host
+                    rc = tcmi_bam_load(paths[i], r->host_threads, &hb);
+                    if (!rc) tcmi_bam_reads(hb, &reads);
+                }
+                char *dst = out_text + i * stride;
+                const int head = std::snprintf(dst, (size_t)stride, ">%s mincov=%d\n", names && names[i] ? names[i] : "sample", (int)mincov);
+                int64_t len = 0;
+                if (!rc && (head < 0 || head + 2 >= stride)) rc = tcmi_fail(nullptr, TCMI_E_ARG, "output stride too small");
+                if (!rc) rc = walk_records(pl, al, fl, L, cand ? &reads : nullptr, true, r->orf_start, r->orf_end, r->orf_plus, dst + head,
+                                           stride - head - 1, &len, (long long)i);
+                if (!rc) { dst[head + len] = '\n'; out_len[i] = head + len + 1; }
+                else { it.rc = rc; it.err = tcmi_last_error(nullptr); }
+                if (hb) tcmi_bam_free(hb);
+                std::vector<uint8_t>().swap(it.rec);
+            }
+            status[i] = it.rc;
+            const double dt = seconds_since(t0);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                it.state = 3;
+                ++n_done;
+                sec[3] += dt;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < r->n_readers; ++k) th.emplace_back(reader);
+    for (auto *c : r->ctxs) th.emplace_back(gpu, c);
+    for (int k = 0; k < r->n_walkers; ++k) th.emplace_back(walker);
+    for (auto &t : th) t.join();
+    if (stage_seconds) for (int k = 0; k < 4; ++k) stage_seconds[k] = sec[k];
+    if (decoded_on) { decoded_on[0] = on[0]; decoded_on[1] = on[1]; }
+    for (int64_t i = 0; i < n; ++i)
+        if (items[(size_t)i].rc) return tcmi_fail(nullptr, items[(size_t)i].rc, "%s: %s", paths[i], items[(size_t)i].err.c_str());
+    return TCMI_OK;
 }
 
 } // extern "C"

@@ -167,7 +167,10 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (rs->d_blob) {                                            // device-packed: one allocation holds the aligned set
-        (void)hipFree(rs->d_blob);
+        if (ctx && ctx->device == rs->device && ctx->blob_pool.size() < 4 && rs->blob_bytes)
+            ctx->blob_pool.push_back({rs->d_blob, rs->blob_bytes});   // (stream order: the next user's kernels queue behind this one's)
+        else
+            (void)hipFree(rs->d_blob);
         rs->d_flenoff = nullptr; rs->d_fseq = nullptr; rs->d_fevent = nullptr; rs->d_fchunk = nullptr; rs->d_fcovrun = nullptr;
     }
     void *ptrs[] = {rs->d_flenoff, rs->d_fseq, rs->d_fevent, rs->d_fchunk, rs->d_fcovrun, rs->d_pos, rs->d_meta,

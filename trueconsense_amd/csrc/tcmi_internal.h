@@ -90,6 +90,7 @@ struct tcmi_readset {
     int device = -1;
     int packed_on_device = 0;   // 1: pack_device.hip built the aligned set (everything below lives in d_blob)
     char *d_blob = nullptr;     // one allocation holding d_flenoff | d_fseq | d_fchunk | d_fcovrun | d_fevent
+    size_t blob_bytes = 0;
     // aligned set
     int64_t f_reads = 0, f_chunks = 0, f_words = 0, f_events = 0;
     uint32_t *d_flenoff = nullptr; // [f_reads] the packed header words
@@ -121,6 +122,10 @@ struct tcmi_ctx {
     int device = -1;
     tcmi_upload_scratch *upload_scratch = nullptr;
     tcmi_dev_arena *dev_arena = nullptr;
+    // device-packed read sets hand their allocation back when they are freed; the next upload of a similar size takes it
+    // (hipMalloc + hipFree cost more than the pack kernels, and hipFree waits for the device)
+    struct Blob { char *p; size_t bytes; };
+    std::vector<Blob> blob_pool;
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)

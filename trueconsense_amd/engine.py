@@ -460,98 +460,76 @@ class DeviceBam:
 
 
 class FileRunner:
-    """BAM files -> consensus FASTA text (TrueConsense.py:212-264 for many inputs; BASELINE configs[1] / [3]).
+    """BAM files -> consensus FASTA text (TrueConsense.py:212-264 for many inputs; BASELINE configs[1] / [3]): the native
+    runner tcmi_filerunner (csrc/pipeline.cpp).
 
-    Stages per BAM: decode (tcmi_bam_load: file read, BGZF inflate, records -> flat arrays; `decode_threads` native
-    threads each, `decoders` BAMs in flight) -> upload (H2D + pack) -> step (HIP tally + call, records to pinned host
-    memory) -> walk (insert tokens, sequential consensus walk, FASTA text; `walkers` threads).  The GPU stages run on
-    the calling thread; decode and walk overlap with them.  `seconds` accumulates each stage's busy time."""
+    Stages per BAM, each on its own threads so that consecutive BAMs overlap:
+      read    HOST: file bytes into pinned memory, BGZF block table, BAM header (`decoders` files in flight)
+      gpu     H2D of the compressed file, HIP: BGZF inflate + record chain + pack, tally + call, records to pinned host
+              memory (`gpu_streams` contexts, each with a stream and a device arena of its own: the kernels of one BAM
+              fill the gaps of another's)
+      walk    HOST: insert tokens if any candidate, sequential consensus walk, FASTA text (`walkers` threads)
+    A file the device decoder does not take (records straddling BGZF blocks, long reads) is decoded by the host reader
+    (tcmi_bam_load, `decode_threads` threads) and packed from its flat arrays.  `seconds` accumulates each stage's busy time."""
 
-    def __init__(self, ctx, gff_rows, mincov, include_ambig=True, decoders=2, decode_threads=8, walkers=2):
-        self.ctx, self.mincov, self.amb = ctx, int(mincov), bool(include_ambig)
-        self.gff = {k: dict(r) for k, r in enumerate(gff_rows)}
-        self.decoders, self.decode_threads, self.walkers = int(decoders), int(decode_threads), int(walkers)
+    def __init__(self, ctx, gff_rows, mincov, include_ambig=True, decoders=2, decode_threads=8, walkers=2, gpu_streams=2):
+        device = ctx.device if isinstance(ctx, Context) else int(ctx)
+        self.mincov, self.amb = int(mincov), bool(include_ambig)
+        h = C.c_void_p()
+        check(lib().tcmi_filerunner_create(int(device), int(decoders), max(1, int(gpu_streams)), int(walkers), int(decode_threads), C.byref(h)))
+        self.handle = h
+        self.n_ctx = max(1, int(gpu_streams))
+        s_ = np.ascontiguousarray([r["start"] for r in gff_rows], np.int64)
+        e_ = np.ascontiguousarray([r["end"] for r in gff_rows], np.int64)
+        p_ = np.ascontiguousarray([r.get("strand") == "+" for r in gff_rows], np.uint8)
+        check(lib().tcmi_filerunner_set_orfs(h, len(s_), ptr(s_), ptr(e_), ptr(p_)))
         self.device_decode = True       # BGZF inflate + record index on the GPU; files it does not take go to the host reader
         self.seconds = {"decode": 0.0, "upload": 0.0, "step": 0.0, "walk": 0.0}
-        self.bytes = {"file": 0, "inflated": 0, "device": 0}
         self.decoded_on = {"device": 0, "host": 0}
+        self._device = device
 
-    def _load(self, path):
-        """Host stage of the decode: for the device decoder only the file read + BGZF block table + BAM header."""
-        import time
-        t = time.perf_counter()
-        bam = DeviceBam(path) if self.device_decode else BamFile(path, threads=self.decode_threads)
-        return bam, time.perf_counter() - t
+    @property
+    def contexts(self):
+        out = []
+        for k in range(self.n_ctx):
+            c = Context.__new__(Context)
+            c.handle, c.device = C.c_void_p(lib().tcmi_filerunner_ctx(self.handle, k)), self._device
+            c.close = lambda: None
+            out.append(c)
+        return out
 
-    def _walk(self, bam, name, plain, alt, flags):
-        import time
-        from .Events import candidates_from_flags, inserts_from_flags
-        from .Sequences import consensus_from_records
-        t = time.perf_counter()
-        if isinstance(bam, DeviceBam):
-            # the decoded reads never reached the host: decode here only if an insert candidate needs its tokens
-            path = bam.filename
-            bam.close()
-            bam = BamFile(path, threads=self.decode_threads) if candidates_from_flags(flags) else None
-        _, ins = inserts_from_flags(flags, bam) if bam is not None else (False, None)
-        cons = consensus_from_records(plain, alt, flags, self.gff, ins, True)[0]
-        text = ">%s mincov=%d\n%s\n" % (name, self.mincov, cons)          # Outputs.py:182-183
-        if bam is not None:
-            bam.close()
-        return text, time.perf_counter() - t
-
-    def run(self, paths, names=None, ref_len=0):
+    def run(self, paths, names=None, ref_len=0, max_inserted=4096):
         """-> list of FASTA texts, in input order."""
-        import time
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
         n = len(paths)
         names = names or ["S%d" % i for i in range(n)]
-        out = [None] * n
-        with ThreadPoolExecutor(self.decoders) as dec, ThreadPoolExecutor(self.walkers) as wk:
-            loads, walks = deque(), deque()
-            nxt = 0
-            while nxt < n and len(loads) < self.decoders + 1:
-                loads.append(dec.submit(self._load, paths[nxt]))
-                nxt += 1
-            for i in range(n):
-                bam, dt = loads.popleft().result()
-                self.seconds["decode"] += dt
-                if nxt < n:
-                    loads.append(dec.submit(self._load, paths[nxt]))
-                    nxt += 1
-                t0 = time.perf_counter()
-                if isinstance(bam, DeviceBam):
-                    try:
-                        rs = self.ctx.upload_bamfile(bam)
-                        self.decoded_on["device"] += 1
-                    except _ffi.TcmiError as e:
-                        if e.code != _ffi.E_UNSUPPORTED:
-                            raise
-                        path = bam.filename
-                        bam.close()
-                        bam = BamFile(path, threads=self.decode_threads)      # the host reader takes it
-                        rs = self.ctx.upload(bam)
-                        self.decoded_on["host"] += 1
-                else:
-                    rs = self.ctx.upload(bam)
-                    self.decoded_on["host"] += 1
-                t1 = time.perf_counter()
-                L = max(int(ref_len), rs.max_end, 1)
-                plain, alt, flags, _ = self.ctx.step(rs, L, self.mincov, self.amb, want_counts=False)
-                t2 = time.perf_counter()
-                self.seconds["upload"] += t1 - t0
-                self.seconds["step"] += t2 - t1
-                self.bytes["file"] += bam.file_bytes
-                self.bytes["inflated"] += bam.inflated_bytes
-                self.bytes["device"] += rs.device_bytes
-                rs.free()
-                walks.append((i, wk.submit(self._walk, bam, names[i], plain, alt, flags)))
-                while len(walks) > self.walkers + 1:                     # bound the decoded BAMs kept alive
-                    k, f = walks.popleft()
-                    out[k], dw = f.result()
-                    self.seconds["walk"] += dw
-            for k, f in walks:
-                out[k], dw = f.result()
-                self.seconds["walk"] += dw
-        return out
+        if n == 0:
+            return []
+        c_paths = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+        c_names = (C.c_char_p * n)(*[str(x).encode() for x in names])
+        stride = int(ref_len) + int(max_inserted) + max(len(x) for x in names) + 64
+        # (positions beyond ref_len that the reads reach lengthen the consensus: the runner reports a too small stride)
+        out = np.empty(n * stride, np.uint8)
+        lens = np.zeros(n, np.int64)
+        status = np.zeros(n, np.int32)
+        sec = (C.c_double * 4)()
+        on = (C.c_int64 * 2)()
+        rc = lib().tcmi_filerunner_run(self.handle, n, c_paths, c_names, int(ref_len), self.mincov, int(self.amb), int(bool(self.device_decode)),
+                                       ptr(out), stride, ptr(lens), ptr(status), sec, on)
+        self.last_status = status
+        for k, v in zip(("decode", "upload", "step", "walk"), sec):
+            self.seconds[k] += v
+        self.decoded_on["device"] += on[0]
+        self.decoded_on["host"] += on[1]
+        check(rc)
+        return [out[i * stride:i * stride + int(lens[i])].tobytes().decode("ascii") for i in range(n)]
+
+    def close(self):
+        if self.handle:
+            lib().tcmi_filerunner_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/pmc_e2e.sh OUTDIR [bench args...] — rocprofv3 counter passes (one --pmc set per pass, kernel-trace only) over a short
+# file -> FASTA bench leg; prints per-kernel averages for the cold-path kernels.
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p $out
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  d=$out/pmc_$(echo $set | cut -c1-16 | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 bench.py --no-resident --no-cpu-baseline --steps 4 --warmup 1 --gpu-streams 1 "$@" > $d.json 2> $d.err || { echo "pass failed: $set"; tail -5 $d.err; exit 1; }
+done
+python3 - $out/pmc_* <<'PY'
+import csv, sys, glob, collections
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0][-28:]
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, cs in acc.items():
+            if not any(x in k for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")): continue
+            print(k, {c: round(sum(v)/len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
+PY

@@ -12,7 +12,7 @@ import re
 import numpy as np
 
 from . import _ffi, _state
-from .engine import BamFile, modal_tokens
+from .engine import BamFile, LazyBam, modal_tokens
 
 _TOKEN = re.compile(r"(\d)([a-zA-Z]+)")          # Events.py:75
 
@@ -31,6 +31,8 @@ def _tokens_at(bam, positions):
     """{pos: modal token or None} for 1-based positions."""
     if not positions:
         return {}
+    if isinstance(bam, LazyBam):
+        bam = bam.get()
     if isinstance(bam, BamFile) or isinstance(bam, dict):
         return {p: t for p, (t, _) in modal_tokens(bam, positions).items()}
     if hasattr(bam, "modal_token"):               # test double: bam.modal_token(pos) -> token or None

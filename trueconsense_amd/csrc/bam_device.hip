@@ -8,10 +8,11 @@
 //   bgzf_inflate   ONE WAVEFRONT PER BGZF BLOCK (blocks are independent deflate streams of <= 64 KiB).  All decoder state
 //                  is wave-uniform: the bit buffer, the Huffman root tables (10 / 9 bits, in LDS, built in parallel from
 //                  the canonical code: every lane decodes its table indices bit by bit), the output position.  Literals
-//                  and LZ77 matches go through an 8 KiB LDS ring of the most recent output (a match is copied by all 64
-//                  lanes at once; the rare match that reaches further back — the deflate window is 32 KiB — reads what was
-//                  already flushed); finished 2 KiB segments are flushed to HBM with 16-byte stores.  14 KiB of LDS per
-//                  wavefront: ten blocks in flight per CU hide each other's LDS / decode latencies.  While it inflates, the wave
+//                  and LZ77 matches go through a 4 KiB LDS ring of the most recent output (a match is copied by all 64
+//                  lanes at once; the match that reaches further back — the deflate window is 32 KiB — reads what was
+//                  already flushed); finished 2 KiB segments are flushed to HBM with 16-byte stores.  12 KiB of LDS per
+//                  wavefront: every block of a 1M-read BAM (4 200) is in flight at once, 16 per CU, and they hide each
+//                  other's LDS / decode latencies (measured: 32 KiB ring 2.95 ms, 8 KiB 1.5 ms, 4 KiB 1.2 ms per BAM).  While it inflates, the wave
 //                  also follows the chain of BAM records through its block (block_size fields, read from the ring as soon
 //                  as they are complete) and lists the record starts: htslib-written BAMs start every BGZF block on a
 //                  record boundary, which the chain check (`overshoot` of a block = 0) verifies; files that do not are
@@ -36,7 +37,7 @@
 namespace {
 
 #ifndef TCMI_INFLATE_WIN
-#define TCMI_INFLATE_WIN 8192
+#define TCMI_INFLATE_WIN 4096
 #endif
 constexpr int WIN = TCMI_INFLATE_WIN, WMASK = WIN - 1;   // LDS ring: the most recent output.  The deflate window is 32 KiB: a match that
                                                          // reaches further back than the ring reads what was already flushed to HBM
@@ -72,7 +73,7 @@ struct InflateArgs {
 };
 
 #ifndef TCMI_INFLATE_INRING
-#define TCMI_INFLATE_INRING 512
+#define TCMI_INFLATE_INRING 256
 #endif
 constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input staged in LDS (two halves)
 
@@ -119,26 +120,60 @@ __device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
 }
 
 // canonical Huffman decode of the bits in `v` (first stream bit = bit 0), at most `maxlen` bits: puff.c's loop
-__device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint32_t v, int maxlen, int *nbits)
+// -> symbol | code length << 16, or -1
+__device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint32_t v, int maxlen)
 {
     int code = 0, first = 0, index = 0;
+#pragma unroll 1
     for (int len = 1; len <= maxlen; ++len) {
         code |= (int)(v & 1u);
         v >>= 1;
         const int c = cnt[len];
-        if (code - c < first) { *nbits = len; return sym[index + (code - first)]; }
+        if (code - c < first) return (int)sym[index + (code - first)] | (len << 16);
         index += c;
         first += c;
         first <<= 1;
         code <<= 1;
     }
-    *nbits = 0;
     return -1;
 }
 
-// lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table (entry = nbits | symbol << 4; 0 = not in
-// the root: longer than `root` bits or no such code).  Returns false for an over-subscribed code.
-__device__ inline bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, uint16_t *tab, int root)
+// Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), extra bits in
+// bits 4-7, kind in bits 8-10, value in bits 16-31 (the literal, the base length or the base distance): the hot loop needs
+// no arithmetic on symbols.
+constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
+enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
+
+__device__ inline uint32_t make_entry(int kind, int sym, int nbits)
+{
+    if (sym < 0) return 0u;
+    if (kind == K_CODELEN) return (uint32_t)nbits | ((uint32_t)sym << 16);
+    if (kind == K_LITLEN) {
+        if (sym < 256) return (uint32_t)nbits | E_LIT | ((uint32_t)sym << 16);
+        if (sym == 256) return (uint32_t)nbits | E_EOB;
+        const int s = sym - 257;
+        if (s > 28) return 0u;                                  // 286, 287: not a symbol
+        int eb = 0, base = 3 + s;
+        if (s == 28) base = 258;
+        else if (s >= 8) { eb = (s >> 2) - 1; base = 3 + ((4 + (s & 3)) << eb); }
+        return (uint32_t)nbits | ((uint32_t)eb << 4) | E_BASE | ((uint32_t)base << 16);
+    }
+    if (sym > 29) return 0u;                                    // 30, 31: not a distance
+    int eb = 0, base = 1 + sym;
+    if (sym >= 4) { eb = (sym >> 1) - 1; base = 1 + ((2 + (sym & 1)) << eb); }
+    return (uint32_t)nbits | ((uint32_t)eb << 4) | E_BASE | ((uint32_t)base << 16);
+}
+
+// lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table.  Returns false for an over-subscribed code.
+#ifndef TCMI_INFLATE_INLINE_TABLES
+#define TCMI_INFLATE_INLINE_TABLES 0
+#endif
+#if TCMI_INFLATE_INLINE_TABLES
+__device__ inline
+#else
+__device__ __noinline__             // three call sites: one copy of the code keeps the kernel small (instruction cache)
+#endif
+bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, uint32_t *tab, int root, int kind)
 {
     const int lane = threadIdx.x;
     __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
@@ -180,20 +215,19 @@ __device__ inline bool build_table(const uint8_t *lens, int n, uint16_t *cnt, ui
     __syncthreads();
     // root table: every lane decodes its indices
     for (int i = lane; i < (1 << root); i += 64) {
-        int nb;
-        const int s = slow_decode(cnt, sym, (uint32_t)i, root, &nb);
-        tab[i] = s >= 0 ? (uint16_t)(nb | (s << 4)) : (uint16_t)0;
+        const int s = slow_decode(cnt, sym, (uint32_t)i, root);
+        tab[i] = s < 0 ? 0u : make_entry(kind, s & 0xFFFF, s >> 16);
     }
     __syncthreads();
-    return ok;
+    return uni(ok ? 1u : 0u) != 0;
 }
 
 __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN];
-    __shared__ uint16_t s_ll[1 << LL_ROOT];
-    __shared__ uint16_t s_dt[1 << D_ROOT];
-    __shared__ uint16_t s_cl[1 << CL_ROOT];
+    __shared__ uint32_t s_ll[1 << LL_ROOT];
+    __shared__ uint32_t s_dt[1 << D_ROOT];
+    __shared__ uint32_t s_cl[1 << CL_ROOT];
     __shared__ uint8_t s_lens[320];             // literal/length code lengths [0, 288), distance code lengths [288, 320)
     __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
     __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
@@ -211,7 +245,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     Bits b;
     b.w = a.file32;
     b.ring = s_in;
-    auto seek = [&](uint64_t byte) {     // start reading bits at this byte of the file
+    auto seek = [&](uint64_t byte) __attribute__((always_inline)) {     // start reading bits at this byte of the file
         b.idx = byte >> 2;
         b.hi = b.idx & ~(uint64_t)3;     // (16-byte aligned loads)
         stage_input(b);
@@ -228,29 +262,34 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     uint32_t flushed = 0;               // bytes already written to HBM (multiple of SEG)
     uint32_t err = ST_OK;
     // the chain of BAM records through this block
-    uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFFFu;
+    uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
     uint32_t n_rec = 0;
+    uint32_t next_evt = 0;              // output position at which the housekeeping below has something to do
 
-    auto flush_segments = [&]() {
-        while (op - flushed >= SEG) {
+    // after every symbol that carries `op` to `next_evt`: list the record starts whose block_size field is complete, and flush
+    // the 2 KiB segments that are complete
+    auto housekeeping = [&]() __attribute__((always_inline)) {
+        const bool over = op > ulen;                            // (ring writes are masked: nothing was overwritten; no flush then)
+        if (over) err = ST_BAD_LENGTH;
+        while (!over && next_rec + 4 <= op && next_rec < ulen) {
+            const uint32_t bs = (uint32_t)s_win[next_rec & WMASK] | ((uint32_t)s_win[(next_rec + 1) & WMASK] << 8) |
+                                ((uint32_t)s_win[(next_rec + 2) & WMASK] << 16) | ((uint32_t)s_win[(next_rec + 3) & WMASK] << 24);
+            const uint32_t ubs = uni(bs);
+            if (ubs < 32u || ubs > (1u << 28) || n_rec >= (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
+            if (lane == 0) slots[n_rec] = next_rec;
+            ++n_rec;
+            next_rec += 4u + ubs;
+        }
+        while (!over && op - flushed >= SEG) {
             const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & WMASK));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);          // uout is a multiple of 16 (host pads blocks)
 #pragma unroll
             for (int k = 0; k < SEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
             flushed += SEG;
         }
+        next_evt = min(flushed + (uint32_t)SEG, next_rec < ulen ? next_rec + 4u : 0xFFFFFFF0u);
     };
-    auto follow_records = [&]() {       // list every record start whose block_size field is complete
-        while (next_rec != 0xFFFFFFFFu && next_rec + 4 <= op && next_rec < ulen) {
-            const uint32_t bs = (uint32_t)s_win[next_rec & WMASK] | ((uint32_t)s_win[(next_rec + 1) & WMASK] << 8) |
-                                ((uint32_t)s_win[(next_rec + 2) & WMASK] << 16) | ((uint32_t)s_win[(next_rec + 3) & WMASK] << 24);
-            const uint32_t ubs = uni(bs);
-            if (ubs < 32u || ubs > (1u << 28) || n_rec >= (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFFFu; break; }
-            if (lane == 0) slots[n_rec] = next_rec;
-            ++n_rec;
-            next_rec += 4u + ubs;
-        }
-    };
+    housekeeping();
 
     bool last = false;
     while (!last && err == ST_OK) {
@@ -270,13 +309,13 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             const uint64_t at = b.idx * 4 - (uint64_t)(b.bc >> 3);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(b.w) + at;
             uint32_t done = 0;
-            while (done < len) {
+            while (done < len && err == ST_OK) {
                 const uint32_t n = min(len - done, (uint32_t)SEG - (op & (SEG - 1)));
+#pragma clang loop vectorize(disable) unroll(disable)
                 for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & WMASK] = src[done + i];
                 op += n;
                 done += n;
-                follow_records();
-                flush_segments();
+                housekeeping();
             }
             seek(at + len);
             continue;
@@ -301,14 +340,14 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 const uint32_t v = take(b, 3);
                 if (lane == 0) s_cll[CL_ORDER[i]] = (uint8_t)v;
             }
-            if (!build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT)) { err = ST_BAD_STREAM; break; }
+            if (uni(build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT, K_CODELEN) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
             for (int i = lane; i < 320; i += 64) s_lens[i] = 0;
             __syncthreads();
             int got = 0, prev = 0;
             while (got < nlen + ndist) {
                 refill(b);
                 const uint32_t e = uni(s_cl[(uint32_t)b.bb & ((1u << CL_ROOT) - 1u)]);
-                const int nb = (int)(e & 15u), sym = (int)(e >> 4);
+                const int nb = (int)(e & 15u), sym = (int)(e >> 16);
                 if (nb == 0) { err = ST_BAD_STREAM; break; }
                 take(b, nb);
                 int rep = 1, val = sym;
@@ -328,66 +367,55 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             __syncthreads();
             if (uni(s_lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
-        if (!build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT)) { err = ST_BAD_STREAM; break; }
-        if (!build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT)) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT, K_LITLEN) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT, K_DIST) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
 
-        // ---- symbols -------------------------------------------------------------------------------------------------
+        // ---- symbols: the hot loop.  Everything in it is wave-uniform (scalar registers); per symbol one LDS table look-up
+        //      (two for a match), no arithmetic on symbol numbers (the entries carry base and extra-bit count), one compare
+        //      for the housekeeping. ----------------------------------------------------------------------------------------
         for (;;) {
-            refill(b);
-            if (b.idx > idx_end) { err = ST_BAD_STREAM; break; }
-            uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
-            int nb = (int)(e & 15u), sym = (int)(e >> 4);
-            if (nb == 0) {                      // a code longer than the root table
-                sym = slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15, &nb);
-                sym = (int)uni((uint32_t)sym);
-                nb = (int)uni((uint32_t)nb);
-                if (sym < 0) { err = ST_BAD_STREAM; break; }
-            }
-            take(b, nb);
-            if (sym < 256) {
-                if (op >= ulen) { err = ST_BAD_LENGTH; break; }
-                if (lane == 0) s_win[op & WMASK] = (uint8_t)sym;
-                ++op;
-            } else if (sym == 256) {
-                break;
-            } else {
-                const int s = sym - 257;
-                if (s > 28) { err = ST_BAD_STREAM; break; }
-                int len;
-                if (s < 8) len = 3 + s;
-                else if (s == 28) len = 258;
-                else { const int eb = (s >> 2) - 1; len = 3 + ((4 + (s & 3)) << eb) + (int)take(b, eb); }
+            asm volatile("; HOT_BEGIN");
+            if (b.bc <= 32) {
+                if (b.idx > idx_end) { err = ST_BAD_STREAM; break; }
                 refill(b);
-                e = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
-                nb = (int)(e & 15u);
-                int ds = (int)(e >> 4);
-                if (nb == 0) {
-                    ds = slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15, &nb);
-                    ds = (int)uni((uint32_t)ds);
-                    nb = (int)uni((uint32_t)nb);
-                    if (ds < 0) { err = ST_BAD_STREAM; break; }
+            }
+            uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
+            if ((e & 15u) == 0) {               // a code longer than the root table (rare) or no code at all
+                const int sl = (int)uni((uint32_t)slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15));
+                e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
+                if ((e & 15u) == 0) { err = ST_BAD_STREAM; break; }
+            }
+            take(b, (int)(e & 15u));
+            if (e & E_LIT) {
+                if (lane == 0) s_win[op & WMASK] = (uint8_t)(e >> 16);
+                ++op;
+            } else if (e & E_BASE) {
+                const uint32_t len = (e >> 16) + take(b, (int)((e >> 4) & 15u));
+                if (b.bc <= 32) refill(b);
+                uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
+                if ((f & 15u) == 0) {
+                    const int sl = (int)uni((uint32_t)slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15));
+                    f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);
+                    if ((f & 15u) == 0) { err = ST_BAD_STREAM; break; }
                 }
-                take(b, nb);
-                if (ds > 29) { err = ST_BAD_STREAM; break; }
-                uint32_t dist;
-                if (ds < 4) dist = 1u + (uint32_t)ds;
-                else {
-                    const int eb = (ds >> 1) - 1;
-                    refill(b);
-                    dist = 1u + ((2u + (uint32_t)(ds & 1)) << eb) + take(b, eb);
-                }
-                if (dist > op || op + (uint32_t)len > ulen) { err = dist > op ? ST_BAD_STREAM : ST_BAD_LENGTH; break; }
+                take(b, (int)(f & 15u));
+                const uint32_t dist = (f >> 16) + take(b, (int)((f >> 4) & 15u));    // (<= 13 extra bits: still in the buffer)
+                if (dist > op) { err = ST_BAD_STREAM; break; }
                 // the match: all lanes copy; with dist < len the pattern of the last `dist` bytes repeats
-                if (dist > (uint32_t)NEAR) {
+                if (dist >= len && dist <= (uint32_t)NEAR) {
+                    uint32_t to = op + (uint32_t)lane, from = to - dist;
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64, to += 64, from += 64) s_win[to & WMASK] = s_win[from & WMASK];
+                } else if (dist > (uint32_t)NEAR) {
                     // beyond the LDS ring: the source lies in a segment that is complete and was flushed right after the
                     // symbol that completed it (same wavefront: its stores are ordered before this load)
                     const uint8_t *src = out + (op - dist);
-                    for (int i = lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
-                } else if (dist >= (uint32_t)len) {
-                    for (int i = lane; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op - dist + i) & WMASK];
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
                 } else {
                     const float inv = 1.0f / (float)dist;
-                    for (int i = lane; i < len; i += 64) {
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (int i = lane; i < (int)len; i += 64) {
                         int qd = (int)((float)i * inv);
                         int r = i - qd * (int)dist;
                         if (r < 0) r += (int)dist;
@@ -395,17 +423,21 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                         s_win[(op + i) & WMASK] = s_win[(op - dist + r) & WMASK];
                     }
                 }
-                op += (uint32_t)len;
+                op += len;
+            } else {
+                break;                          // end of block (E_EOB)
             }
-            if (next_rec + 4 <= op) follow_records();
-            if (op - flushed >= SEG) flush_segments();
+            asm volatile("; HOT_END");
+            if (op >= next_evt) {
+                housekeeping();
+                if (err != ST_OK) break;
+            }
         }
     }
     if (err == ST_OK && op != ulen) err = ST_BAD_LENGTH;
-    // the tail: whole 16-byte pieces, then bytes
+    // the tail: whole segments, then bytes
     if (err == ST_OK) {
-        follow_records();
-        flush_segments();
+        housekeeping();
         const uint32_t rest = op - flushed;
         for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & WMASK];
     }
@@ -413,7 +445,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         a.status[blk] = err;
         a.n_rec[blk] = n_rec;
         // a block that is walked must end on a record boundary, or say by how much its last record runs over
-        a.overshoot[blk] = d.entry >= 0 && next_rec != 0xFFFFFFFFu ? (int32_t)(next_rec - ulen) : 0;
+        a.overshoot[blk] = d.entry >= 0 && next_rec < 0xFFFFFFF0u ? (int32_t)(next_rec - ulen) : 0;
     }
 }
 

@@ -419,6 +419,24 @@ class BamFile:
             pass
 
 
+class LazyBam:
+    """The decoded BAM for the few callers that need reads on the host (insert tokens, Events.py:47-82): decoded by the
+    host reader on first use.  The tally itself never needs it — the device decodes the file."""
+
+    def __init__(self, path, threads=0):
+        self.filename, self._threads, self._bam = str(path), threads, None
+
+    def get(self):
+        if self._bam is None:
+            self._bam = BamFile(self.filename, threads=self._threads)
+        return self._bam
+
+    def close(self):
+        if self._bam is not None:
+            self._bam.close()
+            self._bam = None
+
+
 class DeviceBam:
     """A BAM file headed for the device decoder (tcmi_bamfile): the HOST side only reads the bytes into pinned memory,
     walks the BGZF block headers and parses the BAM header; Context.upload_bamfile() inflates, indexes and packs it with

@@ -10,13 +10,15 @@ import pandas as pd
 
 from . import _state
 from ._ffi import COLS
-from .engine import BamFile
+from . import _ffi
+from .engine import BamFile, DeviceBam, LazyBam
 from .io import fasta, gff
 
 
 def Readbam(f):
-    """indexing.py:6-19 — the decoded BAM (plays pysam.AlignmentFile's role downstream)."""
-    return f if isinstance(f, BamFile) else BamFile(f)
+    """indexing.py:6-19 — the BAM as the later stages see it (plays pysam.AlignmentFile's role downstream): decoded on the
+    host only when somebody asks for reads (insert tokens)."""
+    return f if isinstance(f, (BamFile, LazyBam)) else LazyBam(f)
 
 
 def Gffindex(file):
@@ -36,11 +38,29 @@ def Override_index_positions(index, override_data):
 
 
 def build_counts(bamfile, ref, ctx=None):
-    """BAM (+ reference FASTA, for its length) -> int32 [L,7] count matrix on the GPU path."""
-    bam = Readbam(bamfile)
+    """BAM (+ reference FASTA, for its length) -> int32 [L,7] count matrix on the GPU path.  A path (or LazyBam) is decoded
+    ON THE DEVICE (BGZF inflate, record chain, pack: csrc/bam_device.hip, pack_device.hip); files the device decoder
+    declines, and BamFile objects, go through the host reader's flat arrays."""
     ref_length = fasta.first_length(ref) if isinstance(ref, str) else int(ref)
     ctx = ctx or _state.default_context()
-    return ctx.tally(bam, ref_len=ref_length)
+    if not isinstance(bamfile, BamFile):
+        path = bamfile.filename if isinstance(bamfile, LazyBam) else str(bamfile)
+        d = DeviceBam(path)
+        try:
+            rs = ctx.upload_bamfile(d)
+        except _ffi.TcmiError as e:
+            if e.code != _ffi.E_UNSUPPORTED:
+                raise
+            rs = None
+        finally:
+            d.close()
+        if rs is not None:
+            try:
+                return ctx.step(rs, max(ref_length, rs.max_end, 1), 0, True, want_counts=True)[3]
+            finally:
+                rs.free()
+        bamfile = bamfile.get() if isinstance(bamfile, LazyBam) else BamFile(path)
+    return ctx.tally(bamfile, ref_len=ref_length)
 
 
 def BuildIndex(bamfile, ref):

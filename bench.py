@@ -65,6 +65,18 @@ def write_inputs(tmp, ref, orfs, n_files, n_reads, rank, indels, level):
     return paths, first["reads"]
 
 
+def inflated_size(path):
+    """Sum of the ISIZE fields of a BGZF file's blocks (4 bytes at the end of every gzip member)."""
+    import struct
+    raw = open(path, "rb").read()
+    off = tot = 0
+    while off + 18 <= len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        tot += struct.unpack_from("<I", raw, off + bsize - 4)[0]
+        off += bsize
+    return tot
+
+
 # ----------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(paths, L, mincov, orfs, n_threads, budget_s=12.0):
     """The same stages on the host: oracle/bam_oracle.c (sequential gunzip + record walk), oracle/tally_oracle.c
@@ -227,7 +239,7 @@ def main():
     ap.add_argument("--decoders", type=int, default=0, help="BAMs being decoded at a time (0 = auto)")
     ap.add_argument("--decode-threads", type=int, default=0, help="native threads per BAM decode (0 = auto)")
     ap.add_argument("--walkers", type=int, default=2)
-    ap.add_argument("--gpu-streams", type=int, default=2, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
+    ap.add_argument("--gpu-streams", type=int, default=3, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
     ap.add_argument("--host-decode", action="store_true", help="decode the BAMs on the host (tcmi_bam_load) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -371,7 +383,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
                              "classification / bit-plane pack) -> HIP tally + call (records to pinned host memory) -> host walk + "
                              "FASTA text (%d threads); stages of consecutive BAMs overlap; decoded on: %s"
                              % (decoders, a.walkers, json.dumps(runner.decoded_on)),
-                   "bam_file_bytes": os.path.getsize(paths[0]),
+                   "bam_file_bytes": os.path.getsize(paths[0]), "bam_inflated_bytes": inflated_size(paths[0]),
                    "input_generation_seconds_outside_clock": t_gen},
         "e2e_stage_busy_seconds_per_bam": {k: v / a.steps for k, v in runner.seconds.items()},
         "cold_kernels": cold,
@@ -394,13 +406,53 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     # ---- bit-exactness of what was timed, against the oracle chain (outside the clock) -----------------
     out.update(check_fasta(a, np, fastas[0], reads0, ref, orfs, L))
 
-    # ---- secondary: reads resident in HBM, the kernel rate and its roofline ----------------------------
+    # ---- rooflines of the cold path's kernels (HIP events of the timed run above; traffic from the committed PMC passes) ----
+    out.update(cold_rooflines(a, cold, os.path.getsize(paths[0]), out["config"].get("bam_inflated_bytes", 0), reads0))
+    # ---- secondary: reads resident in HBM, the tally kernel's rate and its roofline ----------------------------
     if not a.no_resident:
         res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
         out["resident"] = res["resident"]
-        out["roofline"] = res["roofline"]
+        out["resident"]["roofline"] = res["roofline"]
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(paths, L, a.mincov, orfs, n_threads=cores)
+    return out
+
+
+def cold_rooflines(a, cold, file_bytes, inflated_bytes, reads0):
+    """Per-kernel bytes against the 8 TB/s HBM roofline for the kernels of the file -> FASTA path.  `roofline` is the kernel
+    with the largest share of the GPU time (bgzf_inflate: serial Huffman decoding, bound by scalar instruction issue, not by
+    HBM — the fraction says how far from HBM-bound it is); `roofline_hot_path` is the dominant kernel of the tally path
+    proper (pk_pack, which reads the BAM-native bytes SURVEY 8-d counts).  `traffic` = HBM bytes from
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round (profiles/traffic.json), not measured in this run."""
+    import numpy as np
+    n = int(reads0["n_reads"])
+    alg_reads = int(np.sum(12 + 4 * np.diff(reads0["cigar_off"].astype(np.int64)) + (reads0["l_qseq"].astype(np.int64) + 1) // 2))
+    traffic = {}
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp))
+        except Exception:
+            traffic = {}
+
+    def block(kernel, us, bytes_moved, note, alg=None, traffic_key=None):
+        ach = bytes_moved / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        b = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": traffic.get(traffic_key), "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of round 2, per 1M-read BAM)" if traffic.get(traffic_key) else None,
+             "bytes_per_launch": bytes_moved, "avg_launch_us": us, "note": note}
+        if alg is not None:
+            b["algorithmic"] = {"bytes_per_launch": alg, "achieved": alg / (us * 1e-6) / 1e9 if us > 0 else 0.0,
+                                "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else 0.0}
+        return b
+
+    inflated = inflated_bytes or 273 * n
+    out = {"roofline": block("bgzf_inflate", cold["inflate"]["us_per_bam"], file_bytes + inflated,
+                             "compressed bytes read + inflated bytes written per BAM; one wavefront per BGZF block, wave-uniform Huffman "
+                             "decoding: bound by scalar instruction issue (profiles/r02_pmc_cold.txt), not by HBM", traffic_key="inflate_hbm_bytes_per_bam"),
+           "roofline_hot_path": block("pk_pack", cold["pack"]["us_per_bam"], alg_reads + 52 * n,
+                                      "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read it writes; it "
+                                      "reads them out of the inflated BAM stream (285 B per record, names and qualities ride along in the cache lines)",
+                                      alg=alg_reads, traffic_key="pack_hbm_bytes_per_bam")}
     return out
 
 
@@ -410,7 +462,19 @@ def check_fasta(a, np, fasta_text, reads0, ref, orfs, L):
     from oracle import c_oracle
     from oracle import tc_oracle as orc
     counts = c_oracle.tally(reads0, L)
-    has, ins = orc.list_inserts(counts, a.mincov, lambda p: orc.region_tokens(reads0, p))
+
+    def tokens_at(pos1):
+        # (the emulator loops over reads in Python: hand it only the sorted reads that can reach the column)
+        c, span = pos1 - 1, int(reads0["sorted_max_span"])
+        i0, i1 = int(np.searchsorted(reads0["pos"], c - span + 1, "left")), int(np.searchsorted(reads0["pos"], c, "right"))
+        co, so, qo = (np.asarray(reads0[k]) for k in ("cigar_off", "seq_off", "qual_off"))
+        sub = {"n_reads": i1 - i0, "pos": reads0["pos"][i0:i1], "flag": reads0["flag"][i0:i1], "l_qseq": reads0["l_qseq"][i0:i1],
+               "tid": reads0["tid"][i0:i1], "cigar_off": (co[i0:i1 + 1] - co[i0]).astype(np.uint64), "cigar": reads0["cigar"][int(co[i0]):int(co[i1])],
+               "seq_off": (so[i0:i1 + 1] - so[i0]).astype(np.uint64), "seq": reads0["seq"][int(so[i0]):int(so[i1])],
+               "qual_off": (qo[i0:i1 + 1] - qo[i0]).astype(np.uint64), "qual": reads0["qual"][int(qo[i0]):int(qo[i1])]}
+        return orc.region_tokens(sub, pos1)
+
+    has, ins = orc.list_inserts(counts, a.mincov, tokens_at)
     want, _ = orc.build_consensus(a.mincov, counts.astype(np.int64), [dict(o) for o in orfs], True, ins if has else None, True)
     want_text = orc.fasta_text("S0", a.mincov, want)
     return {"fasta_bit_exact": bool(fasta_text == want_text), "fasta_sha256": hashlib.sha256(fasta_text.encode()).hexdigest()[:16],

@@ -135,6 +135,14 @@ def gffdict_from_orfs(orfs, extra=False):
     return d
 
 
+def gffdict_cli(orfs):
+    d = {}
+    for k, o in enumerate(orfs):
+        d[k] = {"seqid": "SAMPLE", "source": "x", "type": "CDS", "start": o["start"], "end": o["end"], "score": ".",
+                "strand": o["strand"], "phase": "0", "attributes": "ID=o%d;Name=orf%d" % (k, k), "ID": "o%d" % k, "Name": "orf%d" % k}
+    return d
+
+
 class _TokBam:
     """duck-typed bam for Events.ExtractInserts (Events.py:63-67)."""
     references = ("refid",)
@@ -315,9 +323,40 @@ def golden_outputs(rng):
                 lines = run["vcf"].split("\n")
                 lines[1] = "##fileDate=DATE"
                 run["vcf"] = "\n".join(lines)
+                # the corrected GFF as the command line writes it: rows as a GFF reader hands them over (nine columns, then
+                # one key per attribute in file order) with seqid := sample name (TrueConsense.py:238-241)
+                Outputs.WriteOutputs(spec["mincov"], idict, gffdict_cli(spec["orfs"]), path, amb, None, "SAMPLE", "ref.fa",
+                                     paths["gff"], Hdr, paths["fa"])
+                run["gff_cli"] = open(paths["gff"]).read()
             except (KeyError, ZeroDivisionError, IndexError) as e:
                 run = {"raises": type(e).__name__}
             res["runs"][key] = run
+        # --index-override through the reference's own functions (indexing.py:39-72, TrueConsense.py:232-235): three rows
+        # of the index replaced, then the writers
+        if len(got) >= 12 and "raises" not in res["runs"]["amb1"]:
+            import pandas as pd
+            rows = []
+            for k, p1 in enumerate((2, len(got) // 2, len(got) - 1)):
+                cov = 40 + 7 * k
+                rows.append("%d,%d,%d,%d,%d,%d,%d,%d" % (p1, cov, cov - 9 - k, 4, 3, 2, k, (cov * 3) // 5 if k == 1 else 0))
+            csv = ",coverage,A,T,C,G,X,I\n" + "\n".join(rows) + "\n"
+            pz = "/tmp/_tc_golden_override_run.csv.gz"
+            with gzip.open(pz, "wt") as fh:
+                fh.write(csv)
+            df2 = indexing.Override_index_positions(indexing.BuildIndex(path, "ref.fa"), indexing.read_override_index(pz))
+            idict2 = df2.to_dict("index")
+            try:
+                Coverage.BuildCoverage(idict2, paths["tsv"])
+                Outputs.WriteOutputs(spec["mincov"], idict2, gffdict_cli(spec["orfs"]), path, True, paths["vcf"], "SAMPLE", "ref.fa",
+                                     paths["gff"], Hdr, paths["fa"])
+                orun = {k: open(p).read() for k, p in paths.items()}
+                lines = orun["vcf"].split("\n")
+                lines[1] = "##fileDate=DATE"
+                orun["vcf"] = "\n".join(lines)
+            except (KeyError, ZeroDivisionError, IndexError) as e:
+                orun = {"raises": type(e).__name__}
+            orun["csv"] = csv
+            res["override_run"] = orun
         out.append(res)
     return out
 

@@ -44,7 +44,17 @@ def _work(rank, world, use_gpu, q, td, sy, c_oracle):
         fn = None if use_gpu else (lambda shard, L_: c_oracle.tally(shard, L_))
         got = td.tally_split_bam(reads, L, rank, world, device=0, tally_fn=fn)
         want = c_oracle.tally(reads, L)
-        q.put((rank, bool(np.array_equal(got, want)), int(got[:, 0].sum())))
+        ok = bool(np.array_equal(got, want))
+        # the reduce-to-root form of the same exchange (what bench.py --split-bam does per step): only rank 0 gets the sum
+        import torch
+        part = torch.from_numpy(np.ascontiguousarray(c_oracle.tally(td.shard_reads(reads, rank, world), L).T.astype(np.int32)))
+        mine = part.clone()
+        td.reduce_counts(part, dst=0)
+        if rank == 0:
+            ok = ok and bool(np.array_equal(part.numpy().T, want))
+        else:
+            ok = ok and bool(torch.equal(part, mine) or True)      # (gloo leaves the non-root buffers unspecified)
+        q.put((rank, ok, int(got[:, 0].sum())))
 
 
 def _run(world, use_gpu):
@@ -96,3 +106,32 @@ def test_split_bam_allreduce_gloo_world2():
 @pytest.mark.gpu
 def test_split_bam_allreduce_gpu_tally_gloo_world2():
     _run(2, use_gpu=True)
+
+
+def _bench_ranks(extra, env_extra=None):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed with two ranks on
+    ONE GPU over gloo (TCMI_BENCH_REHEARSE=1: RCCL wants a GPU per rank); returns rank 0's JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, TCMI_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_many_bam_shard_two_ranks_rehearsal():
+    d = _bench_ranks(["--steps", "3", "--warmup", "1", "--reads", "40000", "--files", "2", "--no-cpu-baseline", "--no-resident"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
+    assert d["value"] > 0 and d["unit"] == "positions/s" and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_bench_split_bam_two_ranks_rehearsal():
+    d = _bench_ranks(["--split-bam", "--steps", "3", "--warmup", "1", "--reads", "40000"])
+    assert d["n_gpus"] == 2 and d["coverage_sum"] == d["coverage_sum_expected"] == 150 * 40000 * 2
+    assert d["consensus_len"] == 29903 and "gloo" in d["config"]["collective"]

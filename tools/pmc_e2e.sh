@@ -16,9 +16,9 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0][-28:]
+            k = row["Kernel_Name"][22:52].split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not any(x in k for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")): continue
+            if not any(x in row_name for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")) if False else not any(x in k for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")): continue
             print(k, {c: round(sum(v)/len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
 PY

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TCMI_ABI_VERSION 1
+#define TCMI_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define TCMI_OK            0
@@ -76,6 +76,13 @@ typedef struct tcmi_reads {
     int64_t sorted_max_span;    /* > 0 promises: reads ascend by pos (unplaced reads last) and no read
                                    spans more reference positions than this; lets the sweep visit only
                                    the reads around each candidate position (tcmi_bam_reads fills it)   */
+    /* optional mate fields and read names (SAM spec §4.2 next_refID, next_pos, tlen, read_name): what pysam's default
+     * pileup needs to find overlapping mates (ignore_overlaps, Events.py:66); NULL = not given                         */
+    const int32_t  *next_tid;   /* [n] */
+    const int32_t  *next_pos;   /* [n] */
+    const int32_t  *tlen;       /* [n] */
+    const uint64_t *name_off;   /* [n+1] offsets into names[] */
+    const char     *names;      /* read names, no terminators */
 } tcmi_reads;
 
 typedef struct tcmi_ctx tcmi_ctx;          /* one per device + stream            */
@@ -227,12 +234,19 @@ int tcmi_consensus_walk(const uint8_t *plain, const uint8_t *alt, const uint8_t 
  *   tokens / token_off : concatenated modal tokens, token k = tokens[token_off[k] .. token_off[k+1])
  *                        (empty when the column has no token)
  *   n_tokens[k]        : tokens in column k after filtering (0: empty pileup -> position dropped)
- *   depth_exceeded     : set to 1 when some column holds more than max_depth reads (pysam's
- *                        max_depth=8000 cap is not modelled)                    */
+ *   max_depth          : htslib's maxcnt (pysam's max_depth, default 8000): reads that share their start with the read
+ *                        before them are dropped once the column holds this many; 0 = no cap
+ *   ignore_overlaps    : pysam's default 1: of two overlapping mates only one keeps its base on the column (needs the
+ *                        mate fields and names of tcmi_reads; reads without names are taken as unpaired)
+ *   status_flags       : bit 0 = max_depth dropped reads (modelled, informational); bit 1 = a pair of overlapping mates
+ *                        whose quality tweak depends on positions off the column: the tokens are NOT what pysam gives —
+ *                        callers must refuse (the package raises TCMI_E_UNSUPPORTED)                                    */
+#define TCMI_TOKENS_DEPTH_CAPPED     1
+#define TCMI_TOKENS_OVERLAP_UNKNOWN  2
 int tcmi_modal_tokens(const tcmi_reads *reads, int32_t n_pos, const int64_t *positions,
                       int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans,
-                      int64_t max_depth, char *tokens, int64_t tokens_cap, int64_t *token_off,
-                      int64_t *n_tokens, int32_t *depth_exceeded);
+                      int64_t max_depth, int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off,
+                      int64_t *n_tokens, int32_t *status_flags);
 
 /* ---- many BAMs: native batch runner (BASELINE.json configs[3]: independent BAMs, no collective).
  * The calling thread queues step i+1 behind step i on one stream over `n_slots` workspaces while

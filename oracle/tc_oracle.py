@@ -110,7 +110,7 @@ def _indel_after(cigar, k):
     return 0
 
 
-def read_tokens(reads, i, with_qual=False):
+def read_tokens(reads, i, with_qual=False, qual_override=None):
     """Yield (column, token[, qual_at_qpos]) for read i in column order — the pileup
     entries htslib builds for this read and the text pysam's
     get_query_sequences(add_indels=True) prints for them."""
@@ -130,6 +130,8 @@ def read_tokens(reads, i, with_qual=False):
         return ch.lower() if rev else ch.upper()
 
     def qual_at(q):
+        if qual_override is not None:
+            return int(qual_override[q]) if q < lq else 0
         if qual is None or qual[1] is None:
             return 255
         return int(qual[0][qual[1] + q]) if q < lq else 0
@@ -340,13 +342,115 @@ def list_inserts(counts, mincov, tokens_at):
     return (True, found) if found else (False, None)
 
 
+def _match_positions(reads, i):
+    """{reference position: query index} over the M / = / X bases of read i (what htslib's cigar_iref2iseq_* walk)."""
+    out = {}
+    x, y = int(reads["pos"][i]), 0
+    for op, l in read_cigar(reads, i):
+        if op in _MATCH_OPS:
+            for j in range(l):
+                out[x + j] = y + j
+        if op in _REF_OPS:
+            x += l
+        if op in _QRY_OPS:
+            y += l
+    return out
+
+
+def _read_name(reads, i):
+    if reads.get("names") is None or reads.get("name_off") is None:
+        return None
+    a, b = int(reads["name_off"][i]), int(reads["name_off"][i + 1])
+    return bytes(bytearray(reads["names"][a:b]))
+
+
 def region_tokens(reads, pos1, min_base_quality=13, flag_filter=DEFAULT_FILTER,
-                  ignore_orphans=True):
-    """Tokens pysam's default pileup yields for column pos1-1 (unpinned).
-    Mate-overlap quality tweaking and the max_depth=8000 cap are not modelled."""
-    cols = pileup_columns(reads, flag_filter=flag_filter, ignore_orphans=ignore_orphans,
-                          min_base_quality=min_base_quality, only_column=pos1 - 1)
-    return cols.get(pos1 - 1, [])
+                  ignore_orphans=True, max_depth=8000, ignore_overlaps=True):
+    """Tokens pysam's default-argument region pileup yields for column pos1-1 (Events.py:63-67; PARITY
+    UNPINNED: restated from htslib 1.21's bam_plp_push / overlap_push / tweak_overlap_quality and pysam's
+    pileup_base_qual_skip, neither installed here).
+      * fed to the engine: the reads of the region fetch (those overlapping the column) that pass the samtools stepper
+        (flag filter, orphans), in file order;
+      * max_depth: a read that starts where the read before it started is dropped while the buffer holds max_depth nodes
+        (the list's sentinel counts as one);
+      * ignore_overlaps: when the second of two properly paired mates arrives, every reference position where both have a
+        matched base is tweaked in BOTH quality arrays (agreeing bases: first += second, at most 200, second = 0; differing:
+        the higher one x 0.8, the other 0) — applied here to the whole overlap, as htslib does;
+      * then every entry whose quality (at its query position; for deletion / ref-skip entries that of the next base) is
+        below min_base_quality is skipped."""
+    c = pos1 - 1
+    n = int(reads["n_reads"])
+    fed = []
+    for i in range(n):
+        if not read_piles_up(reads, i):
+            continue
+        f = int(reads["flag"][i])
+        if f & flag_filter:
+            continue
+        if ignore_orphans and (f & FLAG_PAIRED) and not (f & FLAG_PROPER):
+            continue
+        p = int(reads["pos"][i])
+        if p <= c < p + ref_length(read_cigar(reads, i)):
+            fed.append(i)
+    admitted, engine = [], None
+    for i in fed:
+        p = int(reads["pos"][i])
+        if max_depth and p == engine and len(admitted) + 1 > max_depth:
+            continue
+        admitted.append(i)
+        engine = p
+    quals = {}
+    have_q = reads.get("qual") is not None and "qual_off" in reads
+
+    def q_of(i):
+        if i not in quals:
+            o, l = int(reads["qual_off"][i]), int(reads["l_qseq"][i])
+            quals[i] = [int(v) for v in reads["qual"][o:o + l]]
+        return quals[i]
+
+    if ignore_overlaps and have_q and reads.get("names") is not None:
+        waiting = {}
+        for i in admitted:
+            f = int(reads["flag"][i])
+            if (f & 0x8) or not (f & FLAG_PROPER):
+                continue
+            p, l = int(reads["pos"][i]), int(reads["l_qseq"][i])
+            end = p + ref_length(read_cigar(reads, i))
+            mtid = int(reads["next_tid"][i]) if reads.get("next_tid") is not None else -1
+            mpos = int(reads["next_pos"][i]) if reads.get("next_pos") is not None else -1
+            isize = int(reads["tlen"][i]) if reads.get("tlen") is not None else 0
+            tid = int(reads["tid"][i]) if reads.get("tid") is not None else 0
+            if (mtid >= 0 and tid != mtid) or (abs(isize) >= 2 * l and mpos >= end):
+                continue
+            name = _read_name(reads, i)
+            if name not in waiting:
+                if mpos >= p or ((f & FLAG_PAIRED) and mpos == -1):
+                    waiting[name] = i
+                continue
+            a = waiting.pop(name)
+            ma, mb = _match_positions(reads, a), _match_positions(reads, i)
+            qa, qb = q_of(a), q_of(i)
+            for rp in sorted(set(ma) & set(mb)):
+                ia, ib = ma[rp], mb[rp]
+                if ia >= len(qa) or ib >= len(qb):
+                    continue
+                if read_base(reads, a, ia) == read_base(reads, i, ib):
+                    qa[ia] = min(200, qa[ia] + qb[ib])
+                    qb[ib] = 0
+                elif qa[ia] >= qb[ib]:
+                    qa[ia] = int(0.8 * qa[ia])
+                    qb[ib] = 0
+                else:
+                    qb[ib] = int(0.8 * qb[ib])
+                    qa[ia] = 0
+    out = []
+    for i in admitted:
+        for col, tok, q in read_tokens(reads, i, with_qual=True, qual_override=quals.get(i)):
+            if col == c:
+                if q >= min_base_quality:
+                    out.append(tok)
+                break
+    return out
 
 
 # --------------------------------------------------------------------------- stage B, walk

@@ -21,7 +21,7 @@ def parse_cigar(text):
 
 
 def reads_from_spec(spec):
-    """spec['reads'] = [{'pos','flag','cigar','seq','qual'(opt int or list),'tid'(opt)}]
+    """spec['reads'] = [{'pos','flag','cigar','seq','qual'(opt int or list),'tid'(opt),'name','mtid','mpos','tlen'(opt)}]
     -> dict of flat arrays in the tcmi_reads layout (include/tcmi.h)."""
     rs = spec["reads"]
     n = len(rs)
@@ -49,10 +49,18 @@ def reads_from_spec(spec):
         q = r.get("qual", 30)
         qual.extend([q] * len(s) if isinstance(q, int) else q)
         qual_off[i + 1] = len(qual)
-    return {"n_reads": n, "pos": pos, "flag": flag, "l_qseq": lq, "tid": tid,
-            "cigar_off": cig_off, "cigar": np.array(cig, np.uint32),
-            "seq_off": seq_off, "seq": np.frombuffer(bytes(seq), np.uint8).copy(),
-            "qual_off": qual_off, "qual": np.frombuffer(bytes(qual), np.uint8).copy()}
+    out = {"n_reads": n, "pos": pos, "flag": flag, "l_qseq": lq, "tid": tid,
+           "cigar_off": cig_off, "cigar": np.array(cig, np.uint32),
+           "seq_off": seq_off, "seq": np.frombuffer(bytes(seq), np.uint8).copy(),
+           "qual_off": qual_off, "qual": np.frombuffer(bytes(qual), np.uint8).copy()}
+    if any("name" in r for r in rs):                # mate fields and names (optional in tcmi_reads)
+        names = [str(r.get("name", "r%d" % i)).encode() for i, r in enumerate(rs)]
+        out["name_off"] = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.uint64)
+        out["names"] = np.frombuffer(b"".join(names) or b"\0", np.uint8).copy()
+        out["next_tid"] = np.array([r.get("mtid", -1) for r in rs], np.int32)
+        out["next_pos"] = np.array([r.get("mpos", -1) for r in rs], np.int32)
+        out["tlen"] = np.array([r.get("tlen", 0) for r in rs], np.int32)
+    return out
 
 
 def _rand_seq(rng, n, alphabet="ACGT"):

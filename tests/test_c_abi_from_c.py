@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     if (tcmi_reads_extent(&reads, ref_len, &L) != TCMI_OK) return 8;
     int64_t positions[2] = {5, 20}, off[3], cnt[2];
     char toks[4096]; int32_t deep = 0;
-    if (tcmi_modal_tokens(&reads, 2, positions, 13, 0x704, 1, 8000, toks, sizeof toks, off, cnt, &deep) != TCMI_OK) return 9;
+    if (tcmi_modal_tokens(&reads, 2, positions, 13, 0x704, 1, 8000, 1, toks, sizeof toks, off, cnt, &deep) != TCMI_OK) return 9;
     /* the host walk on hand-made call records: ACG with a deletion run outside any ORF */
     const uint8_t plain[6] = {'A','C','G','T','A','C'}, alt[6] = {'a','c','g','t','a','c'};
     const uint8_t flags[6] = {0, TCMI_F_PRIMX, TCMI_F_PRIMX, 0, 0, 0};

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import tc_oracle as orc
 from tests import synth_small as ss
-from trueconsense_amd import Events, Outputs, Sequences, engine
+from trueconsense_amd import Events, Outputs, Sequences, _ffi, engine
 from trueconsense_amd.io import bamwriter
 
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -304,3 +304,65 @@ def test_windowed_token_sweep_equals_full_sweep(tmp_path):
         hinted = dict(reads)
         hinted["sorted_max_span"] = max(spans)
         assert engine.modal_tokens(hinted, positions) == full
+
+
+def test_insert_tokens_max_depth_and_overlapping_mates():
+    """The two remaining defaults of pysam's pileup behind Events.ExtractInserts (Events.py:66): max_depth = 8000 and
+    ignore_overlaps.  The native sweep against the oracle's independent restatement (which tweaks the whole overlap of a
+    pair, as htslib does, where the product only evaluates the column)."""
+    rng = np.random.default_rng(8)
+    # ---- a 9 500-deep insert column: the first reads carry the insertion, the later ones (dropped by the cap) do not ----
+    reads = []
+    for k in range(9500):
+        carrier = k < 4200
+        reads.append({"pos": 100, "flag": 0, "cigar": "10M2I10M" if carrier else "20M",
+                      "seq": "ACGTACGTAC" + ("GG" if carrier else "") + "ACGTACGTAC", "qual": 30})
+    reads += [{"pos": 101 + int(j), "flag": 16, "cigar": "12M", "seq": "CGTACGTACACG", "qual": 35} for j in range(300) for _ in range(1)]
+    reads.sort(key=lambda r: r["pos"])
+    deep = ss.reads_from_spec({"reads": reads})
+    deep["sorted_max_span"] = 20
+    for max_depth, expect_modal in ((8000, "C+2GG"), (0, "C")):
+        want = orc.region_tokens(deep, 110, max_depth=max_depth)
+        got = engine.modal_tokens(deep, [110], max_depth=max_depth)[110]
+        assert got[1] == len(want) and got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0] == expect_modal
+    assert len(orc.region_tokens(deep, 110)) == 8000 + 9            # 8 000 admitted at the shared start, then every later start
+    # ---- overlapping mates: agreeing bases, differing bases, low qualities that only pass when summed, orphans ----
+    pairs = []
+    for k in range(400):
+        start = 200 + int(rng.integers(0, 8))
+        mate = start + int(rng.integers(0, 10))
+        base1 = "ACGT"[int(rng.integers(0, 4))]
+        base2 = base1 if rng.random() < 0.6 else "ACGT"[int(rng.integers(0, 4))]
+        q1, q2 = int(rng.integers(5, 41)), int(rng.integers(5, 41))
+        seq1 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 30))
+        seq2 = seq1[mate - start:] + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, mate - start))
+        # the column of interest is 1-based 215 (0-based 214)
+        i1, i2 = 214 - start, 214 - mate
+        seq1 = seq1[:i1] + base1 + seq1[i1 + 1:]
+        seq2 = seq2[:i2] + base2 + seq2[i2 + 1:]
+        ins = rng.random() < 0.7
+        cig1 = "%dM1I%dM" % (i1 + 1, 30 - i1 - 2) if ins else "30M"
+        flags = (99, 147) if rng.random() < 0.9 else (65, 129)        # proper pair / paired but not proper (orphans are filtered)
+        name = "pair%d" % k
+        pairs.append({"pos": start, "flag": flags[0], "cigar": cig1, "seq": seq1, "qual": [q1] * 30, "name": name, "mtid": 0, "mpos": mate,
+                      "tlen": mate + 30 - start})
+        pairs.append({"pos": mate, "flag": flags[1], "cigar": "30M", "seq": seq2, "qual": [q2] * 30, "name": name, "mtid": 0, "mpos": start,
+                      "tlen": -(mate + 30 - start)})
+    pairs.sort(key=lambda r: r["pos"])
+    pr = ss.reads_from_spec({"reads": pairs})
+    pr["sorted_max_span"] = 30
+    for col in (215, 214, 216):
+        for olap in (True, False):
+            want = orc.region_tokens(pr, col, ignore_overlaps=olap)
+            got = engine.modal_tokens(pr, [col], ignore_overlaps=olap)[col]
+            assert got[1] == len(want), (col, olap, got[1], len(want))
+            assert got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
+    assert len(orc.region_tokens(pr, 215)) < len(orc.region_tokens(pr, 215, ignore_overlaps=False))
+    # ---- a pair with a deletion on the column: the tweak depends on another position -> refused, not guessed ----
+    bad = ss.reads_from_spec({"reads": [
+        {"pos": 10, "flag": 99, "cigar": "5M2D10M", "seq": "ACGTACGTACGTACG", "qual": 30, "name": "p", "mtid": 0, "mpos": 12, "tlen": 30},
+        {"pos": 12, "flag": 147, "cigar": "15M", "seq": "ACGTACGTACGTACG", "qual": 30, "name": "p", "mtid": 0, "mpos": 10, "tlen": -30}]})
+    with pytest.raises(_ffi.TcmiError) as e:
+        engine.modal_tokens(bad, [16])
+    assert e.value.code == _ffi.E_UNSUPPORTED
+    assert engine.modal_tokens(bad, [16], ignore_overlaps=False)[16][1] == 2

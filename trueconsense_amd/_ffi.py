@@ -35,7 +35,9 @@ class Reads(C.Structure):
                 ("cigar_off", C.POINTER(C.c_uint64)), ("cigar", C.POINTER(C.c_uint32)),
                 ("seq_off", C.POINTER(C.c_uint64)), ("seq", C.POINTER(C.c_uint8)),
                 ("qual", C.POINTER(C.c_uint8)), ("tid", C.POINTER(C.c_int32)),
-                ("qual_off", C.POINTER(C.c_uint64)), ("sorted_max_span", C.c_int64)]
+                ("qual_off", C.POINTER(C.c_uint64)), ("sorted_max_span", C.c_int64),
+                ("next_tid", C.POINTER(C.c_int32)), ("next_pos", C.POINTER(C.c_int32)), ("tlen", C.POINTER(C.c_int32)),
+                ("name_off", C.POINTER(C.c_uint64)), ("names", C.POINTER(C.c_char))]
 
 
 _P = C.POINTER
@@ -71,7 +73,7 @@ _SIGS = {
     "tcmi_step_end": (_int, [_vp, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_consensus_walk": (_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, C.c_char_p, _vp,
                                    _int, _vp, _i64, _P(_i64), _vp, _vp, _P(_i64)]),
-    "tcmi_modal_tokens": (_int, [_P(Reads), _i32, _vp, _i32, _u32, _int, _i64, _vp, _i64, _vp, _vp, _P(_i32)]),
+    "tcmi_modal_tokens": (_int, [_P(Reads), _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
     "tcmi_pipeline_create": (_int, [_int, _int, _int, _P(_vp)]),
     "tcmi_pipeline_destroy": (_int, [_vp]),
     "tcmi_pipeline_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
@@ -133,8 +135,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tcmi_abi_version() != 1:
-            raise ImportError("libtcmi ABI version %d, expected 1" % handle.tcmi_abi_version())
+        if handle.tcmi_abi_version() != 2:
+            raise ImportError("libtcmi ABI version %d, expected 2" % handle.tcmi_abi_version())
         _lib = handle
     return _lib
 
@@ -169,9 +171,18 @@ def as_reads(d):
                              ("l_qseq", np.int32, C.c_int32, True), ("cigar_off", np.uint64, C.c_uint64, True),
                              ("cigar", np.uint32, C.c_uint32, True), ("seq_off", np.uint64, C.c_uint64, True),
                              ("seq", np.uint8, C.c_uint8, True), ("qual", np.uint8, C.c_uint8, False),
-                             ("tid", np.int32, C.c_int32, False), ("qual_off", np.uint64, C.c_uint64, False)):
+                             ("tid", np.int32, C.c_int32, False), ("qual_off", np.uint64, C.c_uint64, False),
+                             ("next_tid", np.int32, C.c_int32, False), ("next_pos", np.int32, C.c_int32, False),
+                             ("tlen", np.int32, C.c_int32, False), ("name_off", np.uint64, C.c_uint64, False)):
         a = arr(key, dt, req)
         setattr(r, key, a.ctypes.data_as(C.POINTER(ct)) if a is not None else None)
+    nm = d.get("names")
+    if nm is not None and d.get("name_off") is not None:
+        nm = np.ascontiguousarray(np.frombuffer(nm, np.uint8) if isinstance(nm, (bytes, bytearray)) else nm, np.uint8)
+        if nm.size == 0:
+            nm = np.zeros(1, np.uint8)
+        keep["names"] = nm
+        r.names = nm.ctypes.data_as(C.POINTER(C.c_char))
     r.sorted_max_span = int(d.get("sorted_max_span", 0) or 0)
     return r, keep
 

@@ -36,7 +36,9 @@ struct tcmi_bam {
     std::vector<std::string> ref_name;
     std::vector<int64_t> ref_len;
     int64_t n = 0;
-    std::vector<int32_t> pos, l_qseq, tid;
+    std::vector<int32_t> pos, l_qseq, tid, next_tid, next_pos, tlen;
+    std::vector<uint64_t> name_off;
+    RawBuf<char> names;
     std::vector<uint16_t> flag;
     std::vector<uint8_t> mapq;
     std::vector<uint64_t> cigar_off, seq_off, qual_off;
@@ -203,7 +205,8 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
     rec_at.reserve(N / 200 + 16);
     std::vector<uint64_t> &qual_off = bam->qual_off;
     bam->cigar_off.reserve(N / 200 + 16); bam->seq_off.reserve(N / 200 + 16); qual_off.reserve(N / 200 + 16);
-    uint64_t co = 0, so = 0, qo = 0;
+    uint64_t co = 0, so = 0, qo = 0, no = 0;
+    bam->name_off.reserve(N / 200 + 16);
     while (o < N) {                                              // one walk: record starts and the offsets of the flat arrays
         if (!need(4)) return fail("truncated record length");
         const size_t bs = rd32(p + o);
@@ -212,14 +215,16 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
         if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) return fail("alignment record fields overrun block_size");
         rec_at.push_back(o);
-        bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo);
-        co += n_c; so += (l_seq + 1) / 2; qo += l_seq;
+        bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo); bam->name_off.push_back(no);
+        co += n_c; so += (l_seq + 1) / 2; qo += l_seq; no += l_name ? l_name - 1 : 0;
         o += 4 + bs;
     }
     const auto t_walk = now();
     const int64_t n = (int64_t)rec_at.size();
     bam->n = n;
-    bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo);
+    bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo); bam->name_off.push_back(no);
+    bam->next_tid.resize((size_t)n); bam->next_pos.resize((size_t)n); bam->tlen.resize((size_t)n);
+    bam->names.alloc((size_t)no + 1);
     bam->pos.resize((size_t)n); bam->l_qseq.resize((size_t)n); bam->tid.resize((size_t)n);
     bam->flag.resize((size_t)n); bam->mapq.resize((size_t)n);
     {
@@ -249,6 +254,10 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
                 bam->mapq[(size_t)i] = r[9];
                 bam->flag[(size_t)i] = rd16(r + 14);
                 bam->l_qseq[(size_t)i] = (int32_t)l_seq;
+                bam->next_tid[(size_t)i] = (int32_t)rd32(r + 20);
+                bam->next_pos[(size_t)i] = (int32_t)rd32(r + 24);
+                bam->tlen[(size_t)i] = (int32_t)rd32(r + 28);
+                if (l_name > 1) std::memcpy(bam->names.data() + bam->name_off[(size_t)i], r + 32, l_name - 1);
                 const uint8_t *c = r + 32 + l_name;
                 std::memcpy(bam->cigar.data() + bam->cigar_off[(size_t)i], c, 4 * n_c);     // little-endian host
                 {
@@ -310,6 +319,11 @@ int tcmi_bam_reads(const tcmi_bam *bam, tcmi_reads *reads)
     reads->tid = bam->tid.data();
     reads->qual_off = bam->qual_off.data();
     reads->sorted_max_span = bam->sorted ? std::max<int64_t>(1, bam->max_span) : 0;
+    reads->next_tid = bam->next_tid.data();
+    reads->next_pos = bam->next_pos.data();
+    reads->tlen = bam->tlen.data();
+    reads->name_off = bam->name_off.data();
+    reads->names = bam->names.data();
     return TCMI_OK;
 }
 

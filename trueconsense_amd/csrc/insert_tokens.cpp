@@ -6,8 +6,17 @@
 // min_base_quality 13, no reference attached; it upper-cases every token and takes the modal
 // one with first-seen tie-break (collections.Counter.most_common, Events.py:71-74).
 // Token text follows pysam's PileupColumn.get_query_sequences(add_indels=True).
-// Not modelled (documented in DESIGN.md): mate-overlap quality tweaking (ignore_overlaps) and
-// the max_depth=8000 read cap — `*depth_exceeded` reports when the latter could matter.
+// The two remaining default arguments are modelled after htslib 1.21 (the one pysam 0.23.3 bundles; PARITY UNPINNED —
+// neither is installed here):
+//   max_depth = 8000     bam_plp_push drops a read that starts on the iterator's current column while the buffer holds
+//                        maxcnt nodes (its sentinel included).  A region pileup is fed only the reads that overlap the
+//                        column, all of them still alive: the 8 001st and later reads that share their start with the read
+//                        before them are dropped.
+//   ignore_overlaps      overlap_push / tweak_overlap_quality: of two properly paired mates that both cover the column, the
+//                        one pushed first keeps the base (quality = sum, at most 200, when the bases agree; 0.8 x the higher
+//                        one when they differ) and the other's quality becomes 0, so its token fails min_base_quality.
+//                        Evaluated where both mates have a matched base on the column; a pair where one mate's token takes
+//                        its quality from another position (deletion / ref-skip tokens) is reported, not guessed.
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -50,19 +59,31 @@ int64_t indel_after(const uint32_t *cg, int64_t n, int64_t k)
     return tot;
 }
 
-// Distinct tokens of one column in first-seen order.  A column holds a handful of distinct tokens and one of
-// them nearly always repeats, so a move-to-front probe of a short list beats hashing every token.  Tokens are
-// PACKED into 64 bits where they fit (a base, a deletion of any length, an insertion of <= 12 bases): no string
+// One read on one candidate column, before the filters that depend on the other reads of the column.
+struct Entry {
+    uint64_t key;               // packed token (see below), or 0: `tok` holds the text (insertions of more than 12 bases)
+    std::string tok;
+    uint64_t name_hash;         // 0: unnamed
+    int64_t end;                // end of the read on the reference (exclusive)
+    int32_t pos, tid, mtid, mpos, isize, l_qseq;
+    uint16_t flag;
+    uint8_t qual;               // base quality pysam tests: at the column's query position, or — deletion / ref-skip tokens — of the next base
+    uint8_t base;               // 4-bit code of that base
+    bool on_base;               // the token's first character is a base of this read sitting on the column
+};
+
+// Tokens are PACKED into 64 bits where they fit (a base, a deletion of any length, an insertion of <= 12 bases): no string
 // is built per read; the text is produced once, for the modal token.
 //   bit 63 set | bits 0-7 first character | bits 8-9 kind (0 plain, 1 insertion, 2 deletion)
 //   insertion: bits 10-13 length, bit 14 reverse strand (only if an inserted base is '=': its text depends on the
 //              strand), bits 15-62 the inserted bases as BAM 4-bit codes;  deletion: bits 10-41 length
+// Distinct tokens of one column in first-seen order.  A column holds a handful of distinct tokens and one of
+// them nearly always repeats, so a move-to-front probe of a short list beats hashing every token.
 struct Column {
-    struct Entry { uint64_t key; std::string tok; int64_t count; };   // key == 0: `tok` holds the text (long insertions)
-    std::vector<Entry> seen;
+    struct Seen { uint64_t key; std::string tok; int64_t count; };   // key == 0: `tok` holds the text (long insertions)
+    std::vector<Seen> seen;
     size_t last = 0;       // entry the previous token matched
     int64_t n = 0;
-    int64_t depth = 0;     // reads overlapping the column before base-quality filtering
     std::unordered_map<std::string, size_t> index;                 // only past 64 distinct tokens
     std::unordered_map<uint64_t, size_t> kindex;
 
@@ -85,7 +106,7 @@ struct Column {
             auto it = kindex.find(key);
             if (it != kindex.end()) { ++seen[it->second].count; last = it->second; return; }
         }
-        seen.push_back(Entry{key, std::string(), 1});
+        seen.push_back(Seen{key, std::string(), 1});
         last = seen.size() - 1;
         if (seen.size() > 65) kindex.emplace(key, last);
         grow_index();
@@ -101,12 +122,79 @@ struct Column {
             auto it = index.find(t);
             if (it != index.end()) { ++seen[it->second].count; last = it->second; return; }
         }
-        seen.push_back(Entry{0, t, 1});
+        seen.push_back(Seen{0, t, 1});
         last = seen.size() - 1;
         if (seen.size() > 65) index.emplace(t, last);
         grow_index();
     }
 };
+
+// The column's entries in file order -> the tokens pysam's default pileup would yield, counted.
+//   status bit 0: max_depth dropped reads (modelled);  bit 1: a pair of overlapping mates whose quality tweak could not be
+//   evaluated on this column (the caller refuses rather than guesses)
+void finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, Column &C, int32_t *status)
+{
+    // admission: htslib bam_plp_push
+    std::vector<uint8_t> in(es.size(), 1);
+    if (max_depth > 0) {
+        int64_t live = 0;
+        int64_t engine_pos = INT64_MIN;
+        for (size_t i = 0; i < es.size(); ++i) {
+            if ((int64_t)es[i].pos == engine_pos && live + 1 > max_depth) { in[i] = 0; *status |= 1; continue; }
+            ++live;
+            engine_pos = es[i].pos;
+        }
+    }
+    // overlapping mates: htslib overlap_push + tweak_overlap_quality
+    if (ignore_overlaps) {
+        std::unordered_map<uint64_t, size_t> waiting;
+        for (size_t i = 0; i < es.size(); ++i) {
+            Entry &b = es[i];
+            if (!in[i] || !b.name_hash) continue;
+            if ((b.flag & 0x8) || !(b.flag & 0x2)) continue;                         // mate unmapped / not a proper pair
+            if ((b.mtid >= 0 && b.tid != b.mtid) ||
+                (std::llabs((long long)b.isize) >= 2ll * b.l_qseq && (int64_t)b.mpos >= b.end)) continue;
+            auto it = waiting.find(b.name_hash);
+            if (it == waiting.end()) {
+                if (b.mpos >= b.pos || ((b.flag & 0x1) && b.mpos == -1)) waiting.emplace(b.name_hash, i);
+                continue;
+            }
+            Entry &a = es[it->second];
+            waiting.erase(it);
+            if (a.on_base && b.on_base) {
+                if (a.base == b.base) {
+                    const int q = (int)a.qual + (int)b.qual;
+                    a.qual = (uint8_t)(q > 200 ? 200 : q);
+                    b.qual = 0;
+                } else if (a.qual >= b.qual) {
+                    a.qual = (uint8_t)(0.8 * a.qual);
+                    b.qual = 0;
+                } else {
+                    b.qual = (uint8_t)(0.8 * b.qual);
+                    a.qual = 0;
+                }
+            } else if (!a.on_base && !b.on_base) {
+                *status |= 2;       // both tokens take their quality from a later base: the tweak there is outside this column
+            } else {
+                // the mate without a base here leaves the other's quality alone on this column; its own quality comes from
+                // a later position where the pair may or may not overlap
+                *status |= 2;
+            }
+        }
+    }
+    for (size_t i = 0; i < es.size(); ++i) {
+        if (!in[i] || (int)es[i].qual < min_base_quality) continue;                   // pileup_base_qual_skip
+        if (es[i].key) C.add_key(es[i].key);
+        else C.add_text(es[i].tok);
+    }
+}
+
+uint64_t fnv1a(const char *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= (uint8_t)p[i]; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
 
 inline void append_number(std::string &s, int64_t v)
 {
@@ -142,15 +230,16 @@ std::string text_of(uint64_t key)
 
 extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64_t *positions /* 1-based, ascending */,
                                  int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
-                                 char *tokens, int64_t tokens_cap, int64_t *token_off /* [n_pos+1] */,
-                                 int64_t *n_tokens /* [n_pos] */, int32_t *depth_exceeded)
+                                 int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off /* [n_pos+1] */,
+                                 int64_t *n_tokens /* [n_pos] */, int32_t *status_flags)
 {
     if (!r || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
         return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
     for (int32_t k = 1; k < n_pos; ++k)
         if (positions[k] <= positions[k - 1]) return tcmi_fail(nullptr, TCMI_E_ARG, "positions must ascend");
-    if (depth_exceeded) *depth_exceeded = 0;
+    int32_t status = 0;
     std::vector<Column> cols((size_t)n_pos);
+    std::vector<std::vector<Entry>> entries((size_t)n_pos);
     // Which reads to visit: all of them, or — when the caller promises sorted reads and a span bound
     // (tcmi_reads.sorted_max_span) — only those that can reach one of the candidate columns.
     std::vector<std::pair<int64_t, int64_t>> ranges;           // [first, last) read indices, ascending, disjoint
@@ -201,8 +290,7 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         const int64_t *lo = std::lower_bound(positions, positions + n_pos, beg + 1);
         for (const int64_t *pp = lo; pp < positions + n_pos && *pp - 1 < end; ++pp) {
             const int64_t col = *pp - 1;
-            Column &C = cols[(size_t)(pp - positions)];
-            ++C.depth;
+            std::vector<Entry> &E = entries[(size_t)(pp - positions)];
             // locate the op covering col
             int64_t x = beg, y = 0;
             for (int64_t k = 0; k < nc; ++k) {
@@ -221,7 +309,17 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                         const int64_t qpos = is_match(op) ? y + (col - x) : y;
                         int q = 255;
                         if (r->qual) q = qpos < lq ? r->qual[my_qoff + qpos] : 0;
-                        if (q < min_base_quality) break;                     // pileup_base_qual_skip
+                        Entry e;
+                        e.key = 0;
+                        e.qual = (uint8_t)q;
+                        e.on_base = is_match(op);
+                        e.base = (uint8_t)(qpos < lq ? ((qpos & 1) ? (s[qpos >> 1] & 0xF) : (s[qpos >> 1] >> 4)) : 15);
+                        e.pos = r->pos[i]; e.end = end; e.flag = (uint16_t)fl; e.l_qseq = (int32_t)lq;
+                        e.tid = r->tid ? r->tid[i] : 0;
+                        e.mtid = r->next_tid ? r->next_tid[i] : -1;
+                        e.mpos = r->next_pos ? r->next_pos[i] : -1;
+                        e.isize = r->tlen ? r->tlen[i] : 0;
+                        e.name_hash = (r->names && r->name_off) ? fnv1a(r->names + r->name_off[i], (size_t)(r->name_off[i + 1] - r->name_off[i])) : 0;
                         const char first = is_match(op) ? base(qpos) : (op == 3 ? (rev ? '<' : '>') : '*');
                         const int64_t indel = col == x + len - 1 ? indel_after(cg, nc, k) : 0;
                         if (indel <= 12 && -indel <= 0xFFFFFFFFll) {
@@ -240,15 +338,16 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                             } else if (indel < 0) {
                                 key |= (2ull << 8) | ((uint64_t)(-indel) << 10);
                             }
-                            C.add_key(key);
+                            e.key = key;
                         } else {
                             tok.clear();
                             tok.push_back(first);
                             tok.push_back('+');
                             append_number(tok, indel);
                             for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
-                            C.add_text(tok);
+                            e.tok = tok;
                         }
+                        E.push_back(std::move(e));
                         break;
                     }
                     x += len;
@@ -259,10 +358,10 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
     }
     int64_t off = 0;
     for (int32_t k = 0; k < n_pos; ++k) {
+        finalize_column(entries[(size_t)k], min_base_quality, max_depth, ignore_overlaps, cols[(size_t)k], &status);
         token_off[k] = off;
         n_tokens[k] = cols[(size_t)k].n;
-        if (max_depth > 0 && cols[(size_t)k].depth > max_depth && depth_exceeded) *depth_exceeded = 1;
-        const Column::Entry *best = nullptr;
+        const Column::Seen *best = nullptr;
         int64_t bc = 0;
         for (auto &e : cols[(size_t)k].seen)                     // first-seen order: ties go to the earliest
             if (e.count > bc) {
@@ -276,5 +375,6 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         }
     }
     token_off[n_pos] = off;
+    if (status_flags) *status_flags = status;
     return TCMI_OK;
 }

@@ -20,9 +20,6 @@
 
 #include "tcmi_internal.h"
 
-extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64_t *positions, int32_t min_base_quality,
-                                 uint32_t flag_filter, int ignore_orphans, int64_t max_depth, char *tokens,
-                                 int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *depth_exceeded);
 
 struct tcmi_pipeline {
     int device = 0;
@@ -86,11 +83,12 @@ int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags,
     if (!cand.empty()) {
         std::vector<int64_t> off(cand.size() + 1), cnt(cand.size());
         std::vector<char> toks(1 << 16);
-        int32_t deep = 0;
+        int32_t tok_status = 0;
         int rc;
         for (;;) {
-            rc = tcmi_modal_tokens(reads, (int32_t)cand.size(), cand.data(), 13, 0x4 | 0x100 | 0x200 | 0x400, 1, 8000,
-                                   toks.data(), (int64_t)toks.size(), off.data(), cnt.data(), &deep);
+            // pysam's defaults for AlignmentFile.pileup() (Events.py:66 passes none): SURVEY §8-Q8
+            rc = tcmi_modal_tokens(reads, (int32_t)cand.size(), cand.data(), 13, 0x4 | 0x100 | 0x200 | 0x400, 1, 8000, 1,
+                                   toks.data(), (int64_t)toks.size(), off.data(), cnt.data(), &tok_status);
             if (rc == TCMI_E_ARG && toks.size() < ((size_t)1 << 30) && std::strstr(tcmi_last_error(nullptr), "token buffer too small")) {
                 toks.resize(toks.size() * 16);
                 continue;
@@ -98,6 +96,9 @@ int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags,
             break;
         }
         if (rc) return rc;
+        if (tok_status & TCMI_TOKENS_OVERLAP_UNKNOWN)
+            return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED,
+                             "item %lld: overlapping mates with a deletion on an insert-candidate column: pysam's overlap quality tweak there is not modelled", item);
         for (size_t k = 0; k < cand.size(); ++k) {
             if (cnt[k] == 0) continue;
             int digit;

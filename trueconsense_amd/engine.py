@@ -338,8 +338,10 @@ DEFAULT_MAX_DEPTH = 8000
 
 
 def modal_tokens(reads, positions, min_base_quality=DEFAULT_MIN_BASE_QUALITY, flag_filter=DEFAULT_FLAG_FILTER,
-                 ignore_orphans=True, max_depth=DEFAULT_MAX_DEPTH):
-    """For each 1-based position: (modal upper-cased token or None, n_tokens)."""
+                 ignore_orphans=True, max_depth=DEFAULT_MAX_DEPTH, ignore_overlaps=True):
+    """For each 1-based position: (modal upper-cased token or None, n_tokens) under pysam's default pileup arguments
+    (Events.py:66).  Raises TcmiError(E_UNSUPPORTED) where overlapping mates meet a deletion on the column (the one case of
+    pysam's overlap handling that is not modelled)."""
     positions = np.ascontiguousarray(sorted(int(p) for p in positions), np.int64)
     n = len(positions)
     if n == 0:
@@ -352,7 +354,7 @@ def modal_tokens(reads, positions, min_base_quality=DEFAULT_MIN_BASE_QUALITY, fl
         cnt = np.zeros(n, np.int64)
         deep = C.c_int32(0)
         rc = lib().tcmi_modal_tokens(C.byref(r), n, ptr(positions), int(min_base_quality), int(flag_filter),
-                                     int(bool(ignore_orphans)), int(max_depth), C.cast(buf, C.c_void_p), cap,
+                                     int(bool(ignore_orphans)), int(max_depth), int(bool(ignore_overlaps)), C.cast(buf, C.c_void_p), cap,
                                      ptr(off), ptr(cnt), C.byref(deep))
         if rc == _ffi.E_ARG and b"token buffer too small" in (lib().tcmi_last_error(None) or b"") and cap < (1 << 30):
             cap *= 16
@@ -360,6 +362,9 @@ def modal_tokens(reads, positions, min_base_quality=DEFAULT_MIN_BASE_QUALITY, fl
         check(rc)
         break
     del keep
+    if deep.value & 2:
+        raise _ffi.TcmiError(_ffi.E_UNSUPPORTED, "overlapping mates with a deletion on an insert-candidate column: pysam's overlap "
+                                                  "quality tweak there is not modelled")
     out = {}
     for k in range(n):
         tok = buf.raw[off[k]:off[k + 1]].decode("ascii") if cnt[k] else None
@@ -402,7 +407,10 @@ class BamFile:
             return np.ctypeslib.as_array(p, shape=(cnt,))
         cig_off = view(r.cigar_off, n + 1)
         seq_off = view(r.seq_off, n + 1)
+        name_off = view(r.name_off, n + 1)
         return {"n_reads": n, "pos": view(r.pos, n), "flag": view(r.flag, n), "l_qseq": view(r.l_qseq, n),
+                "next_tid": view(r.next_tid, n), "next_pos": view(r.next_pos, n), "tlen": view(r.tlen, n), "name_off": name_off,
+                "names": np.ctypeslib.as_array(C.cast(r.names, C.POINTER(C.c_uint8)), shape=(max(1, int(name_off[n]) if n else 1),)),
                 "tid": view(r.tid, n), "cigar_off": cig_off, "cigar": view(r.cigar, max(1, self.n_cigar)),
                 "seq_off": seq_off, "seq": view(r.seq, max(1, int(seq_off[n]) if n else 1)),
                 "qual": view(r.qual, max(1, self.n_qual)), "_owner": self}

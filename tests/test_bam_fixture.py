@@ -150,3 +150,24 @@ def test_hand_assembled_bam_on_the_device(tmp_path):
     assert e.value.code == _ffi.E_UNSUPPORTED
     d2.close()
     assert np.array_equal(ctx.tally(engine.BamFile(p2), L=510), want)
+
+
+def test_cigar_in_cg_tag_is_refused(tmp_path):
+    """SAM spec §4.2.2: more than 65 535 CIGAR operations live in a CG:B,I tag behind the placeholder <l_seq>S<n>N; htslib
+    swaps the real CIGAR in.  The same placeholder WITHOUT the tag is an ordinary (if odd) read."""
+    from trueconsense_amd import _ffi
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:100\n"
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\0" + struct.pack("<i", 100)
+    cg_tag = b"CGBI" + struct.pack("<i", 2) + struct.pack("<II", (4 << 4) | 0, (4 << 4) | 0)
+    for aux, ok in ((b"", True), (b"NMC\x01" + cg_tag, False)):
+        p = str(tmp_path / ("cg%d.bam" % ok))
+        with open(p, "wb") as fh:
+            fh.write(bgzf(head))
+            fh.write(bgzf(rec(0, 5, "x", 0, [(8, "S"), (8, "N")], "ACGTACGT", [30] * 8, aux)))
+            fh.write(EOF_BLOCK)
+        if ok:
+            assert engine.BamFile(p).n_reads == 1
+        else:
+            with pytest.raises(_ffi.TcmiError) as e:
+                engine.BamFile(p)
+            assert e.value.code == _ffi.E_UNSUPPORTED and "CG tag" in str(e.value)

@@ -234,7 +234,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
     {
         int nt = n_threads;
         if ((int64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
-        std::vector<int> unsorted((size_t)nt, 0);
+        std::vector<int> unsorted((size_t)nt, 0), long_cigar((size_t)nt, 0);
         std::vector<int64_t> spans((size_t)nt, 0);
         auto fill = [&](int t) {
             const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
@@ -263,6 +263,26 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
                 {
                     int64_t span = 0;
                     const uint32_t *cg = bam->cigar.data() + bam->cigar_off[(size_t)i];
+                    // SAM spec §4.2.2: a CIGAR of more than 65 535 ops is stored in the CG:B,I tag behind the placeholder
+                    // <l_seq>S<ref_len>N.  htslib (bam_tag2cigar) substitutes the real CIGAR when that tag is present; this
+                    // reader does not: a read that has both the placeholder and the tag is refused.
+                    if (n_c == 2 && (cg[0] & 0xF) == 4 && (cg[0] >> 4) == l_seq && (cg[1] & 0xF) == 3 && l_seq > 0) {
+                        const uint8_t *a = c + 4 * n_c + (l_seq + 1) / 2 + l_seq, *e = r + rd32(r - 4);
+                        while (a + 3 <= e) {                     // aux fields: tag[2] type value
+                            const char ty = (char)a[2];
+                            if (a[0] == 'C' && a[1] == 'G' && ty == 'B') { long_cigar[(size_t)t] = 1; break; }
+                            a += 3;
+                            if (ty == 'A' || ty == 'c' || ty == 'C') a += 1;
+                            else if (ty == 's' || ty == 'S') a += 2;
+                            else if (ty == 'i' || ty == 'I' || ty == 'f') a += 4;
+                            else if (ty == 'Z' || ty == 'H') { while (a < e && *a) ++a; ++a; }
+                            else if (ty == 'B' && a + 5 <= e) {
+                                const char st = (char)a[0];
+                                const size_t cnt = rd32(a + 1), sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                                a += 5 + cnt * sz;
+                            } else break;                        // unknown type: stop scanning
+                        }
+                    }
                     for (size_t k = 0; k < n_c; ++k) {
                         const unsigned op = cg[k] & 0xF;
                         if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cg[k] >> 4;
@@ -289,6 +309,11 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         }
         for (int u : unsorted)
             if (u) bam->sorted = 0;
+        for (int u : long_cigar)
+            if (u) {
+                delete bam;
+                return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED, "%s: a read keeps its CIGAR in the CG tag (more than 65 535 operations): not supported", path);
+            }
         for (int64_t sp : spans) bam->max_span = std::max(bam->max_span, sp);
     }
     if (timing)

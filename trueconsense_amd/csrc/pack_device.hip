@@ -150,6 +150,10 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
                 else simple = false;
             }
             simple = simple && ph >= 2 && m > 0 && y0 < (1 << 20);
+            if (v.n_cigar == 2 && v.l_seq > 0) {            // <l_seq>S<n>N: the placeholder of a CIGAR kept in the CG tag (SAM spec §4.2.2)
+                const uint32_t c0 = ld_u32(v.cigar), c1 = ld_u32(v.cigar + 4);
+                if ((c0 & 0xFu) == 4 && (c0 >> 4) == (uint32_t)v.l_seq && (c1 & 0xFu) == 3) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
+            }
             kept = span > 0;
             if (kept) {
                 const int64_t end = (int64_t)v.pos + s.pos_shift + span;

@@ -265,6 +265,7 @@ static int upload_impl(tcmi_ctx *ctx, const tcmi_reads *const *batch, int32_t n_
             const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
             if (nc > 65535) return fail(TCMI_E_UNSUPPORTED, "read %lld has %lld CIGAR ops (> 65535)%.0lld", i, nc, 0);
             const int64_t lq = r->l_qseq[i];
+
             if (lq < 0) return fail(TCMI_E_ARG, "read %lld has negative l_qseq%.0lld%.0lld", i, 0, 0);
             const int64_t nbytes = (int64_t)(r->seq_off[i + 1] - r->seq_off[i]);
             if (nbytes < (lq + 1) / 2) return fail(TCMI_E_ARG, "read %lld: seq bytes %lld < ceil(l_qseq/2)%.0lld", i, nbytes, 0);

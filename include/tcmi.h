@@ -301,6 +301,15 @@ int  tcmi_bamfile_info(const tcmi_bamfile *f, int64_t *file_bytes, int64_t *infl
                        const char **ref0_name, int64_t *ref0_len);
 const char *tcmi_bamfile_text(const tcmi_bamfile *f);
 int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads);
+/* Events.ExtractInserts for a read set the DEVICE decoded (tcmi_readset_from_bamfile): same arguments and results as
+ * tcmi_modal_tokens, but the reads of every candidate column are examined by a HIP kernel where they lie (the inflated
+ * stream stays resident on the context until its next upload) and only a few thousand 48-byte entries per column reach
+ * the host.  TCMI_E_UNSUPPORTED when the stream is gone (another upload happened on the context), the read set was not
+ * decoded on the device, or an insertion of more than 12 bases sits on a column: use tcmi_bam_load + tcmi_modal_tokens. */
+int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions,
+                               int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
+                               int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,
+                               int32_t *status_flags);
 /* for tests and tools: the device-inflated stream and the record offsets copied back to the host */
 int  tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *stream, int64_t stream_cap,
                                  uint64_t *rec_off, int64_t rec_cap, int64_t *n_rec);

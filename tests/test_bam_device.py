@@ -151,3 +151,76 @@ def test_files_the_device_decoder_leaves_to_the_host(ctx, tmp_path):
     else:                                               # the flipped bit may decode to a valid stream of the right length:
         rs.free()                                       # then only the CRC (checked by the host reader) can tell
     d.close()
+
+
+def test_insert_tokens_resolved_on_the_device(ctx, tmp_path):
+    """Events.ExtractInserts (Events.py:47-82) for a BAM the device decoded: the HIP kernel's entries + the host vote against
+    the host sweep over the host-decoded file and against the oracle — indel sites of the configs[2] kind, a column deeper than
+    max_depth = 8000, and overlapping mates."""
+    from tests import synth_small as ss
+    from oracle import tc_oracle as orc
+    ref, orfs = sy.make_reference()
+    L = len(ref)
+    reads = sy.make_reads(ref, 120_000, seed=21, indel_sites=sy.default_indel_sites(orfs))
+    rng = np.random.default_rng(3)
+    reads["qual"] = rng.integers(5, 41, len(reads["qual"])).astype(np.uint8)          # the BQ >= 13 filter has something to do
+    p = str(tmp_path / "ind.bam")
+    bamwriter.write_bam(p, reads, "MN908947.3", L, level=1)
+    d = engine.DeviceBam(p)
+    rs = ctx.upload_bamfile(d)
+    plain, alt, flags, counts = ctx.step(rs, L, 30, True)
+    cand = (np.nonzero(flags & _ffi.F_INSCAND)[0] + 1).tolist()
+    sites = sorted(s[0] for s in sy.default_indel_sites(orfs))
+    cols = sorted(set(cand + sites))
+    assert len(cand) >= 3
+    got = ctx.readset_modal_tokens(rs, cols)
+    host = engine.modal_tokens(engine.BamFile(p), cols)
+    assert got == host
+    reads["sorted_max_span"] = int(reads["sorted_max_span"])
+    for c in cols:
+        lo, hi = int(np.searchsorted(reads["pos"], c - 1 - 200, "left")), int(np.searchsorted(reads["pos"], c - 1, "right"))
+        sub = {"n_reads": hi - lo, "pos": reads["pos"][lo:hi], "flag": reads["flag"][lo:hi], "l_qseq": reads["l_qseq"][lo:hi], "tid": reads["tid"][lo:hi],
+               "cigar_off": (reads["cigar_off"][lo:hi + 1] - reads["cigar_off"][lo]).astype(np.uint64), "cigar": reads["cigar"][int(reads["cigar_off"][lo]):int(reads["cigar_off"][hi])],
+               "seq_off": (reads["seq_off"][lo:hi + 1] - reads["seq_off"][lo]).astype(np.uint64), "seq": reads["seq"][int(reads["seq_off"][lo]):int(reads["seq_off"][hi])],
+               "qual_off": (reads["qual_off"][lo:hi + 1] - reads["qual_off"][lo]).astype(np.uint64), "qual": reads["qual"][int(reads["qual_off"][lo]):int(reads["qual_off"][hi])]}
+        want = orc.region_tokens(sub, c)
+        assert got[c][1] == len(want), c
+        if want:
+            assert got[c][0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0], c
+    # after another upload on the context the stream is gone: refused, and the caller takes the host sweep
+    rs2 = ctx.upload_bamfile(d)
+    with pytest.raises(_ffi.TcmiError) as e:
+        ctx.readset_modal_tokens(rs, cols)
+    assert e.value.code == _ffi.E_UNSUPPORTED
+    assert ctx.readset_modal_tokens(rs2, cols) == host
+    rs.free(); rs2.free(); d.close()
+    # ---- deeper than max_depth, and overlapping mates with names ----
+    deep = [{"pos": 100, "flag": 0, "cigar": "10M2I10M" if k < 4200 else "20M", "seq": "ACGTACGTAC" + ("GG" if k < 4200 else "") + "ACGTACGTAC",
+             "qual": 30, "name": "d%d" % k} for k in range(9500)]
+    pairs = []
+    for k in range(300):
+        start, mate = 200 + int(rng.integers(0, 8)), 208 + int(rng.integers(0, 8))
+        b1 = "ACGT"[int(rng.integers(0, 4))]
+        b2 = b1 if rng.random() < 0.6 else "ACGT"[int(rng.integers(0, 4))]
+        s1 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 30))
+        s2 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 30))
+        i1, i2 = 220 - start, 220 - mate
+        s1, s2 = s1[:i1] + b1 + s1[i1 + 1:], s2[:i2] + b2 + s2[i2 + 1:]
+        pairs.append({"pos": start, "flag": 99, "cigar": "%dM1I%dM" % (i1 + 1, 28 - i1), "seq": s1, "qual": [int(rng.integers(5, 41))] * 30,
+                      "name": "p%d" % k, "mtid": 0, "mpos": mate, "tlen": mate + 30 - start})
+        pairs.append({"pos": mate, "flag": 147, "cigar": "30M", "seq": s2, "qual": [int(rng.integers(5, 41))] * 30, "name": "p%d" % k, "mtid": 0,
+                      "mpos": start, "tlen": -(mate + 30 - start)})
+    allr = sorted(deep + pairs, key=lambda r: r["pos"])
+    rd = ss.reads_from_spec({"reads": allr})
+    p2 = str(tmp_path / "deep.bam")
+    bamwriter.write_bam(p2, rd, "r", 400)
+    d2 = engine.DeviceBam(p2)
+    rs = ctx.upload_bamfile(d2)
+    got = ctx.readset_modal_tokens(rs, [110, 221])
+    hb = engine.BamFile(p2)
+    assert got == engine.modal_tokens(hb, [110, 221])
+    assert got[110] == ("C+2GG", 8000)
+    want = orc.region_tokens(rd, 221)
+    assert got[221][1] == len(want) and got[221][0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
+    assert got[221][1] < len(orc.region_tokens(rd, 221, ignore_overlaps=False))
+    rs.free(); d2.close()

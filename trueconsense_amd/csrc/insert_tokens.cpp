@@ -226,7 +226,64 @@ std::string text_of(uint64_t key)
     return t;
 }
 
+// every column's entries -> its modal token (first-seen tie-break) and its token count
+int emit_modal(std::vector<std::vector<Entry>> &entries, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens,
+               int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status)
+{
+    const size_t n_pos = entries.size();
+    int64_t off = 0;
+    for (size_t k = 0; k < n_pos; ++k) {
+        Column col;
+        finalize_column(entries[k], min_base_quality, max_depth, ignore_overlaps, col, status);
+        token_off[k] = off;
+        n_tokens[k] = col.n;
+        const Column::Seen *best = nullptr;
+        int64_t bc = 0;
+        for (auto &e : col.seen)                                 // first-seen order: ties go to the earliest
+            if (e.count > bc) {
+                best = &e; bc = e.count;
+            }
+        if (best) {
+            const std::string text = best->key ? text_of(best->key) : best->tok;
+            if (off + (int64_t)text.size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");
+            std::memcpy(tokens + off, text.data(), text.size());
+            off += (int64_t)text.size();
+        }
+    }
+    token_off[n_pos] = off;
+    return TCMI_OK;
+}
+
 } // namespace
+
+// Entries produced on the device (pack_device.hip, ins_entries_kernel) -> the same finalisation as the host sweep.
+int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
+                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens, int64_t tokens_cap,
+                                int64_t *token_off, int64_t *n_tokens, int32_t *status_flags)
+{
+    std::vector<std::vector<Entry>> entries((size_t)n_pos);
+    int32_t status = 0;
+    for (int32_t k = 0; k < n_pos; ++k) {
+        std::vector<const tcmi_dev_entry *> order;
+        order.reserve((size_t)ent_cnt[k]);
+        for (int32_t t = 0; t < ent_cnt[k]; ++t) order.push_back(ents + ent_off[k] + t);
+        std::sort(order.begin(), order.end(), [](const tcmi_dev_entry *a, const tcmi_dev_entry *b) { return a->j < b->j; });   // file order
+        auto &E = entries[(size_t)k];
+        E.reserve(order.size());
+        for (const tcmi_dev_entry *d : order) {
+            if (d->bits & 0x40) return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED, "an insertion of more than 12 bases on a candidate column: host sweep");
+            Entry e;
+            e.key = d->key; e.name_hash = d->name_hash; e.end = d->end; e.pos = d->pos; e.tid = 0;
+            e.mtid = (d->bits & 0x20) ? 1 : 0;                 // only "same reference or not" matters
+            e.mpos = d->mpos; e.isize = d->isize; e.l_qseq = d->l_qseq; e.flag = d->flag; e.qual = d->qual;
+            e.base = d->bits & 0xF; e.on_base = (d->bits & 0x10) != 0;
+            E.push_back(std::move(e));
+        }
+    }
+    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap, token_off, n_tokens, &status);
+    if (status_flags) *status_flags = status;
+    return rc;
+}
 
 extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64_t *positions /* 1-based, ascending */,
                                  int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
@@ -238,7 +295,6 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
     for (int32_t k = 1; k < n_pos; ++k)
         if (positions[k] <= positions[k - 1]) return tcmi_fail(nullptr, TCMI_E_ARG, "positions must ascend");
     int32_t status = 0;
-    std::vector<Column> cols((size_t)n_pos);
     std::vector<std::vector<Entry>> entries((size_t)n_pos);
     // Which reads to visit: all of them, or — when the caller promises sorted reads and a span bound
     // (tcmi_reads.sorted_max_span) — only those that can reach one of the candidate columns.
@@ -276,7 +332,7 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         const int64_t my_qoff = qoff;
         qoff += lq;
         const unsigned fl = r->flag[i];
-        if ((fl & 0x4) || (r->tid && r->tid[i] < 0) || r->pos[i] < 0) continue;
+        if ((fl & 0x4) || (r->tid && r->tid[i] != 0) || r->pos[i] < 0) continue;   // Events.py:64: references[0] only
         if (fl & flag_filter) continue;
         if (ignore_orphans && (fl & 0x1) && !(fl & 0x2)) continue;
         const uint32_t *cg = r->cigar + r->cigar_off[i];
@@ -356,25 +412,8 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
             }
         }
     }
-    int64_t off = 0;
-    for (int32_t k = 0; k < n_pos; ++k) {
-        finalize_column(entries[(size_t)k], min_base_quality, max_depth, ignore_overlaps, cols[(size_t)k], &status);
-        token_off[k] = off;
-        n_tokens[k] = cols[(size_t)k].n;
-        const Column::Seen *best = nullptr;
-        int64_t bc = 0;
-        for (auto &e : cols[(size_t)k].seen)                     // first-seen order: ties go to the earliest
-            if (e.count > bc) {
-                best = &e; bc = e.count;
-            }
-        if (best) {
-            const std::string text = best->key ? text_of(best->key) : best->tok;
-            if (off + (int64_t)text.size() > tokens_cap) return tcmi_fail(nullptr, TCMI_E_ARG, "token buffer too small");
-            std::memcpy(tokens + off, text.data(), text.size());
-            off += (int64_t)text.size();
-        }
-    }
-    token_off[n_pos] = off;
+    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap, token_off, n_tokens, &status);
+    if (rc) return rc;
     if (status_flags) *status_flags = status;
     return TCMI_OK;
 }

@@ -81,6 +81,39 @@ __device__ inline ReadView view(const PackSrc &s, int64_t i)
     return v;
 }
 
+__device__ inline uint32_t nib_at(const uint8_t *seq, int32_t q)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(seq + (q >> 1));
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3) >> ((a & 3) * 8);
+    return (q & 1) ? (w & 15u) : ((w >> 4) & 15u);
+}
+__device__ inline uint32_t byte_at(const uint8_t *p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return (*reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3) >> ((a & 3) * 8)) & 0xFFu;
+}
+
+// does the record carry a CG:B aux field (the real CIGAR of a read with more than 65 535 operations, SAM spec §4.2.2)?
+__device__ inline bool has_cg_tag(const uint8_t *aux, const uint8_t *end)
+{
+    for (int guard = 0; guard < 4096 && aux + 3 <= end; ++guard) {
+        const uint32_t t0 = byte_at(aux), t1 = byte_at(aux + 1), ty = byte_at(aux + 2);
+        if (t0 == 'C' && t1 == 'G' && ty == 'B') return true;
+        aux += 3;
+        if (ty == 'A' || ty == 'c' || ty == 'C') aux += 1;
+        else if (ty == 's' || ty == 'S') aux += 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') aux += 4;
+        else if (ty == 'Z' || ty == 'H') { while (aux < end && byte_at(aux)) ++aux; ++aux; }
+        else if (ty == 'B' && aux + 5 <= end) {
+            const uint32_t st = byte_at(aux), cnt = ld_u32(aux + 1);
+            const uint32_t sz = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u;
+            if (cnt > (1u << 28)) return false;
+            aux += 5 + (size_t)cnt * sz;
+        } else return false;
+    }
+    return false;
+}
+
 __device__ inline bool consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 __device__ inline bool is_match(uint32_t op) { return op == 0 || op == 7 || op == 8; }
 
@@ -150,9 +183,13 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
                 else simple = false;
             }
             simple = simple && ph >= 2 && m > 0 && y0 < (1 << 20);
-            if (v.n_cigar == 2 && v.l_seq > 0) {            // <l_seq>S<n>N: the placeholder of a CIGAR kept in the CG tag (SAM spec §4.2.2)
+            if (s.mode == 1 && v.n_cigar == 2 && v.l_seq > 0) {   // <l_seq>S<n>N + a CG:B tag: the real CIGAR lives in the tag (SAM spec §4.2.2)
                 const uint32_t c0 = ld_u32(v.cigar), c1 = ld_u32(v.cigar + 4);
-                if ((c0 & 0xFu) == 4 && (c0 >> 4) == (uint32_t)v.l_seq && (c1 & 0xFu) == 3) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
+                if ((c0 & 0xFu) == 4 && (c0 >> 4) == (uint32_t)v.l_seq && (c1 & 0xFu) == 3) {
+                    const uint8_t *rec = s.stream + s.rec_off[i];
+                    if (has_cg_tag(v.seq + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq, rec + 4 + ld_u32(rec)))
+                        atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);   // (the host reader words the refusal)
+                }
             }
             kept = span > 0;
             if (kept) {
@@ -515,6 +552,121 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
     }
 }
 
+
+// ---- insert-candidate columns: every read of a column as an entry for the host's token vote (Events.py:47-82) -----------------
+// One lane per (candidate column, read that starts within TCMI_D_MAXLEN positions before it).  The lane applies the samtools
+// stepper's filters, finds the CIGAR op that covers the column and builds what pysam's get_query_sequences(add_indels=True)
+// would print for it as a packed 64-bit key (insert_tokens.cpp), with the quality pysam tests, the base, the mate fields and a
+// hash of the read name; the few thousand entries per column go to the host, which applies the rules that depend on the other
+// reads of the column (max_depth admission, overlapping mates, the vote).  The decoded reads themselves never leave the device.
+struct InsArgs {
+    PackSrc src;
+    const uint32_t *c_idx;
+    const int32_t *cols;            // [n_cand] 0-based columns
+    const int64_t *lo;              // [n_cand] first compacted read index to look at
+    const int64_t *off;             // [n_cand + 1] pair offsets: candidate k owns pairs [off[k], off[k+1])
+    tcmi_dev_entry *out;            // [off[n_cand]]: candidate k's entries are compacted at out + off[k]
+    int32_t *count;                 // [n_cand]
+    int32_t n_cand;
+    uint32_t flag_filter;
+    int32_t ignore_orphans;
+};
+
+
+__global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
+{
+    const int64_t p = (int64_t)blockIdx.x * PB + threadIdx.x;
+    if (p >= a.off[a.n_cand]) return;
+    int k = 0;
+    while (k + 1 < a.n_cand && p >= a.off[k + 1]) ++k;          // (a handful of candidates)
+    const int64_t j = a.lo[k] + (p - a.off[k]);
+    const int32_t col = a.cols[k];
+    const uint32_t i = a.c_idx[j];
+    const ReadView v = view(a.src, i);
+    if (v.flag & a.flag_filter) return;
+    if (a.ignore_orphans && (v.flag & 0x1u) && !(v.flag & 0x2u)) return;
+    // the op that covers the column
+    int64_t x = v.pos, y = 0;
+    int64_t span = 0;
+    for (uint32_t c = 0; c < v.n_cigar; ++c) {
+        const uint32_t w = ld_u32(v.cigar + 4 * (size_t)c);
+        if (consumes_ref(w & 0xFu)) span += w >> 4;
+    }
+    if (col < v.pos || col >= v.pos + span) return;
+    for (uint32_t c = 0; c < v.n_cigar; ++c) {
+        const uint32_t w = ld_u32(v.cigar + 4 * (size_t)c), op = w & 0xFu;
+        const int64_t len = w >> 4;
+        if (consumes_ref(op)) {
+            if (col < x + len) {
+                const bool rev = v.flag & 0x10u;
+                const int32_t lq = v.l_seq;
+                const int64_t qpos = is_match(op) ? y + (col - x) : y;
+                const uint8_t *qual = v.seq + ((size_t)lq + 1) / 2;
+                tcmi_dev_entry e;
+                e.qual = (uint8_t)(qpos < lq ? byte_at(qual + qpos) : 0u);
+                const uint32_t nib = qpos < lq ? nib_at(v.seq, (int32_t)qpos) : 15u;
+                e.bits = (uint8_t)(nib | (is_match(op) ? 0x10u : 0u));
+                // first character: "=ACMGRSVTWYHKDBN", '=' prints as '.' / ',' by strand; '*' for a deleted base, '>' '<' for a skip
+                const char *NT = "=ACMGRSVTWYHKDBN";
+                char first = is_match(op) ? NT[nib] : (op == 3 ? (rev ? '<' : '>') : '*');
+                if (first == '=') first = rev ? ',' : '.';
+                // p->indel of htslib's resolve_cigar2 on the last reference base of the op
+                int64_t indel = 0;
+                if (col == x + len - 1 && c + 1 < v.n_cigar) {
+                    const uint32_t w2 = ld_u32(v.cigar + 4 * (size_t)(c + 1)), op2 = w2 & 0xFu;
+                    if (op2 == 2 && op != 2) {
+                        indel = -(int64_t)(w2 >> 4);
+                        for (uint32_t t = c + 2; t < v.n_cigar; ++t) { const uint32_t wt = ld_u32(v.cigar + 4 * (size_t)t); if ((wt & 0xFu) != 2) break; indel -= wt >> 4; }
+                    } else if (op2 == 1) {
+                        indel = w2 >> 4;
+                        for (uint32_t t = c + 2; t < v.n_cigar; ++t) {
+                            const uint32_t wt = ld_u32(v.cigar + 4 * (size_t)t), o = wt & 0xFu;
+                            if (o == 1) indel += wt >> 4; else if (o != 6) break;
+                        }
+                    } else if (op2 == 6 && c + 2 < v.n_cigar) {
+                        for (uint32_t t = c + 2; t < v.n_cigar; ++t) {
+                            const uint32_t wt = ld_u32(v.cigar + 4 * (size_t)t), o = wt & 0xFu;
+                            if (o == 1) indel += wt >> 4; else if (consumes_ref(o)) break;
+                        }
+                    }
+                }
+                uint64_t key = (1ull << 63) | (uint8_t)first;
+                if (indel > 12) e.bits |= 0x40;                   // does not fit the key: the host sweep takes the BAM
+                else if (indel > 0) {
+                    key |= (1ull << 8) | ((uint64_t)indel << 10);
+                    bool any_eq = false;
+                    for (int64_t t = 1; t <= indel; ++t) {
+                        const int64_t q2 = qpos + t;
+                        const uint32_t nb = q2 >= lq ? 15u : nib_at(v.seq, (int32_t)q2);
+                        any_eq |= nb == 0;
+                        key |= (uint64_t)nb << (15 + 4 * (t - 1));
+                    }
+                    if (any_eq && rev) key |= 1ull << 14;
+                } else if (indel < 0) {
+                    key |= (2ull << 8) | ((uint64_t)(-indel) << 10);
+                }
+                e.key = key;
+                // mate fields and the name (behind block_size: refID 0, pos 4, l_read_name 8, ..., next_refID 20, next_pos 24, tlen 28, name 32)
+                const uint8_t *r = a.src.stream + a.src.rec_off[i] + 4;
+                const int32_t mtid = (int32_t)ld_u32(r + 20);
+                e.mpos = (int32_t)ld_u32(r + 24);
+                e.isize = (int32_t)ld_u32(r + 28);
+                if (mtid >= 0 && mtid != v.tid) e.bits |= 0x20;
+                const uint32_t l_name = ld_u32(r + 8) & 0xFFu;
+                uint64_t h = 1469598103934665603ull;
+                for (uint32_t t = 0; t + 1 < l_name; ++t) { h ^= byte_at(r + 32 + t); h *= 1099511628211ull; }
+                e.name_hash = h ? h : 1;
+                e.j = (uint32_t)j; e.pos = v.pos; e.end = (int32_t)(v.pos + span); e.l_qseq = lq; e.flag = (uint16_t)v.flag; e.pad_ = 0;
+                const int slot = atomicAdd(&a.count[k], 1);
+                a.out[a.off[k] + slot] = e;
+                return;
+            }
+            x += len;
+        }
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
+    }
+}
+
 } // namespace
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -528,6 +680,7 @@ static int arena_reserve(tcmi_ctx *ctx, size_t bytes)
     if (!ctx->dev_arena) ctx->dev_arena = new tcmi_dev_arena();
     tcmi_dev_arena &A = *ctx->dev_arena;
     A.used = 0;
+    ++ctx->arena_epoch;                         // whatever lived in the arena is gone
     if (A.cap >= bytes) return TCMI_OK;
     if (A.base) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(A.base); A.base = nullptr; A.cap = 0; }
     const size_t want = bytes + bytes / 8 + (1 << 20);
@@ -665,6 +818,10 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
             return TCMI_E_UNSUPPORTED;
         }
         rs->d_flenoff = o.lenoff; rs->d_fseq = o.seq; rs->d_fchunk = o.chunks; rs->d_fcovrun = o.covrun; rs->d_fevent = o.events;
+        if (src.mode == 1) {                    // the stream and the index stay in the arena until this context's next upload
+            rs->d_stream = src.stream; rs->d_rec_off = src.rec_off; rs->d_cidx = c_idx; rs->d_cpos = c_pos;
+            rs->arena_epoch = ctx->arena_epoch;
+        }
         rs->f_chunks = tot.n_chunks; rs->f_words = tot.word_cursor; rs->f_events = tot.n_events;
         rs->dev_bytes = nf * 4 + (int64_t)tot.word_cursor * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) +
                         (int64_t)tot.n_runs * 4 + (int64_t)tot.n_events * 4;
@@ -702,4 +859,74 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
     }
     if (n == 0) { rs->packed_on_device = 1; return TCMI_OK; }
     return tcmi_pack_on_device(ctx, &s, rs, why);
+}
+
+extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions,
+                                         int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
+                                         int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,
+                                         int32_t *status_flags)
+{
+    if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
+        return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (!rs->d_stream || rs->arena_epoch != ctx->arena_epoch || rs->device != ctx->device)
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "the read set's decoded stream is no longer (or never was) resident on this context: host sweep");
+    for (int32_t k = 1; k < n_pos; ++k)
+        if (positions[k] <= positions[k - 1]) return tcmi_fail(ctx, TCMI_E_ARG, "positions must ascend");
+    if (n_pos == 0) { if (status_flags) *status_flags = 0; return TCMI_OK; }
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nf = rs->f_reads;
+    // the kept reads ascend by position (a BAM the device decoder took is coordinate-sorted or was declined): which of them
+    // can reach each column?  Their positions come back once (4 bytes per read).
+    std::vector<int32_t> cpos((size_t)nf);
+    TCMI_HIP(ctx, hipMemcpyAsync(cpos.data(), rs->d_cpos, (size_t)nf * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!std::is_sorted(cpos.begin(), cpos.end()))
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "reads are not sorted by position: host sweep");
+    std::vector<int32_t> cols((size_t)n_pos);
+    std::vector<int64_t> lo((size_t)n_pos), off((size_t)n_pos + 1, 0);
+    for (int32_t k = 0; k < n_pos; ++k) {
+        const int64_t c = positions[k] - 1;
+        cols[(size_t)k] = (int32_t)c;
+        const int64_t a = std::lower_bound(cpos.begin(), cpos.end(), (int32_t)std::max<int64_t>(c - TCMI_D_MAXLEN + 1, INT32_MIN / 2)) - cpos.begin();
+        const int64_t b = std::upper_bound(cpos.begin(), cpos.end(), (int32_t)std::min<int64_t>(c, INT32_MAX)) - cpos.begin();
+        lo[(size_t)k] = a;
+        off[(size_t)k + 1] = off[(size_t)k] + std::max<int64_t>(0, b - a);
+    }
+    const int64_t total = off[(size_t)n_pos];
+    std::vector<tcmi_dev_entry> ents((size_t)std::max<int64_t>(total, 1));
+    std::vector<int32_t> cnt((size_t)n_pos, 0);
+    if (total > 0) {
+        // the entries live outside the arena (it holds the stream): one transient allocation, only for BAMs with candidates
+        char *buf = nullptr;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_ent = al((size_t)total * sizeof(tcmi_dev_entry)), b_cols = al((size_t)n_pos * 4), b_lo = al((size_t)n_pos * 8),
+                     b_off = al(((size_t)n_pos + 1) * 8), b_cnt = al((size_t)n_pos * 4);
+        TCMI_HIP(ctx, hipMalloc((void **)&buf, b_ent + b_cols + b_lo + b_off + b_cnt));
+        InsArgs a;
+        a.src = {};
+        a.src.stream = rs->d_stream; a.src.rec_off = rs->d_rec_off; a.src.mode = 1; a.src.n = rs->n_reads;
+        a.c_idx = rs->d_cidx;
+        a.out = (tcmi_dev_entry *)buf;
+        a.cols = (const int32_t *)(buf + b_ent);
+        a.lo = (const int64_t *)(buf + b_ent + b_cols);
+        a.off = (const int64_t *)(buf + b_ent + b_cols + b_lo);
+        a.count = (int32_t *)(buf + b_ent + b_cols + b_lo + b_off);
+        a.n_cand = n_pos; a.flag_filter = flag_filter; a.ignore_orphans = ignore_orphans;
+        hipError_t e = hipMemcpyAsync((void *)a.cols, cols.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((void *)a.lo, lo.data(), (size_t)n_pos * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((void *)a.off, off.data(), ((size_t)n_pos + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(a.count, 0, (size_t)n_pos * 4, ctx->stream);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(ins_entries_kernel, dim3((unsigned)((total + PB - 1) / PB)), dim3(PB), 0, ctx->stream, a);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), a.count, (size_t)n_pos * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ents.data(), a.out, (size_t)total * sizeof(tcmi_dev_entry), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(buf);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "insert-token kernel failed: %s", hipGetErrorString(e));
+    }
+    return tcmi_modal_from_dev_entries(n_pos, ents.data(), off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap,
+                                       token_off, n_tokens, status_flags);
 }

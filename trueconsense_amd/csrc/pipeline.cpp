@@ -66,9 +66,12 @@ bool parse_token(const char *t, int64_t n, int *size_digit, const char **bases, 
 }
 
 // call records of one BAM -> consensus: insert candidates -> modal tokens (Events.py:5-82), then the sequential walk
+// modal tokens of the candidate columns resolved beforehand (on the device: tcmi_readset_modal_tokens)
+struct PreTokens { std::vector<int64_t> cand, off, cnt; std::vector<char> toks; bool valid = false; };
+
 int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags, int64_t L, const tcmi_reads *reads, bool reads_known,
                  const std::vector<int64_t> &orf_start, const std::vector<int64_t> &orf_end, const std::vector<uint8_t> &orf_plus,
-                 char *out, int64_t cap, int64_t *out_len, long long item)
+                 char *out, int64_t cap, int64_t *out_len, long long item, const PreTokens *pre = nullptr)
 {
     // insert candidates (Events.py:29-36 evaluated by the call kernel) -> accepted inserts
     std::vector<int64_t> cand;
@@ -77,15 +80,17 @@ int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags,
     std::vector<int64_t> ins_pos, ins_off(1, 0);
     std::vector<int32_t> ins_shift;
     std::string ins_seq;
-    if (!cand.empty() && !reads_known)
+    const bool use_pre = pre && pre->valid && pre->cand == cand;
+    if (!cand.empty() && !reads_known && !use_pre)
         return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED,
                          "item %lld has %zu insert candidates but no host reads were given to resolve their tokens", item, cand.size());
     if (!cand.empty()) {
         std::vector<int64_t> off(cand.size() + 1), cnt(cand.size());
         std::vector<char> toks(1 << 16);
         int32_t tok_status = 0;
-        int rc;
-        for (;;) {
+        int rc = TCMI_OK;
+        if (use_pre) { off = pre->off; cnt = pre->cnt; toks = pre->toks; }
+        else for (;;) {
             // pysam's defaults for AlignmentFile.pileup() (Events.py:66 passes none): SURVEY §8-Q8
             rc = tcmi_modal_tokens(reads, (int32_t)cand.size(), cand.data(), 13, 0x4 | 0x100 | 0x200 | 0x400, 1, 8000, 1,
                                    toks.data(), (int64_t)toks.size(), off.data(), cnt.data(), &tok_status);
@@ -323,6 +328,7 @@ struct FileItem {
     int rc = TCMI_OK;
     std::string err;
     bool on_device = false;
+    PreTokens pre;                      // insert tokens resolved on the device while the decoded stream was still resident
 };
 
 double seconds_since(std::chrono::steady_clock::time_point t0)
@@ -456,6 +462,32 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                         std::memcpy(it.rec.data(), pl, (size_t)L);
                         std::memcpy(it.rec.data() + L, al, (size_t)L);
                         std::memcpy(it.rec.data() + 2 * L, fl, (size_t)L);
+                        // insert candidates of a BAM the device decoded: their tokens are voted on now, from the stream that is
+                        // still resident in this context's arena (Events.py:47-82 without the reads ever reaching the host)
+                        if (it.on_device) {
+                            for (int64_t k = 0; k < L; ++k)
+                                if (fl[k] & TCMI_F_INSCAND) it.pre.cand.push_back(k + 1);
+                            if (!it.pre.cand.empty()) {
+                                const size_t nc = it.pre.cand.size();
+                                it.pre.off.assign(nc + 1, 0);
+                                it.pre.cnt.assign(nc, 0);
+                                it.pre.toks.assign(1 << 16, 0);
+                                int32_t st = 0;
+                                int rt;
+                                for (;;) {
+                                    rt = tcmi_readset_modal_tokens(ctx, rs, (int32_t)nc, it.pre.cand.data(), 13, 0x4 | 0x100 | 0x200 | 0x400, 1, 8000, 1,
+                                                                   it.pre.toks.data(), (int64_t)it.pre.toks.size(), it.pre.off.data(), it.pre.cnt.data(), &st);
+                                    if (rt == TCMI_E_ARG && it.pre.toks.size() < ((size_t)1 << 30) && std::strstr(tcmi_last_error(ctx), "token buffer too small")) {
+                                        it.pre.toks.resize(it.pre.toks.size() * 16);
+                                        continue;
+                                    }
+                                    break;
+                                }
+                                // (anything the device path declines — a long insertion, overlapping mates with a deletion on the
+                                // column — is left to the walker's host sweep, which words the refusal if it is one)
+                                it.pre.valid = rt == TCMI_OK && !(st & TCMI_TOKENS_OVERLAP_UNKNOWN);
+                            }
+                        }
                     }
                 }
                 t_step = seconds_since(t1);
@@ -489,6 +521,7 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                 const uint8_t *pl = it.rec.data(), *al = pl + L, *fl = pl + 2 * L;
                 bool cand = false;
                 for (int64_t k = 0; k < L && !cand; ++k) cand = (fl[k] & TCMI_F_INSCAND) != 0;
+                if (it.pre.valid) cand = false;                  // already resolved on the device
                 tcmi_bam *hb = nullptr;
                 tcmi_reads reads;
                 int rc = TCMI_OK;
@@ -501,7 +534,7 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                 int64_t len = 0;
                 if (!rc && (head < 0 || head + 2 >= stride)) rc = tcmi_fail(nullptr, TCMI_E_ARG, "output stride too small");
                 if (!rc) rc = walk_records(pl, al, fl, L, cand ? &reads : nullptr, true, r->orf_start, r->orf_end, r->orf_plus, dst + head,
-                                           stride - head - 1, &len, (long long)i);
+                                           stride - head - 1, &len, (long long)i, &it.pre);
                 if (!rc) { dst[head + len] = '\n'; out_len[i] = head + len + 1; }
                 else { it.rc = rc; it.err = tcmi_last_error(nullptr); }
                 if (hb) tcmi_bam_free(hb);

@@ -89,6 +89,13 @@ struct tcmi_readset {
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
     int device = -1;
     int packed_on_device = 0;   // 1: pack_device.hip built the aligned set (everything below lives in d_blob)
+    // device-decoded read sets: the inflated stream and the packer's index stay in the context's arena until its next upload
+    // (arena_epoch tells): the insert-token kernel reads qualities, inserted bases, names and mate fields from there
+    const uint8_t *d_stream = nullptr;
+    const uint64_t *d_rec_off = nullptr;
+    const uint32_t *d_cidx = nullptr;
+    const int32_t *d_cpos = nullptr;
+    uint64_t arena_epoch = 0;
     char *d_blob = nullptr;     // one allocation holding d_flenoff | d_fseq | d_fchunk | d_fcovrun | d_fevent
     size_t blob_bytes = 0;
     // aligned set
@@ -122,6 +129,7 @@ struct tcmi_ctx {
     int device = -1;
     tcmi_upload_scratch *upload_scratch = nullptr;
     tcmi_dev_arena *dev_arena = nullptr;
+    uint64_t arena_epoch = 0;        // bumped whenever the arena is handed out anew
     // device-packed read sets hand their allocation back when they are freed; the next upload of a similar size takes it
     // (hipMalloc + hipFree cost more than the pack kernels, and hipFree waits for the device)
     struct Blob { char *p; size_t bytes; };
@@ -193,6 +201,20 @@ struct tcmi_pack_src {
     int64_t n;
     int32_t mode, pos_shift;
 };
+// one read on one insert-candidate column, as the device kernel hands it to the host (pack_device.hip -> insert_tokens.cpp)
+struct tcmi_dev_entry {
+    uint64_t key;               // packed token (insert_tokens.cpp)
+    uint64_t name_hash;         // FNV-1a of the read name
+    uint32_t j;                 // the read's place in file order (compacted index)
+    int32_t pos, end, mpos, isize, l_qseq;
+    uint16_t flag;
+    uint8_t qual;
+    uint8_t bits;               // base code | on_base << 4 | mate on another reference << 5 | insertion too long for the key << 6
+    uint32_t pad_;
+};
+int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
+                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens, int64_t tokens_cap,
+                                int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
 // device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);

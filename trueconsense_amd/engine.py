@@ -117,6 +117,24 @@ class Context:
         rs = ReadSet(self, h, None)
         return rs
 
+    def readset_modal_tokens(self, readset, positions, min_base_quality=13, flag_filter=0x4 | 0x100 | 0x200 | 0x400,
+                             ignore_orphans=True, max_depth=8000, ignore_overlaps=True):
+        """modal_tokens() for a read set the device decoded: the reads of each candidate column are examined by a HIP kernel in
+        the still-resident inflated stream.  Raises TcmiError(E_UNSUPPORTED) when that stream is gone or a token does not fit."""
+        positions = np.ascontiguousarray(sorted(int(p) for p in positions), np.int64)
+        n = len(positions)
+        if n == 0:
+            return {}
+        cap = 1 << 16
+        buf = C.create_string_buffer(cap)
+        off, cnt, st = np.zeros(n + 1, np.int64), np.zeros(n, np.int64), C.c_int32(0)
+        check(lib().tcmi_readset_modal_tokens(self.handle, readset.handle, n, ptr(positions), int(min_base_quality), int(flag_filter),
+                                              int(bool(ignore_orphans)), int(max_depth), int(bool(ignore_overlaps)), C.cast(buf, C.c_void_p), cap,
+                                              ptr(off), ptr(cnt), C.byref(st)), self.handle)
+        if st.value & 2:
+            raise _ffi.TcmiError(_ffi.E_UNSUPPORTED, "overlapping mates with a deletion on an insert-candidate column")
+        return {int(positions[k]): (buf.raw[off[k]:off[k + 1]].decode("ascii") if cnt[k] else None, int(cnt[k])) for k in range(n)}
+
     def tally(self, reads, L=None, ref_len=0):
         """reads -> int32 [L,7] (coverage,A,T,C,G,X,I); L defaults to max(ref_len, read extent)."""
         r, keep = reads.as_struct() if isinstance(reads, BamFile) else _ffi.as_reads(reads)

@@ -58,6 +58,9 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
         cg_b = np.ascontiguousarray(cg, "<u4").tobytes()
         sq_b = np.ascontiguousarray(sq, np.uint8).tobytes()
         q_b = np.ascontiguousarray(qual, np.uint8).tobytes() if qual is not None else None
+        nm_off, nm = reads.get("name_off"), reads.get("names")
+        nm_b = bytes(bytearray(nm)) if nm is not None else None
+        mt, mp, tl = reads.get("next_tid"), reads.get("next_pos"), reads.get("tlen")
         for i in range(n):
             c0, c1 = int(co[i]), int(co[i + 1])
             s0 = int(so[i])
@@ -67,12 +70,13 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
             for k in range(c0, c1):
                 if (int(cg[k]) & 0xF) in (0, 2, 3, 7, 8):
                     span += int(cg[k]) >> 4
-            name = b"r%d\0" % i
+            name = (nm_b[int(nm_off[i]):int(nm_off[i + 1])] + b"\0") if nm_b is not None and nm_off is not None else b"r%d\0" % i
             t = int(tid[i]) if tid is not None else 0
             p = int(pos[i])
             q = q_b[int(qoff[i]):int(qoff[i]) + l] if q_b is not None else b"\xff" * l
             rec = (struct.pack("<iiBBHHHIiii", t, p, len(name), 60, _reg2bin(max(p, 0), max(p, 0) + max(span, 1)), nc,
-                               int(flag[i]), l, -1, -1, 0) + name + cg_b[4 * c0:4 * c1] +
+                               int(flag[i]), l, int(mt[i]) if mt is not None else -1, int(mp[i]) if mp is not None else -1,
+                               int(tl[i]) if tl is not None else 0) + name + cg_b[4 * c0:4 * c1] +
                    sq_b[s0:s0 + (l + 1) // 2] + q)
             if split_records:
                 out += struct.pack("<i", len(rec)) + rec

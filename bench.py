@@ -420,7 +420,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     out.update(check_fasta(a, np, fastas[0], reads0, ref, orfs, L))
 
     # ---- rooflines of the cold path's kernels (HIP events of the timed run above; traffic from the committed PMC passes) ----
-    out.update(cold_rooflines(a, cold, os.path.getsize(paths[0]), out["config"].get("bam_inflated_bytes", 0), reads0))
+    out.update(cold_rooflines(a, out["cold_kernels_pipelined"], cold, os.path.getsize(paths[0]), out["config"].get("bam_inflated_bytes", 0), reads0))
     # ---- secondary: reads resident in HBM, the tally kernel's rate and its roofline ----------------------------
     if not a.no_resident:
         res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
@@ -431,8 +431,11 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     return out
 
 
-def cold_rooflines(a, cold, file_bytes, inflated_bytes, reads0):
-    """Per-kernel bytes against the 8 TB/s HBM roofline for the kernels of the file -> FASTA path.  `roofline` is the kernel
+def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
+    """Per-kernel bytes against the 8 TB/s HBM roofline for the kernels of the file -> FASTA path.  `avg_launch_us` is the HIP-event
+    time of the launches of the TIMED region (three contexts: kernels of different BAMs share the GPU, which stretches each
+    of them — rocprofv3's per-kernel average of the same command, profiles/, shows the same stretch); `single_stream_us` is the
+    same kernel with nothing else on the GPU.  `roofline` is the kernel
     with the largest share of the GPU time (bgzf_inflate: serial Huffman decoding, bound by scalar instruction issue, not by
     HBM — the fraction says how far from HBM-bound it is); `roofline_hot_path` is the dominant kernel of the tally path
     proper (pk_pack, which reads the BAM-native bytes SURVEY 8-d counts).  `traffic` = HBM bytes from
@@ -448,9 +451,11 @@ def cold_rooflines(a, cold, file_bytes, inflated_bytes, reads0):
         except Exception:
             traffic = {}
 
-    def block(kernel, us, bytes_moved, note, alg=None, traffic_key=None):
+    def block(kernel, key, bytes_moved, note, alg=None, traffic_key=None):
+        us, us1 = timed[key]["us_per_bam"], cold[key]["us_per_bam"]
         ach = bytes_moved / (us * 1e-6) / 1e9 if us > 0 else 0.0
         b = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "single_stream_us": us1, "single_stream_frac": (bytes_moved / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS) if us1 > 0 else None,
              "traffic": traffic.get(traffic_key), "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of round 2, per 1M-read BAM)" if traffic.get(traffic_key) else None,
              "bytes_per_launch": bytes_moved, "avg_launch_us": us, "note": note}
         if alg is not None:
@@ -459,10 +464,10 @@ def cold_rooflines(a, cold, file_bytes, inflated_bytes, reads0):
         return b
 
     inflated = inflated_bytes or 273 * n
-    out = {"roofline": block("bgzf_inflate", cold["inflate"]["us_per_bam"], file_bytes + inflated,
+    out = {"roofline": block("bgzf_inflate", "inflate", file_bytes + inflated,
                              "compressed bytes read + inflated bytes written per BAM; one wavefront per BGZF block, wave-uniform Huffman "
                              "decoding: bound by scalar instruction issue (profiles/r02_pmc_cold.txt), not by HBM", traffic_key="inflate_hbm_bytes_per_bam"),
-           "roofline_hot_path": block("pk_pack", cold["pack"]["us_per_bam"], alg_reads + 52 * n,
+           "roofline_hot_path": block("pk_pack", "pack", alg_reads + 52 * n,
                                       "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read it writes; it "
                                       "reads them out of the inflated BAM stream (285 B per record, names and qualities ride along in the cache lines)",
                                       alg=alg_reads, traffic_key="pack_hbm_bytes_per_bam")}

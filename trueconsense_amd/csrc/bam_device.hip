@@ -41,9 +41,9 @@ namespace {
 #endif
 constexpr int WIN = TCMI_INFLATE_WIN, WMASK = WIN - 1;   // LDS ring: the most recent output.  The deflate window is 32 KiB: a match that
                                                          // reaches further back than the ring reads what was already flushed to HBM
-constexpr int SEG = 2048;                       // flush granularity
+constexpr int SEG = TCMI_INFLATE_WIN >= 4096 ? 2048 : TCMI_INFLATE_WIN / 2;   // flush granularity
 constexpr int NEAR = WIN - 264;                 // matches up to this distance are copied LDS -> LDS
-static_assert(SEG <= WIN - 528 && (WIN & (WIN - 1)) == 0 && WIN % SEG == 0, "a far match must find its source flushed");
+static_assert(SEG <= WIN - 528 && (WIN & (WIN - 1)) == 0 && WIN % SEG == 0 && SEG % 1024 == 0, "a far match must find its source flushed");
 constexpr int LL_ROOT = 10, D_ROOT = 9, CL_ROOT = 7;
 constexpr int MAX_REC_PER_BLOCK = 65536 / 36 + 2;   // a record is at least 36 bytes (block_size + 32 fixed + 1 name byte ..)
 
@@ -138,11 +138,20 @@ __device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint
     return -1;
 }
 
+#ifndef TCMI_INFLATE_COMPACT
+#define TCMI_INFLATE_COMPACT 0      // 1: 16-bit root-table entries (code length | symbol << 4), base and extra bits computed per symbol: half the
+#endif                              //    table LDS (more blocks in flight per CU) for ~6 more scalar instructions per match
 // Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), extra bits in
 // bits 4-7, kind in bits 8-10, value in bits 16-31 (the literal, the base length or the base distance): the hot loop needs
 // no arithmetic on symbols.
 constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
 enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
+
+#if TCMI_INFLATE_COMPACT
+typedef uint16_t tab_t;
+#else
+typedef uint32_t tab_t;
+#endif
 
 __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 {
@@ -173,7 +182,7 @@ __device__ inline
 #else
 __device__ __noinline__             // three call sites: one copy of the code keeps the kernel small (instruction cache)
 #endif
-bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, uint32_t *tab, int root, int kind)
+bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, tab_t *tab, int root, int kind)
 {
     const int lane = threadIdx.x;
     __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
@@ -216,7 +225,11 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
     // root table: every lane decodes its indices
     for (int i = lane; i < (1 << root); i += 64) {
         const int s = slow_decode(cnt, sym, (uint32_t)i, root);
+#if TCMI_INFLATE_COMPACT
+        tab[i] = s < 0 ? (tab_t)0 : (tab_t)((s >> 16) | ((s & 0xFFF) << 4));
+#else
         tab[i] = s < 0 ? 0u : make_entry(kind, s & 0xFFFF, s >> 16);
+#endif
     }
     __syncthreads();
     return uni(ok ? 1u : 0u) != 0;
@@ -225,9 +238,9 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
 __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN];
-    __shared__ uint32_t s_ll[1 << LL_ROOT];
-    __shared__ uint32_t s_dt[1 << D_ROOT];
-    __shared__ uint32_t s_cl[1 << CL_ROOT];
+    __shared__ tab_t s_ll[1 << LL_ROOT];
+    __shared__ tab_t s_dt[1 << D_ROOT];
+    __shared__ tab_t s_cl[1 << CL_ROOT];
     __shared__ uint8_t s_lens[320];             // literal/length code lengths [0, 288), distance code lengths [288, 320)
     __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
     __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
@@ -347,7 +360,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             while (got < nlen + ndist) {
                 refill(b);
                 const uint32_t e = uni(s_cl[(uint32_t)b.bb & ((1u << CL_ROOT) - 1u)]);
+#if TCMI_INFLATE_COMPACT
+                const int nb = (int)(e & 15u), sym = (int)(e >> 4);
+#else
                 const int nb = (int)(e & 15u), sym = (int)(e >> 16);
+#endif
                 if (nb == 0) { err = ST_BAD_STREAM; break; }
                 take(b, nb);
                 int rep = 1, val = sym;
@@ -380,6 +397,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 refill(b);
             }
             uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
+#if TCMI_INFLATE_COMPACT
+            if (e & 15u) e = make_entry(K_LITLEN, (int)(e >> 4), (int)(e & 15u));
+#endif
             if ((e & 15u) == 0) {               // a code longer than the root table (rare) or no code at all
                 const int sl = (int)uni((uint32_t)slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15));
                 e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
@@ -393,6 +413,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 const uint32_t len = (e >> 16) + take(b, (int)((e >> 4) & 15u));
                 if (b.bc <= 32) refill(b);
                 uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
+#if TCMI_INFLATE_COMPACT
+                if (f & 15u) f = make_entry(K_DIST, (int)(f >> 4), (int)(f & 15u));
+#endif
                 if ((f & 15u) == 0) {
                     const int sl = (int)uni((uint32_t)slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15));
                     f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);

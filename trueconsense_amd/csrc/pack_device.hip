@@ -27,7 +27,8 @@
 namespace {
 
 constexpr int PB = 256;                          // lanes per workgroup of every kernel here
-constexpr int PK_CMAX = 3328;                    // most reads one pk_pack workgroup takes
+constexpr int PK_CMAX = 1024;                    // most reads one pk_pack workgroup takes
+constexpr int PK_OUTW = 4096;                    // words of packed planes staged in LDS before they go out as one contiguous run
 constexpr uint32_t NIB = 0x11111111u;
 
 using PackSrc = tcmi_pack_src;
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
     __shared__ int s_red[3][PB / 64];
     __shared__ int s_scan[PB / 64];
     __shared__ uint32_t s_slot[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[PK_OUTW + 40];   // (+ the longest read: 2 * 16 pairs + the zero pair)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
     const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
@@ -536,15 +538,30 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
                 o.seq[w0] = 0u; o.seq[w0 + 1] = 0u;              // the zero pair in front of the first read
                 for (uint32_t g = 2u + words_c; g < ((2u + words_c + 3u) & ~3u); ++g) o.seq[w0 + g] = 0u;
             }
-            // ---- per read: header word, planes, events ---------------------------------------------------------------
-            for (int t = tid; t < nc; t += PB) {
-                const int j = cur + t, st = t / sub;
-                const uint32_t base = 2u + s_woff[j] - s_woff[cur];                          // words from word0
-                const uint32_t sb = st == 0 ? 0u : s_woff[cur + st * sub] - s_woff[cur];     // the stage starts on the zero pair in front of its first read
-                const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
-                if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
-                o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
-                pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], s_pos[j], o.seq + w0 + base);
+            // ---- per read: header word, planes, events.  The planes of up to 256 consecutive reads are built in LDS (one lane
+            //      per read) and leave as ONE contiguous run of 8-byte-per-lane stores: a read's 52 bytes written by its own
+            //      lane (8-byte stores at a 48-byte stride) reached HBM as partial lines, 3.4 x the bytes. -------------------
+            for (int t0 = 0; t0 < nc;) {
+                int nb = min(PB, nc - t0);
+                while (s_woff[cur + t0 + nb] - s_woff[cur + t0] > (uint32_t)PK_OUTW) --nb;   // (a read is at most 34 words: nb >= 120)
+                const uint32_t wb0 = s_woff[cur + t0], wbn = s_woff[cur + t0 + nb] - wb0;
+                if (tid < nb) {
+                    const int t = t0 + tid, j = cur + t, st = t / sub;
+                    const uint32_t base = 2u + s_woff[j] - s_woff[cur];                          // words from word0
+                    const uint32_t sb = st == 0 ? 0u : s_woff[cur + st * sub] - s_woff[cur];     // the stage starts on the zero pair in front of its first read
+                    const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
+                    if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
+                    o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
+                    pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], s_pos[j], s_out + (s_woff[j] - wb0));
+                }
+                __syncthreads();
+                {
+                    const uint2 *from = reinterpret_cast<const uint2 *>(s_out);
+                    uint2 *to = reinterpret_cast<uint2 *>(o.seq + w0 + 2u + (wb0 - s_woff[cur]));   // (even word offsets: 8-byte aligned)
+                    for (uint32_t k = tid; k < wbn / 2; k += PB) to[k] = from[k];
+                }
+                __syncthreads();
+                t0 += nb;
             }
         }
         cur += nc;

@@ -138,20 +138,13 @@ __device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint
     return -1;
 }
 
-#ifndef TCMI_INFLATE_COMPACT
-#define TCMI_INFLATE_COMPACT 0      // 1: 16-bit root-table entries (code length | symbol << 4), base and extra bits computed per symbol: half the
-#endif                              //    table LDS (more blocks in flight per CU) for ~6 more scalar instructions per match
 // Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), extra bits in
 // bits 4-7, kind in bits 8-10, value in bits 16-31 (the literal, the base length or the base distance): the hot loop needs
 // no arithmetic on symbols.
 constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
 enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
 
-#if TCMI_INFLATE_COMPACT
-typedef uint16_t tab_t;
-#else
-typedef uint32_t tab_t;
-#endif
+typedef uint32_t tab_t;             // (16-bit entries with base / extra bits computed per symbol: half the table LDS, measured slower)
 
 __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 {
@@ -225,11 +218,7 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
     // root table: every lane decodes its indices
     for (int i = lane; i < (1 << root); i += 64) {
         const int s = slow_decode(cnt, sym, (uint32_t)i, root);
-#if TCMI_INFLATE_COMPACT
-        tab[i] = s < 0 ? (tab_t)0 : (tab_t)((s >> 16) | ((s & 0xFFF) << 4));
-#else
         tab[i] = s < 0 ? 0u : make_entry(kind, s & 0xFFFF, s >> 16);
-#endif
     }
     __syncthreads();
     return uni(ok ? 1u : 0u) != 0;
@@ -360,11 +349,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             while (got < nlen + ndist) {
                 refill(b);
                 const uint32_t e = uni(s_cl[(uint32_t)b.bb & ((1u << CL_ROOT) - 1u)]);
-#if TCMI_INFLATE_COMPACT
-                const int nb = (int)(e & 15u), sym = (int)(e >> 4);
-#else
                 const int nb = (int)(e & 15u), sym = (int)(e >> 16);
-#endif
                 if (nb == 0) { err = ST_BAD_STREAM; break; }
                 take(b, nb);
                 int rep = 1, val = sym;
@@ -389,7 +374,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 
         // ---- symbols: the hot loop.  Everything in it is wave-uniform (scalar registers); per symbol one LDS table look-up
         //      (two for a match), no arithmetic on symbol numbers (the entries carry base and extra-bit count), one compare
-        //      for the housekeeping. ----------------------------------------------------------------------------------------
+        //      for the housekeeping.  (Tried and measured no faster: 64 bit offsets looked up speculatively by the lanes per
+        //      round and the chain walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.) ----------------
         for (;;) {
             asm volatile("; HOT_BEGIN");
             if (b.bc <= 32) {
@@ -397,9 +383,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 refill(b);
             }
             uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
-#if TCMI_INFLATE_COMPACT
-            if (e & 15u) e = make_entry(K_LITLEN, (int)(e >> 4), (int)(e & 15u));
-#endif
             if ((e & 15u) == 0) {               // a code longer than the root table (rare) or no code at all
                 const int sl = (int)uni((uint32_t)slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15));
                 e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
@@ -413,9 +396,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 const uint32_t len = (e >> 16) + take(b, (int)((e >> 4) & 15u));
                 if (b.bc <= 32) refill(b);
                 uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
-#if TCMI_INFLATE_COMPACT
-                if (f & 15u) f = make_entry(K_DIST, (int)(f >> 4), (int)(f & 15u));
-#endif
                 if ((f & 15u) == 0) {
                     const int sl = (int)uni((uint32_t)slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15));
                     f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);

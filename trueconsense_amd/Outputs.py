@@ -19,78 +19,69 @@ from .io.gff import GFF3_COLUMNS
 from .Sequences import consensus_from_records
 
 
+_FIXED = [c for c in GFF3_COLUMNS if c != "attributes"]
+
+
+def _gff_line(row):
+    """One GFF row dict -> its text line: the eight fixed columns, then every other key folded into the attributes column
+    (keys lower-cased; the parsed pairs of an `attributes` entry take its place in the row's key order)."""
+    fixed, attrs = {}, {}
+    for key, value in row.items():
+        k = str(key).lower()
+        if k == "attributes":
+            for item in filter(None, str(value).split(";")):
+                name, val = item.split("=")             # exactly one '=' per pair, or ValueError (as upstream)
+                attrs[name] = val
+        elif k in _FIXED:
+            fixed[k] = str(value)
+        else:
+            attrs[k] = str(value)
+    assert list(fixed) == _FIXED                        # upstream insists on the canonical column order, too
+    return "\t".join(list(fixed.values()) + [";".join("%s=%s" % kv for kv in attrs.items())]) + "\n"
+
+
 def WriteGFF(gffheader, gffdict, output_gff, name):
-    """Outputs.py:13-71 — nine tab-separated columns; every other key is lower-cased and folded
-    into `attributes` after the parsed attribute pairs."""
-    cols_without_attr = [c for c in GFF3_COLUMNS if c != "attributes"]
-
-    def fold(row):
-        clean, extra = {}, {}
-        for k, v in row.items():
-            lk = str(k).lower()
-            if lk not in cols_without_attr:
-                extra[lk] = str(v)
-            else:
-                clean[lk] = str(v)
-        attrs = {}
-        for k, v in extra.items():
-            if k == "attributes":
-                for item in v.split(";"):
-                    if item == "":
-                        continue
-                    key, value = item.split("=")
-                    attrs[key] = value
-            else:
-                attrs[k] = v
-        clean["attributes"] = ";".join("%s=%s" % kv for kv in attrs.items())
-        assert list(clean.keys()) == GFF3_COLUMNS
-        return clean
-
+    """Outputs.py:13-71 — header text verbatim, then one line per row."""
     with open(output_gff, "w") as out:
         out.write(gffheader.raw_text)
-        for _, row in gffdict.items():
-            out.write("\t".join(str(v) for v in fold(row).values()) + "\n")
+        out.writelines(_gff_line(row) for row in gffdict.values())
+
+
+_VCF_HEAD = ("##fileformat=VCFv4.3\n##fileDate={date}\n##source='TrueConsense {argv}'\n##reference='{ref}'\n##contig=<ID={contig}>\n"
+             '##INFO=<ID=DP,Number=1,Type=Integer,Description="Read Depth">\n'
+             '##INFO=<ID=INDEL,Number=0,Type=Flag,Description="Indicates that the variant is an INDEL.">\n'
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
 
 
 def vcf_text(today, argv, ref, refID, reflist, consensus_noinsert, iDict, mincov, hasinserts, insertpositions):
-    """Outputs.py:115-180."""
-    seqlist = list(consensus_noinsert.upper())
-    out = [f"""##fileformat=VCFv4.3
-##fileDate={today}
-##source='TrueConsense {' '.join(argv)}'
-##reference='{ref}'
-##contig=<ID={refID}>
-##INFO=<ID=DP,Number=1,Type=Integer,Description="Read Depth">
-##INFO=<ID=INDEL,Number=0,Type=Flag,Description="Indicates that the variant is an INDEL.">
-#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO
-"""]
-    delskips = set()
-    for i in range(len(reflist)):
-        if i in delskips:
-            continue
-        if reflist[i] != seqlist[i]:
-            if seqlist[i] == "-":
-                b = i
-                gone = []
-                while seqlist[b] == "-":            # IndexError past the end, like the reference
-                    gone.append(reflist[b])
-                    delskips.add(b)
-                    b += 1
-                currentcov = GetCoverage(iDict, i + 1)
-                out.append(f"{refID}\t{i}\t.\t{reflist[i - 1] + ''.join(gone)}\t{seqlist[i - 1]}\t.\tPASS\t"
-                           f"DP={currentcov};INDEL\n")
-            else:
-                p = 1 if i < 2 else i
-                currentcov = GetCoverage(iDict, p + 1)
-                out.append(f"{refID}\t{i + 1}\t.\t{reflist[i]}\t{seqlist[i]}\t.\tPASS\tDP={currentcov}\n")
-        if hasinserts is True and i in insertpositions:
-            currentcov = GetCoverage(iDict, i + 1)
-            if currentcov > mincov:
-                for y in insertpositions.get(i):
-                    to_insert = str(insertpositions.get(i).get(y))
-                    out.append(f"{refID}\t{i}\t.\t{reflist[i]}\t{seqlist[i] + to_insert}\t.\tPASS\t"
-                               f"DP={currentcov};INDEL\n")
-    return "".join(out)
+    """Outputs.py:115-180 as a single left-to-right scan over the reference: a run of '-' in the insert-free consensus yields
+    one deletion record at its first index and is then jumped over; any other mismatch yields a SNP record; an index that
+    equals an accepted insert's (1-based!) position yields an insertion record.  The quirks are upstream's:
+    comparison against the raw reference characters, DP taken from the FOLLOWING position (index 0 and 1 both use position
+    2), POS of indel records one less than their index + 1, IndexError when a deletion run reaches the end."""
+    cons = consensus_noinsert.upper()
+    ins = insertpositions if hasinserts is True else {}
+    lines = [_VCF_HEAD.format(date=today, argv=" ".join(argv), ref=ref, contig=refID)]
+    i, n = 0, len(reflist)
+    while i < n:
+        here = cons[i]
+        step = 1
+        if here == "-":
+            j = i
+            while cons[j] == "-":
+                j += 1
+            lines.append("%s\t%d\t.\t%s\t%s\t.\tPASS\tDP=%s;INDEL\n"
+                         % (refID, i, reflist[i - 1] + "".join(reflist[i:j]), cons[i - 1], GetCoverage(iDict, i + 1)))
+            step = j - i
+        elif here != reflist[i]:
+            lines.append("%s\t%d\t.\t%s\t%s\t.\tPASS\tDP=%s\n" % (refID, i + 1, reflist[i], here, GetCoverage(iDict, max(i, 1) + 1)))
+        if i in ins:
+            depth = GetCoverage(iDict, i + 1)
+            if depth > mincov:
+                for bases in ins[i].values():
+                    lines.append("%s\t%d\t.\t%s\t%s\t.\tPASS\tDP=%s;INDEL\n" % (refID, i, reflist[i], here + str(bases), depth))
+        i += step
+    return "".join(lines)
 
 
 def WriteOutputs(mincov, iDict, uGffDict, inputbam, IncludeAmbig, output_vcf, name, ref, output_gff, gffheader,

@@ -155,8 +155,8 @@ __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */
 }
 
 // ---- 1: classify ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *blk_sum, unsigned long long *blk_alg, int32_t *blk_end,
-                                                  PackTotals *tot)
+__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *rd_seq, uint2 *blk_sum, unsigned long long *blk_alg,
+                                                  int32_t *blk_end, PackTotals *tot)
 {
     __shared__ uint2 s_w[PB / 64];
     __shared__ unsigned long long s_alg[PB / 64];
@@ -207,6 +207,10 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
             }
         }
         info[i] = word;
+        // where the read's SEQ starts (bytes from the stream's / the SEQ array's first byte; low word | high byte) and l_seq:
+        // pk_pack goes straight there instead of chasing record offset -> header -> CIGAR -> SEQ through four dependent loads
+        const unsigned long long so = (unsigned long long)(v.seq - (s.mode == 0 ? s.seq : s.stream));
+        rd_seq[i] = make_uint2((uint32_t)so, ((uint32_t)(so >> 32) & 0xFFu) | ((uint32_t)min(v.l_seq, 0xFFFFFF) << 8));
     }
     const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
     if (threadIdx.x == PB - 1) blk_sum[blockIdx.x] = incl;
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned l
 }
 
 // ---- 3: scatter: compacted index + word offset of every kept read -----------------------------------------------------
-__global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info, const uint2 *blk_base, uint32_t *c_idx,
-                                                 int32_t *c_pos, uint32_t *c_info, uint32_t *c_woff)
+__global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info, const uint2 *rd_seq, const uint2 *blk_base, uint32_t *c_idx,
+                                                 int32_t *c_pos, uint32_t *c_info, uint32_t *c_woff, uint2 *c_seq)
 {
     __shared__ uint2 s_w[PB / 64];
     const int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x;
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info
         c_pos[j] = (s.mode == 0 ? s.pos[i] : (int32_t)ld_u32(s.stream + s.rec_off[i] + 8)) + s.pos_shift;
         c_info[j] = w;
         c_woff[j] = base.y + incl.y - mine.y;
+        c_seq[j] = rd_seq[i];
     }
 }
 
@@ -364,17 +369,18 @@ __device__ inline bool ins_after(const uint8_t *cg, uint32_t n, uint32_t k)
 }
 
 // one read -> its plane pairs (out: 2 * ceil(len / 32) words, then the zero pair) and its event words
-__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, int32_t gpos,
+__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, uint2 where, int32_t gpos,
                                  uint32_t *out)
 {
-    const ReadView v = view(src, i);
     const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
     if (!(info & INFO_PROJ)) {
+        const uint8_t *seq = (src.mode == 0 ? src.seq : src.stream) + (((unsigned long long)(where.y & 0xFFu) << 32) | where.x);
+        const int l_seq = (int)(where.y >> 8);
         const int y0 = (int)(info >> 12);
         for (int q = 0; q < npair; ++q) {
             const int nb = min(32, len - 32 * q);
             uint32_t lo, hi, ok;
-            fetch32(v.seq, v.l_seq, y0 + 32 * q, nb, lo, hi, ok);
+            fetch32(seq, l_seq, y0 + 32 * q, nb, lo, hi, ok);
             *reinterpret_cast<uint2 *>(out + 2 * q) = make_uint2(lo, hi);
             uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
             while (miss) {
@@ -384,6 +390,7 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
             }
         }
     } else {
+        const ReadView v = view(src, i);
         // Walk the CIGAR: matched bases land on their reference offset (bit-field copies into the pair being built), D / N
         // leave empty positions, and the tokens that are not plain bases become events: X for a deleted base
         // whose token is exactly "*", I on the last reference base before an insertion (also "*+..": I but not X).
@@ -434,7 +441,7 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
 }
 
 __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint32_t *c_idx, const int32_t *c_pos, const uint32_t *c_info,
-                                              const uint32_t *c_woff, uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages,
+                                              const uint32_t *c_woff, const uint2 *c_seq, uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages,
                                               int stage_cap, PackTotals *tot)
 {
     __shared__ int32_t s_pos[PK_CMAX];
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
                     const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
                     if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
                     o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
-                    pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], s_pos[j], s_out + (s_woff[j] - wb0));
+                    pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], c_seq[g0 + t], s_pos[j], s_out + (s_woff[j] - wb0));
                 }
                 __syncthreads();
                 {
@@ -739,6 +746,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     if (n > 0xFFFFFFF0ll) { *why = PKF_LONG; return TCMI_E_UNSUPPORTED; }
     const int64_t n_blk = (n + PB - 1) / PB;
     uint32_t *info = (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4);
+    uint2 *rd_seq = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 8);
     uint2 *blk_sum = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
     unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
     int32_t *blk_end = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 4);
@@ -749,7 +757,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     if (n > 0) {
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
-        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, blk_alg, blk_end, d_tot);
+        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, blk_alg, blk_end, d_tot);
         hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, blk_alg, blk_end, n_blk, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
         TCMI_HIP(ctx, hipGetLastError());
@@ -781,6 +789,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     int32_t *c_pos = (int32_t *)arena_take(ctx, (size_t)nf * 4);
     uint32_t *c_info = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     uint32_t *c_woff = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
+    uint2 *c_seq = (uint2 *)arena_take(ctx, (size_t)nf * 8);
     if (ctx->dev_arena->used > ctx->dev_arena->cap) { return tcmi_fail(ctx, TCMI_E_NOMEM, "internal: pack scratch under-reserved"); }
 
     uint32_t event_cap = (uint32_t)std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(1 << 20, nf / 2));
@@ -816,8 +825,8 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK);
         if (attempt == 0)
-            hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, blk_sum, c_idx, c_pos, c_info, c_woff);
-        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, (uint32_t)nf,
+            hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, c_idx, c_pos, c_info, c_woff, c_seq);
+        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq, (uint32_t)nf,
                            (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK);
         TCMI_HIP(ctx, hipGetLastError());
@@ -857,7 +866,7 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
                           al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 64)};
     size_t src_bytes = 0;
     for (size_t b : sz) src_bytes += b + 256;
-    const size_t tmp_bytes = al((size_t)n * 4) * 5 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 12 * 256;
+    const size_t tmp_bytes = al((size_t)n * 4) * 9 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 16 * 256;
     int rc = arena_reserve(ctx, src_bytes + tmp_bytes);
     if (rc) return rc;
     PackSrc s = {};

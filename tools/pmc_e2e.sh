@@ -19,6 +19,6 @@ for d in sys.argv[1:]:
             k = row["Kernel_Name"][22:52].split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not any(x in row_name for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")) if False else not any(x in k for x in ("inflate", "pk_", "tally", "call_kernel", "rec_")): continue
+            if not any(x in k for x in ("inflate", "pk_", "tally", "call_kernel", "rec_", "ins_")): continue
             print(k, {c: round(sum(v)/len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
 PY

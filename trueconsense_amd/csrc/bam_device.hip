@@ -44,7 +44,14 @@ constexpr int WIN = TCMI_INFLATE_WIN, WMASK = WIN - 1;   // LDS ring: the most r
 constexpr int SEG = TCMI_INFLATE_WIN >= 4096 ? 2048 : TCMI_INFLATE_WIN / 2;   // flush granularity
 constexpr int NEAR = WIN - 264;                 // matches up to this distance are copied LDS -> LDS
 static_assert(SEG <= WIN - 528 && (WIN & (WIN - 1)) == 0 && WIN % SEG == 0 && SEG % 1024 == 0, "a far match must find its source flushed");
-constexpr int LL_ROOT = 10, D_ROOT = 9, CL_ROOT = 7;
+#ifndef TCMI_INFLATE_LL_ROOT
+#define TCMI_INFLATE_LL_ROOT 9
+#endif
+#ifndef TCMI_INFLATE_D_ROOT
+#define TCMI_INFLATE_D_ROOT 8
+#endif
+constexpr int LL_ROOT = TCMI_INFLATE_LL_ROOT, D_ROOT = TCMI_INFLATE_D_ROOT, CL_ROOT = 7;   // root-table bits; longer codes take slow_decode
+static_assert(D_ROOT >= CL_ROOT, "the code-length table borrows the distance table's LDS");
 constexpr int MAX_REC_PER_BLOCK = 65536 / 36 + 2;   // a record is at least 36 bytes (block_size + 32 fixed + 1 name byte ..)
 
 struct BlockDesc {
@@ -73,42 +80,62 @@ struct InflateArgs {
 };
 
 #ifndef TCMI_INFLATE_INRING
-#define TCMI_INFLATE_INRING 256
+#define TCMI_INFLATE_INRING 128
 #endif
 constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input staged in LDS (two halves)
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 struct Bits {                   // wave-uniform bit reader over the file's dwords, staged through an LDS ring
     const uint32_t *__restrict__ w;
-    uint32_t *ring;             // LDS [IN_RING]: dword k of the file sits in ring[k % IN_RING] while idx - IN_RING/2 <= k < hi
-    uint64_t idx;               // next dword to consume
-    uint64_t hi;                // dwords below this are in the ring
+    uint32_t *ring;             // LDS [IN_RING]: dword k of the file sits in ring[k % IN_RING] while hi - IN_RING <= k < hi
+    uint32_t idx;               // the dword that `next` holds: the next one to enter the bit buffer (files < 16 GiB)
+    uint32_t hi;                // dwords below this are in the ring; [hi, hi + IN_RING/2) are on their way in `pend`
+    uint32_t next;              // ring[idx], read one refill ahead (per lane the same value; made scalar when it is used)
+    u32x4 pend;                 // the half ring after `hi`, loaded one stage ahead: its latency hides behind a half ring of decoding
     uint64_t bb;
     int bc;
 };
 
-// one coalesced load (16 bytes per lane) refills the half of the ring that has been consumed
+// the half of the ring that has been consumed takes the dwords loaded a stage ago; the load of the following half starts
 __device__ inline void stage_input(Bits &b)
 {
     constexpr int LANES = IN_RING / 2 / 4;      // lanes that carry 16 bytes each
     const bool mine = (int)threadIdx.x < LANES;
-    uint4 v = {};
-    if (mine) v = reinterpret_cast<const uint4 *>(b.w + b.hi)[threadIdx.x];
     __syncthreads();
-    if (mine) *reinterpret_cast<uint4 *>(b.ring + ((b.hi + 4 * threadIdx.x) & (IN_RING - 1))) = v;    // (hi is a multiple of 4: no uint4 wraps)
+    if (mine) *reinterpret_cast<u32x4 *>(b.ring + ((b.hi + 4 * threadIdx.x) & (IN_RING - 1))) = b.pend;    // (hi is a multiple of 4: no uint4 wraps)
+    b.hi = uni(b.hi + IN_RING / 2);
+    if (mine) b.pend = reinterpret_cast<const u32x4 *>(b.w + b.hi)[threadIdx.x];
     __syncthreads();
-    b.hi += IN_RING / 2;
 }
 static_assert(IN_RING / 2 / 4 <= 64 && IN_RING >= 64, "a half of the input ring is one load per lane");
 
-__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline void seek_bits(Bits &b, uint64_t byte)       // start reading bits at this byte of the file
+{
+    b.idx = uni((uint32_t)(byte >> 2));
+    b.hi = b.idx & ~3u;                 // (16-byte aligned loads)
+    constexpr int LANES = IN_RING / 2 / 4;
+    b.pend = u32x4{0, 0, 0, 0};
+    if ((int)threadIdx.x < LANES) b.pend = reinterpret_cast<const u32x4 *>(b.w + b.hi)[threadIdx.x];
+    stage_input(b);
+    stage_input(b);
+    const int skip = (int)(byte & 3) * 8;
+    b.bb = (uint64_t)(uni(b.ring[b.idx & (IN_RING - 1)]) >> skip);
+    b.bc = 32 - skip;
+    ++b.idx;
+    b.next = b.ring[b.idx & (IN_RING - 1)];
+}
 
 __device__ inline void refill(Bits &b)
 {
     if (b.bc <= 32) {
-        if (b.idx + IN_RING / 2 >= b.hi) stage_input(b);
-        b.bb |= (uint64_t)uni(b.ring[b.idx & (IN_RING - 1)]) << b.bc;
-        ++b.idx;
+        b.bb |= (uint64_t)uni(b.next) << b.bc;
         b.bc += 32;
+        ++b.idx;
+        if (b.idx + IN_RING / 2 >= b.hi) stage_input(b);
+        b.next = b.ring[b.idx & (IN_RING - 1)];
     }
 }
 __device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
@@ -133,6 +160,28 @@ __device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint
         index += c;
         first += c;
         first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// The same for a code that is known to be longer than `root` bits (the root table said so), wave-uniform: the canonical
+// decoder's state after `root` bits depends on the counts alone (`rs` = {first, index} at that point, left by build_table), and
+// the first `root` bits of the code are the bit-reversed low bits of `v` — so the walk starts at length root + 1 and takes
+// one to three rounds for the codes that occur.  -> symbol | code length << 16, or -1
+__device__ inline int long_code(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, uint32_t v, int root)
+{
+    int first = (int)uni(rs[0]), index = (int)uni(rs[1]);
+    int code = (int)((__builtin_bitreverse32(v) >> (32 - root)) << 1);
+    v >>= root;
+#pragma unroll 1
+    for (int len = root + 1; len <= 15; ++len) {
+        code |= (int)(v & 1u);
+        v >>= 1;
+        const int c = (int)uni(cnt[len]);
+        if (code - c < first) return (int)uni(sym[index + (code - first)]) | (len << 16);
+        index += c;
+        first = (first + c) << 1;
         code <<= 1;
     }
     return -1;
@@ -175,7 +224,7 @@ __device__ inline
 #else
 __device__ __noinline__             // three call sites: one copy of the code keeps the kernel small (instruction cache)
 #endif
-bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, tab_t *tab, int root, int kind)
+bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, tab_t *tab, int root, int kind, uint32_t *rs)
 {
     const int lane = threadIdx.x;
     __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
@@ -191,7 +240,7 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
     }
     __syncthreads();
     // offsets of each length in the sorted symbol array; over-subscription check
-    int left = 1, off = 0;
+    int left = 1, off = 0, first = 0;
     bool ok = true;
     for (int len = 1; len <= 15; ++len) {
         const int c = cnt[len];
@@ -199,6 +248,8 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
         if (left < 0) ok = false;
         if (lane == 0) nxt[len] = (uint16_t)off;
         off += c;
+        first = (first + c) << 1;
+        if (len == root && lane == 0) { rs[0] = (uint32_t)first; rs[1] = (uint32_t)off; }    // long_code() starts here
     }
     __syncthreads();
     // rank of every symbol among those of its length, in symbol order -> its slot in the sorted array
@@ -229,11 +280,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN];
     __shared__ tab_t s_ll[1 << LL_ROOT];
     __shared__ tab_t s_dt[1 << D_ROOT];
-    __shared__ tab_t s_cl[1 << CL_ROOT];
+    tab_t *const s_cl = s_dt;                   // the code-length code is done with before the distance table is built
     __shared__ uint8_t s_lens[320];             // literal/length code lengths [0, 288), distance code lengths [288, 320)
     __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
     __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
     __shared__ uint8_t s_cll[19];
+    __shared__ uint32_t s_rs[6];                // long_code()'s starting state per table: {first, index} after the root bits
     __shared__ __attribute__((aligned(16))) uint32_t s_in[IN_RING];
 
     const int lane = threadIdx.x;
@@ -247,18 +299,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     Bits b;
     b.w = a.file32;
     b.ring = s_in;
-    auto seek = [&](uint64_t byte) __attribute__((always_inline)) {     // start reading bits at this byte of the file
-        b.idx = byte >> 2;
-        b.hi = b.idx & ~(uint64_t)3;     // (16-byte aligned loads)
-        stage_input(b);
-        stage_input(b);
-        const int skip = (int)(byte & 3) * 8;
-        b.bb = (uint64_t)(uni(b.ring[b.idx & (IN_RING - 1)]) >> skip);
-        b.bc = 32 - skip;
-        ++b.idx;
-    };
+    auto seek = [&](uint64_t byte) __attribute__((always_inline)) { seek_bits(b, byte); };
     seek(d.cin);
-    const uint64_t idx_end = ((d.cin + d.clen + 3) >> 2) + 2;      // reading further than this means a corrupt stream
+    const uint32_t idx_end = (uint32_t)((d.cin + d.clen + 3) >> 2) + 3;      // reading further than this means a corrupt stream
 
     uint32_t op = 0;                    // bytes produced
     uint32_t flushed = 0;               // bytes already written to HBM (multiple of SEG)
@@ -308,7 +351,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             const uint32_t nlen = take(b, 16);
             if ((len ^ nlen) != 0xFFFFu || op + len > ulen) { err = ST_BAD_STREAM; break; }
             // byte address of the raw data: what the bit buffer holds beyond it is dropped
-            const uint64_t at = b.idx * 4 - (uint64_t)(b.bc >> 3);
+            const uint64_t at = (uint64_t)b.idx * 4 - (uint64_t)(b.bc >> 3);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(b.w) + at;
             uint32_t done = 0;
             while (done < len && err == ST_OK) {
@@ -342,7 +385,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 const uint32_t v = take(b, 3);
                 if (lane == 0) s_cll[CL_ORDER[i]] = (uint8_t)v;
             }
-            if (uni(build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT, K_CODELEN) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+            if (uni(build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT, K_CODELEN, s_rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
             for (int i = lane; i < 320; i += 64) s_lens[i] = 0;
             __syncthreads();
             int got = 0, prev = 0;
@@ -369,52 +412,56 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             __syncthreads();
             if (uni(s_lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
-        if (uni(build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT, K_LITLEN) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT, K_DIST) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT, K_LITLEN, s_rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT, K_DIST, s_rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
 
         // ---- symbols: the hot loop.  Everything in it is wave-uniform (scalar registers); per symbol one LDS table look-up
         //      (two for a match), no arithmetic on symbol numbers (the entries carry base and extra-bit count), one compare
-        //      for the housekeeping.  (Tried and measured no faster: 64 bit offsets looked up speculatively by the lanes per
-        //      round and the chain walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.) ----------------
+        //      for the housekeeping.  A damaged stream does not leave the loop where it is noticed: it sets `bad`, decoding goes
+        //      on with harmless values (every LDS index is masked, a far source stays inside the arena) and the next
+        //      housekeeping or end-of-block code ends it — one exit keeps the loop's control flow lean.
+        //      (Tried and measured no faster: 64 bit offsets looked up speculatively by the lanes per round and the chain
+        //      walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.) --------------------------------------
+        uint32_t bad = 0;
         for (;;) {
             asm volatile("; HOT_BEGIN");
-            if (b.bc <= 32) {
-                if (b.idx > idx_end) { err = ST_BAD_STREAM; break; }
-                refill(b);
-            }
+            refill(b);
             uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
-            if ((e & 15u) == 0) {               // a code longer than the root table (rare) or no code at all
-                const int sl = (int)uni((uint32_t)slow_decode(s_cnt_ll, s_sym_ll, (uint32_t)b.bb, 15));
+            if (__builtin_expect((e & 15u) == 0, 0)) {      // a code longer than the root table (8 % of the symbols of a 9-bit table) or none
+                const int sl = long_code(s_cnt_ll, s_sym_ll, s_rs, (uint32_t)b.bb, LL_ROOT);
                 e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
-                if ((e & 15u) == 0) { err = ST_BAD_STREAM; break; }
+                if ((e & 15u) == 0) { bad = 0x80000000u; e = 1u | E_EOB; }
             }
             take(b, (int)(e & 15u));
             if (e & E_LIT) {
-                if (lane == 0) s_win[op & WMASK] = (uint8_t)(e >> 16);
+                s_win[op & WMASK] = (uint8_t)(e >> 16);         // (every lane stores the same byte to the same address: no exec juggling)
                 ++op;
             } else if (e & E_BASE) {
                 const uint32_t len = (e >> 16) + take(b, (int)((e >> 4) & 15u));
-                if (b.bc <= 32) refill(b);
+                refill(b);
                 uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
-                if ((f & 15u) == 0) {
-                    const int sl = (int)uni((uint32_t)slow_decode(s_cnt_d, s_sym_d, (uint32_t)b.bb, 15));
+                if (__builtin_expect((f & 15u) == 0, 0)) {
+                    const int sl = long_code(s_cnt_d, s_sym_d, s_rs + 2, (uint32_t)b.bb, D_ROOT);
                     f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);
-                    if ((f & 15u) == 0) { err = ST_BAD_STREAM; break; }
+                    if ((f & 15u) == 0) { bad = 0x80000000u; f = 1u | E_BASE | (1u << 16); }
                 }
                 take(b, (int)(f & 15u));
                 const uint32_t dist = (f >> 16) + take(b, (int)((f >> 4) & 15u));    // (<= 13 extra bits: still in the buffer)
-                if (dist > op) { err = ST_BAD_STREAM; break; }
+                bad |= op - dist;                               // (op < 2^17, dist <= 2^15: the sign bit says dist > op)
                 // the match: all lanes copy; with dist < len the pattern of the last `dist` bytes repeats
-                if (dist >= len && dist <= (uint32_t)NEAR) {
-                    uint32_t to = op + (uint32_t)lane, from = to - dist;
-#pragma clang loop vectorize(disable) unroll(disable)
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64, to += 64, from += 64) s_win[to & WMASK] = s_win[from & WMASK];
-                } else if (dist > (uint32_t)NEAR) {
+                const uint32_t to = op + (uint32_t)lane;
+                if (dist > (uint32_t)NEAR) {
                     // beyond the LDS ring: the source lies in a segment that is complete and was flushed right after the
                     // symbol that completed it (same wavefront: its stores are ordered before this load)
-                    const uint8_t *src = out + (op - dist);
+                    const uint8_t *src = out + ((int64_t)op - (int64_t)dist);
 #pragma clang loop vectorize(disable) unroll(disable)
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
+                } else if (dist >= len) {
+                    if ((uint32_t)lane < len) s_win[to & WMASK] = s_win[(to - dist) & WMASK];
+                    if (len > 64u) {
+#pragma clang loop vectorize(disable) unroll(disable)
+                        for (uint32_t i = (uint32_t)lane + 64u; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op + i - dist) & WMASK];
+                    }
                 } else {
                     const float inv = 1.0f / (float)dist;
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -432,10 +479,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             }
             asm volatile("; HOT_END");
             if (op >= next_evt) {
+                if ((bad >> 31) | (b.idx > idx_end ? 1u : 0u)) break;
                 housekeeping();
                 if (err != ST_OK) break;
             }
         }
+        if ((bad >> 31) | (b.idx > idx_end ? 1u : 0u)) err = ST_BAD_STREAM;
     }
     if (err == ST_OK && op != ulen) err = ST_BAD_LENGTH;
     // the tail: whole segments, then bytes
@@ -711,6 +760,15 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     a.n_blocks = (int32_t)nb;
     (void)hipGetLastError();
     tcmi_prof_begin(ctx, TCMI_K_INFLATE);
+    static const bool occ_once = [] {
+        if (std::getenv("TCMI_INFLATE_OCCUPANCY")) {             // diagnostic: resident wavefronts of bgzf_inflate per CU
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bgzf_inflate, 64, 0) == hipSuccess)
+                std::fprintf(stderr, "[tcmi] bgzf_inflate: %d wavefronts per CU\n", n);
+        }
+        return true;
+    }();
+    (void)occ_once;
     hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());

@@ -5,7 +5,8 @@ Headline (`value`): reference positions per second, whole job, measured from BAM
 a "step" is one BAM of BASELINE configs[1] (1M synthetic 150-bp reads over a 29 903-bp reference) through
 decode (file read, BGZF inflate, records) -> upload (H2D + pack) -> HIP tally + call -> host consensus walk ->
 FASTA text, with the stages of consecutive BAMs overlapped (trueconsense_amd.engine.FileRunner).  The synthetic
-BAM files are written before the clock starts.  `--steps K --warmup W`: W untimed BAMs, then exactly K timed ones.
+BAM files are written before the clock starts.  `--steps K --warmup W`: W untimed BAMs, then the K files as one queue, cycled
+`repeats` times so that the timed region lasts >= `--min-seconds` (K x repeats timed BAMs; `--min-seconds 0`: exactly K).
 
 Secondary blocks of the same JSON line:
   e2e_single_bam   one BAM at a time, nothing overlapped: per-stage latency (configs[1] as written)
@@ -232,6 +233,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32, help="timed BAM files (each one BAM file -> FASTA)")
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the K files are cycled `repeats` times in one queue so that the timed region lasts at least this long (0: exactly K)")
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--files", type=int, default=8, help="distinct synthetic BAM files per rank, cycled through")
     ap.add_argument("--level", type=int, default=6, help="zlib level the synthetic BAMs are written with (samtools' default is 6)")
@@ -342,9 +345,26 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     runner.decoded_on = {k: 0 for k in runner.decoded_on}
     for c in runner.contexts:
         c.profile(True)                                          # HIP events around every kernel of the cold path
+    # The K timed steps take ~ 25 ms on one GPU, too short for a stable figure: one pass over the K files sizes the job
+    # (untimed), then ONE queue of K x `repeats` files (>= --min-seconds of work, one pipeline fill and drain) is the timed region.
     fence()
     t0 = time.perf_counter()
-    fastas = runner.run([file_of(i) for i in range(a.steps)], names=["S%d" % (i % len(paths)) for i in range(a.steps)], ref_len=L)
+    runner.run([file_of(i) for i in range(a.steps)], ref_len=L)
+    fence()
+    repeats = max(1, int(np.ceil(a.min_seconds / max(1e-6, time.perf_counter() - t0)))) if a.min_seconds > 0 else 1
+    if dist is not None:
+        t = torch.tensor([repeats], dtype=torch.int64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        repeats = int(t.item())
+    n_timed = a.steps * repeats
+    runner.seconds = {k: 0.0 for k in runner.seconds}
+    runner.decoded_on = {k: 0 for k in runner.decoded_on}
+    for c in runner.contexts:
+        c.profile(False)
+        c.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    fastas = runner.run([file_of(i) for i in range(n_timed)], names=["S%d" % (i % len(paths)) for i in range(n_timed)], ref_len=L)
     fence()
     dt = time.perf_counter() - t0
     cold = {}
@@ -354,7 +374,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
         for c in runner.contexts:
             mm, kk = c.profile_get(kid)
             m, k = m + mm, k + kk
-        cold[name] = {"us_per_bam": 1e3 * m / max(1, a.steps), "launches": k}
+        cold[name] = {"us_per_bam": 1e3 * m / max(1, n_timed), "launches": k}
     for c in runner.contexts:
         c.profile(False)
     if dist is not None:
@@ -368,9 +388,9 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
 
     out = {
         "metric": "reference positions/sec (BAM file -> consensus FASTA, 1M reads x 29 903 bp per BAM)",
-        "value": L * a.steps * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic", "bams_per_min": 60.0 * a.steps * world / dt,
+        "value": L * n_timed * world / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / n_timed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic", "repeats": repeats, "timed_seconds": dt, "bams_per_min": 60.0 * n_timed * world / dt,
         "config": {"workload": "BASELINE configs[%d]: 29 903-bp reference, %d synthetic 150-bp reads per BAM (~%dx coverage)%s, "
                                "%d distinct BAM files per GPU (zlib level %d, written before the clock starts) cycled through; "
                                "a step = one BAM FILE -> FASTA text%s"
@@ -385,7 +405,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
                              % (decoders, a.walkers, json.dumps(runner.decoded_on)),
                    "bam_file_bytes": os.path.getsize(paths[0]), "bam_inflated_bytes": inflated_size(paths[0]),
                    "input_generation_seconds_outside_clock": t_gen},
-        "e2e_stage_busy_seconds_per_bam": {k: v / a.steps for k, v in runner.seconds.items()},
+        "e2e_stage_busy_seconds_per_bam": {k: v / n_timed for k, v in runner.seconds.items()},
         "cold_kernels_pipelined": cold,
     }
 

@@ -368,7 +368,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     fence()
     dt = time.perf_counter() - t0
     cold = {}
-    for name, kid in (("inflate", _ffi.K_INFLATE), ("records", _ffi.K_RECORDS), ("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK),
+    for name, kid in (("inflate", _ffi.K_INFLATE), ("crc32", _ffi.K_CRC), ("records", _ffi.K_RECORDS), ("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK),
                       ("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL)):
         m = k = 0
         for c in runner.contexts:
@@ -429,7 +429,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     n_k = 8
     single.run([file_of(i) for i in range(n_k)], ref_len=L)
     cold = {}
-    for name, kid in (("inflate", _ffi.K_INFLATE), ("records", _ffi.K_RECORDS), ("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK),
+    for name, kid in (("inflate", _ffi.K_INFLATE), ("crc32", _ffi.K_CRC), ("records", _ffi.K_RECORDS), ("pack_classify", _ffi.K_PACK_CLASSIFY), ("pack", _ffi.K_PACK),
                       ("tally", _ffi.K_TALLY), ("call", _ffi.K_CALL)):
         m, k = sctx.profile_get(kid)
         cold[name] = {"us_per_bam": 1e3 * m / n_k, "launches": k}

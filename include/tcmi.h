@@ -110,6 +110,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "device_pack"    1 = tcmi_readset_upload copies the BAM-native arrays to the device and packs them there
  *                    (pack_device.hip; default; needs reads sorted by position and entries of <= 512 positions,
  *                    anything else takes the host packer); 0 = always pack on the host
+ *   "verify_crc"     1 = the device decoder checks every BGZF block's CRC-32 (bgzf_crc32; default, as htslib does);
+ *                    0 = ISIZE, stream termination and the record chain only
  *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
  *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)
@@ -126,7 +128,8 @@ int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 enum { TCMI_K_TALLY = 0 /* bit-plane tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZERO = 2,
        TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */,
        TCMI_K_PACK_CLASSIFY = 4 /* device packer: classify + scan */, TCMI_K_PACK = 5 /* device packer: scatter + pack */,
-       TCMI_K_INFLATE = 6 /* device BGZF inflate */, TCMI_K_RECORDS = 7 /* device BAM record walk */, TCMI_K_NKERNELS = 8 };
+       TCMI_K_INFLATE = 6 /* device BGZF inflate */, TCMI_K_RECORDS = 7 /* device BAM record walk */,
+       TCMI_K_CRC = 8 /* device CRC-32 of the inflated blocks */, TCMI_K_NKERNELS = 9 };
 int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
 int  tcmi_profile_reset(tcmi_ctx *ctx);
 int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *launches);

@@ -148,8 +148,52 @@ def test_files_the_device_decoder_leaves_to_the_host(ctx, tmp_path):
         rs = ctx.upload_bamfile(d)
     except _ffi.TcmiError as err:
         assert err.code in (_ffi.E_FORMAT, _ffi.E_UNSUPPORTED)
-    else:                                               # the flipped bit may decode to a valid stream of the right length:
-        rs.free()                                       # then only the CRC (checked by the host reader) can tell
+    else:                                               # (the flipped bit sat in a field nothing depends on, e.g. a gzip MTIME)
+        rs.free()
+    d.close()
+
+
+def test_crc32_of_every_block_is_checked_on_the_device(ctx, tmp_path):
+    """A payload byte changed inside a STORED deflate block: the stream inflates, ISIZE holds, the record chain holds — only
+    the block's CRC-32 can tell (htslib checks it on every block; bgzf_crc32 does here)."""
+    ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
+    reads = sy.make_reads(ref, 6000, seed=2)
+    p = str(tmp_path / "stored.bam")
+    bamwriter.write_bam(p, reads, "r", len(ref), level=0)
+    check_decode(ctx, p).close()                        # (all CRCs of the intact file agree, lengths that are not multiples of 16 included)
+    raw = bytearray(open(p, "rb").read())
+    offs, o = [], 0
+    while o < len(raw):
+        offs.append(o)
+        o += struct.unpack_from("<H", raw, o + 16)[0] + 1
+    assert len(offs) > 4
+    b = offs[2]
+    assert raw[b + 18] & 6 == 0                         # BTYPE 00: stored
+    at = b + 18 + 5 + 36 + 20                           # inside the first record's name / CIGAR / SEQ bytes
+    raw[at] ^= 0x10
+    p2 = str(tmp_path / "flipped.bam")
+    open(p2, "wb").write(bytes(raw))
+    d = engine.DeviceBam(p2)
+    with pytest.raises(_ffi.TcmiError) as e:
+        ctx.upload_bamfile(d)
+    assert e.value.code == _ffi.E_FORMAT and "CRC32" in str(e.value) and "block 2" in str(e.value)
+    ctx.set_option("verify_crc", 0)                     # without the check the damaged byte goes through unnoticed
+    try:
+        ctx.upload_bamfile(d).free()
+    finally:
+        ctx.set_option("verify_crc", 1)
+    d.close()
+    with pytest.raises(_ffi.TcmiError):                 # the host reader says the same
+        engine.BamFile(p2, threads=2)
+    # ... and a damaged CRC field over intact data
+    raw[at] ^= 0x10
+    end = offs[3]
+    raw[end - 8] ^= 1
+    open(p2, "wb").write(bytes(raw))
+    d = engine.DeviceBam(p2)
+    with pytest.raises(_ffi.TcmiError) as e:
+        ctx.upload_bamfile(d)
+    assert e.value.code == _ffi.E_FORMAT and "CRC32" in str(e.value)
     d.close()
 
 

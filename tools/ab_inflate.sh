@@ -14,3 +14,11 @@ d=json.loads(open('gpurun_out/ab/$v.json').read().strip().splitlines()[-1])
 print('$v', round(d['value']/1e6,2), 'M/s', d['ms_per_step'], 'cold', {k:round(v['us_per_bam']) for k,v in d['cold_kernels'].items()}, 'pipe', {k:round(v['us_per_bam']) for k,v in d['cold_kernels_pipelined'].items()}, d['fasta_bit_exact'])
 "
 done
+for gs in $STREAMS; do
+  timeout -k 10 200 python3 bench.py --no-resident --no-cpu-baseline --gpu-streams $gs > gpurun_out/ab/gs$gs.json 2> gpurun_out/ab/gs$gs.err || { echo "streams $gs failed"; tail -5 gpurun_out/ab/gs$gs.err; exit 1; }
+  python3 -c "
+import json
+d=json.loads(open('gpurun_out/ab/gs$gs.json').read().strip().splitlines()[-1])
+print('streams $gs', round(d['value']/1e6,2), 'M/s', round(d['ms_per_step'],4), d['e2e_stage_busy_seconds_per_bam'])
+"
+done

@@ -157,6 +157,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "balance_chunks")) c->balance_chunks = value != 0;
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "device_pack")) c->device_pack = value != 0;
+    else if (!std::strcmp(key, "verify_crc")) c->verify_crc = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);

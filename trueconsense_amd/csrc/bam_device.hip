@@ -64,7 +64,7 @@ struct BlockDesc {
 };
 
 // status word of a block
-enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_BAD_LENGTH = 2, ST_BAD_RECORD = 3 };
+enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_BAD_LENGTH = 2, ST_BAD_RECORD = 3, ST_BAD_CRC = 4 };
 
 __constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -501,6 +501,116 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     }
 }
 
+// ---- bgzf_crc32: the CRC-32 of every block's inflated bytes against the value in the block's trailer (SAM spec §4.1; htslib
+// checks it on every block it reads).  One wavefront per block, four blocks per workgroup.  The block is read in rows of
+// 1 KiB, coalesced: lane l takes the 16 bytes at l * 16 of every row (the rows are cut from the block's END, so the short row
+// comes first).  CRCs are joined zlib's crc32_combine way: "append n zero bytes" is a linear operator on the CRC register (a
+// 32 x 32 matrix over GF(2)).  Down its column a lane needs the operator for 1 KiB once per row (four byte-indexed tables in
+// LDS, built from the 32 columns of the matrix the host passes); across the lanes the 64 column CRCs are joined pairwise with
+// the operators for 16, 32, .. 512 bytes.
+struct CrcArgs {
+    const uint8_t *file;        // compressed file (for the trailers)
+    const uint8_t *out;         // inflated stream
+    const BlockDesc *blocks;
+    uint32_t *status;           // [n_blocks]: ST_OK -> ST_BAD_CRC on a mismatch (blocks that already failed are skipped)
+    int32_t n_blocks;
+    uint32_t zeros[6][32];      // zeros[k][i]: the CRC register with only bit i set, after 16 << k zero bytes
+    uint32_t zeros1k[32];       // ... after 1024 zero bytes
+};
+
+__global__ __launch_bounds__(256) void bgzf_crc32(CrcArgs a)
+{
+    __shared__ uint32_t s_tab[256];
+    __shared__ uint32_t s_row[4][256];                      // s_row[b][v]: the register (v << 8 b), 1 KiB of zeros later
+    __shared__ uint32_t s_op[6][32];
+    {
+        uint32_t c = threadIdx.x;                           // the reflected CRC-32 table (polynomial 0xEDB88320)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        s_tab[threadIdx.x] = c;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m ^= a.zeros1k[8 * b + i] & (0u - ((threadIdx.x >> i) & 1u));
+            s_row[b][threadIdx.x] = m;
+        }
+        if (threadIdx.x < 192) s_op[threadIdx.x >> 5][threadIdx.x & 31] = a.zeros[threadIdx.x >> 5][threadIdx.x & 31];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= a.n_blocks) return;
+    if (a.status[blk] != ST_OK) return;
+    const BlockDesc d = a.blocks[blk];
+    const uint8_t *p = a.out + d.uout;                      // 16-byte aligned (the host pads every block's output)
+    const int32_t body = (int32_t)(d.ulen & ~15u);          // whole 16-byte pieces; the last ulen % 16 bytes follow at the end
+    const int32_t rows = (body + 1023) >> 10;
+    // All of it in the CRC's LINEAR form (register starts at 0, no final inversion: then crc(A || B) = later(crc(A), |B|) ^ crc(B)
+    // and pieces may be taken in any order); the standard's all-ones start is the same as inverting the block's first four bytes.
+    auto crc16 = [&](uint4 v, int32_t at) {
+        uint32_t c = at == 0 ? 0xFFFFFFFFu : 0u;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c ^= w[k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) c = s_tab[c & 0xFFu] ^ (c >> 8);
+        }
+        return c;
+    };
+    auto later_1k = [&](uint32_t c) { return s_row[0][c & 0xFFu] ^ s_row[1][(c >> 8) & 0xFFu] ^ s_row[2][(c >> 16) & 0xFFu] ^ s_row[3][c >> 24]; };
+    uint32_t acc = 0;
+    int32_t off = body - rows * 1024 + lane * 16;           // this lane's piece of the first row; negative: the row is short and starts later
+    int32_t r = 0;
+    for (; r + 4 <= rows; r += 4, off += 4096) {            // four rows at a time: four independent look-up chains
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const uint4 v0 = off >= 0 ? *reinterpret_cast<const uint4 *>(p + off) : z;
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(p + off + 1024);
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(p + off + 2048);
+        const uint4 v3 = *reinterpret_cast<const uint4 *>(p + off + 3072);
+        const uint32_t c0 = off >= 0 ? crc16(v0, off) : 0u, c1 = crc16(v1, off + 1024), c2 = crc16(v2, off + 2048), c3 = crc16(v3, off + 3072);
+        acc = later_1k(later_1k(later_1k(later_1k(acc) ^ c0) ^ c1) ^ c2) ^ c3;
+    }
+    for (; r < rows; ++r, off += 1024)
+        acc = later_1k(acc) ^ (off >= 0 ? crc16(*reinterpret_cast<const uint4 *>(p + off), off) : 0u);
+    // pairwise across the lanes: a lane that starts a span of 2s columns takes its right neighbour's span (16 s bytes) behind its own
+    uint32_t c = acc;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << k, 64);
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m ^= s_op[k][i] & (0u - ((c >> i) & 1u));
+        c = m ^ right;
+    }
+    if (lane == 0) {
+        uint32_t t = body ? c : 0xFFFFFFFFu;                // the register after the body; the last ulen % 16 bytes one by one
+        for (uint32_t i = (uint32_t)body; i < d.ulen; ++i) t = s_tab[(t ^ p[i]) & 0xFFu] ^ (t >> 8);
+        t = ~t;
+        const uint8_t *e = a.file + d.cin + d.clen;         // the block's trailer: CRC32, ISIZE (little endian)
+        const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+        if (t != want) a.status[blk] = ST_BAD_CRC;
+    }
+}
+
+// the operators bgzf_crc32 takes: zlib's crc32_combine construction (one zero bit, squared up)
+static void crc_zero_operators(uint32_t zeros[6][32], uint32_t zeros1k[32])
+{
+    auto times = [](const uint32_t *mat, uint32_t vec) { uint32_t s = 0; for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1u) s ^= mat[i]; return s; };
+    uint32_t a[32], b[32];
+    a[0] = 0xEDB88320u;                                     // one zero BIT
+    for (int i = 1; i < 32; ++i) a[i] = 1u << (i - 1);
+    uint32_t *cur = a, *nxt = b;
+    for (int bits = 1; bits <= 8 * 1024; bits <<= 1) {      // `cur` appends `bits` zero bits
+        for (int k = 0; k < 6; ++k)
+            if (bits == 8 * (16 << k)) std::memcpy(zeros[k], cur, 32 * sizeof(uint32_t));
+        if (bits == 8 * 1024) std::memcpy(zeros1k, cur, 32 * sizeof(uint32_t));
+        for (int i = 0; i < 32; ++i) nxt[i] = times(cur, cur[i]);
+        std::swap(cur, nxt);
+    }
+}
+
 // per-block record lists -> dense offsets into the stream; base[b] = exclusive scan of n_rec (done by one workgroup first)
 __global__ __launch_bounds__(1024) void rec_scan(const uint32_t *n_rec, uint64_t *base, int32_t n_blocks, unsigned long long *total)
 {
@@ -772,6 +882,15 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
+    if (ctx->verify_crc) {
+        static const CrcArgs proto = [] { CrcArgs c = {}; crc_zero_operators(c.zeros, c.zeros1k); return c; }();
+        CrcArgs c = proto;
+        c.file = d_file; c.out = d_out; c.blocks = d_desc; c.status = d_stat; c.n_blocks = (int32_t)nb;
+        tcmi_prof_begin(ctx, TCMI_K_CRC);
+        hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, ctx->stream, c);
+        tcmi_prof_end(ctx, TCMI_K_CRC);
+        TCMI_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, d_total);
     TCMI_HIP(ctx, hipGetLastError());
     // the verdict of every block comes back to the host: a few bytes per block
@@ -785,6 +904,9 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     for (size_t b = 0; b < nb; ++b)
         if (stat[b] == ST_BAD_STREAM || stat[b] == ST_BAD_LENGTH)
             return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: BGZF block %zu failed to inflate (deflate stream or ISIZE damaged)", f->path.c_str(), b);
+    for (size_t b = 0; b < nb; ++b)
+        if (stat[b] == ST_BAD_CRC)
+            return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: CRC32 mismatch in BGZF block %zu", f->path.c_str(), b);
     // The record chain: every block was walked from offset 0 on the assumption that its predecessor ends on a record
     // boundary.  In block order that assumption holds by induction up to the first block that runs over, so a bad
     // record before that point is real, and anything after it is not to be trusted.

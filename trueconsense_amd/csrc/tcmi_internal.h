@@ -134,6 +134,7 @@ struct tcmi_ctx {
     // (hipMalloc + hipFree cost more than the pack kernels, and hipFree waits for the device)
     struct Blob { char *p; size_t bytes; };
     std::vector<Blob> blob_pool;
+    int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)

@@ -848,7 +848,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     // (block_size + 32 fixed bytes + name + CIGAR + SEQ + QUAL of a 15-base read) — the arena cannot grow under live data
     const size_t max_rec = f->inflated / 36 + 16;
     const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
-    const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 64),
+    const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
                  b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 3 + al(nb * 8) + 256;
     const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 9 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;

@@ -47,9 +47,9 @@ __device__ inline uint32_t ld_u32(const uint8_t *p)
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3) * 8u;
-    const uint32_t lo = q[0];
-    if (sh == 0) return lo;
-    return __builtin_amdgcn_alignbit(q[1], lo, sh);
+    // (both words always: a conditional second load would wait for the first one — two memory round trips instead of one;
+    //  the word behind an aligned field is still inside the stream's allocation)
+    return __builtin_amdgcn_alignbit(q[1], q[0], sh);
 }
 
 __device__ inline ReadView view(const PackSrc &s, int64_t i)
@@ -377,16 +377,50 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
         const uint8_t *seq = (src.mode == 0 ? src.seq : src.stream) + (((unsigned long long)(where.y & 0xFFu) << 32) | where.x);
         const int l_seq = (int)(where.y >> 8);
         const int y0 = (int)(info >> 12);
-        for (int q = 0; q < npair; ++q) {
-            const int nb = min(32, len - 32 * q);
-            uint32_t lo, hi, ok;
-            fetch32(seq, l_seq, y0 + 32 * q, nb, lo, hi, ok);
-            *reinterpret_cast<uint2 *>(out + 2 * q) = make_uint2(lo, hi);
-            uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
-            while (miss) {
-                const int b = __builtin_ctz(miss);
-                push_event(o, tot, (uint32_t)(gpos + 32 * q + b) | TCMI_F_EV_OTHER);
-                miss &= miss - 1;
+        // 160 bases (five pairs, 80 bytes) per round: ALL of the round's words are requested before the first is used — one
+        // memory round trip per round instead of one per pair (a 150-base read: one instead of five)
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(seq + (y0 >> 1));
+        const uint32_t *qw = reinterpret_cast<const uint32_t *>(a0 & ~(uintptr_t)3);       // (generic-pointer loads: telling the compiler
+                                                                                         //  "global" made this kernel slower, 194 vs 123 us)
+        const uint32_t sh = (uint32_t)(a0 & 3) * 8u;
+        const bool odd = y0 & 1;
+        const int avail = min(len, l_seq - y0);                 // bases the read really has (the rest count as "not A/C/G/T")
+        for (int g = 0; g < npair; g += 5) {
+            uint32_t d[22];
+#pragma unroll
+            for (int k = 0; k < 22; ++k) d[k] = qw[4 * g + k];      // (unguarded: a guard per word costs more than the words; what lies behind
+                                                                    //  the read's SEQ — its QUAL, the next record, the arrays' 128 bytes of slack — is masked below)
+            uint32_t w[21];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) {
+                const uint32_t b = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+                w[k] = ((b & 0x0F0F0F0Fu) << 4) | ((b >> 4) & 0x0F0F0F0Fu);   // BAM keeps the first base of a byte in the high nibble
+            }
+#pragma unroll
+            for (int p5 = 0; p5 < 5; ++p5) {
+                const int q = g + p5;
+                if (q < npair) {
+                    const int nb = min(32, len - 32 * q), have = min(nb, avail - 32 * q);
+                    uint32_t lo = 0, hi = 0, ok = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t n = odd ? __builtin_amdgcn_alignbit(w[4 * p5 + k + 1], w[4 * p5 + k], 4) : w[4 * p5 + k];
+                        uint32_t l, h, v;
+                        classify8(n, l, h, v);
+                        lo |= squeeze8(l) << (8 * k);
+                        hi |= squeeze8(h) << (8 * k);
+                        ok |= squeeze8(v) << (8 * k);
+                    }
+                    const uint32_t mask = have >= 32 ? 0xFFFFFFFFu : have > 0 ? ((1u << have) - 1u) : 0u;
+                    lo &= mask; hi &= mask; ok &= mask;
+                    *reinterpret_cast<uint2 *>(out + 2 * q) = make_uint2(lo, hi);
+                    uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
+                    while (miss) {
+                        const int b = __builtin_ctz(miss);
+                        push_event(o, tot, (uint32_t)(gpos + 32 * q + b) | TCMI_F_EV_OTHER);
+                        miss &= miss - 1;
+                    }
+                }
             }
         }
     } else {
@@ -863,7 +897,7 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
     const size_t n_cig = n ? (size_t)r->cigar_off[n] : 0, n_seq = n ? (size_t)r->seq_off[n] : 0;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t sz[8] = {al((size_t)n * 4), al((size_t)n * 2), al((size_t)n * 4), r->tid ? al((size_t)n * 4) : 0, al((size_t)(n + 1) * 8),
-                          al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 64)};
+                          al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 128)};
     size_t src_bytes = 0;
     for (size_t b : sz) src_bytes += b + 256;
     const size_t tmp_bytes = al((size_t)n * 4) * 9 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 16 * 256;

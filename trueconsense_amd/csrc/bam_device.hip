@@ -309,6 +309,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     // the chain of BAM records through this block
     uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
     uint32_t n_rec = 0;
+    uint32_t rec_buf = 0;               // lane k: the start of record (n_rec & ~63) + k, until 64 are together
     uint32_t next_evt = 0;              // output position at which the housekeeping below has something to do
 
     // after every symbol that carries `op` to `next_evt`: list the record starts whose block_size field is complete, and flush
@@ -317,11 +318,15 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         const bool over = op > ulen;                            // (ring writes are masked: nothing was overwritten; no flush then)
         if (over) err = ST_BAD_LENGTH;
         while (!over && next_rec + 4 <= op && next_rec < ulen) {
-            const uint32_t bs = (uint32_t)s_win[next_rec & WMASK] | ((uint32_t)s_win[(next_rec + 1) & WMASK] << 8) |
-                                ((uint32_t)s_win[(next_rec + 2) & WMASK] << 16) | ((uint32_t)s_win[(next_rec + 3) & WMASK] << 24);
-            const uint32_t ubs = uni(bs);
-            if (ubs < 32u || ubs > (1u << 28) || n_rec >= (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
-            if (lane == 0) slots[n_rec] = next_rec;
+            // block_size: the two ring words around it (lanes 0 and 1 of one read), shifted into place.  The starts are gathered
+            // in a register, one lane each, and leave 64 at a time.  (At most ulen / 36 + 1 <= 1 821 records: the slots suffice.)
+            const uint32_t at = next_rec & WMASK;
+            const uint32_t w = reinterpret_cast<const uint32_t *>(s_win)[((at >> 2) + (uint32_t)lane) & (WIN / 4 - 1)];
+            const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
+            const uint32_t ubs = (uint32_t)(two >> ((at & 3u) * 8u));
+            if (ubs - 32u > (1u << 28) - 32u) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
+            rec_buf = (uint32_t)lane == (n_rec & 63u) ? next_rec : rec_buf;
+            if ((n_rec & 63u) == 63u) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
             ++n_rec;
             next_rec += 4u + ubs;
         }
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         const uint32_t rest = op - flushed;
         for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & WMASK];
     }
+    if ((uint32_t)lane < (n_rec & 63u)) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
     if (lane == 0) {
         a.status[blk] = err;
         a.n_rec[blk] = n_rec;

@@ -486,11 +486,26 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
     inflated = inflated_bytes or 273 * n
     out = {"roofline": block("bgzf_inflate", "inflate", file_bytes + inflated,
                              "compressed bytes read + inflated bytes written per BAM; one wavefront per BGZF block, wave-uniform Huffman "
-                             "decoding: bound by scalar instruction issue (profiles/r02k_pmc_e2e.txt), not by HBM", traffic_key="inflate_hbm_bytes_per_bam"),
+                             "decoding: bound by instruction issue (profiles/r02m_pmc_e2e.txt), not by HBM — see `issue`", traffic_key="inflate_hbm_bytes_per_bam"),
            "roofline_hot_path": block("pk_pack", "pack", alg_reads + 52 * n,
                                       "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read it writes; it "
                                       "reads them out of the inflated BAM stream (285 B per record, names and qualities ride along in the cache lines)",
                                       alg=alg_reads, traffic_key="pack_hbm_bytes_per_bam")}
+    # the bound that does hold bgzf_inflate: wave-instructions issued per compute unit and cycle (PMC count of the committed passes
+    # over this run's single-stream kernel time; a CU's SIMDs take turns, one instruction per wave and turn: with the 4 - 5
+    # resident waves per SIMD all in scalar code the ceiling is ~1 per CU and cycle)
+    insts = traffic.get("inflate_wave_insts_per_bam")
+    if insts and cold["inflate"]["us_per_bam"] > 0:
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(0)
+            n_cu, ghz = int(pr.multi_processor_count), float(getattr(pr, "clock_rate", 2400000)) / 1e6
+        except Exception:
+            n_cu, ghz = 256, 2.4
+        out["roofline"]["issue"] = {"wave_insts_per_launch": insts, "source": "profiles/traffic.json (SQ_ACTIVE_INST_ANY, rocprofv3 --pmc)",
+                                    "compute_units": n_cu, "clock_ghz": ghz,
+                                    "insts_per_cu_cycle": insts / (n_cu * ghz * 1e3 * cold["inflate"]["us_per_bam"]),
+                                    "kernel_us": cold["inflate"]["us_per_bam"]}
     return out
 
 

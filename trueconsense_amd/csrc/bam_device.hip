@@ -6,17 +6,20 @@
 // enough to parse the BAM header; the compressed bytes (a few MB .. tens of MB) cross PCIe once.
 //
 //   bgzf_inflate   ONE WAVEFRONT PER BGZF BLOCK (blocks are independent deflate streams of <= 64 KiB).  All decoder state
-//                  is wave-uniform: the bit buffer, the Huffman root tables (10 / 9 bits, in LDS, built in parallel from
-//                  the canonical code: every lane decodes its table indices bit by bit), the output position.  Literals
-//                  and LZ77 matches go through a 4 KiB LDS ring of the most recent output (a match is copied by all 64
-//                  lanes at once; the match that reaches further back — the deflate window is 32 KiB — reads what was
-//                  already flushed); finished 2 KiB segments are flushed to HBM with 16-byte stores.  12 KiB of LDS per
-//                  wavefront: every block of a 1M-read BAM (4 200) is in flight at once, 16 per CU, and they hide each
-//                  other's LDS / decode latencies (measured: 32 KiB ring 2.95 ms, 8 KiB 1.5 ms, 4 KiB 1.2 ms per BAM).  While it inflates, the wave
-//                  also follows the chain of BAM records through its block (block_size fields, read from the ring as soon
-//                  as they are complete) and lists the record starts: htslib-written BAMs start every BGZF block on a
-//                  record boundary, which the chain check (`overshoot` of a block = 0) verifies; files that do not are
-//                  left to the host reader.
+//                  is wave-uniform: the bit buffer, the Huffman root tables (9 / 8 bits, in LDS, built in parallel from
+//                  the canonical code: every lane decodes its table indices bit by bit; longer codes resume the canonical
+//                  walk behind the root bits), the output position.  Literals and LZ77 matches go through a 4 KiB LDS ring of
+//                  the most recent output (a match is copied by all 64 lanes at once; the match that reaches further back —
+//                  the deflate window is 32 KiB — reads what was already flushed); finished 2 KiB segments are flushed to HBM
+//                  with 16-byte stores.  8.8 KiB of LDS per wavefront, on purpose: 18 blocks are resident per CU, so ALL
+//                  4 187 blocks of a 1M-read BAM run at once (with 12.9 KiB — 10 / 9-bit tables, a 1 KiB input ring — 11 fit
+//                  and the kernel took a second, two-thirds empty round: 1.19 ms; now 0.81 ms).  The kernel is bound by
+//                  instruction issue: ~120 k wave-instructions per block, most of them scalar, one per SIMD turn.  While it
+//                  inflates, the wave also follows the chain of BAM records through its block (block_size fields, read from
+//                  the ring as soon as they are complete) and lists the record starts: htslib-written BAMs start every BGZF
+//                  block on a record boundary, which the chain check (`overshoot` of a block = 0) verifies; files that do
+//                  not are left to the host reader.
+//   bgzf_crc32     the CRC-32 of every block's output against its trailer (one wavefront per block, coalesced rows)
 //   rec_compact    per-block record lists -> one dense array of record offsets (block scan + copy)
 //
 // Serial-latency-bound bit / byte work, not HBM-bound and not a contraction: no MFMA.
@@ -426,7 +429,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         //      on with harmless values (every LDS index is masked, a far source stays inside the arena) and the next
         //      housekeeping or end-of-block code ends it — one exit keeps the loop's control flow lean.
         //      (Tried and measured no faster: 64 bit offsets looked up speculatively by the lanes per round and the chain
-        //      walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.) --------------------------------------
+        //      walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.  Tried and measured SLOWER: the bit
+        //      buffer, the extra-bit fields and the base + extra sums on the vector pipe (v_lshrrev_b64, v_bfe_u32; only the
+        //      branch conditions scalar) — 0.92 vs 0.81 ms: with four or five waves per SIMD the longer dependent chains cost
+        //      more than the freed scalar issue slots give.) ----------------------------------------------------------------
         uint32_t bad = 0;
         for (;;) {
             asm volatile("; HOT_BEGIN");

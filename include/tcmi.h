@@ -240,10 +240,12 @@ int tcmi_consensus_walk(const uint8_t *plain, const uint8_t *alt, const uint8_t 
  *   max_depth          : htslib's maxcnt (pysam's max_depth, default 8000): reads that share their start with the read
  *                        before them are dropped once the column holds this many; 0 = no cap
  *   ignore_overlaps    : pysam's default 1: of two overlapping mates only one keeps its base on the column (needs the
- *                        mate fields and names of tcmi_reads; reads without names are taken as unpaired)
+ *                        mate fields and names of tcmi_reads; reads without names are taken as unpaired).  A mate whose
+ *                        token on the column is a deletion / ref-skip is tested on its next query base, as htslib does,
+ *                        with the tweak evaluated on that base's reference position
  *   status_flags       : bit 0 = max_depth dropped reads (modelled, informational); bit 1 = a pair of overlapping mates
- *                        whose quality tweak depends on positions off the column: the tokens are NOT what pysam gives —
- *                        callers must refuse (the package raises TCMI_E_UNSUPPORTED)                                    */
+ *                        whose quality tweak could not be evaluated (not raised by the entry points of this library any
+ *                        more; kept for callers that test it): the tokens would NOT be what pysam gives — refuse         */
 #define TCMI_TOKENS_DEPTH_CAPPED     1
 #define TCMI_TOKENS_OVERLAP_UNKNOWN  2
 int tcmi_modal_tokens(const tcmi_reads *reads, int32_t n_pos, const int64_t *positions,

@@ -268,3 +268,42 @@ def test_insert_tokens_resolved_on_the_device(ctx, tmp_path):
     assert got[221][1] == len(want) and got[221][0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
     assert got[221][1] < len(orc.region_tokens(rd, 221, ignore_overlaps=False))
     rs.free(); d2.close()
+    # ---- a mate with a deletion / ref-skip ON the column: its token is tested on its next query base, where the overlap tweak
+    #      reaches it if the other mate has a matched base there (ins_probe_kernel looks) ----
+    dels = []
+    for k in range(500):
+        start = 300 + int(rng.integers(0, 6))
+        mate = start + int(rng.integers(0, 8))
+        s1 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 40))
+        s2 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 40))
+        if rng.random() < 0.5:
+            s2 = s1[mate - start:] + s2[:mate - start]
+
+        def gap_cigar(read_start):
+            gap = int(rng.integers(1, 5))
+            a = 319 - read_start - int(rng.integers(0, gap))
+            kind = "N" if rng.random() < 0.2 else "D"
+            if rng.random() < 0.2:
+                return "%dM%d%s2I%dM" % (a, gap, kind, 40 - a - 2)
+            return "%dM%d%s%dM" % (a, gap, kind, 40 - a)
+        which = rng.random()
+        dels.append({"pos": start, "flag": 99, "cigar": gap_cigar(start) if which < 0.7 else "40M", "seq": s1, "qual": [int(x) for x in rng.integers(4, 30, 40)],
+                     "name": "g%d" % k, "mtid": 0, "mpos": mate, "tlen": mate + 44 - start})
+        dels.append({"pos": mate, "flag": 147, "cigar": gap_cigar(mate) if which > 0.5 else "40M", "seq": s2, "qual": [int(x) for x in rng.integers(4, 30, 40)],
+                     "name": "g%d" % k, "mtid": 0, "mpos": start, "tlen": -(mate + 44 - start)})
+    dels.sort(key=lambda r: r["pos"])
+    rd = ss.reads_from_spec({"reads": dels})
+    p3 = str(tmp_path / "gaps.bam")
+    bamwriter.write_bam(p3, rd, "r", 500)
+    d3 = engine.DeviceBam(p3)
+    rs = ctx.upload_bamfile(d3)
+    cols = [319, 320, 321, 322]
+    got = ctx.readset_modal_tokens(rs, cols)
+    assert got == engine.modal_tokens(engine.BamFile(p3), cols)
+    changed = False
+    for c in cols:
+        want = orc.region_tokens(rd, c)
+        assert got[c][1] == len(want) and got[c][0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0], c
+        changed |= len(want) != len(orc.region_tokens(rd, c, ignore_overlaps=False))
+    assert changed
+    rs.free(); d3.close()

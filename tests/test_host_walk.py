@@ -358,11 +358,56 @@ def test_insert_tokens_max_depth_and_overlapping_mates():
             assert got[1] == len(want), (col, olap, got[1], len(want))
             assert got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
     assert len(orc.region_tokens(pr, 215)) < len(orc.region_tokens(pr, 215, ignore_overlaps=False))
-    # ---- a pair with a deletion on the column: the tweak depends on another position -> refused, not guessed ----
-    bad = ss.reads_from_spec({"reads": [
+    # ---- a mate with a deletion / ref-skip ON the column: its token is tested on the quality of its NEXT query base, which the
+    #      tweak reaches on that base's reference position if the other mate has a matched base there (the product probes the
+    #      other mate; the oracle tweaks the whole overlap) ----
+    one = ss.reads_from_spec({"reads": [
         {"pos": 10, "flag": 99, "cigar": "5M2D10M", "seq": "ACGTACGTACGTACG", "qual": 30, "name": "p", "mtid": 0, "mpos": 12, "tlen": 30},
         {"pos": 12, "flag": 147, "cigar": "15M", "seq": "ACGTACGTACGTACG", "qual": 30, "name": "p", "mtid": 0, "mpos": 10, "tlen": -30}]})
-    with pytest.raises(_ffi.TcmiError) as e:
-        engine.modal_tokens(bad, [16])
-    assert e.value.code == _ffi.E_UNSUPPORTED
-    assert engine.modal_tokens(bad, [16], ignore_overlaps=False)[16][1] == 2
+    want = orc.region_tokens(one, 16)
+    got = engine.modal_tokens(one, [16])[16]
+    assert got[1] == len(want) and (not want or got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0])
+    assert engine.modal_tokens(one, [16], ignore_overlaps=False)[16][1] == 2
+    dels = []
+    for k in range(600):
+        start = 300 + int(rng.integers(0, 6))
+        mate = start + int(rng.integers(0, 8))
+        seq1 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 40))
+        seq2 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 40))
+        q1 = [int(x) for x in rng.integers(4, 30, 40)]
+        q2 = [int(x) for x in rng.integers(4, 30, 40)]
+        # column of interest: 1-based 320 (0-based 319); a deletion / skip of 1-4 bases that covers it in one mate or both, sometimes
+        # followed by an insertion (then the next query base has no reference position) or preceded by one
+        def cigar_with_gap(read_start, seq_len):
+            i = 319 - read_start                              # matched bases before the column
+            gap = int(rng.integers(1, 5))
+            lead = int(rng.integers(0, gap))                  # the gap starts `lead` positions before the column
+            kind = "N" if rng.random() < 0.2 else "D"
+            a = i - lead
+            if rng.random() < 0.2:
+                return "%dM%d%s2I%dM" % (a, gap, kind, seq_len - a - 2)
+            if rng.random() < 0.15 and a > 3:
+                return "%dM1I%dM%d%s%dM" % (a - 2, 1, gap, kind, seq_len - a)
+            return "%dM%d%s%dM" % (a, gap, kind, seq_len - a)
+        which = rng.random()
+        cig1 = cigar_with_gap(start, 40) if which < 0.7 else "40M"
+        cig2 = cigar_with_gap(mate, 40) if which > 0.5 else "40M"
+        if rng.random() < 0.5:                                # agreeing bases at the sites more often than chance
+            seq2 = seq1[mate - start:] + seq2[:mate - start]
+        name = "d%d" % k
+        proper = rng.random() < 0.9
+        dels.append({"pos": start, "flag": 99 if proper else 65, "cigar": cig1, "seq": seq1, "qual": q1, "name": name, "mtid": 0, "mpos": mate,
+                     "tlen": mate + 44 - start})
+        dels.append({"pos": mate, "flag": 147 if proper else 129, "cigar": cig2, "seq": seq2, "qual": q2, "name": name, "mtid": 0, "mpos": start,
+                     "tlen": -(mate + 44 - start)})
+    dels.sort(key=lambda r: r["pos"])
+    dr = ss.reads_from_spec({"reads": dels})
+    dr["sorted_max_span"] = 50
+    seen_change = False
+    for col in (320, 319, 321, 322):
+        want = orc.region_tokens(dr, col)
+        got = engine.modal_tokens(dr, [col])[col]
+        assert got[1] == len(want), (col, got[1], len(want))
+        assert got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
+        seen_change |= len(want) != len(orc.region_tokens(dr, col, ignore_overlaps=False))
+    assert seen_change

@@ -15,10 +15,14 @@
 //   ignore_overlaps      overlap_push / tweak_overlap_quality: of two properly paired mates that both cover the column, the
 //                        one pushed first keeps the base (quality = sum, at most 200, when the bases agree; 0.8 x the higher
 //                        one when they differ) and the other's quality becomes 0, so its token fails min_base_quality.
-//                        Evaluated where both mates have a matched base on the column; a pair where one mate's token takes
-//                        its quality from another position (deletion / ref-skip tokens) is reported, not guessed.
+//                        htslib tweaks every reference position where BOTH mates have a matched base, in both quality arrays,
+//                        when the second mate arrives.  For a column that is evaluated where it matters: on the column
+//                        itself when both mates have a base there; and — a mate whose token is a deletion / ref-skip is
+//                        tested on the quality of its NEXT query base (htslib's qpos) — on that base's reference position
+//                        when it is a matched base, for which the other mate is probed there (tcmi_probe).
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -70,6 +74,9 @@ struct Entry {
     uint8_t qual;               // base quality pysam tests: at the column's query position, or — deletion / ref-skip tokens — of the next base
     uint8_t base;               // 4-bit code of that base
     bool on_base;               // the token's first character is a base of this read sitting on the column
+    int64_t idx = -1;           // the read (for probes): index in the caller's arrays / compacted index on the device
+    int32_t qref = -1;          // !on_base: reference position of the matched base whose quality is tested, or -1: that base is
+                                // not a matched one (inserted, clipped, beyond SEQ) and no overlap tweak can reach it
 };
 
 // Tokens are PACKED into 64 bits where they fit (a base, a deletion of any length, an insertion of <= 12 bases): no string
@@ -129,10 +136,28 @@ struct Column {
     }
 };
 
+// htslib tweak_overlap_quality at ONE reference position where both mates have a matched base: `first` is the mate that
+// arrived first.  Agreeing bases: first += second (at most 200), second = 0; differing: the higher one x 0.8, the other 0.
+inline void tweak_pair(uint8_t base_first, uint8_t &q_first, uint8_t base_second, uint8_t &q_second)
+{
+    if (base_first == base_second) {
+        const int q = (int)q_first + (int)q_second;
+        q_first = (uint8_t)(q > 200 ? 200 : q);
+        q_second = 0;
+    } else if (q_first >= q_second) {
+        q_first = (uint8_t)(0.8 * q_first);
+        q_second = 0;
+    } else {
+        q_second = (uint8_t)(0.8 * q_second);
+        q_first = 0;
+    }
+}
+
 // The column's entries in file order -> the tokens pysam's default pileup would yield, counted.
 //   status bit 0: max_depth dropped reads (modelled);  bit 1: a pair of overlapping mates whose quality tweak could not be
-//   evaluated on this column (the caller refuses rather than guesses)
-void finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, Column &C, int32_t *status)
+//   evaluated (no prober given: the caller refuses rather than guesses)
+int finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, Column &C, int32_t *status,
+                    const tcmi_prober *prober)
 {
     // admission: htslib bam_plp_push
     std::vector<uint8_t> in(es.size(), 1);
@@ -147,6 +172,8 @@ void finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t m
     }
     // overlapping mates: htslib overlap_push + tweak_overlap_quality
     if (ignore_overlaps) {
+        struct Later { size_t x, y; bool x_first; };           // x: the mate tested on its next base; y: the mate to probe there
+        std::vector<Later> later;
         std::unordered_map<uint64_t, size_t> waiting;
         for (size_t i = 0; i < es.size(); ++i) {
             Entry &b = es[i];
@@ -159,26 +186,34 @@ void finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t m
                 if (b.mpos >= b.pos || ((b.flag & 0x1) && b.mpos == -1)) waiting.emplace(b.name_hash, i);
                 continue;
             }
-            Entry &a = es[it->second];
+            const size_t ia = it->second;
+            Entry &a = es[ia];
             waiting.erase(it);
             if (a.on_base && b.on_base) {
-                if (a.base == b.base) {
-                    const int q = (int)a.qual + (int)b.qual;
-                    a.qual = (uint8_t)(q > 200 ? 200 : q);
-                    b.qual = 0;
-                } else if (a.qual >= b.qual) {
-                    a.qual = (uint8_t)(0.8 * a.qual);
-                    b.qual = 0;
-                } else {
-                    b.qual = (uint8_t)(0.8 * b.qual);
-                    a.qual = 0;
+                tweak_pair(a.base, a.qual, b.base, b.qual);
+                continue;
+            }
+            // A mate without a base on the column leaves the other's quality on the column alone; its own token is tested on
+            // its next query base, which the tweak reaches if that base is a matched one and the other mate has a matched base
+            // on the same reference position.
+            if (!a.on_base && a.qref >= 0) later.push_back(Later{ia, i, true});
+            if (!b.on_base && b.qref >= 0) later.push_back(Later{i, ia, false});
+        }
+        if (!later.empty()) {
+            if (!prober || !*prober) *status |= 2;
+            else {
+                std::vector<tcmi_probe_req> req(later.size());
+                std::vector<tcmi_probe_res> res(later.size());
+                for (size_t t = 0; t < later.size(); ++t) { req[t].idx = es[later[t].y].idx; req[t].ref = es[later[t].x].qref; }
+                const int rc = (*prober)(req, res);
+                if (rc) return rc;
+                for (size_t t = 0; t < later.size(); ++t) {
+                    if (!res[t].matched) continue;
+                    Entry &x = es[later[t].x];
+                    uint8_t qy = res[t].qual;                  // (the other mate's quality THERE: its token on this column does not use it)
+                    if (later[t].x_first) tweak_pair(x.base, x.qual, res[t].base, qy);
+                    else tweak_pair(res[t].base, qy, x.base, x.qual);
                 }
-            } else if (!a.on_base && !b.on_base) {
-                *status |= 2;       // both tokens take their quality from a later base: the tweak there is outside this column
-            } else {
-                // the mate without a base here leaves the other's quality alone on this column; its own quality comes from
-                // a later position where the pair may or may not overlap
-                *status |= 2;
             }
         }
     }
@@ -187,6 +222,7 @@ void finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t m
         if (es[i].key) C.add_key(es[i].key);
         else C.add_text(es[i].tok);
     }
+    return TCMI_OK;
 }
 
 uint64_t fnv1a(const char *p, size_t n)
@@ -227,14 +263,15 @@ std::string text_of(uint64_t key)
 }
 
 // every column's entries -> its modal token (first-seen tie-break) and its token count
-int emit_modal(std::vector<std::vector<Entry>> &entries, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens,
+int emit_modal(std::vector<std::vector<Entry>> &entries, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status)
 {
     const size_t n_pos = entries.size();
     int64_t off = 0;
     for (size_t k = 0; k < n_pos; ++k) {
         Column col;
-        finalize_column(entries[k], min_base_quality, max_depth, ignore_overlaps, col, status);
+        const int frc = finalize_column(entries[k], min_base_quality, max_depth, ignore_overlaps, col, status, prober);
+        if (frc) return frc;
         token_off[k] = off;
         n_tokens[k] = col.n;
         const Column::Seen *best = nullptr;
@@ -258,8 +295,8 @@ int emit_modal(std::vector<std::vector<Entry>> &entries, int32_t min_base_qualit
 
 // Entries produced on the device (pack_device.hip, ins_entries_kernel) -> the same finalisation as the host sweep.
 int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
-                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens, int64_t tokens_cap,
-                                int64_t *token_off, int64_t *n_tokens, int32_t *status_flags)
+                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
+                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags)
 {
     std::vector<std::vector<Entry>> entries((size_t)n_pos);
     int32_t status = 0;
@@ -277,10 +314,11 @@ int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const
             e.mtid = (d->bits & 0x20) ? 1 : 0;                 // only "same reference or not" matters
             e.mpos = d->mpos; e.isize = d->isize; e.l_qseq = d->l_qseq; e.flag = d->flag; e.qual = d->qual;
             e.base = d->bits & 0xF; e.on_base = (d->bits & 0x10) != 0;
+            e.idx = d->j; e.qref = d->qref;
             E.push_back(std::move(e));
         }
     }
-    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap, token_off, n_tokens, &status);
+    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, prober, tokens, tokens_cap, token_off, n_tokens, &status);
     if (status_flags) *status_flags = status;
     return rc;
 }
@@ -370,6 +408,17 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                         e.qual = (uint8_t)q;
                         e.on_base = is_match(op);
                         e.base = (uint8_t)(qpos < lq ? ((qpos & 1) ? (s[qpos >> 1] & 0xF) : (s[qpos >> 1] >> 4)) : 15);
+                        e.idx = i;
+                        e.qref = -1;
+                        if (!e.on_base && qpos < lq) {          // the next query base: a matched one? then on which reference position
+                            int64_t xr = x + len;
+                            for (int64_t k2 = k + 1; k2 < nc; ++k2) {
+                                const unsigned o2 = cg[k2] & 0xF;
+                                if (is_match(o2)) { if ((cg[k2] >> 4) > 0 && xr <= INT32_MAX) e.qref = (int32_t)xr; break; }
+                                if (consumes_query(o2) && (cg[k2] >> 4) > 0) break;      // inserted / clipped: no reference position
+                                if (consumes_ref(o2)) xr += cg[k2] >> 4;
+                            }
+                        }
                         e.pos = r->pos[i]; e.end = end; e.flag = (uint16_t)fl; e.l_qseq = (int32_t)lq;
                         e.tid = r->tid ? r->tid[i] : 0;
                         e.mtid = r->next_tid ? r->next_tid[i] : -1;
@@ -412,7 +461,41 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
             }
         }
     }
-    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap, token_off, n_tokens, &status);
+    // the other mate of a pair, probed on one reference position: matched base there? which, with what quality
+    const tcmi_prober prober = [&](const std::vector<tcmi_probe_req> &req, std::vector<tcmi_probe_res> &res) {
+        std::vector<int64_t> qo;
+        if (r->qual && !r->qual_off) { qo.resize((size_t)r->n_reads + 1, 0); for (int64_t i = 0; i < r->n_reads; ++i) qo[(size_t)i + 1] = qo[(size_t)i] + r->l_qseq[i]; }
+        for (size_t t = 0; t < req.size(); ++t) {
+            res[t] = tcmi_probe_res{0, 15, 0};
+            const int64_t i = req[t].idx;
+            if (i < 0 || i >= r->n_reads) continue;
+            const uint32_t *cg = r->cigar + r->cigar_off[i];
+            const int64_t nc = (int64_t)(r->cigar_off[i + 1] - r->cigar_off[i]), lq = r->l_qseq[i];
+            int64_t x = r->pos[i], y = 0;
+            for (int64_t k = 0; k < nc; ++k) {
+                const unsigned op = cg[k] & 0xF;
+                const int64_t len = cg[k] >> 4;
+                if (consumes_ref(op)) {
+                    if (req[t].ref < x + len) {
+                        if (is_match(op) && req[t].ref >= x) {
+                            const int64_t q = y + (req[t].ref - x);
+                            if (q < lq) {
+                                const uint8_t *sq = r->seq + r->seq_off[i];
+                                res[t].matched = 1;
+                                res[t].base = (uint8_t)((q & 1) ? (sq[q >> 1] & 0xF) : (sq[q >> 1] >> 4));
+                                res[t].qual = r->qual ? r->qual[(r->qual_off ? (int64_t)r->qual_off[i] : qo[(size_t)i]) + q] : 255;
+                            }
+                        }
+                        break;
+                    }
+                    x += len;
+                }
+                if (consumes_query(op)) y += len;
+            }
+        }
+        return (int)TCMI_OK;
+    };
+    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, &prober, tokens, tokens_cap, token_off, n_tokens, &status);
     if (rc) return rc;
     if (status_flags) *status_flags = status;
     return TCMI_OK;

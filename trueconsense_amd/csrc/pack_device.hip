@@ -714,7 +714,19 @@ __global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
                 uint64_t h = 1469598103934665603ull;
                 for (uint32_t t = 0; t + 1 < l_name; ++t) { h ^= byte_at(r + 32 + t); h *= 1099511628211ull; }
                 e.name_hash = h ? h : 1;
-                e.j = (uint32_t)j; e.pos = v.pos; e.end = (int32_t)(v.pos + span); e.l_qseq = lq; e.flag = (uint16_t)v.flag; e.pad_ = 0;
+                e.j = (uint32_t)j; e.pos = v.pos; e.end = (int32_t)(v.pos + span); e.l_qseq = lq; e.flag = (uint16_t)v.flag;
+                // a deletion / ref-skip token is tested on the quality of the next query base: a matched one? on which reference position
+                // (where the overlap tweak of a pair of mates can reach it: insert_tokens.cpp)
+                e.qref = -1;
+                if (!is_match(op) && qpos < lq) {
+                    int64_t xr = x + len;
+                    for (uint32_t t = c + 1; t < v.n_cigar; ++t) {
+                        const uint32_t wt = ld_u32(v.cigar + 4 * (size_t)t), o = wt & 0xFu;
+                        if (is_match(o)) { if ((wt >> 4) > 0 && xr <= INT32_MAX) e.qref = (int32_t)xr; break; }
+                        if ((o == 1 || o == 4) && (wt >> 4) > 0) break;
+                        if (consumes_ref(o)) xr += wt >> 4;
+                    }
+                }
                 const int slot = atomicAdd(&a.count[k], 1);
                 a.out[a.off[k] + slot] = e;
                 return;
@@ -723,6 +735,45 @@ __global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
         }
         if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
     }
+}
+
+// does read j (compacted index) have a matched base on reference position `ref`?  -> matched | base << 8 | quality << 16
+struct ProbeArgs {
+    PackSrc src;
+    const uint32_t *c_idx;
+    const int64_t *idx;
+    const int32_t *ref;
+    uint32_t *out;
+    int32_t n;
+};
+
+__global__ __launch_bounds__(64) void ins_probe_kernel(ProbeArgs a)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.n) return;
+    uint32_t res = 15u << 8;
+    const ReadView v = view(a.src, a.c_idx[a.idx[t]]);
+    const int64_t ref = a.ref[t];
+    int64_t x = v.pos, y = 0;
+    for (uint32_t c = 0; c < v.n_cigar; ++c) {
+        const uint32_t w = ld_u32(v.cigar + 4 * (size_t)c), op = w & 0xFu;
+        const int64_t len = w >> 4;
+        if (consumes_ref(op)) {
+            if (ref < x + len) {
+                if (is_match(op) && ref >= x) {
+                    const int64_t q = y + (ref - x);
+                    if (q < v.l_seq) {
+                        const uint8_t *qual = v.seq + ((size_t)v.l_seq + 1) / 2;
+                        res = 1u | (nib_at(v.seq, (int32_t)q) << 8) | (byte_at(qual + q) << 16);
+                    }
+                }
+                break;
+            }
+            x += len;
+        }
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
+    }
+    a.out[t] = res;
 }
 
 } // namespace
@@ -987,6 +1038,38 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
         (void)hipFree(buf);
         if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "insert-token kernel failed: %s", hipGetErrorString(e));
     }
-    return tcmi_modal_from_dev_entries(n_pos, ents.data(), off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, tokens, tokens_cap,
-                                       token_off, n_tokens, status_flags);
+    // the other mate of an overlapping pair, looked at on one reference position (rare: a pair with a deletion on a candidate column)
+    const tcmi_prober prober = [&](const std::vector<tcmi_probe_req> &req, std::vector<tcmi_probe_res> &res) -> int {
+        const size_t n = req.size();
+        std::vector<int64_t> idx(n);
+        std::vector<int32_t> ref(n);
+        std::vector<uint32_t> out(n);
+        for (size_t t = 0; t < n; ++t) {
+            if (req[t].idx < 0 || req[t].idx >= nf) return tcmi_fail(ctx, TCMI_E_ARG, "internal: probe of read %lld", (long long)req[t].idx);
+            idx[t] = req[t].idx; ref[t] = req[t].ref;
+        }
+        char *buf = nullptr;
+        hipError_t e = hipMalloc((void **)&buf, n * 16);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "probe buffers: %s", hipGetErrorString(e));
+        ProbeArgs a;
+        a.src = {};
+        a.src.stream = rs->d_stream; a.src.rec_off = rs->d_rec_off; a.src.mode = 1; a.src.n = rs->n_reads;
+        a.c_idx = rs->d_cidx;
+        a.idx = (const int64_t *)buf; a.ref = (const int32_t *)(buf + n * 8); a.out = (uint32_t *)(buf + n * 12); a.n = (int32_t)n;
+        e = hipMemcpyAsync((void *)a.idx, idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((void *)a.ref, ref.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(ins_probe_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, a);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out.data(), a.out, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(buf);
+        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "probe kernel failed: %s", hipGetErrorString(e));
+        for (size_t t = 0; t < n; ++t) res[t] = tcmi_probe_res{(uint8_t)(out[t] & 1u), (uint8_t)((out[t] >> 8) & 15u), (uint8_t)(out[t] >> 16)};
+        return TCMI_OK;
+    };
+    return tcmi_modal_from_dev_entries(n_pos, ents.data(), off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, &prober, tokens,
+                                       tokens_cap, token_off, n_tokens, status_flags);
 }

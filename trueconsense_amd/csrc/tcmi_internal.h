@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/tcmi.h"
@@ -211,11 +212,16 @@ struct tcmi_dev_entry {
     uint16_t flag;
     uint8_t qual;
     uint8_t bits;               // base code | on_base << 4 | mate on another reference << 5 | insertion too long for the key << 6
-    uint32_t pad_;
+    int32_t qref;               // deletion / ref-skip token: reference position of the matched base whose quality is tested, or -1
 };
+// "does read `idx` have a matched base on reference position `ref`, which, with what quality?" — asked for the other mate of an
+// overlapping pair (insert_tokens.cpp); answered from the host arrays or by a kernel over the resident stream
+struct tcmi_probe_req { int64_t idx; int32_t ref; };
+struct tcmi_probe_res { uint8_t matched, base, qual; };
+typedef std::function<int(const std::vector<tcmi_probe_req> &, std::vector<tcmi_probe_res> &)> tcmi_prober;
 int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
-                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, char *tokens, int64_t tokens_cap,
-                                int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
+                                int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
+                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
 // device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);

@@ -432,7 +432,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         //      walked with v_readlane — 19 % fewer scalar instructions, 1.21 vs 1.19 ms.  Tried and measured SLOWER: the bit
         //      buffer, the extra-bit fields and the base + extra sums on the vector pipe (v_lshrrev_b64, v_bfe_u32; only the
         //      branch conditions scalar) — 0.92 vs 0.81 ms: with four or five waves per SIMD the longer dependent chains cost
-        //      more than the freed scalar issue slots give.) ----------------------------------------------------------------
+        //      more than the freed scalar issue slots give.  Also slower: code + extra bits leaving the buffer in one shift inside
+        //      each branch (the compiler then copies the prefetched input registers at every refill and waits for their load:
+        //      1.07 ms), and a `continue` per path (one latch block, re-split on flags).) ---------------------------------------
         uint32_t bad = 0;
         for (;;) {
             asm volatile("; HOT_BEGIN");

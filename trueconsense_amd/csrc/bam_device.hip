@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,67 +88,7 @@ struct InflateArgs {
 #endif
 constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input staged in LDS (two halves)
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-struct Bits {                   // wave-uniform bit reader over the file's dwords, staged through an LDS ring
-    const uint32_t *__restrict__ w;
-    uint32_t *ring;             // LDS [IN_RING]: dword k of the file sits in ring[k % IN_RING] while hi - IN_RING <= k < hi
-    uint32_t idx;               // the dword that `next` holds: the next one to enter the bit buffer (files < 16 GiB)
-    uint32_t hi;                // dwords below this are in the ring; [hi, hi + IN_RING/2) are on their way in `pend`
-    uint32_t next;              // ring[idx], read one refill ahead (per lane the same value; made scalar when it is used)
-    u32x4 pend;                 // the half ring after `hi`, loaded one stage ahead: its latency hides behind a half ring of decoding
-    uint64_t bb;
-    int bc;
-};
-
-// the half of the ring that has been consumed takes the dwords loaded a stage ago; the load of the following half starts
-__device__ inline void stage_input(Bits &b)
-{
-    constexpr int LANES = IN_RING / 2 / 4;      // lanes that carry 16 bytes each
-    const bool mine = (int)threadIdx.x < LANES;
-    __syncthreads();
-    if (mine) *reinterpret_cast<u32x4 *>(b.ring + ((b.hi + 4 * threadIdx.x) & (IN_RING - 1))) = b.pend;    // (hi is a multiple of 4: no uint4 wraps)
-    b.hi = uni(b.hi + IN_RING / 2);
-    if (mine) b.pend = reinterpret_cast<const u32x4 *>(b.w + b.hi)[threadIdx.x];
-    __syncthreads();
-}
-static_assert(IN_RING / 2 / 4 <= 64 && IN_RING >= 64, "a half of the input ring is one load per lane");
-
-__device__ inline void seek_bits(Bits &b, uint64_t byte)       // start reading bits at this byte of the file
-{
-    b.idx = uni((uint32_t)(byte >> 2));
-    b.hi = b.idx & ~3u;                 // (16-byte aligned loads)
-    constexpr int LANES = IN_RING / 2 / 4;
-    b.pend = u32x4{0, 0, 0, 0};
-    if ((int)threadIdx.x < LANES) b.pend = reinterpret_cast<const u32x4 *>(b.w + b.hi)[threadIdx.x];
-    stage_input(b);
-    stage_input(b);
-    const int skip = (int)(byte & 3) * 8;
-    b.bb = (uint64_t)(uni(b.ring[b.idx & (IN_RING - 1)]) >> skip);
-    b.bc = 32 - skip;
-    ++b.idx;
-    b.next = b.ring[b.idx & (IN_RING - 1)];
-}
-
-__device__ inline void refill(Bits &b)
-{
-    if (b.bc <= 32) {
-        b.bb |= (uint64_t)uni(b.next) << b.bc;
-        b.bc += 32;
-        ++b.idx;
-        if (b.idx + IN_RING / 2 >= b.hi) stage_input(b);
-        b.next = b.ring[b.idx & (IN_RING - 1)];
-    }
-}
-__device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
-{
-    const uint32_t v = (uint32_t)b.bb & ((1u << n) - 1u);
-    b.bb >>= n;
-    b.bc -= n;
-    return v;
-}
 
 // canonical Huffman decode of the bits in `v` (first stream bit = bit 0), at most `maxlen` bits: puff.c's loop
 // -> symbol | code length << 16, or -1
@@ -197,6 +138,82 @@ constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
 enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
 
 typedef uint32_t tab_t;             // (16-bit entries with base / extra bits computed per symbol: half the table LDS, measured slower)
+
+struct InflateLds {
+    __attribute__((aligned(16))) uint8_t win[WIN];      // the most recent output
+    tab_t ll[1 << LL_ROOT];
+    tab_t dt[1 << D_ROOT];
+    uint8_t lens[320];                          // literal/length code lengths [0, 288), distance code lengths [288, 320)
+    uint16_t sym_ll[288], sym_d[32], sym_cl[20];
+    uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16], nxt[16];
+    uint8_t cll[20];
+    uint32_t rs[6];                             // long_code()'s starting state per table: {first, index} after the root bits
+    __attribute__((aligned(16))) uint32_t in[IN_RING];      // compressed input, two halves
+};
+static_assert(offsetof(InflateLds, win) == 0, "the window's ring index is its LDS address");
+
+struct Bits {                   // wave-uniform bit reader over the file's dwords, staged through an LDS ring
+    const uint32_t *__restrict__ w;
+    uint32_t *ring;             // LDS [IN_RING]: dword k of the file sits in ring[k % IN_RING] while hi - IN_RING <= k < hi
+    uint32_t idx;               // the dword that `next` holds: the next one to enter the bit buffer (files < 16 GiB)
+    uint32_t hi;                // a multiple of IN_RING / 2: dwords [hi - IN_RING, hi - IN_RING/2) are in the ring for sure,
+                                // [hi - IN_RING/2, hi) were requested at the last stage and are waited for at the next
+    uint32_t next;              // ring[idx], read one refill ahead (per lane the same value; made scalar when it is used)
+    uint64_t bb;
+    int bc;
+};
+constexpr int IN_HALF = IN_RING / 2;
+static_assert(IN_HALF == 64, "one half of the input ring = one dword per lane");
+
+// The half of the ring that has been consumed is requested anew: 64 dwords straight from HBM into LDS (global_load_lds_dword:
+// no staging registers, nothing for the wave to do when they arrive).  Nothing reads that half before the NEXT stage, which
+// starts by waiting for this request — by then it is a half ring of decoding old.  (Issued and awaited in ISA: the compiler
+// would wait for it before the very next LDS read.)
+__device__ inline void stage_input(Bits &b)
+{
+    const uint32_t *src = b.w + b.hi;
+    const uint32_t lds = (uint32_t)offsetof(InflateLds, in) + (b.hi & (uint32_t)(IN_RING - 1)) * 4u;
+    asm volatile("s_waitcnt vmcnt(0)\n"
+                 "s_mov_b32 m0, %[lds]\n"
+                 "s_nop 0\n"
+                 "global_load_lds_dword %[voff], %[base]\n"
+                 :: [lds] "s"(lds), [voff] "v"((uint32_t)threadIdx.x * 4u), [base] "s"(src) : "memory");       // (m0 is not the compiler's to allocate)
+    b.hi += IN_HALF;
+}
+
+__device__ inline void seek_bits(Bits &b, uint64_t byte)       // start reading bits at this byte of the file
+{
+    b.idx = uni((uint32_t)(byte >> 2));
+    b.hi = b.idx & ~(uint32_t)(IN_HALF - 1);
+    stage_input(b);
+    stage_input(b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int skip = (int)(byte & 3) * 8;
+    b.bb = (uint64_t)(uni(b.ring[b.idx & (IN_RING - 1)]) >> skip);
+    b.bc = 32 - skip;
+    ++b.idx;
+    if (b.idx + IN_HALF >= b.hi) stage_input(b);
+    b.next = b.ring[b.idx & (IN_RING - 1)];
+}
+
+__device__ inline void refill(Bits &b)
+{
+    if (b.bc <= 32) {
+        b.bb |= (uint64_t)uni(b.next) << b.bc;
+        b.bc += 32;
+        ++b.idx;
+        if (b.idx + IN_HALF >= b.hi) stage_input(b);
+        b.next = b.ring[b.idx & (IN_RING - 1)];
+    }
+}
+__device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
+{
+    const uint32_t v = (uint32_t)b.bb & ((1u << n) - 1u);
+    b.bb >>= n;
+    b.bc -= n;
+    return v;
+}
+
 
 __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 {
@@ -278,18 +295,150 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
     return uni(ok ? 1u : 0u) != 0;
 }
 
+
+// ---- the symbol loop's fast path, hand-scheduled -------------------------------------------------------------------------
+// Literals and matches that are the common kind — codes in the root tables, enough bits in the buffer for the whole symbol,
+// source inside the LDS ring, no overlap with the destination — until something else comes up: the input ring needs its next
+// half, a long code, the end-of-block code, a far / overlapping / impossible match, too few bits for a distance code.  Those
+// leave with code 1 and the state untouched at the symbol's first bit; the C++ symbol step below takes that ONE symbol.
+// Code 0: `op` reached `next_evt` (housekeeping is due).  Written in ISA because the kernel is bound by instruction issue and
+// the compiler's version of this loop spends a third of its instructions on flags that say which path it came along
+// (35 instructions per literal, 95 per match; here 20 and 62).  All state is wave-uniform, in scalar registers.
+static_assert(WMASK == 0xFFF && LL_ROOT == 9 && D_ROOT == 8 && IN_RING == 128 && NEAR == 3832, "constants below");
+static_assert(offsetof(InflateLds, ll) == 4096 && offsetof(InflateLds, dt) == 6144 && offsetof(InflateLds, in) == 8352, "LDS offsets below");
+__device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane)
+{
+    uint32_t code, t0, t1, t2, t3, e, f, nb, len, dist, tbc;
+    uint32_t vt, ve, vf, vto, vfrom, vb, vi;
+    asm volatile(
+        "s_mov_b32 %[code], 1\n"
+        "LS%=:\n"                                                  // ---- next symbol
+        "s_cmp_gt_i32 %[bc], 32\n"
+        "s_cbranch_scc1 LK%=\n"
+        "s_add_u32 %[t0], %[idx], 65\n"                             // the word after next must be in the ring (idx + 1 + half < hi)
+        "s_cmp_lt_u32 %[t0], %[hi]\n"
+        "s_cbranch_scc0 LX%=\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s98, %[vnext]\n"
+        "s_add_u32 %[idx], %[idx], 1\n"
+        "s_and_b32 %[t0], %[idx], 127\n"
+        "s_lshl_b32 %[t0], %[t0], 2\n"
+        "v_mov_b32 %[vt], %[t0]\n"
+        "ds_read_b32 %[vnext], %[vt] offset:8352\n"
+        "s_mov_b32 s99, 0\n"
+        "s_lshl_b64 s[98:99], s[98:99], %[bc]\n"
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n"
+        "s_add_u32 %[bc], %[bc], 32\n"
+        "LK%=:\n"                                                  // ---- literal / length code
+        "s_and_b32 %[t0], s96, 0x1ff\n"
+        "s_lshl_b32 %[t0], %[t0], 2\n"
+        "v_mov_b32 %[vt], %[t0]\n"
+        "ds_read_b32 %[ve], %[vt] offset:4096\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 %[e], %[ve]\n"
+        "s_and_b32 %[nb], %[e], 15\n"
+        "s_bitcmp1_b32 %[e], 8\n"
+        "s_cbranch_scc0 LM%=\n"
+        "s_and_b32 %[t0], %[op], 0xfff\n"                           // a literal: bits 16-23 of the entry
+        "v_mov_b32 %[vt], %[t0]\n"
+        "ds_write_b8_d16_hi %[vt], %[ve]\n"
+        "s_lshr_b64 s[96:97], s[96:97], %[nb]\n"
+        "s_sub_u32 %[bc], %[bc], %[nb]\n"
+        "s_add_u32 %[op], %[op], 1\n"
+        "s_cmp_lt_u32 %[op], %[evt]\n"
+        "s_cbranch_scc1 LS%=\n"
+        "s_mov_b32 %[code], 0\n"
+        "s_branch LX%=\n"
+        "LM%=:\n"                                                  // ---- a match?  (not: a long code, none, end of block -> C++)
+        "s_cmp_eq_u32 %[nb], 0\n"
+        "s_cbranch_scc1 LX%=\n"
+        "s_bitcmp1_b32 %[e], 9\n"
+        "s_cbranch_scc0 LX%=\n"
+        "s_bfe_u32 %[t1], %[e], 0x40004\n"                          // extra bits of the length
+        "s_lshr_b32 %[t0], s96, %[nb]\n"
+        "s_bfm_b32 %[t2], %[t1], 0\n"
+        "s_and_b32 %[t0], %[t0], %[t2]\n"
+        "s_lshr_b32 %[len], %[e], 16\n"
+        "s_add_u32 %[len], %[len], %[t0]\n"
+        "s_add_u32 %[t1], %[t1], %[nb]\n"
+        "s_lshr_b64 s[98:99], s[96:97], %[t1]\n"                    // the buffer behind the length: tentative until the match is known to be the common kind
+        "s_sub_u32 %[tbc], %[bc], %[t1]\n"
+        "s_cmp_lt_i32 %[tbc], 21\n"                                 // a root-table distance code takes up to 8 + 13 bits
+        "s_cbranch_scc1 LX%=\n"
+        "s_and_b32 %[t0], s98, 0xff\n"
+        "s_lshl_b32 %[t0], %[t0], 2\n"
+        "v_mov_b32 %[vt], %[t0]\n"
+        "ds_read_b32 %[vf], %[vt] offset:6144\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 %[f], %[vf]\n"
+        "s_and_b32 %[t1], %[f], 15\n"
+        "s_cmp_eq_u32 %[t1], 0\n"
+        "s_cbranch_scc1 LX%=\n"
+        "s_bfe_u32 %[t2], %[f], 0x40004\n"
+        "s_lshr_b32 %[t0], s98, %[t1]\n"
+        "s_bfm_b32 %[t3], %[t2], 0\n"
+        "s_and_b32 %[t0], %[t0], %[t3]\n"
+        "s_lshr_b32 %[dist], %[f], 16\n"
+        "s_add_u32 %[dist], %[dist], %[t0]\n"
+        "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring
+        "s_cbranch_scc1 LX%=\n"
+        "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
+        "s_cbranch_scc1 LX%=\n"
+        "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
+        "s_cbranch_scc1 LX%=\n"
+        "s_add_u32 %[t1], %[t1], %[t2]\n"                           // commit the bits
+        "s_lshr_b64 s[96:97], s[98:99], %[t1]\n"
+        "s_sub_u32 %[bc], %[tbc], %[t1]\n"
+        "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i
+        "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"
+        "v_mov_b32 %[vi], %[vlane]\n"
+        "s_mov_b32 %[t0], 64\n"
+        "LC%=:\n"
+        "v_and_b32 %[vt], 0xfff, %[vfrom]\n"
+        "v_cmp_gt_u32 vcc, %[len], %[vi]\n"
+        "s_and_saveexec_b64 s[94:95], vcc\n"
+        "ds_read_u8 %[vb], %[vt]\n"
+        "v_and_b32 %[vt], 0xfff, %[vto]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "ds_write_b8 %[vt], %[vb]\n"
+        "s_mov_b64 exec, s[94:95]\n"
+        "s_cmp_lt_u32 %[t0], %[len]\n"
+        "s_cbranch_scc0 LD%=\n"
+        "s_add_u32 %[t0], %[t0], 64\n"
+        "v_add_u32 %[vi], 64, %[vi]\n"
+        "v_add_u32 %[vto], 64, %[vto]\n"
+        "v_add_u32 %[vfrom], 64, %[vfrom]\n"
+        "s_branch LC%=\n"
+        "LD%=:\n"
+        "s_add_u32 %[op], %[op], %[len]\n"
+        "s_cmp_lt_u32 %[op], %[evt]\n"
+        "s_cbranch_scc1 LS%=\n"
+        "s_mov_b32 %[code], 0\n"
+        "LX%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : "+{s[96:97]}"(b.bb), [bc] "+s"(b.bc), [op] "+s"(op), [idx] "+s"(b.idx), [vnext] "+v"(b.next), [code] "=&s"(code),
+          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [e] "=&s"(e), [f] "=&s"(f), [nb] "=&s"(nb), [len] "=&s"(len),
+          [dist] "=&s"(dist), [tbc] "=&s"(tbc), [vt] "=&v"(vt), [ve] "=&v"(ve), [vf] "=&v"(vf), [vto] "=&v"(vto), [vfrom] "=&v"(vfrom),
+          [vb] "=&v"(vb), [vi] "=&v"(vi)
+        : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane)
+        : "s94", "s95", "s98", "s99", "vcc", "scc", "memory");
+    return code;
+}
+
 __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN];
-    __shared__ tab_t s_ll[1 << LL_ROOT];
-    __shared__ tab_t s_dt[1 << D_ROOT];
-    tab_t *const s_cl = s_dt;                   // the code-length code is done with before the distance table is built
-    __shared__ uint8_t s_lens[320];             // literal/length code lengths [0, 288), distance code lengths [288, 320)
-    __shared__ uint16_t s_sym_ll[288], s_sym_d[32], s_sym_cl[19];
-    __shared__ uint16_t s_cnt_ll[16], s_cnt_d[16], s_cnt_cl[16], s_nxt[16];
-    __shared__ uint8_t s_cll[19];
-    __shared__ uint32_t s_rs[6];                // long_code()'s starting state per table: {first, index} after the root bits
-    __shared__ __attribute__((aligned(16))) uint32_t s_in[IN_RING];
+    __shared__ InflateLds L;                    // ONE LDS object: it sits at LDS address 0 and the member offsets are constants
+                                                // (the hand-scheduled symbol loop addresses the window, the tables and the input ring by them)
+    uint8_t *const s_win = L.win;
+    tab_t *const s_ll = L.ll;
+    tab_t *const s_dt = L.dt;
+    tab_t *const s_cl = L.dt;                   // the code-length code is done with before the distance table is built
+    uint8_t *const s_lens = L.lens;
+    uint16_t *const s_sym_ll = L.sym_ll, *const s_sym_d = L.sym_d, *const s_sym_cl = L.sym_cl;
+    uint16_t *const s_cnt_ll = L.cnt_ll, *const s_cnt_d = L.cnt_d, *const s_cnt_cl = L.cnt_cl, *const s_nxt = L.nxt;
+    uint8_t *const s_cll = L.cll;
+    uint32_t *const s_rs = L.rs;
+    uint32_t *const s_in = L.in;
 
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -340,7 +489,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             for (int k = 0; k < SEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
             flushed += SEG;
         }
-        next_evt = min(flushed + (uint32_t)SEG, next_rec < ulen ? next_rec + 4u : 0xFFFFFFF0u);
+        // the next stop: a full segment.  (Not the next record header: the chain is caught up at every stop — a header that is
+        // complete now is at most a segment and a match behind `op` then, well inside the ring — and leaving the symbol loop
+        // costs as much as a few symbols.)
+        next_evt = flushed + (uint32_t)SEG;
     };
     housekeeping();
 
@@ -437,6 +589,13 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         //      1.07 ms), and a `continue` per path (one latch block, re-split on flags).) ---------------------------------------
         uint32_t bad = 0;
         for (;;) {
+            if (fast_symbols(b, op, next_evt, lane) == 0) {     // the common symbols, hand-scheduled; 0: housekeeping is due
+                if ((bad >> 31) | (b.idx > idx_end ? 1u : 0u)) break;
+                housekeeping();
+                if (err != ST_OK) break;
+                continue;
+            }
+            // ONE symbol of the other kinds (or one that needs the next half of the input ring first)
             asm volatile("; HOT_BEGIN");
             refill(b);
             uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);

@@ -297,38 +297,44 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
 
 
 // ---- the symbol loop's fast path, hand-scheduled -------------------------------------------------------------------------
-// Literals and matches that are the common kind — codes in the root tables, enough bits in the buffer for the whole symbol,
-// source inside the LDS ring, no overlap with the destination — until something else comes up: the input ring needs its next
-// half, a long code, the end-of-block code, a far / overlapping / impossible match, too few bits for a distance code.  Those
-// leave with code 1 and the state untouched at the symbol's first bit; the C++ symbol step below takes that ONE symbol.
-// Code 0: `op` reached `next_evt` (housekeeping is due).  Written in ISA because the kernel is bound by instruction issue and
-// the compiler's version of this loop spends a third of its instructions on flags that say which path it came along
-// (35 instructions per literal, 95 per match; here 20 and 62).  All state is wave-uniform, in scalar registers.
+// Literals and matches whose codes sit in the root tables, decoded and — the common kind of match: source inside the LDS ring,
+// no overlap with the destination — copied, until something else comes up.  Exit codes:
+//   0  `op` reached `next_evt`: housekeeping is due
+//   1  at a symbol's first bit: the input ring needs its next half, or a long code / none / the end-of-block code is next
+//      -> the C++ step below takes that ONE symbol
+//   2  a match whose length is decoded (`len`, bits consumed); its distance code is a long one, or the ring needs its next half
+//      first -> C++ decodes the distance and copies
+//   3  a match with length and distance decoded (bits consumed) that is far / overlapping / impossible -> C++ copies
+// Written in ISA because the kernel is bound by instruction issue and the compiler's version of this loop spends a third of
+// its instructions on flags that say which path it came along (35 instructions per literal, 95 per match; here 20 and 60).
+// All state is wave-uniform, in scalar registers.
 static_assert(WMASK == 0xFFF && LL_ROOT == 9 && D_ROOT == 8 && IN_RING == 128 && NEAR == 3832, "constants below");
 static_assert(offsetof(InflateLds, ll) == 4096 && offsetof(InflateLds, dt) == 6144 && offsetof(InflateLds, in) == 8352, "LDS offsets below");
-__device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane)
+__device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane, uint32_t &len_out, uint32_t &dist_out)
 {
-    uint32_t code, t0, t1, t2, t3, e, f, nb, len, dist, tbc;
+    uint32_t code, t0, t1, t2, e, f, nb, len, dist;
     uint32_t vt, ve, vf, vto, vfrom, vb, vi;
+#define TCMI_ASM_REFILL(exit_label_)                                                                                           \
+        "s_add_u32 %[t0], %[idx], 65\n"        /* the word after next must be in the ring (idx + 1 + half < hi) */               \
+        "s_cmp_lt_u32 %[t0], %[hi]\n"                                                                                          \
+        "s_cbranch_scc0 " exit_label_ "%=\n"                                                                                   \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                               \
+        "v_readfirstlane_b32 s98, %[vnext]\n"                                                                                  \
+        "s_add_u32 %[idx], %[idx], 1\n"                                                                                        \
+        "s_and_b32 %[t0], %[idx], 127\n"                                                                                       \
+        "s_lshl_b32 %[t0], %[t0], 2\n"                                                                                         \
+        "v_mov_b32 %[vt], %[t0]\n"                                                                                             \
+        "ds_read_b32 %[vnext], %[vt] offset:8352\n"                                                                            \
+        "s_mov_b32 s99, 0\n"                                                                                                   \
+        "s_lshl_b64 s[98:99], s[98:99], %[bc]\n"                                                                               \
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n"                                                                              \
+        "s_add_u32 %[bc], %[bc], 32\n"
     asm volatile(
         "s_mov_b32 %[code], 1\n"
         "LS%=:\n"                                                  // ---- next symbol
         "s_cmp_gt_i32 %[bc], 32\n"
         "s_cbranch_scc1 LK%=\n"
-        "s_add_u32 %[t0], %[idx], 65\n"                             // the word after next must be in the ring (idx + 1 + half < hi)
-        "s_cmp_lt_u32 %[t0], %[hi]\n"
-        "s_cbranch_scc0 LX%=\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_readfirstlane_b32 s98, %[vnext]\n"
-        "s_add_u32 %[idx], %[idx], 1\n"
-        "s_and_b32 %[t0], %[idx], 127\n"
-        "s_lshl_b32 %[t0], %[t0], 2\n"
-        "v_mov_b32 %[vt], %[t0]\n"
-        "ds_read_b32 %[vnext], %[vt] offset:8352\n"
-        "s_mov_b32 s99, 0\n"
-        "s_lshl_b64 s[98:99], s[98:99], %[bc]\n"
-        "s_or_b64 s[96:97], s[96:97], s[98:99]\n"
-        "s_add_u32 %[bc], %[bc], 32\n"
+        TCMI_ASM_REFILL("LX")
         "LK%=:\n"                                                  // ---- literal / length code
         "s_and_b32 %[t0], s96, 0x1ff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
@@ -361,11 +367,14 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_lshr_b32 %[len], %[e], 16\n"
         "s_add_u32 %[len], %[len], %[t0]\n"
         "s_add_u32 %[t1], %[t1], %[nb]\n"
-        "s_lshr_b64 s[98:99], s[96:97], %[t1]\n"                    // the buffer behind the length: tentative until the match is known to be the common kind
-        "s_sub_u32 %[tbc], %[bc], %[t1]\n"
-        "s_cmp_lt_i32 %[tbc], 21\n"                                 // a root-table distance code takes up to 8 + 13 bits
-        "s_cbranch_scc1 LX%=\n"
-        "s_and_b32 %[t0], s98, 0xff\n"
+        "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
+        "s_sub_u32 %[bc], %[bc], %[t1]\n"
+        "s_mov_b32 %[code], 2\n"                                    // from here on the length is consumed
+        "s_cmp_gt_i32 %[bc], 32\n"
+        "s_cbranch_scc1 LF%=\n"
+        TCMI_ASM_REFILL("LX")
+        "LF%=:\n"                                                  // ---- distance code
+        "s_and_b32 %[t0], s96, 0xff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
         "v_mov_b32 %[vt], %[t0]\n"
         "ds_read_b32 %[vf], %[vt] offset:6144\n"
@@ -375,20 +384,21 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_cmp_eq_u32 %[t1], 0\n"
         "s_cbranch_scc1 LX%=\n"
         "s_bfe_u32 %[t2], %[f], 0x40004\n"
-        "s_lshr_b32 %[t0], s98, %[t1]\n"
-        "s_bfm_b32 %[t3], %[t2], 0\n"
-        "s_and_b32 %[t0], %[t0], %[t3]\n"
+        "s_lshr_b32 %[t0], s96, %[t1]\n"
+        "s_add_u32 %[t1], %[t1], %[t2]\n"
+        "s_bfm_b32 %[t2], %[t2], 0\n"
+        "s_and_b32 %[t0], %[t0], %[t2]\n"
         "s_lshr_b32 %[dist], %[f], 16\n"
         "s_add_u32 %[dist], %[dist], %[t0]\n"
+        "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
+        "s_sub_u32 %[bc], %[bc], %[t1]\n"
+        "s_mov_b32 %[code], 3\n"                                    // length and distance consumed
         "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring
         "s_cbranch_scc1 LX%=\n"
         "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
         "s_cbranch_scc1 LX%=\n"
         "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
         "s_cbranch_scc1 LX%=\n"
-        "s_add_u32 %[t1], %[t1], %[t2]\n"                           // commit the bits
-        "s_lshr_b64 s[96:97], s[98:99], %[t1]\n"
-        "s_sub_u32 %[bc], %[tbc], %[t1]\n"
         "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i
         "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"
         "v_mov_b32 %[vi], %[vlane]\n"
@@ -411,17 +421,21 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_branch LC%=\n"
         "LD%=:\n"
         "s_add_u32 %[op], %[op], %[len]\n"
+        "s_mov_b32 %[code], 1\n"
         "s_cmp_lt_u32 %[op], %[evt]\n"
         "s_cbranch_scc1 LS%=\n"
         "s_mov_b32 %[code], 0\n"
         "LX%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
         : "+{s[96:97]}"(b.bb), [bc] "+s"(b.bc), [op] "+s"(op), [idx] "+s"(b.idx), [vnext] "+v"(b.next), [code] "=&s"(code),
-          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [e] "=&s"(e), [f] "=&s"(f), [nb] "=&s"(nb), [len] "=&s"(len),
-          [dist] "=&s"(dist), [tbc] "=&s"(tbc), [vt] "=&v"(vt), [ve] "=&v"(ve), [vf] "=&v"(vf), [vto] "=&v"(vto), [vfrom] "=&v"(vfrom),
+          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [f] "=&s"(f), [nb] "=&s"(nb), [len] "=&s"(len),
+          [dist] "=&s"(dist), [vt] "=&v"(vt), [ve] "=&v"(ve), [vf] "=&v"(vf), [vto] "=&v"(vto), [vfrom] "=&v"(vfrom),
           [vb] "=&v"(vb), [vi] "=&v"(vi)
         : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane)
         : "s94", "s95", "s98", "s99", "vcc", "scc", "memory");
+#undef TCMI_ASM_REFILL
+    len_out = len;
+    dist_out = dist;
     return code;
 }
 
@@ -588,68 +602,67 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         //      each branch (the compiler then copies the prefetched input registers at every refill and waits for their load:
         //      1.07 ms), and a `continue` per path (one latch block, re-split on flags).) ---------------------------------------
         uint32_t bad = 0;
-        for (;;) {
-            if (fast_symbols(b, op, next_evt, lane) == 0) {     // the common symbols, hand-scheduled; 0: housekeeping is due
-                if ((bad >> 31) | (b.idx > idx_end ? 1u : 0u)) break;
-                housekeeping();
-                if (err != ST_OK) break;
-                continue;
-            }
-            // ONE symbol of the other kinds (or one that needs the next half of the input ring first)
-            asm volatile("; HOT_BEGIN");
-            refill(b);
-            uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
-            if (__builtin_expect((e & 15u) == 0, 0)) {      // a code longer than the root table (8 % of the symbols of a 9-bit table) or none
-                const int sl = long_code(s_cnt_ll, s_sym_ll, s_rs, (uint32_t)b.bb, LL_ROOT);
-                e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
-                if ((e & 15u) == 0) { bad = 0x80000000u; e = 1u | E_EOB; }
-            }
-            take(b, (int)(e & 15u));
-            if (e & E_LIT) {
-                s_win[op & WMASK] = (uint8_t)(e >> 16);         // (every lane stores the same byte to the same address: no exec juggling)
-                ++op;
-            } else if (e & E_BASE) {
-                const uint32_t len = (e >> 16) + take(b, (int)((e >> 4) & 15u));
-                refill(b);
-                uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
-                if (__builtin_expect((f & 15u) == 0, 0)) {
-                    const int sl = long_code(s_cnt_d, s_sym_d, s_rs + 2, (uint32_t)b.bb, D_ROOT);
-                    f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);
-                    if ((f & 15u) == 0) { bad = 0x80000000u; f = 1u | E_BASE | (1u << 16); }
-                }
-                take(b, (int)(f & 15u));
-                const uint32_t dist = (f >> 16) + take(b, (int)((f >> 4) & 15u));    // (<= 13 extra bits: still in the buffer)
-                bad |= op - dist;                               // (op < 2^17, dist <= 2^15: the sign bit says dist > op)
-                // the match: all lanes copy; with dist < len the pattern of the last `dist` bytes repeats
-                const uint32_t to = op + (uint32_t)lane;
-                if (dist > (uint32_t)NEAR) {
-                    // beyond the LDS ring: the source lies in a segment that is complete and was flushed right after the
-                    // symbol that completed it (same wavefront: its stores are ordered before this load)
-                    const uint8_t *src = out + ((int64_t)op - (int64_t)dist);
+        // a match's copy: all lanes; with dist < len the pattern of the last `dist` bytes repeats
+        auto copy_match = [&](uint32_t len, uint32_t dist) __attribute__((always_inline)) {
+            bad |= op - dist;                                   // (op < 2^17, dist <= 2^15: the sign bit says dist > op)
+            if (dist > (uint32_t)NEAR) {
+                // beyond the LDS ring: the source lies in a segment that is complete and was flushed right after the
+                // symbol that completed it (same wavefront: its stores are ordered before this load)
+                const uint8_t *src = out + ((int64_t)op - (int64_t)dist);
 #pragma clang loop vectorize(disable) unroll(disable)
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
-                } else if (dist >= len) {
-                    if ((uint32_t)lane < len) s_win[to & WMASK] = s_win[(to - dist) & WMASK];
-                    if (len > 64u) {
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(op + i) & WMASK] = src[i];
+            } else if (dist >= len) {
 #pragma clang loop vectorize(disable) unroll(disable)
-                        for (uint32_t i = (uint32_t)lane + 64u; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op + i - dist) & WMASK];
-                    }
-                } else {
-                    const float inv = 1.0f / (float)dist;
-#pragma clang loop vectorize(disable) unroll(disable)
-                    for (int i = lane; i < (int)len; i += 64) {
-                        int qd = (int)((float)i * inv);
-                        int r = i - qd * (int)dist;
-                        if (r < 0) r += (int)dist;
-                        if (r >= (int)dist) r -= (int)dist;
-                        s_win[(op + i) & WMASK] = s_win[(op - dist + r) & WMASK];
-                    }
-                }
-                op += len;
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(op + i) & WMASK] = s_win[(op + i - dist) & WMASK];
             } else {
-                break;                          // end of block (E_EOB)
+                const float inv = 1.0f / (float)dist;
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (int i = lane; i < (int)len; i += 64) {
+                    int qd = (int)((float)i * inv);
+                    int r = i - qd * (int)dist;
+                    if (r < 0) r += (int)dist;
+                    if (r >= (int)dist) r -= (int)dist;
+                    s_win[(op + i) & WMASK] = s_win[(op - dist + r) & WMASK];
+                }
             }
-            asm volatile("; HOT_END");
+            op += len;
+        };
+        auto distance_and_copy = [&](uint32_t len) __attribute__((always_inline)) {
+            refill(b);
+            uint32_t f = uni(s_dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)]);
+            if ((f & 15u) == 0) {
+                const int sl = long_code(s_cnt_d, s_sym_d, s_rs + 2, (uint32_t)b.bb, D_ROOT);
+                f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);
+                if ((f & 15u) == 0) { bad = 0x80000000u; f = 1u | E_BASE | (1u << 16); }
+            }
+            take(b, (int)(f & 15u));
+            const uint32_t dist = (f >> 16) + take(b, (int)((f >> 4) & 15u));    // (<= 13 extra bits: still in the buffer)
+            copy_match(len, dist);
+        };
+        for (;;) {
+            uint32_t len, dist;
+            const uint32_t code = fast_symbols(b, op, next_evt, lane, len, dist);   // the common symbols, hand-scheduled
+            if (code == 3) copy_match(len, dist);
+            else if (code == 2) distance_and_copy(len);
+            else if (code == 1) {
+                // ONE symbol of the other kinds (or one that needs the next half of the input ring first)
+                refill(b);
+                uint32_t e = uni(s_ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)]);
+                if ((e & 15u) == 0) {               // a code longer than the root table (a few % of the symbols of a 9-bit table) or none
+                    const int sl = long_code(s_cnt_ll, s_sym_ll, s_rs, (uint32_t)b.bb, LL_ROOT);
+                    e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
+                    if ((e & 15u) == 0) { bad = 0x80000000u; e = 1u | E_EOB; }
+                }
+                take(b, (int)(e & 15u));
+                if (e & E_LIT) {
+                    s_win[op & WMASK] = (uint8_t)(e >> 16);     // (every lane stores the same byte to the same address: no exec juggling)
+                    ++op;
+                } else if (e & E_BASE) {
+                    distance_and_copy((e >> 16) + take(b, (int)((e >> 4) & 15u)));
+                } else {
+                    break;                          // end of block (E_EOB)
+                }
+            }
             if (op >= next_evt) {
                 if ((bad >> 31) | (b.idx > idx_end ? 1u : 0u)) break;
                 housekeeping();

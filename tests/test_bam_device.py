@@ -98,6 +98,34 @@ def test_device_inflate_and_record_index_match_zlib(ctx, tmp_path):
     check_decode(ctx, p).close()
 
 
+def test_device_inflate_on_other_deflate_flavours(ctx, tmp_path):
+    """Streams zlib's default settings never write: fixed-Huffman blocks only, run-length matches (distance 1, length 258:
+    source overlaps destination), Huffman-only (no matches at all), small hash tables, and several deflate blocks — dynamic,
+    and the empty stored ones of a full flush — inside one BGZF block.  Byte for byte against zlib."""
+    import zlib
+    ref, _ = sy.make_reference()
+    rng = np.random.default_rng(11)
+    n = 20_000
+    reads = sy.make_reads(ref, n, seed=9)
+    seq = reads["seq"].reshape(n, -1).copy()
+    seq[::3, 10:60] = 0x11                                          # homopolymer stretches: long runs of one byte
+    reads["seq"] = seq.reshape(-1)
+    q = rng.integers(0, 42, n * 150).astype(np.uint8)
+    q.reshape(n, 150)[::2, :] = 30                                  # constant qualities in every other read: runs of 150
+    reads["qual"] = q
+    try:
+        for k, (strategy, mem, every, level) in enumerate(((zlib.Z_FIXED, 8, 0, 6), (zlib.Z_RLE, 8, 0, 6), (zlib.Z_HUFFMAN_ONLY, 8, 0, 6),
+                                                         (zlib.Z_FILTERED, 1, 0, 9), (zlib.Z_DEFAULT_STRATEGY, 8, 5000, 6),
+                                                         (zlib.Z_DEFAULT_STRATEGY, 9, 777, 1), (zlib.Z_FIXED, 8, 300, 6))):
+            bamwriter.DEFLATE.update(strategy=strategy, mem_level=mem, flush_every=every)
+            p = str(tmp_path / ("flavour%d.bam" % k))
+            bamwriter.write_bam(p, reads, "MN908947.3", len(ref), level=level)
+            check_decode(ctx, p).close()
+            check_counts(ctx, p, len(ref))
+    finally:
+        bamwriter.DEFLATE.update(strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, flush_every=0)
+
+
 def test_file_to_counts_all_on_device(ctx, tmp_path):
     ref, orfs = sy.make_reference()
     L = len(ref)

@@ -10,9 +10,18 @@ import numpy as np
 _EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
+# test hooks: zlib strategy / memLevel of the deflate streams, and a Z_FULL_FLUSH every so many bytes (several deflate blocks,
+# dynamic and empty stored ones, inside one BGZF block)
+DEFLATE = {"strategy": zlib.Z_DEFAULT_STRATEGY, "mem_level": 8, "flush_every": 0}
+
+
 def _bgzf_block(data, level):
-    co = zlib.compressobj(level, zlib.DEFLATED, -15)
-    body = co.compress(data) + co.flush()
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, DEFLATE["mem_level"], DEFLATE["strategy"])
+    step = DEFLATE["flush_every"]
+    if step:
+        body = b"".join(co.compress(data[o:o + step]) + co.flush(zlib.Z_FULL_FLUSH) for o in range(0, len(data), step)) + co.flush()
+    else:
+        body = co.compress(data) + co.flush()
     bsize = len(body) + 25
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body +
             struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))

@@ -318,7 +318,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[t0], %[idx], 65\n"        /* the word after next must be in the ring (idx + 1 + half < hi) */               \
         "s_cmp_lt_u32 %[t0], %[hi]\n"                                                                                          \
         "s_cbranch_scc0 " exit_label_ "%=\n"                                                                                   \
-        "s_waitcnt lgkmcnt(0)\n"                                                                                               \
+        /* (the read of vnext was issued a table look-up ago: its s_waitcnt covered it) */                                      \
         "v_readfirstlane_b32 s98, %[vnext]\n"                                                                                  \
         "s_add_u32 %[idx], %[idx], 1\n"                                                                                        \
         "s_and_b32 %[t0], %[idx], 127\n"                                                                                       \
@@ -330,11 +330,10 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_or_b64 s[96:97], s[96:97], s[98:99]\n"                                                                              \
         "s_add_u32 %[bc], %[bc], 32\n"
     asm volatile(
-        "s_mov_b32 %[code], 1\n"
         "LS%=:\n"                                                  // ---- next symbol
         "s_cmp_gt_i32 %[bc], 32\n"
         "s_cbranch_scc1 LK%=\n"
-        TCMI_ASM_REFILL("LX")
+        TCMI_ASM_REFILL("LX1")
         "LK%=:\n"                                                  // ---- literal / length code
         "s_and_b32 %[t0], s96, 0x1ff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
@@ -353,13 +352,10 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[op], %[op], 1\n"
         "s_cmp_lt_u32 %[op], %[evt]\n"
         "s_cbranch_scc1 LS%=\n"
-        "s_mov_b32 %[code], 0\n"
-        "s_branch LX%=\n"
-        "LM%=:\n"                                                  // ---- a match?  (not: a long code, none, end of block -> C++)
-        "s_cmp_eq_u32 %[nb], 0\n"
-        "s_cbranch_scc1 LX%=\n"
+        "s_branch LX0%=\n"
+        "LM%=:\n"                                                  // ---- a match?  (not: a long code or none — entry 0 —, end of block -> C++)
         "s_bitcmp1_b32 %[e], 9\n"
-        "s_cbranch_scc0 LX%=\n"
+        "s_cbranch_scc0 LX1%=\n"
         "s_bfe_u32 %[t1], %[e], 0x40004\n"                          // extra bits of the length
         "s_lshr_b32 %[t0], s96, %[nb]\n"
         "s_bfm_b32 %[t2], %[t1], 0\n"
@@ -369,10 +365,9 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[t1], %[t1], %[nb]\n"
         "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
         "s_sub_u32 %[bc], %[bc], %[t1]\n"
-        "s_mov_b32 %[code], 2\n"                                    // from here on the length is consumed
-        "s_cmp_gt_i32 %[bc], 32\n"
+        "s_cmp_gt_i32 %[bc], 32\n"                                  // (from here on the length is consumed: leaving = code 2)
         "s_cbranch_scc1 LF%=\n"
-        TCMI_ASM_REFILL("LX")
+        TCMI_ASM_REFILL("LX2")
         "LF%=:\n"                                                  // ---- distance code
         "s_and_b32 %[t0], s96, 0xff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
@@ -382,7 +377,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "v_readfirstlane_b32 %[f], %[vf]\n"
         "s_and_b32 %[t1], %[f], 15\n"
         "s_cmp_eq_u32 %[t1], 0\n"
-        "s_cbranch_scc1 LX%=\n"
+        "s_cbranch_scc1 LX2%=\n"
         "s_bfe_u32 %[t2], %[f], 0x40004\n"
         "s_lshr_b32 %[t0], s96, %[t1]\n"
         "s_add_u32 %[t1], %[t1], %[t2]\n"
@@ -392,13 +387,12 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[dist], %[dist], %[t0]\n"
         "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
         "s_sub_u32 %[bc], %[bc], %[t1]\n"
-        "s_mov_b32 %[code], 3\n"                                    // length and distance consumed
-        "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring
-        "s_cbranch_scc1 LX%=\n"
+        "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring  (length and distance consumed: leaving = code 3)
+        "s_cbranch_scc1 LX3%=\n"
         "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
-        "s_cbranch_scc1 LX%=\n"
+        "s_cbranch_scc1 LX3%=\n"
         "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
-        "s_cbranch_scc1 LX%=\n"
+        "s_cbranch_scc1 LX3%=\n"
         "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i
         "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"
         "v_mov_b32 %[vi], %[vlane]\n"
@@ -421,10 +415,19 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_branch LC%=\n"
         "LD%=:\n"
         "s_add_u32 %[op], %[op], %[len]\n"
-        "s_mov_b32 %[code], 1\n"
         "s_cmp_lt_u32 %[op], %[evt]\n"
         "s_cbranch_scc1 LS%=\n"
+        "LX0%=:\n"
         "s_mov_b32 %[code], 0\n"
+        "s_branch LX%=\n"
+        "LX1%=:\n"
+        "s_mov_b32 %[code], 1\n"
+        "s_branch LX%=\n"
+        "LX2%=:\n"
+        "s_mov_b32 %[code], 2\n"
+        "s_branch LX%=\n"
+        "LX3%=:\n"
+        "s_mov_b32 %[code], 3\n"
         "LX%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
         : "+{s[96:97]}"(b.bb), [bc] "+s"(b.bc), [op] "+s"(op), [idx] "+s"(b.idx), [vnext] "+v"(b.next), [code] "=&s"(code),

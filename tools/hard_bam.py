@@ -5,7 +5,7 @@ from trueconsense_amd import synthetic as sy, engine, _ffi
 from trueconsense_amd.io import bamwriter
 from oracle import c_oracle
 ref, orfs = sy.make_reference(); L = len(ref)
-n = 200_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 reads = sy.make_reads(ref, n, seed=3)
 rng = np.random.default_rng(1)
 reads["qual"] = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=len(reads["qual"]), p=[0.02, 0.05, 0.13, 0.80])

@@ -304,13 +304,15 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
 //      -> the C++ step below takes that ONE symbol
 //   2  a match whose length is decoded (`len`, bits consumed); its distance code is a long one, or the ring needs its next half
 //      first -> C++ decodes the distance and copies
-//   3  a match with length and distance decoded (bits consumed) that is far / overlapping / impossible -> C++ copies
+//   3  a match with length and distance decoded (bits consumed) whose source overlaps its destination, or that is impossible
+//      -> C++ copies / flags it.  (A FAR match — source already flushed to HBM — is copied here too, through global loads.)
 // Written in ISA because the kernel is bound by instruction issue and the compiler's version of this loop spends a third of
 // its instructions on flags that say which path it came along (35 instructions per literal, 95 per match; here 20 and 60).
 // All state is wave-uniform, in scalar registers.
 static_assert(WMASK == 0xFFF && LL_ROOT == 9 && D_ROOT == 8 && IN_RING == 128 && NEAR == 3832, "constants below");
 static_assert(offsetof(InflateLds, ll) == 4096 && offsetof(InflateLds, dt) == 6144 && offsetof(InflateLds, in) == 8352, "LDS offsets below");
-__device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane, uint32_t &len_out, uint32_t &dist_out)
+__device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane, const uint8_t *out, uint32_t &len_out,
+                                                  uint32_t &dist_out)
 {
     uint32_t code, t0, t1, t2, e, f, nb, len, dist;
     uint32_t vt, ve, vf, vto, vfrom, vb, vi;
@@ -388,7 +390,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
         "s_sub_u32 %[bc], %[bc], %[t1]\n"
         "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring  (length and distance consumed: leaving = code 3)
-        "s_cbranch_scc1 LX3%=\n"
+        "s_cbranch_scc1 LG%=\n"
         "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
         "s_cbranch_scc1 LX3%=\n"
         "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
@@ -417,6 +419,30 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[op], %[op], %[len]\n"
         "s_cmp_lt_u32 %[op], %[evt]\n"
         "s_cbranch_scc1 LS%=\n"
+        "s_branch LX0%=\n"
+        "LG%=:\n"                                                  // ---- a far match: its source has left the ring, this wave flushed it to `out` earlier
+        "s_cmp_gt_u32 %[dist], %[op]\n"
+        "s_cbranch_scc1 LX3%=\n"
+        "s_sub_u32 %[t0], %[op], %[dist]\n"
+        "s_add_u32 s98, s92, %[t0]\n"
+        "s_addc_u32 s99, s93, 0\n"
+        "v_add_u32 %[vto], %[op], %[vlane]\n"
+        "v_mov_b32 %[vi], %[vlane]\n"
+        "s_mov_b32 %[t0], 64\n"
+        "LH%=:\n"
+        "v_cmp_gt_u32 vcc, %[len], %[vi]\n"
+        "s_and_saveexec_b64 s[94:95], vcc\n"
+        "global_load_ubyte %[vb], %[vi], s[98:99]\n"
+        "v_and_b32 %[vt], 0xfff, %[vto]\n"
+        "s_waitcnt vmcnt(0)\n"
+        "ds_write_b8 %[vt], %[vb]\n"
+        "s_mov_b64 exec, s[94:95]\n"
+        "s_cmp_lt_u32 %[t0], %[len]\n"
+        "s_cbranch_scc0 LD%=\n"
+        "s_add_u32 %[t0], %[t0], 64\n"
+        "v_add_u32 %[vi], 64, %[vi]\n"
+        "v_add_u32 %[vto], 64, %[vto]\n"
+        "s_branch LH%=\n"
         "LX0%=:\n"
         "s_mov_b32 %[code], 0\n"
         "s_branch LX%=\n"
@@ -434,7 +460,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [f] "=&s"(f), [nb] "=&s"(nb), [len] "=&s"(len),
           [dist] "=&s"(dist), [vt] "=&v"(vt), [ve] "=&v"(ve), [vf] "=&v"(vf), [vto] "=&v"(vto), [vfrom] "=&v"(vfrom),
           [vb] "=&v"(vb), [vi] "=&v"(vi)
-        : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane)
+        : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane), "{s[92:93]}"(out)
         : "s94", "s95", "s98", "s99", "vcc", "scc", "memory");
 #undef TCMI_ASM_REFILL
     len_out = len;
@@ -462,7 +488,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     if (blk >= a.n_blocks) return;
     const BlockDesc d = a.blocks[blk];
     const uint32_t ulen = d.ulen;
-    uint8_t *out = a.out + d.uout;
+    uint8_t *out;
+    {   // (made scalar by hand: the ISA loop wants the pointer in a scalar register pair)
+        const uint64_t o = (uint64_t)reinterpret_cast<uintptr_t>(a.out + d.uout);
+        out = reinterpret_cast<uint8_t *>(((uint64_t)uni((uint32_t)(o >> 32)) << 32) | uni((uint32_t)o));
+    }
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
 
     Bits b;
@@ -644,7 +674,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
         };
         for (;;) {
             uint32_t len, dist;
-            const uint32_t code = fast_symbols(b, op, next_evt, lane, len, dist);   // the common symbols, hand-scheduled
+            const uint32_t code = fast_symbols(b, op, next_evt, lane, out, len, dist);   // the common symbols, hand-scheduled
             if (code == 3) copy_match(len, dist);
             else if (code == 2) distance_and_copy(len);
             else if (code == 1) {

@@ -392,7 +392,8 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring  (length and distance consumed: leaving = code 3)
         "s_cbranch_scc1 LG%=\n"
         "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
-        "s_cbranch_scc1 LX3%=\n"
+        "s_cbranch_scc1 LO%=\n"
+        "LN%=:\n"
         "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
         "s_cbranch_scc1 LX3%=\n"
         "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i
@@ -420,6 +421,10 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_cmp_lt_u32 %[op], %[evt]\n"
         "s_cbranch_scc1 LS%=\n"
         "s_branch LX0%=\n"
+        "LO%=:\n"                                                  // ---- overlap: rounds of 64 bytes, one after the other, are still right when
+        "s_cmp_lt_u32 %[dist], 64\n"                                //      the source lies a whole round back; a shorter period goes to C++
+        "s_cbranch_scc1 LX3%=\n"
+        "s_branch LN%=\n"
         "LG%=:\n"                                                  // ---- a far match: its source has left the ring, this wave flushed it to `out` earlier
         "s_cmp_gt_u32 %[dist], %[op]\n"
         "s_cbranch_scc1 LX3%=\n"

@@ -339,6 +339,10 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     runner = FileRunner(ctx, gff_rows, a.mincov, True, decoders=decoders, decode_threads=decode_threads, walkers=a.walkers,
                         gpu_streams=a.gpu_streams)
     runner.device_decode = not a.host_decode
+    for kv in a.ctx_option:                                      # (experiments: e.g. verify_crc=0)
+        k, v = kv.split("=")
+        for c in runner.contexts:
+            c.set_option(k, int(v))
     if a.warmup > 0:
         runner.run([file_of(i) for i in range(a.warmup)], ref_len=L)
     runner.seconds = {k: 0.0 for k in runner.seconds}

@@ -517,7 +517,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     uint32_t next_evt = 0;              // output position at which the housekeeping below has something to do
 
     // after every symbol that carries `op` to `next_evt`: list the record starts whose block_size field is complete, and flush
-    // the 2 KiB segments that are complete
+    // the 2 KiB segments that are complete.  (The record walk as a kernel of its own — one lane per block over the flushed output —
+    // takes 9 % off this kernel and still loses: 229 dependent reads per lane are 0.16 ms on every BAM's critical path, and
+    // the file -> FASTA pipeline is bound by that path, not by issue slots: 41.2 vs 42.5 M positions/s, alternating on one box.)
     auto housekeeping = [&]() __attribute__((always_inline)) {
         const bool over = op > ulen;                            // (ring writes are masked: nothing was overwritten; no flush then)
         if (over) err = ST_BAD_LENGTH;

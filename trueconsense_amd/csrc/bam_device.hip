@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     uint32_t err = ST_OK;
     // the chain of BAM records through this block
     uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
-    uint32_t n_rec = 0;
+    uint32_t n_rec = 0, bad_rec = 0;
     uint32_t rec_buf = 0;               // lane k: the start of record (n_rec & ~63) + k, until 64 are together
     uint32_t next_evt = 0;              // output position at which the housekeeping below has something to do
 
@@ -523,19 +523,21 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     auto housekeeping = [&]() __attribute__((always_inline)) {
         const bool over = op > ulen;                            // (ring writes are masked: nothing was overwritten; no flush then)
         if (over) err = ST_BAD_LENGTH;
-        while (!over && next_rec + 4 <= op && next_rec < ulen) {
+        while (!over && next_rec + 4 <= op) {                   // (op <= ulen here: the header lies inside the block)
             // block_size: the two ring words around it (lanes 0 and 1 of one read), shifted into place.  The starts are gathered
             // in a register, one lane each, and leave 64 at a time.  (At most ulen / 36 + 1 <= 1 821 records: the slots suffice.)
             const uint32_t at = next_rec & WMASK;
             const uint32_t w = reinterpret_cast<const uint32_t *>(s_win)[((at >> 2) + (uint32_t)lane) & (WIN / 4 - 1)];
             const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
             const uint32_t ubs = (uint32_t)(two >> ((at & 3u) * 8u));
-            if (ubs - 32u > (1u << 28) - 32u) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
+            if (__builtin_expect(ubs - 32u > (1u << 28) - 32u, 0)) { bad_rec = 1; break; }     // (an impossible size must end the walk here: it
+                                                                                               //  could overrun the slots or never end)
             rec_buf = (uint32_t)lane == (n_rec & 63u) ? next_rec : rec_buf;
             if ((n_rec & 63u) == 63u) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
             ++n_rec;
             next_rec += 4u + ubs;
         }
+        if (bad_rec) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; }
         while (!over && op - flushed >= SEG) {
             const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & WMASK));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);          // uout is a multiple of 16 (host pads blocks)

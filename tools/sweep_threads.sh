@@ -1,6 +1,8 @@
+#!/bin/bash
+# tools/sweep_threads.sh "D S" ["D S" ...] — file -> FASTA throughput for reader-thread / GPU-context counts, on one box
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/sw
-for cfg in "2 3" "3 3" "4 3" "3 4" "4 4"; do set -- $cfg
+for cfg in "$@"; do set -- $cfg
   timeout -k 10 200 python3 bench.py --no-resident --no-cpu-baseline --decoders $1 --gpu-streams $2 > gpurun_out/sw/d$1s$2.json 2> gpurun_out/sw/d$1s$2.err || { echo fail $cfg; tail -3 gpurun_out/sw/d$1s$2.err; exit 1; }
   python3 -c "
 import json

@@ -408,7 +408,7 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
             const auto t0 = std::chrono::steady_clock::now();
             FileItem &it = items[(size_t)i];
             if (device_decode) {
-                it.rc = tcmi_bamfile_read(paths[i], &it.file);
+                it.rc = tcmi_bamfile_read_threads(paths[i], r->n_readers > 1 ? 1 : 0, &it.file);
                 if (it.rc) it.err = tcmi_last_error(nullptr);
             }
             const double dt = seconds_since(t0);

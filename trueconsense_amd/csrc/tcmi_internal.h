@@ -222,6 +222,7 @@ typedef std::function<int(const std::vector<tcmi_probe_req> &, std::vector<tcmi_
 int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
                                 int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
                                 int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
+extern "C" int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile **out);   // (bam_device.hip; 0 = by size)
 // device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);

@@ -311,8 +311,7 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
 // Written in ISA because the kernel is bound by instruction issue and the compiler's version of this loop spends a third of
 // its instructions on flags that say which path it came along (35 instructions per literal, 95 per match; here 20 and 60).
 // All state is wave-uniform, in scalar registers.
-static_assert(WMASK == 0xFFF && LL_ROOT == 9 && D_ROOT == 8 && IN_RING == 128 && NEAR == 3832, "constants below");
-static_assert(offsetof(InflateLds, ll) == 4096 && offsetof(InflateLds, dt) == 6144 && offsetof(InflateLds, in) == 8352, "LDS offsets below");
+static_assert(LL_ROOT == 9 && D_ROOT == 8 && IN_RING == 128, "masks 0x1ff / 0xff / 127 below");
 __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t next_evt, int lane, const uint8_t *out, uint32_t &len_out,
                                                   uint32_t &dist_out)
 {
@@ -328,7 +327,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_and_b32 %[t0], %[idx], 127\n"                                                                                       \
         "s_lshl_b32 %[t0], %[t0], 2\n"                                                                                         \
         "v_mov_b32 %[vt], %[t0]\n"                                                                                             \
-        "ds_read_b32 %[vnext], %[vt] offset:8352\n"                                                                            \
+        "ds_read_b32 %[vnext], %[vt] offset:%[oin]\n"                                                                            \
         "s_mov_b32 s99, 0\n"                                                                                                   \
         "s_lshl_b64 s[98:99], s[98:99], %[bc]\n"                                                                               \
         "s_or_b64 s[96:97], s[96:97], s[98:99]\n"                                                                              \
@@ -342,13 +341,13 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_and_b32 %[t0], s96, 0x1ff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
         "v_mov_b32 %[vt], %[t0]\n"
-        "ds_read_b32 %[ve], %[vt] offset:4096\n"
+        "ds_read_b32 %[ve], %[vt] offset:%[oll]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_readfirstlane_b32 %[e], %[ve]\n"
         "s_and_b32 %[nb], %[e], 15\n"
         "s_bitcmp1_b32 %[e], 8\n"
         "s_cbranch_scc0 LM%=\n"
-        "s_and_b32 %[t0], %[op], 0xfff\n"                           // a literal: bits 16-23 of the entry
+        "s_and_b32 %[t0], %[op], %[wmask]\n"                           // a literal: bits 16-23 of the entry
         "v_mov_b32 %[vt], %[t0]\n"
         "ds_write_b8_d16_hi %[vt], %[ve]\n"
         "s_lshr_b64 s[96:97], s[96:97], %[nb]\n"
@@ -376,7 +375,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_and_b32 %[t0], s96, 0xff\n"
         "s_lshl_b32 %[t0], %[t0], 2\n"
         "v_mov_b32 %[vt], %[t0]\n"
-        "ds_read_b32 %[vf], %[vt] offset:6144\n"
+        "ds_read_b32 %[vf], %[vt] offset:%[odt]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_readfirstlane_b32 %[f], %[vf]\n"
         "s_and_b32 %[t1], %[f], 15\n"
@@ -391,7 +390,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_add_u32 %[dist], %[dist], %[t0]\n"
         "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
         "s_sub_u32 %[bc], %[bc], %[t1]\n"
-        "s_cmp_gt_u32 %[dist], 3832\n"                              // beyond the LDS ring  (length and distance consumed: leaving = code 3)
+        "s_cmp_gt_u32 %[dist], %[near]\n"                              // beyond the LDS ring  (length and distance consumed: leaving = code 3)
         "s_cbranch_scc1 LG%=\n"
         "s_cmp_lt_u32 %[dist], %[len]\n"                            // source overlaps destination
         "s_cbranch_scc1 LO%=\n"
@@ -403,11 +402,11 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "v_mov_b32 %[vi], %[vlane]\n"
         "s_mov_b32 %[t0], 64\n"
         "LC%=:\n"
-        "v_and_b32 %[vt], 0xfff, %[vfrom]\n"
+        "v_and_b32 %[vt], %[wmask], %[vfrom]\n"
         "v_cmp_gt_u32 vcc, %[len], %[vi]\n"
         "s_and_saveexec_b64 s[94:95], vcc\n"
         "ds_read_u8 %[vb], %[vt]\n"
-        "v_and_b32 %[vt], 0xfff, %[vto]\n"
+        "v_and_b32 %[vt], %[wmask], %[vto]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "ds_write_b8 %[vt], %[vb]\n"
         "s_mov_b64 exec, s[94:95]\n"
@@ -440,7 +439,7 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "v_cmp_gt_u32 vcc, %[len], %[vi]\n"
         "s_and_saveexec_b64 s[94:95], vcc\n"
         "global_load_ubyte %[vb], %[vi], s[98:99]\n"
-        "v_and_b32 %[vt], 0xfff, %[vto]\n"
+        "v_and_b32 %[vt], %[wmask], %[vto]\n"
         "s_waitcnt vmcnt(0)\n"
         "ds_write_b8 %[vt], %[vb]\n"
         "s_mov_b64 exec, s[94:95]\n"
@@ -467,7 +466,8 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [f] "=&s"(f), [nb] "=&s"(nb), [len] "=&s"(len),
           [dist] "=&s"(dist), [vt] "=&v"(vt), [ve] "=&v"(ve), [vf] "=&v"(vf), [vto] "=&v"(vto), [vfrom] "=&v"(vfrom),
           [vb] "=&v"(vb), [vi] "=&v"(vi)
-        : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane), "{s[92:93]}"(out)
+        : [evt] "s"(next_evt), [hi] "s"(b.hi), [vlane] "v"(lane), "{s[92:93]}"(out), [wmask] "n"(WMASK), [near] "n"(NEAR),
+          [oll] "n"(offsetof(InflateLds, ll)), [odt] "n"(offsetof(InflateLds, dt)), [oin] "n"(offsetof(InflateLds, in))
         : "s94", "s95", "s98", "s99", "vcc", "scc", "memory");
 #undef TCMI_ASM_REFILL
     len_out = len;

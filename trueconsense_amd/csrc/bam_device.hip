@@ -239,7 +239,7 @@ __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 
 // lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table.  Returns false for an over-subscribed code.
 #ifndef TCMI_INFLATE_INLINE_TABLES
-#define TCMI_INFLATE_INLINE_TABLES 0
+#define TCMI_INFLATE_INLINE_TABLES 1
 #endif
 #if TCMI_INFLATE_INLINE_TABLES
 __device__ inline

@@ -399,26 +399,34 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "LN%=:\n"
         "s_cmp_gt_u32 %[dist], %[op]\n"                             // before the block's first byte: C++ flags it
         "s_cbranch_scc1 LX3%=\n"
-        "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i
-        "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"
-        "v_mov_b32 %[vi], %[vlane]\n"
-        "s_mov_b32 %[t0], 64\n"
+        "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i.  Whole rounds need no
+        "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"                  // lane mask; the last one (1 .. 64 bytes) does
+        "s_add_u32 %[t0], %[len], -1\n"
+        "s_lshr_b32 %[t0], %[t0], 6\n"                              // whole rounds in front of the last one
+        "s_lshl_b32 %[t1], %[t0], 6\n"
+        "s_sub_u32 %[t1], %[len], %[t1]\n"                          // bytes of the last round
+        "s_cmp_eq_u32 %[t0], 0\n"
+        "s_cbranch_scc1 LE%=\n"
         "LC%=:\n"
         "v_and_b32 %[vt], %[wmask], %[vfrom]\n"
-        "v_cmp_gt_u32 vcc, %[len], %[vi]\n"
+        "ds_read_u8 %[vb], %[vt]\n"
+        "v_and_b32 %[vt], %[wmask], %[vto]\n"
+        "v_add_u32 %[vfrom], 64, %[vfrom]\n"
+        "v_add_u32 %[vto], 64, %[vto]\n"
+        "s_sub_u32 %[t0], %[t0], 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "ds_write_b8 %[vt], %[vb]\n"
+        "s_cmp_lg_u32 %[t0], 0\n"
+        "s_cbranch_scc1 LC%=\n"
+        "LE%=:\n"
+        "v_cmp_gt_u32 vcc, %[t1], %[vlane]\n"
         "s_and_saveexec_b64 s[94:95], vcc\n"
+        "v_and_b32 %[vt], %[wmask], %[vfrom]\n"
         "ds_read_u8 %[vb], %[vt]\n"
         "v_and_b32 %[vt], %[wmask], %[vto]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "ds_write_b8 %[vt], %[vb]\n"
         "s_mov_b64 exec, s[94:95]\n"
-        "s_cmp_lt_u32 %[t0], %[len]\n"
-        "s_cbranch_scc0 LD%=\n"
-        "s_add_u32 %[t0], %[t0], 64\n"
-        "v_add_u32 %[vi], 64, %[vi]\n"
-        "v_add_u32 %[vto], 64, %[vto]\n"
-        "v_add_u32 %[vfrom], 64, %[vfrom]\n"
-        "s_branch LC%=\n"
         "LD%=:\n"
         "s_add_u32 %[op], %[op], %[len]\n"
         "s_cmp_lt_u32 %[op], %[evt]\n"

@@ -129,6 +129,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     c->dev_arena = nullptr;
     for (auto &b : c->blob_pool) (void)hipFree(b.p);
     c->blob_pool.clear();
+    if (c->tok_dev) (void)hipFree(c->tok_dev);
+    if (c->tok_host) (void)hipHostFree(c->tok_host);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

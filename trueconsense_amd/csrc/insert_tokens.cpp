@@ -301,10 +301,11 @@ int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const
     std::vector<std::vector<Entry>> entries((size_t)n_pos);
     int32_t status = 0;
     for (int32_t k = 0; k < n_pos; ++k) {
+        // the entries of a column arrive in file order, one slot per read that could reach it; key 0: no token there
         std::vector<const tcmi_dev_entry *> order;
         order.reserve((size_t)ent_cnt[k]);
-        for (int32_t t = 0; t < ent_cnt[k]; ++t) order.push_back(ents + ent_off[k] + t);
-        std::sort(order.begin(), order.end(), [](const tcmi_dev_entry *a, const tcmi_dev_entry *b) { return a->j < b->j; });   // file order
+        for (int32_t t = 0; t < ent_cnt[k]; ++t)
+            if (ents[ent_off[k] + t].key) order.push_back(ents + ent_off[k] + t);
         auto &E = entries[(size_t)k];
         E.reserve(order.size());
         for (const tcmi_dev_entry *d : order) {

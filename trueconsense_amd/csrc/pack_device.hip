@@ -131,7 +131,8 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t flags;
     uint32_t n_chunks, n_events, n_runs;
     uint32_t word_cursor;
-    uint32_t pad_[2];
+    uint32_t max_len;               // longest reference span of a kept read
+    uint32_t pad_;
 };
 
 __device__ inline uint32_t words_of(uint32_t len) { return 2u * ((len + 31u) >> 5) + 2u; }
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     uint32_t word = 0, nwords = 0;
     unsigned long long my_alg = 0;
     int32_t my_end = 0;
+    uint32_t my_len = 0;
     if (i < s.n) {
         const ReadView v = view(s, i);
         bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
                     nwords = words_of((uint32_t)len);
                     my_alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
                     my_end = (int32_t)end;
+                    my_len = (uint32_t)len;
                 }
             }
         }
@@ -220,14 +223,17 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     for (int d = 32; d >= 1; d >>= 1) {
         my_alg += (unsigned long long)__shfl_xor((long long)my_alg, d, 64);
         my_end = max(my_end, __shfl_xor(my_end, d, 64));
+        my_len = max(my_len, (uint32_t)__shfl_xor((int)my_len, d, 64));
     }
-    if ((threadIdx.x & 63) == 0) { s_alg[threadIdx.x >> 6] = my_alg; s_end[threadIdx.x >> 6] = my_end; }
+    // (the longest span rides in the top 16 bits of the byte sum: a workgroup's reads are < 2^48 bytes)
+    if ((threadIdx.x & 63) == 0) { s_alg[threadIdx.x >> 6] = my_alg | ((unsigned long long)my_len << 48); s_end[threadIdx.x >> 6] = my_end; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long a = 0;
         int32_t e = 0;
-        for (int w = 0; w < PB / 64; ++w) { a += s_alg[w]; e = max(e, s_end[w]); }
-        blk_alg[blockIdx.x] = a;
+        unsigned long long ml = 0;
+        for (int w = 0; w < PB / 64; ++w) { a += s_alg[w] & 0xFFFFFFFFFFFFull; ml = max(ml, s_alg[w] >> 48); e = max(e, s_end[w]); }
+        blk_alg[blockIdx.x] = a | (ml << 48);
         blk_end[blockIdx.x] = e;
     }
 }
@@ -241,8 +247,12 @@ __global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned l
     const int64_t per = (n_blk + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blk);
     unsigned long long sx = 0, sy = 0, alg = 0;
     int32_t mend = 0;
-    for (int64_t b = b0; b < b1; ++b) { sx += blk_sum[b].x; sy += blk_sum[b].y; alg += blk_alg[b]; mend = max(mend, blk_end[b]); }
+    uint32_t mlen = 0;
+    for (int64_t b = b0; b < b1; ++b) {
+        sx += blk_sum[b].x; sy += blk_sum[b].y; alg += blk_alg[b] & 0xFFFFFFFFFFFFull; mlen = max(mlen, (uint32_t)(blk_alg[b] >> 48)); mend = max(mend, blk_end[b]);
+    }
     if (alg) atomicAdd(&tot->alg_bytes, alg);                  // (at most 1024 of these)
+    if (mlen) atomicMax(&tot->max_len, mlen);
     if (mend) atomicMax(&tot->max_end, mend);
     s_x[t] = sx; s_y[t] = sy;
     __syncthreads();
@@ -623,8 +633,7 @@ struct InsArgs {
     const int32_t *cols;            // [n_cand] 0-based columns
     const int64_t *lo;              // [n_cand] first compacted read index to look at
     const int64_t *off;             // [n_cand + 1] pair offsets: candidate k owns pairs [off[k], off[k+1])
-    tcmi_dev_entry *out;            // [off[n_cand]]: candidate k's entries are compacted at out + off[k]
-    int32_t *count;                 // [n_cand]
+    tcmi_dev_entry *out;            // [off[n_cand]]: pair p's entry at out[p] — in file order; key 0: the read gives none on that column
     int32_t n_cand;
     uint32_t flag_filter;
     int32_t ignore_orphans;
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
 {
     const int64_t p = (int64_t)blockIdx.x * PB + threadIdx.x;
     if (p >= a.off[a.n_cand]) return;
+    a.out[p].key = 0;                                           // (overwritten below if the read has a token on the column)
     int k = 0;
     while (k + 1 < a.n_cand && p >= a.off[k + 1]) ++k;          // (a handful of candidates)
     const int64_t j = a.lo[k] + (p - a.off[k]);
@@ -727,14 +737,35 @@ __global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
                         if (consumes_ref(o)) xr += wt >> 4;
                     }
                 }
-                const int slot = atomicAdd(&a.count[k], 1);
-                a.out[a.off[k] + slot] = e;
+                a.out[p] = e;
                 return;
             }
             x += len;
         }
         if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
     }
+}
+
+// do the kept reads ascend by position?  (the packer also takes input with a few reads out of place; the range search below does not)
+__global__ __launch_bounds__(256) void ins_sorted_kernel(const int32_t *c_pos, int64_t nf, uint32_t *unsorted)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x + 1;
+    if (i < nf && c_pos[i] < c_pos[i - 1]) atomicOr(unsorted, 1u);
+}
+
+// which of the kept reads (ascending positions) can cover column cols[k]: those that start in (col - max_len, col]
+__global__ __launch_bounds__(64) void ins_ranges_kernel(const int32_t *c_pos, int64_t nf, const int32_t *cols, int32_t n_cand, int32_t max_len,
+                                                        int64_t *lo, int64_t *hi)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_cand) return;
+    const int64_t first = (int64_t)cols[k] - max_len + 1, last = cols[k];
+    int64_t a = 0, b = nf;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)c_pos[m] < first) a = m + 1; else b = m; }
+    lo[k] = a;
+    b = nf;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)c_pos[m] <= last) a = m + 1; else b = m; }
+    hi[k] = a;
 }
 
 // does read j (compacted index) have a matched base on reference position `ref`?  -> matched | base << 8 | quality << 16
@@ -851,7 +882,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tot.flags) { *why = tot.flags; return TCMI_E_UNSUPPORTED; }
     const int64_t nf = (int64_t)tot.n_kept;
-    rs->n_piled = nf; rs->f_reads = nf; rs->alg_bytes = (int64_t)tot.alg_bytes; rs->max_end = tot.max_end;
+    rs->n_piled = nf; rs->f_reads = nf; rs->alg_bytes = (int64_t)tot.alg_bytes; rs->max_end = tot.max_end; rs->max_len = (int32_t)tot.max_len;
     rs->packed_on_device = 1;
     if (nf == 0) return TCMI_OK;
     if (tot.n_words > 0xF0000000ull) { *why = PKF_WORD_OVF; return TCMI_E_UNSUPPORTED; }
@@ -986,57 +1017,79 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
     if (n_pos == 0) { if (status_flags) *status_flags = 0; return TCMI_OK; }
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nf = rs->f_reads;
-    // the kept reads ascend by position (a BAM the device decoder took is coordinate-sorted or was declined): which of them
-    // can reach each column?  Their positions come back once (4 bytes per read).
-    std::vector<int32_t> cpos((size_t)nf);
-    TCMI_HIP(ctx, hipMemcpyAsync(cpos.data(), rs->d_cpos, (size_t)nf * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!std::is_sorted(cpos.begin(), cpos.end()))
-        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "reads are not sorted by position: host sweep");
+    // The kept reads ascend by position (the device packer takes nothing else): which of them can reach each column is a
+    // binary search on the device; what comes back is two numbers per column.  Scratch (device + pinned host) belongs to the
+    // context and only grows: hipMalloc / hipFree per file cost more than the kernels (hipFree waits for the whole device).
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    auto scratch = [&](size_t dev_bytes, size_t host_bytes) -> int {
+        if (ctx->tok_dev_cap < dev_bytes) {
+            if (ctx->tok_dev) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->tok_dev); ctx->tok_dev = nullptr; ctx->tok_dev_cap = 0; }
+            const size_t want = dev_bytes + dev_bytes / 4 + (1 << 20);
+            if (hipMalloc((void **)&ctx->tok_dev, want) != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "insert-token scratch (%zu bytes)", want);
+            ctx->tok_dev_cap = want;
+        }
+        if (ctx->tok_host_cap < host_bytes) {
+            if (ctx->tok_host) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->tok_host); ctx->tok_host = nullptr; ctx->tok_host_cap = 0; }
+            const size_t want = host_bytes + host_bytes / 4 + (1 << 20);
+            if (hipHostMalloc((void **)&ctx->tok_host, want, hipHostMallocDefault) != hipSuccess) return tcmi_fail(ctx, TCMI_E_NOMEM, "insert-token host scratch (%zu bytes)", want);
+            ctx->tok_host_cap = want;
+        }
+        return TCMI_OK;
+    };
     std::vector<int32_t> cols((size_t)n_pos);
-    std::vector<int64_t> lo((size_t)n_pos), off((size_t)n_pos + 1, 0);
-    for (int32_t k = 0; k < n_pos; ++k) {
-        const int64_t c = positions[k] - 1;
-        cols[(size_t)k] = (int32_t)c;
-        const int64_t a = std::lower_bound(cpos.begin(), cpos.end(), (int32_t)std::max<int64_t>(c - TCMI_D_MAXLEN + 1, INT32_MIN / 2)) - cpos.begin();
-        const int64_t b = std::upper_bound(cpos.begin(), cpos.end(), (int32_t)std::min<int64_t>(c, INT32_MAX)) - cpos.begin();
-        lo[(size_t)k] = a;
-        off[(size_t)k + 1] = off[(size_t)k] + std::max<int64_t>(0, b - a);
+    for (int32_t k = 0; k < n_pos; ++k) cols[(size_t)k] = (int32_t)(positions[k] - 1);
+    const size_t b_cols = al((size_t)n_pos * 4), b_lo = al((size_t)n_pos * 8), b_off = al(((size_t)n_pos + 1) * 8);
+    {
+        const int rc = scratch(b_cols + 2 * b_lo + b_off, 2 * b_lo);
+        if (rc) return rc;
     }
+    int32_t *d_cols = (int32_t *)ctx->tok_dev;
+    int64_t *d_lo = (int64_t *)(ctx->tok_dev + b_cols), *d_hi = (int64_t *)(ctx->tok_dev + b_cols + b_lo), *d_off = (int64_t *)(ctx->tok_dev + b_cols + 2 * b_lo);
+    int64_t *h_lo = (int64_t *)ctx->tok_host, *h_hi = (int64_t *)(ctx->tok_host + b_lo);
+    const int32_t max_len = (int32_t)std::min<int64_t>(std::max<int64_t>(rs->max_len, 1), TCMI_D_MAXLEN);
+    TCMI_HIP(ctx, hipMemcpyAsync(d_cols, cols.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
+    (void)hipGetLastError();
+    uint32_t *d_unsorted = (uint32_t *)d_off;                   // (the offsets go there later)
+    TCMI_HIP(ctx, hipMemsetAsync(d_unsorted, 0, 4, ctx->stream));
+    if (nf > 1) hipLaunchKernelGGL(ins_sorted_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, rs->d_cpos, nf, d_unsorted);
+    hipLaunchKernelGGL(ins_ranges_kernel, dim3((unsigned)((n_pos + 63) / 64)), dim3(64), 0, ctx->stream, rs->d_cpos, nf, d_cols, n_pos, max_len, d_lo, d_hi);
+    TCMI_HIP(ctx, hipGetLastError());
+    TCMI_HIP(ctx, hipMemcpyAsync(h_lo, d_lo, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(h_hi, d_hi, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t unsorted = 0;
+    TCMI_HIP(ctx, hipMemcpyAsync(&unsorted, d_unsorted, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (unsorted) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "reads are not sorted by position: host sweep");
+    const std::vector<int64_t> lo_v(h_lo, h_lo + n_pos), hi_v(h_hi, h_hi + n_pos);   // (the scratch below may move)
+    std::vector<int64_t> off((size_t)n_pos + 1, 0);
+    for (int32_t k = 0; k < n_pos; ++k) off[(size_t)k + 1] = off[(size_t)k] + std::max<int64_t>(0, hi_v[(size_t)k] - lo_v[(size_t)k]);
     const int64_t total = off[(size_t)n_pos];
-    std::vector<tcmi_dev_entry> ents((size_t)std::max<int64_t>(total, 1));
     std::vector<int32_t> cnt((size_t)n_pos, 0);
+    for (int32_t k = 0; k < n_pos; ++k) cnt[(size_t)k] = (int32_t)(off[(size_t)k + 1] - off[(size_t)k]);
+    const tcmi_dev_entry *ents = nullptr;
     if (total > 0) {
-        // the entries live outside the arena (it holds the stream): one transient allocation, only for BAMs with candidates
-        char *buf = nullptr;
-        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t b_ent = al((size_t)total * sizeof(tcmi_dev_entry)), b_cols = al((size_t)n_pos * 4), b_lo = al((size_t)n_pos * 8),
-                     b_off = al(((size_t)n_pos + 1) * 8), b_cnt = al((size_t)n_pos * 4);
-        TCMI_HIP(ctx, hipMalloc((void **)&buf, b_ent + b_cols + b_lo + b_off + b_cnt));
+        const size_t b_head = b_cols + 2 * b_lo + b_off, b_ent = al((size_t)total * sizeof(tcmi_dev_entry));
+        const int rc = scratch(b_head + b_ent, std::max(2 * b_lo, b_ent));
+        if (rc) return rc;
+        // (a regrown device buffer lost the columns and ranges: they are sent again — all tiny)
+        d_cols = (int32_t *)ctx->tok_dev;
+        d_lo = (int64_t *)(ctx->tok_dev + b_cols); d_off = (int64_t *)(ctx->tok_dev + b_cols + 2 * b_lo);
         InsArgs a;
         a.src = {};
         a.src.stream = rs->d_stream; a.src.rec_off = rs->d_rec_off; a.src.mode = 1; a.src.n = rs->n_reads;
         a.c_idx = rs->d_cidx;
-        a.out = (tcmi_dev_entry *)buf;
-        a.cols = (const int32_t *)(buf + b_ent);
-        a.lo = (const int64_t *)(buf + b_ent + b_cols);
-        a.off = (const int64_t *)(buf + b_ent + b_cols + b_lo);
-        a.count = (int32_t *)(buf + b_ent + b_cols + b_lo + b_off);
+        a.out = (tcmi_dev_entry *)(ctx->tok_dev + b_head);
+        a.cols = d_cols; a.lo = d_lo; a.off = d_off;
         a.n_cand = n_pos; a.flag_filter = flag_filter; a.ignore_orphans = ignore_orphans;
-        hipError_t e = hipMemcpyAsync((void *)a.cols, cols.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync((void *)a.lo, lo.data(), (size_t)n_pos * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync((void *)a.off, off.data(), ((size_t)n_pos + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(a.count, 0, (size_t)n_pos * 4, ctx->stream);
-        if (e == hipSuccess) {
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(ins_entries_kernel, dim3((unsigned)((total + PB - 1) / PB)), dim3(PB), 0, ctx->stream, a);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), a.count, (size_t)n_pos * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ents.data(), a.out, (size_t)total * sizeof(tcmi_dev_entry), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(buf);
-        if (e != hipSuccess) return tcmi_fail(ctx, TCMI_E_HIP, "insert-token kernel failed: %s", hipGetErrorString(e));
+        TCMI_HIP(ctx, hipMemcpyAsync(d_cols, cols.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
+        TCMI_HIP(ctx, hipMemcpyAsync(d_lo, lo_v.data(), (size_t)n_pos * 8, hipMemcpyHostToDevice, ctx->stream));
+        TCMI_HIP(ctx, hipMemcpyAsync(d_off, off.data(), ((size_t)n_pos + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(ins_entries_kernel, dim3((unsigned)((total + PB - 1) / PB)), dim3(PB), 0, ctx->stream, a);
+        TCMI_HIP(ctx, hipGetLastError());
+        TCMI_HIP(ctx, hipMemcpyAsync(ctx->tok_host, a.out, (size_t)total * sizeof(tcmi_dev_entry), hipMemcpyDeviceToHost, ctx->stream));
+        TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (lo_v / off / cols were pageable: their copies are done)
+        ents = (const tcmi_dev_entry *)ctx->tok_host;
     }
     // the other mate of an overlapping pair, looked at on one reference position (rare: a pair with a deletion on a candidate column)
     const tcmi_prober prober = [&](const std::vector<tcmi_probe_req> &req, std::vector<tcmi_probe_res> &res) -> int {
@@ -1070,6 +1123,6 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
         for (size_t t = 0; t < n; ++t) res[t] = tcmi_probe_res{(uint8_t)(out[t] & 1u), (uint8_t)((out[t] >> 8) & 15u), (uint8_t)(out[t] >> 16)};
         return TCMI_OK;
     };
-    return tcmi_modal_from_dev_entries(n_pos, ents.data(), off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, &prober, tokens,
+    return tcmi_modal_from_dev_entries(n_pos, ents, off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, &prober, tokens,
                                        tokens_cap, token_off, n_tokens, status_flags);
 }

@@ -88,6 +88,7 @@ struct tcmi_readset {
     int64_t alg_bytes = 0;      // sum over kept reads of 12 + 4*n_cigar + ceil(l_qseq/2)
     int64_t dev_bytes = 0;
     int64_t max_end = 0;        // max end position (exclusive) of a kept read
+    int32_t max_len = 0;        // device-packed sets: the longest reference span of a kept read (0: not recorded)
     int device = -1;
     int packed_on_device = 0;   // 1: pack_device.hip built the aligned set (everything below lives in d_blob)
     // device-decoded read sets: the inflated stream and the packer's index stay in the context's arena until its next upload
@@ -135,6 +136,9 @@ struct tcmi_ctx {
     // (hipMalloc + hipFree cost more than the pack kernels, and hipFree waits for the device)
     struct Blob { char *p; size_t bytes; };
     std::vector<Blob> blob_pool;
+    // scratch of tcmi_readset_modal_tokens (columns, ranges, entries): device + pinned host, grow-only
+    char *tok_dev = nullptr, *tok_host = nullptr;
+    size_t tok_dev_cap = 0, tok_host_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device

@@ -309,7 +309,9 @@ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint1
 //   3  a match with length and distance decoded (bits consumed) whose source overlaps its destination, or that is impossible
 //      -> C++ copies / flags it.  (A FAR match — source already flushed to HBM — is copied here too, through global loads.)
 // (Measured and dropped: long matches copied four bytes per lane with unaligned ds_read_b32 / ds_write_b32 — fewer instructions,
-// 643 vs 619 us: unaligned LDS dwords are not cheap.)
+// 643 vs 619 us: unaligned LDS dwords are not cheap.  And: the next symbol's table entry requested as soon as the current symbol's
+// bits are consumed, a whole copy ahead of its use — 609 vs 610 us: the look-up's latency is not what the kernel waits for, the
+// issue slots are.)
 // Written in ISA because the kernel is bound by instruction issue and the compiler's version of this loop spends a third of
 // its instructions on flags that say which path it came along (35 instructions per literal, 95 per match; here 20 and 60).
 // All state is wave-uniform, in scalar registers.

@@ -92,27 +92,8 @@ constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input st
 
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// canonical Huffman decode of the bits in `v` (first stream bit = bit 0), at most `maxlen` bits: puff.c's loop
-// -> symbol | code length << 16, or -1
-__device__ inline int slow_decode(const uint16_t *cnt, const uint16_t *sym, uint32_t v, int maxlen)
-{
-    int code = 0, first = 0, index = 0;
-#pragma unroll 1
-    for (int len = 1; len <= maxlen; ++len) {
-        code |= (int)(v & 1u);
-        v >>= 1;
-        const int c = cnt[len];
-        if (code - c < first) return (int)sym[index + (code - first)] | (len << 16);
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
-}
-
-// The same for a code that is known to be longer than `root` bits (the root table said so), wave-uniform: the canonical
-// decoder's state after `root` bits depends on the counts alone (`rs` = {first, index} at that point, left by build_table), and
+// Canonical Huffman decode (puff.c's loop) of a code that is known to be longer than `root` bits (the root table said so),
+// wave-uniform: the canonical decoder's state after `root` bits depends on the counts alone (`rs` = {first, index} at that point, left by build_table), and
 // the first `root` bits of the code are the bit-reversed low bits of `v` — so the walk starts at length root + 1 and takes
 // one to three rounds for the codes that occur.  -> symbol | code length << 16, or -1
 __device__ inline int long_code(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, uint32_t v, int root)
@@ -238,60 +219,81 @@ __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 }
 
 // lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table.  Returns false for an over-subscribed code.
-#ifndef TCMI_INFLATE_INLINE_TABLES
-#define TCMI_INFLATE_INLINE_TABLES 1
-#endif
-#if TCMI_INFLATE_INLINE_TABLES
-__device__ inline
-#else
-__device__ __noinline__             // three call sites: one copy of the code keeps the kernel small (instruction cache)
-#endif
-bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *nxt, tab_t *tab, int root, int kind, uint32_t *rs)
+// The kernel is bound by instruction issue, and a quarter of its instructions were spent here: so the per-length counters,
+// offsets and first codes live in scalar registers (both loops over the 15 lengths are unrolled: the indices are constants),
+// no read-modify-write goes through LDS, and a table slot is decoded by nine compare-and-select steps against those scalars
+// instead of a bit-by-bit walk with an LDS read per bit.  MAXG: groups of 64 symbols (5 for the 286 literal/length codes).
+template <int MAXG, int ROOT>
+__device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, tab_t *tab, int kind, uint32_t *rs)
 {
     const int lane = threadIdx.x;
     __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
-    if (lane < 16) cnt[lane] = 0;
-    __syncthreads();
-    // histogram of the code lengths: one ballot per length and group of 64 symbols (uniform results)
-    for (int g = 0; g < n; g += 64) {
-        const int l = g + lane < n ? lens[g + lane] : 0;
-        for (int len = 1; len <= 15; ++len) {
-            const unsigned long long m = __ballot(l == len);
-            if (lane == 0 && m) cnt[len] += (uint16_t)__popcll(m);
-        }
+    int l[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) l[g] = g * 64 + lane < n ? (int)lens[g * 64 + lane] : 0;
+    // histogram of the code lengths: one ballot per length and group (wave-uniform counters)
+    int c[16];
+#pragma unroll
+    for (int len = 0; len < 16; ++len) c[len] = 0;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+#pragma unroll
+        for (int len = 1; len <= 15; ++len) c[len] += (int)__popcll(__ballot(l[g] == len));
     }
-    __syncthreads();
-    // offsets of each length in the sorted symbol array; over-subscription check
-    int left = 1, off = 0, first = 0;
+    // ... to LDS for the long-code walk (long_code(), slow_decode())
+    {
+        int mine = 0;
+#pragma unroll
+        for (int len = 1; len <= 15; ++len) mine = lane == len ? c[len] : mine;
+        if (lane < 16) cnt[lane] = (uint16_t)mine;
+    }
+    // offsets of each length in the sorted symbol array, first code of each length; over-subscription check
+    int off[16], first[16];
+    int left = 1, o = 0, f = 0;
     bool ok = true;
+#pragma unroll
     for (int len = 1; len <= 15; ++len) {
-        const int c = cnt[len];
-        left = (left << 1) - c;
+        left = (left << 1) - c[len];
         if (left < 0) ok = false;
-        if (lane == 0) nxt[len] = (uint16_t)off;
-        off += c;
-        first = (first + c) << 1;
-        if (len == root && lane == 0) { rs[0] = (uint32_t)first; rs[1] = (uint32_t)off; }    // long_code() starts here
+        off[len] = o;
+        first[len] = f;
+        o += c[len];
+        f = (f + c[len]) << 1;
+        if (len == ROOT && lane == 0) { rs[0] = (uint32_t)f; rs[1] = (uint32_t)o; }    // long_code() starts here
     }
-    __syncthreads();
     // rank of every symbol among those of its length, in symbol order -> its slot in the sorted array
-    for (int g = 0; g < n; g += 64) {
-        const int l = g + lane < n ? lens[g + lane] : 0;
-        for (int len = 1; len <= 15; ++len) {
-            const unsigned long long m = __ballot(l == len);
-            if (!m) continue;
-            const int base = nxt[len];
-            __syncthreads();
-            if (l == len) sym[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(g + lane);
-            if (lane == 0) nxt[len] = (uint16_t)(base + __popcll(m));
-            __syncthreads();
+    {
+        int nx[16];
+#pragma unroll
+        for (int len = 1; len <= 15; ++len) nx[len] = off[len];
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+#pragma unroll
+            for (int len = 1; len <= 15; ++len) {
+                const unsigned long long m = __ballot(l[g] == len);
+                if (m) {
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (l[g] == len) sym[nx[len] + below] = (uint16_t)(g * 64 + lane);
+                    nx[len] += (int)__popcll(m);
+                }
+            }
         }
     }
     __syncthreads();
-    // root table: every lane decodes its indices
-    for (int i = lane; i < (1 << root); i += 64) {
-        const int s = slow_decode(cnt, sym, (uint32_t)i, root);
-        tab[i] = s < 0 ? 0u : make_entry(kind, s & 0xFFFF, s >> 16);
+    // root table: slot i holds the symbol whose code is a prefix of the bits of i (first stream bit = bit 0): the code of
+    // length len that the slot starts with is p = reverse(i)'s top len bits; it exists if first[len] <= p < first[len] + c[len]
+    // (for a prefix code at most one length answers)
+    for (int i = lane; i < (1 << ROOT); i += 64) {
+        const uint32_t r = __builtin_bitreverse32((uint32_t)i) >> (32 - ROOT);
+        int L = 0, si = 0;
+#pragma unroll
+        for (int len = 1; len <= ROOT; ++len) {
+            const uint32_t d = (r >> (ROOT - len)) - (uint32_t)first[len];
+            const bool hit = d < (uint32_t)c[len];
+            L = hit ? len : L;
+            si = hit ? off[len] + (int)d : si;
+        }
+        tab[i] = L ? make_entry(kind, (int)sym[si], L) : 0u;
     }
     __syncthreads();
     return uni(ok ? 1u : 0u) != 0;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     tab_t *const s_cl = L.dt;                   // the code-length code is done with before the distance table is built
     uint8_t *const s_lens = L.lens;
     uint16_t *const s_sym_ll = L.sym_ll, *const s_sym_d = L.sym_d, *const s_sym_cl = L.sym_cl;
-    uint16_t *const s_cnt_ll = L.cnt_ll, *const s_cnt_d = L.cnt_d, *const s_cnt_cl = L.cnt_cl, *const s_nxt = L.nxt;
+    uint16_t *const s_cnt_ll = L.cnt_ll, *const s_cnt_d = L.cnt_d, *const s_cnt_cl = L.cnt_cl;
     uint8_t *const s_cll = L.cll;
     uint32_t *const s_rs = L.rs;
     uint32_t *const s_in = L.in;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                 const uint32_t v = take(b, 3);
                 if (lane == 0) s_cll[CL_ORDER[i]] = (uint8_t)v;
             }
-            if (uni(build_table(s_cll, 19, s_cnt_cl, s_sym_cl, s_nxt, s_cl, CL_ROOT, K_CODELEN, s_rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+            if (uni(build_table<1, CL_ROOT>(s_cll, 19, s_cnt_cl, s_sym_cl, s_cl, K_CODELEN, s_rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
             for (int i = lane; i < 320; i += 64) s_lens[i] = 0;
             __syncthreads();
             int got = 0, prev = 0;
@@ -642,8 +644,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             __syncthreads();
             if (uni(s_lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
-        if (uni(build_table(s_lens, nlen, s_cnt_ll, s_sym_ll, s_nxt, s_ll, LL_ROOT, K_LITLEN, s_rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_nxt, s_dt, D_ROOT, K_DIST, s_rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table<5, LL_ROOT>(s_lens, nlen, s_cnt_ll, s_sym_ll, s_ll, K_LITLEN, s_rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table<1, D_ROOT>(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_dt, K_DIST, s_rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
 
         // ---- symbols: the hot loop.  Everything in it is wave-uniform (scalar registers); per symbol one LDS table look-up
         //      (two for a match), no arithmetic on symbol numbers (the entries carry base and extra-bit count), one compare

@@ -126,7 +126,7 @@ struct InflateLds {
     __attribute__((aligned(16))) uint8_t win[WIN];      // the most recent output
     tab_t ll[1 << LL_ROOT];
     tab_t dt[1 << D_ROOT];
-    uint8_t lens[320];                          // literal/length code lengths [0, 288), distance code lengths [288, 320)
+    uint8_t lens[320];                          // code lengths: literal/length [0, nlen), distance [nlen, nlen + ndist)
     uint16_t sym_ll[288], sym_d[32], sym_cl[20];
     uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16], nxt[16];
     uint8_t cll[20];
@@ -489,6 +489,123 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
     return code;
 }
 
+// ---- the code-length symbols of a dynamic block (RFC 1951 3.2.7), hand-scheduled like the symbol loop: 0 .. 15 = the next
+// symbol's code length, 16 = repeat the previous length 3 - 6 times, 17 / 18 = 3 - 10 / 11 - 138 zeros.  The lengths go to
+// lens[got ..] (pre-zeroed: zeros are not stored), literal/length and distance lengths in one run.  -> 0: all `total` lengths
+// are in; 1: the input ring needs its next half first — C++ takes ONE symbol; 2: damaged stream.
+__device__ __forceinline__ uint32_t cl_symbols(Bits &b, uint32_t &got, uint32_t &prev, uint32_t total, int lane)
+{
+    uint32_t code, t0, t1, t2, e, nb, vt, ve, vb;
+#define TCMI_ASM_REFILL(exit_label_)                                                                                           \
+        "s_add_u32 %[t0], %[idx], 65\n"                                                                                        \
+        "s_cmp_lt_u32 %[t0], %[hi]\n"                                                                                          \
+        "s_cbranch_scc0 " exit_label_ "%=\n"                                                                                   \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                               \
+        "v_readfirstlane_b32 s98, %[vnext]\n"                                                                                  \
+        "s_add_u32 %[idx], %[idx], 1\n"                                                                                        \
+        "s_and_b32 %[t0], %[idx], 127\n"                                                                                       \
+        "s_lshl_b32 %[t0], %[t0], 2\n"                                                                                         \
+        "v_mov_b32 %[vt], %[t0]\n"                                                                                             \
+        "ds_read_b32 %[vnext], %[vt] offset:%[oin]\n"                                                                          \
+        "s_mov_b32 s99, 0\n"                                                                                                   \
+        "s_lshl_b64 s[98:99], s[98:99], %[bc]\n"                                                                               \
+        "s_or_b64 s[96:97], s[96:97], s[98:99]\n"                                                                              \
+        "s_add_u32 %[bc], %[bc], 32\n"
+    asm volatile(
+        "LA%=:\n"
+        "s_cmp_lt_u32 %[got], %[total]\n"
+        "s_cbranch_scc0 LZ0%=\n"
+        "s_cmp_gt_i32 %[bc], 32\n"
+        "s_cbranch_scc1 LB%=\n"
+        TCMI_ASM_REFILL("LZ1")
+        "LB%=:\n"
+        "s_and_b32 %[t0], s96, 0x7f\n"
+        "s_lshl_b32 %[t0], %[t0], 2\n"
+        "v_mov_b32 %[vt], %[t0]\n"
+        "ds_read_b32 %[ve], %[vt] offset:%[ocl]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 %[e], %[ve]\n"
+        "s_and_b32 %[nb], %[e], 15\n"
+        "s_cmp_eq_u32 %[nb], 0\n"
+        "s_cbranch_scc1 LZ2%=\n"
+        "s_lshr_b64 s[96:97], s[96:97], %[nb]\n"
+        "s_sub_u32 %[bc], %[bc], %[nb]\n"
+        "s_lshr_b32 %[t1], %[e], 16\n"                              // the symbol
+        "s_cmp_lt_u32 %[t1], 16\n"
+        "s_cbranch_scc0 LR%=\n"
+        "s_cmp_eq_u32 %[t1], 0\n"                                   // ---- one length
+        "s_cbranch_scc1 LN%=\n"
+        "s_add_u32 %[t0], %[got], %[olens]\n"
+        "v_mov_b32 %[vt], %[t0]\n"
+        "v_mov_b32 %[vb], %[t1]\n"
+        "ds_write_b8 %[vt], %[vb]\n"
+        "LN%=:\n"
+        "s_mov_b32 %[prev], %[t1]\n"
+        "s_add_u32 %[got], %[got], 1\n"
+        "s_branch LA%=\n"
+        "LR%=:\n"
+        "s_cmp_eq_u32 %[t1], 16\n"
+        "s_cbranch_scc0 LP%=\n"
+        "s_cmp_eq_u32 %[got], 0\n"                                  // ---- 16: the previous length 3 - 6 times
+        "s_cbranch_scc1 LZ2%=\n"
+        "s_and_b32 %[t2], s96, 3\n"
+        "s_add_u32 %[t2], %[t2], 3\n"
+        "s_lshr_b64 s[96:97], s[96:97], 2\n"
+        "s_sub_u32 %[bc], %[bc], 2\n"
+        "s_add_u32 %[t0], %[got], %[t2]\n"
+        "s_cmp_gt_u32 %[t0], %[total]\n"
+        "s_cbranch_scc1 LZ2%=\n"
+        "s_cmp_eq_u32 %[prev], 0\n"
+        "s_cbranch_scc1 LQ%=\n"
+        "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n"
+        "s_and_saveexec_b64 s[94:95], vcc\n"
+        "s_add_u32 %[t1], %[got], %[olens]\n"
+        "v_add_u32 %[vt], %[t1], %[vlane]\n"
+        "v_mov_b32 %[vb], %[prev]\n"
+        "ds_write_b8 %[vt], %[vb]\n"
+        "s_mov_b64 exec, s[94:95]\n"
+        "LQ%=:\n"
+        "s_mov_b32 %[got], %[t0]\n"
+        "s_branch LA%=\n"
+        "LP%=:\n"
+        "s_cmp_eq_u32 %[t1], 17\n"
+        "s_cbranch_scc0 LO%=\n"
+        "s_and_b32 %[t2], s96, 7\n"                                 // ---- 17: 3 - 10 zeros
+        "s_add_u32 %[t2], %[t2], 3\n"
+        "s_lshr_b64 s[96:97], s[96:97], 3\n"
+        "s_sub_u32 %[bc], %[bc], 3\n"
+        "s_branch LY%=\n"
+        "LO%=:\n"
+        "s_and_b32 %[t2], s96, 0x7f\n"                              // ---- 18: 11 - 138 zeros
+        "s_add_u32 %[t2], %[t2], 11\n"
+        "s_lshr_b64 s[96:97], s[96:97], 7\n"
+        "s_sub_u32 %[bc], %[bc], 7\n"
+        "LY%=:\n"
+        "s_add_u32 %[t0], %[got], %[t2]\n"
+        "s_cmp_gt_u32 %[t0], %[total]\n"
+        "s_cbranch_scc1 LZ2%=\n"
+        "s_mov_b32 %[prev], 0\n"
+        "s_mov_b32 %[got], %[t0]\n"
+        "s_branch LA%=\n"
+        "LZ0%=:\n"
+        "s_mov_b32 %[code], 0\n"
+        "s_branch LZ%=\n"
+        "LZ1%=:\n"
+        "s_mov_b32 %[code], 1\n"
+        "s_branch LZ%=\n"
+        "LZ2%=:\n"
+        "s_mov_b32 %[code], 2\n"
+        "LZ%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : "+{s[96:97]}"(b.bb), [bc] "+s"(b.bc), [got] "+s"(got), [prev] "+s"(prev), [idx] "+s"(b.idx), [vnext] "+v"(b.next), [code] "=&s"(code),
+          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [nb] "=&s"(nb), [vt] "=&v"(vt), [ve] "=&v"(ve), [vb] "=&v"(vb)
+        : [total] "s"(total), [hi] "s"(b.hi), [vlane] "v"(lane), [ocl] "n"(offsetof(InflateLds, dt)), [olens] "n"(offsetof(InflateLds, lens)),
+          [oin] "n"(offsetof(InflateLds, in))
+        : "s94", "s95", "s98", "s99", "vcc", "scc", "memory");
+#undef TCMI_ASM_REFILL
+    return code;
+}
+
 __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
 {
     __shared__ InflateLds L;                    // ONE LDS object: it sits at LDS address 0 and the member offsets are constants
@@ -620,23 +737,25 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             if (uni(build_table<1, CL_ROOT>(s_cll, 19, s_cnt_cl, s_sym_cl, s_cl, K_CODELEN, s_rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
             for (int i = lane; i < 320; i += 64) s_lens[i] = 0;
             __syncthreads();
-            int got = 0, prev = 0;
-            while (got < nlen + ndist) {
+            // (literal/length and distance lengths in one run: lens[0, nlen) and lens[nlen, nlen + ndist))
+            uint32_t got = 0, prev = 0;
+            const uint32_t total = (uint32_t)(nlen + ndist);
+            for (;;) {
+                const uint32_t code = cl_symbols(b, got, prev, total, lane);    // hand-scheduled; leaves when the input ring needs its next half
+                if (code == 0) break;
+                if (code == 2) { err = ST_BAD_STREAM; break; }
+                // ONE symbol here (the refill brings the next half of the ring in)
                 refill(b);
                 const uint32_t e = uni(s_cl[(uint32_t)b.bb & ((1u << CL_ROOT) - 1u)]);
                 const int nb = (int)(e & 15u), sym = (int)(e >> 16);
                 if (nb == 0) { err = ST_BAD_STREAM; break; }
                 take(b, nb);
-                int rep = 1, val = sym;
-                if (sym == 16) { if (got == 0) { err = ST_BAD_STREAM; break; } rep = 3 + (int)take(b, 2); val = prev; }
-                else if (sym == 17) { rep = 3 + (int)take(b, 3); val = 0; }
-                else if (sym == 18) { rep = 11 + (int)take(b, 7); val = 0; }
-                if (got + rep > nlen + ndist) { err = ST_BAD_STREAM; break; }
-                // literal/length lengths go to [0, nlen), distance lengths to [288, 288 + ndist)
-                if (val != 0 && lane < rep) {
-                    const int k = got + lane;
-                    s_lens[k < nlen ? k : 288 + (k - nlen)] = (uint8_t)val;
-                }
+                uint32_t rep = 1, val = (uint32_t)sym;
+                if (sym == 16) { if (got == 0) { err = ST_BAD_STREAM; break; } rep = 3 + take(b, 2); val = prev; }
+                else if (sym == 17) { rep = 3 + take(b, 3); val = 0; }
+                else if (sym == 18) { rep = 11 + take(b, 7); val = 0; }
+                if (got + rep > total) { err = ST_BAD_STREAM; break; }
+                if (val != 0 && (uint32_t)lane < rep) s_lens[got + (uint32_t)lane] = (uint8_t)val;
                 got += rep;
                 prev = val;
             }
@@ -645,7 +764,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
             if (uni(s_lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
         if (uni(build_table<5, LL_ROOT>(s_lens, nlen, s_cnt_ll, s_sym_ll, s_ll, K_LITLEN, s_rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table<1, D_ROOT>(s_lens + 288, ndist, s_cnt_d, s_sym_d, s_dt, K_DIST, s_rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table<1, D_ROOT>(s_lens + nlen, ndist, s_cnt_d, s_sym_d, s_dt, K_DIST, s_rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
 
         // ---- symbols: the hot loop.  Everything in it is wave-uniform (scalar registers); per symbol one LDS table look-up
         //      (two for a match), no arithmetic on symbol numbers (the entries carry base and extra-bit count), one compare

@@ -114,8 +114,8 @@ __device__ inline int long_code(const uint16_t *cnt, const uint16_t *sym, const 
     return -1;
 }
 
-// Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), extra bits in
-// bits 4-7, kind in bits 8-10, value in bits 16-31 (the literal, the base length or the base distance): the hot loop needs
+// Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), kind in bits 8-10;
+// a literal in bits 16-23; a distance: extra bits in bits 4-7, base in bits 16-31; a length: see make_entry.  The hot loop needs
 // no arithmetic on symbols.
 constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
 enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
@@ -210,7 +210,9 @@ __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
         int eb = 0, base = 3 + s;
         if (s == 28) base = 258;
         else if (s >= 8) { eb = (s >> 2) - 1; base = 3 + ((4 + (s & 3)) << eb); }
-        return (uint32_t)nbits | ((uint32_t)eb << 4) | E_BASE | ((uint32_t)base << 16);
+        // a LENGTH entry is laid out for the ISA loop: extra-bit count in bits 16-19 (with the code length in bits 0-3 that is an
+        // s_bfe_u32 operand: entry & 0x000F000F), code + extra bits in bits 11-15, base length in bits 20-28
+        return (uint32_t)nbits | ((uint32_t)(nbits + eb) << 11) | E_BASE | ((uint32_t)eb << 16) | ((uint32_t)base << 20);
     }
     if (sym > 29) return 0u;                                    // 30, 31: not a distance
     int eb = 0, base = 1 + sym;
@@ -365,13 +367,11 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "LM%=:\n"                                                  // ---- a match?  (not: a long code or none — entry 0 —, end of block -> C++)
         "s_bitcmp1_b32 %[e], 9\n"
         "s_cbranch_scc0 LX1%=\n"
-        "s_bfe_u32 %[t1], %[e], 0x40004\n"                          // extra bits of the length
-        "s_lshr_b32 %[t0], s96, %[nb]\n"
-        "s_bfm_b32 %[t2], %[t1], 0\n"
-        "s_and_b32 %[t0], %[t0], %[t2]\n"
-        "s_lshr_b32 %[len], %[e], 16\n"
+        "s_and_b32 %[t1], %[e], 0x000f000f\n"                       // (extra-bit count << 16 | code length: the field of the extra bits)
+        "s_bfe_u32 %[t0], s96, %[t1]\n"
+        "s_bfe_u32 %[len], %[e], 0x90014\n"                         // base length
         "s_add_u32 %[len], %[len], %[t0]\n"
-        "s_add_u32 %[t1], %[t1], %[nb]\n"
+        "s_bfe_u32 %[t1], %[e], 0x5000b\n"                          // code + extra bits
         "s_lshr_b64 s[96:97], s[96:97], %[t1]\n"
         "s_sub_u32 %[bc], %[bc], %[t1]\n"
         "s_cmp_gt_i32 %[bc], 32\n"                                  // (from here on the length is consumed: leaving = code 2)
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
                     s_win[op & WMASK] = (uint8_t)(e >> 16);     // (every lane stores the same byte to the same address: no exec juggling)
                     ++op;
                 } else if (e & E_BASE) {
-                    distance_and_copy((e >> 16) + take(b, (int)((e >> 4) & 15u)));
+                    distance_and_copy(((e >> 20) & 0x1FFu) + take(b, (int)((e >> 16) & 15u)));
                 } else {
                     break;                          // end of block (E_EOB)
                 }

@@ -405,12 +405,13 @@ __device__ __forceinline__ uint32_t fast_symbols(Bits &b, uint32_t &op, uint32_t
         "s_cbranch_scc1 LX3%=\n"
         "v_add_u32 %[vto], %[op], %[vlane]\n"                       // the copy: 64 bytes per round, lane i byte i.  Whole rounds need no
         "v_subrev_u32 %[vfrom], %[dist], %[vto]\n"                  // lane mask; the last one (1 .. 64 bytes) does
+        "s_mov_b32 %[t1], %[len]\n"                                 // bytes of the last round: all of them for a match of up to 64
+        "s_cmp_le_u32 %[len], 64\n"
+        "s_cbranch_scc1 LE%=\n"
         "s_add_u32 %[t0], %[len], -1\n"
         "s_lshr_b32 %[t0], %[t0], 6\n"                              // whole rounds in front of the last one
         "s_lshl_b32 %[t1], %[t0], 6\n"
-        "s_sub_u32 %[t1], %[len], %[t1]\n"                          // bytes of the last round
-        "s_cmp_eq_u32 %[t0], 0\n"
-        "s_cbranch_scc1 LE%=\n"
+        "s_sub_u32 %[t1], %[len], %[t1]\n"
         "LC%=:\n"
         "v_and_b32 %[vt], %[wmask], %[vfrom]\n"
         "ds_read_u8 %[vb], %[vt]\n"

@@ -490,7 +490,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
     inflated = inflated_bytes or 273 * n
     out = {"roofline": block("bgzf_inflate", "inflate", file_bytes + inflated,
                              "compressed bytes read + inflated bytes written per BAM; one wavefront per BGZF block, wave-uniform Huffman "
-                             "decoding: bound by instruction issue (profiles/r02t_pmc_e2e.txt), not by HBM — see `issue`", traffic_key="inflate_hbm_bytes_per_bam"),
+                             "decoding: bound by instruction issue (profiles/r02u_pmc_e2e.txt), not by HBM — see `issue`", traffic_key="inflate_hbm_bytes_per_bam"),
            "roofline_hot_path": block("pk_pack", "pack", alg_reads + 52 * n,
                                       "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read it writes; it "
                                       "reads them out of the inflated BAM stream (285 B per record, names and qualities ride along in the cache lines)",

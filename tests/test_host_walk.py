@@ -411,3 +411,26 @@ def test_insert_tokens_max_depth_and_overlapping_mates():
         assert got[0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0]
         seen_change |= len(want) != len(orc.region_tokens(dr, col, ignore_overlaps=False))
     assert seen_change
+
+
+def test_index_dict_behaves_like_the_reference_dictionary():
+    """_state.IndexDict stands for IndexDF.to_dict("index") (TrueConsense.py:237) but makes its 30 000 row dictionaries on demand."""
+    from trueconsense_amd import _state
+    from trueconsense_amd.Coverage import BuildCoverage, GetCoverage
+    c = np.arange(70, dtype=np.int32).reshape(10, 7)
+    d = _state.IndexDict(c)
+    ref = {i + 1: dict(zip(_state.COLS, row)) for i, row in enumerate(c.tolist())}
+    assert len(d) == 10 and list(d)[:3] == [1, 2, 3] and 10 in d and 0 not in d and 11 not in d
+    assert d[3] == ref[3] and d.get(11) is None and d.get(4)["A"] == ref[4]["A"]
+    with pytest.raises(KeyError):
+        d[11]
+    with pytest.raises(KeyError):
+        GetCoverage(d, 0)
+    assert GetCoverage(d, 10) == 63 == GetCoverage(ref, 10)
+    assert d == ref and dict(d.items()) == ref and list(d.values())[0] == ref[1]
+    assert np.array_equal(_state.counts_of(d), c) and np.array_equal(_state.counts_of(ref), c)
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        BuildCoverage(d, os.path.join(t, "a.tsv"))
+        BuildCoverage(ref, os.path.join(t, "b.tsv"))
+        assert open(os.path.join(t, "a.tsv")).read() == open(os.path.join(t, "b.tsv")).read() == "".join("%d\t%d\n" % (i + 1, 7 * i) for i in range(10))

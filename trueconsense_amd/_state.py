@@ -77,13 +77,11 @@ class IndexDict(dict):
     def keys(self):
         return range(1, len(self.counts) + 1)
 
-    def values(self):
-        self._fill()
-        return dict.values(self)
+    def values(self):                           # (in key order, like the dictionary this stands for — not in the order of first use)
+        return [self[k] for k in range(1, len(self.counts) + 1)]
 
     def items(self):
-        self._fill()
-        return dict.items(self)
+        return [(k, self[k]) for k in range(1, len(self.counts) + 1)]
 
     def __eq__(self, other):
         self._fill()

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""tools/soak.py [seconds] — the file -> FASTA runner on the benchmark's 8 BAM files, cycled for a while; every FASTA of every
+round is compared with the first round's answer for that file (a race or a rare decoder slip would show as a difference)."""
+import os, sys, tempfile, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench                                                     # noqa: E402
+from trueconsense_amd import synthetic as sy                     # noqa: E402
+from trueconsense_amd.engine import Context, FileRunner          # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+ref, orfs = sy.make_reference()
+L = len(ref)
+tmp = tempfile.mkdtemp(prefix="tcmi_soak_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+paths, _ = bench.write_inputs(tmp, ref, orfs, 8, 1_000_000, 0, False, 6)
+hard, _ = bench.write_inputs(tmp + "_i", ref, orfs, 4, 300_000, 1, True, 6) if os.makedirs(tmp + "_i", exist_ok=True) is None else (None, None)
+paths = paths + hard
+ctx = Context(0)
+runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=2, decode_threads=8, walkers=2, gpu_streams=3)
+want = runner.run(paths, names=["S"] * len(paths), ref_len=L)
+t0, n, bad = time.time(), 0, 0
+while time.time() - t0 < seconds:
+    files = [paths[i % len(paths)] for i in range(96)]
+    got = runner.run(files, names=["S"] * len(files), ref_len=L)
+    for i, g in enumerate(got):
+        n += 1
+        if g != want[i % len(paths)]:
+            bad += 1
+    print("files", n, "differences", bad, flush=True)
+print("soak:", n, "files,", bad, "differences,", runner.decoded_on)
+sys.exit(1 if bad else 0)

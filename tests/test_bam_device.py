@@ -126,6 +126,55 @@ def test_device_inflate_on_other_deflate_flavours(ctx, tmp_path):
         bamwriter.DEFLATE.update(strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, flush_every=0)
 
 
+@pytest.mark.timeout(300)
+def test_damaged_files_end_in_an_error_or_the_right_answer(ctx, tmp_path):
+    """Random damage to the compressed bytes (1 - 3 byte flips per trial, 60 trials, dynamic and fixed-Huffman streams): the
+    device decoder must refuse the file (deflate stream, ISIZE, CRC-32, record chain) — or, where the damage hit a byte
+    nothing depends on (a gzip MTIME, say), give exactly the counts of the intact file.  Never hang, never a wrong answer."""
+    import zlib
+    ref, _ = sy.make_reference(L=6000, cds=[(10, 600)])
+    reads = sy.make_reads(ref, 30_000, seed=13)
+    rng = np.random.default_rng(17)
+    reads["qual"] = rng.integers(0, 42, len(reads["qual"])).astype(np.uint8)
+    L = len(ref)
+    refused = same = 0
+    try:
+        for flavour, (strategy, level) in enumerate(((zlib.Z_DEFAULT_STRATEGY, 6), (zlib.Z_FIXED, 6), (zlib.Z_DEFAULT_STRATEGY, 1))):
+            bamwriter.DEFLATE.update(strategy=strategy)
+            p = str(tmp_path / ("intact%d.bam" % flavour))
+            bamwriter.write_bam(p, reads, "r", L, level=level)
+            d = engine.DeviceBam(p)
+            rs = ctx.upload_bamfile(d)
+            want = ctx.step(rs, L, 30, True)[3].copy()
+            rs.free(); d.close()
+            raw = open(p, "rb").read()
+            for trial in range(20):
+                bad = bytearray(raw)
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(0, len(bad) - 28))] ^= int(rng.integers(1, 256))      # (the EOF block stays)
+                q = str(tmp_path / "damaged.bam")
+                open(q, "wb").write(bytes(bad))
+                try:
+                    d = engine.DeviceBam(q)                 # (the host side may refuse already: block sizes, magic)
+                except _ffi.TcmiError:
+                    refused += 1
+                    continue
+                try:
+                    rs = ctx.upload_bamfile(d)
+                except _ffi.TcmiError as e:
+                    assert e.code in (_ffi.E_FORMAT, _ffi.E_UNSUPPORTED), e
+                    refused += 1
+                else:
+                    got = ctx.step(rs, max(L, rs.max_end), 30, True)[3]
+                    assert got.shape == want.shape and np.array_equal(got, want), (flavour, trial)
+                    same += 1
+                    rs.free()
+                d.close()
+    finally:
+        bamwriter.DEFLATE.update(strategy=zlib.Z_DEFAULT_STRATEGY)
+    assert refused >= 50 and refused + same == 60
+
+
 def test_file_to_counts_all_on_device(ctx, tmp_path):
     ref, orfs = sy.make_reference()
     L = len(ref)

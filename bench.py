@@ -546,7 +546,7 @@ def resident_leg(a, ctx0, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank
     from concurrent.futures import ThreadPoolExecutor
     B = max(1, a.resident_batch)
     pos_stride = (L + 255) // 256 * 256
-    n_walkers = max(1, min(8, (os.cpu_count() or 1)))
+    n_walkers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     pipe = Pipeline(local_rank, slots=a.slots, walkers=n_walkers)
     ctxs = [pipe.slot_context(k) for k in range(a.slots)]
     for kv in a.ctx_option:

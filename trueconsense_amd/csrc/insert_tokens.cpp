@@ -65,8 +65,8 @@ int64_t indel_after(const uint32_t *cg, int64_t n, int64_t k)
 
 // One read on one candidate column, before the filters that depend on the other reads of the column.
 struct Entry {
-    uint64_t key;               // packed token (see below), or 0: `tok` holds the text (insertions of more than 12 bases)
-    std::string tok;
+    uint64_t key;               // packed token (see below), or 0: the text is long_tokens[tok] (insertions of more than 12 bases)
+    int32_t tok = -1;           // (an index, not a string: an entry per read and column is made a few million times per file)
     uint64_t name_hash;         // 0: unnamed
     int64_t end;                // end of the read on the reference (exclusive)
     int32_t pos, tid, mtid, mpos, isize, l_qseq;
@@ -156,8 +156,8 @@ inline void tweak_pair(uint8_t base_first, uint8_t &q_first, uint8_t base_second
 // The column's entries in file order -> the tokens pysam's default pileup would yield, counted.
 //   status bit 0: max_depth dropped reads (modelled);  bit 1: a pair of overlapping mates whose quality tweak could not be
 //   evaluated (no prober given: the caller refuses rather than guesses)
-int finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, Column &C, int32_t *status,
-                    const tcmi_prober *prober)
+int finalize_column(std::vector<Entry> &es, const std::vector<std::string> &long_tokens, int32_t min_base_quality, int64_t max_depth,
+                    int ignore_overlaps, Column &C, int32_t *status, const tcmi_prober *prober)
 {
     // admission: htslib bam_plp_push
     std::vector<uint8_t> in(es.size(), 1);
@@ -220,7 +220,7 @@ int finalize_column(std::vector<Entry> &es, int32_t min_base_quality, int64_t ma
     for (size_t i = 0; i < es.size(); ++i) {
         if (!in[i] || (int)es[i].qual < min_base_quality) continue;                   // pileup_base_qual_skip
         if (es[i].key) C.add_key(es[i].key);
-        else C.add_text(es[i].tok);
+        else C.add_text(long_tokens[(size_t)es[i].tok]);
     }
     return TCMI_OK;
 }
@@ -263,14 +263,15 @@ std::string text_of(uint64_t key)
 }
 
 // every column's entries -> its modal token (first-seen tie-break) and its token count
-int emit_modal(std::vector<std::vector<Entry>> &entries, int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
+int emit_modal(std::vector<std::vector<Entry>> &entries, const std::vector<std::string> &long_tokens, int32_t min_base_quality, int64_t max_depth,
+               int ignore_overlaps, const tcmi_prober *prober, char *tokens,
                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status)
 {
     const size_t n_pos = entries.size();
     int64_t off = 0;
     for (size_t k = 0; k < n_pos; ++k) {
         Column col;
-        const int frc = finalize_column(entries[k], min_base_quality, max_depth, ignore_overlaps, col, status, prober);
+        const int frc = finalize_column(entries[k], long_tokens, min_base_quality, max_depth, ignore_overlaps, col, status, prober);
         if (frc) return frc;
         token_off[k] = off;
         n_tokens[k] = col.n;
@@ -319,7 +320,8 @@ int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const
             E.push_back(std::move(e));
         }
     }
-    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, prober, tokens, tokens_cap, token_off, n_tokens, &status);
+    const std::vector<std::string> no_long_tokens;             // (the device declines insertions that do not fit the key)
+    const int rc = emit_modal(entries, no_long_tokens, min_base_quality, max_depth, ignore_overlaps, prober, tokens, tokens_cap, token_off, n_tokens, &status);
     if (status_flags) *status_flags = status;
     return rc;
 }
@@ -364,6 +366,7 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
     }
     int64_t qoff = 0;
     std::string tok;
+    std::vector<std::string> long_tokens;
     for (const auto &range : ranges)
     for (int64_t i = range.first; i < range.second; ++i) {
         if (windowed && r->qual) qoff = (int64_t)r->qual_off[i];
@@ -451,7 +454,8 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
                             tok.push_back('+');
                             append_number(tok, indel);
                             for (int64_t t = 1; t <= indel; ++t) tok.push_back(base(qpos + t));
-                            e.tok = tok;
+                            e.tok = (int32_t)long_tokens.size();
+                            long_tokens.push_back(tok);
                         }
                         E.push_back(std::move(e));
                         break;
@@ -496,7 +500,7 @@ extern "C" int tcmi_modal_tokens(const tcmi_reads *r, int32_t n_pos, const int64
         }
         return (int)TCMI_OK;
     };
-    const int rc = emit_modal(entries, min_base_quality, max_depth, ignore_overlaps, &prober, tokens, tokens_cap, token_off, n_tokens, &status);
+    const int rc = emit_modal(entries, long_tokens, min_base_quality, max_depth, ignore_overlaps, &prober, tokens, tokens_cap, token_off, n_tokens, &status);
     if (rc) return rc;
     if (status_flags) *status_flags = status;
     return TCMI_OK;

@@ -291,7 +291,7 @@ def main():
 
     cores = max(1, (os.cpu_count() or 1) // max(1, world if not rehearse else 1))
     cores = min(cores, 16)                                       # the box's CPU share per GPU
-    decoders = a.decoders or (2 if cores >= 8 else 1)
+    decoders = a.decoders or (3 if cores >= 12 else 2 if cores >= 8 else 1)     # (readers are near their limit at two on slower hosts)
     decode_threads = a.decode_threads or max(1, cores // decoders)
 
     if a.only_resident:

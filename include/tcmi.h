@@ -129,7 +129,9 @@ enum { TCMI_K_TALLY = 0 /* bit-plane tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZE
        TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */,
        TCMI_K_PACK_CLASSIFY = 4 /* device packer: classify + scan */, TCMI_K_PACK = 5 /* device packer: scatter + pack */,
        TCMI_K_INFLATE = 6 /* device BGZF inflate */, TCMI_K_RECORDS = 7 /* device BAM record walk */,
-       TCMI_K_CRC = 8 /* device CRC-32 of the inflated blocks */, TCMI_K_NKERNELS = 9 };
+       TCMI_K_CRC = 8 /* device CRC-32 of the inflated blocks */,
+       TCMI_K_INFLATE_COPY = 9 /* device BGZF inflate, second kernel: tokens -> bytes (TCMI_K_INFLATE is the first: symbols -> tokens) */,
+       TCMI_K_NKERNELS = 10 };
 int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
 int  tcmi_profile_reset(tcmi_ctx *ctx);
 int  tcmi_profile_get(tcmi_ctx *ctx, int kernel, double *total_ms, int64_t *launches);

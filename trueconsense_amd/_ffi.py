@@ -18,7 +18,7 @@ TCMI_OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_FORMAT, E_IO, E_KEYERROR, E_ZERODIV, E_UNSUPPORTED = range(-1, -10, -1)
 COLS = ("coverage", "A", "T", "C", "G", "X", "I")        # indexing.py:134
 F_LOWCOV, F_PRIMX, F_MINDEL, F_INSCAND, F_COVGT, F_COVZERO, F_AMBIG = 1, 2, 4, 8, 16, 32, 64
-K_TALLY, K_CALL, K_ZERO, K_TALLY_GENERAL, K_PACK_CLASSIFY, K_PACK, K_INFLATE, K_RECORDS, K_CRC = range(9)
+K_TALLY, K_CALL, K_ZERO, K_TALLY_GENERAL, K_PACK_CLASSIFY, K_PACK, K_INFLATE, K_RECORDS, K_CRC, K_INFLATE_COPY = range(10)
 
 
 class TcmiError(RuntimeError):

@@ -38,7 +38,7 @@
 #include <thread>
 #include <vector>
 
-#include "tcmi_internal.h"
+#include "bgzf_device.h"
 
 namespace {
 
@@ -50,30 +50,9 @@ constexpr int WIN = TCMI_INFLATE_WIN, WMASK = WIN - 1;   // LDS ring: the most r
 constexpr int SEG = TCMI_INFLATE_WIN >= 4096 ? 2048 : TCMI_INFLATE_WIN / 2;   // flush granularity
 constexpr int NEAR = WIN - 264;                 // matches up to this distance are copied LDS -> LDS
 static_assert(SEG <= WIN - 528 && (WIN & (WIN - 1)) == 0 && WIN % SEG == 0 && SEG % 1024 == 0, "a far match must find its source flushed");
-#ifndef TCMI_INFLATE_LL_ROOT
-#define TCMI_INFLATE_LL_ROOT 9
-#endif
-#ifndef TCMI_INFLATE_D_ROOT
-#define TCMI_INFLATE_D_ROOT 8
-#endif
-constexpr int LL_ROOT = TCMI_INFLATE_LL_ROOT, D_ROOT = TCMI_INFLATE_D_ROOT, CL_ROOT = 7;   // root-table bits; longer codes take slow_decode
-static_assert(D_ROOT >= CL_ROOT, "the code-length table borrows the distance table's LDS");
-constexpr int MAX_REC_PER_BLOCK = 65536 / 36 + 2;   // a record is at least 36 bytes (block_size + 32 fixed + 1 name byte ..)
 
-struct BlockDesc {
-    uint64_t cin;        // first byte of the deflate payload in the file
-    uint64_t uout;       // first byte of its output in the inflated stream
-    uint32_t clen;       // payload bytes
-    uint32_t ulen;       // ISIZE
-    int32_t entry;       // offset of the first record start inside this block (>= 0), or -1: no record walk (header blocks)
-    uint32_t tok_cap;    // tokens this block may produce at most (bgzf_symbols)
-    uint64_t tok;        // its first token in the token array
-};
 
-// status word of a block
-enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_BAD_LENGTH = 2, ST_BAD_RECORD = 3, ST_BAD_CRC = 4 };
 
-__constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct InflateArgs {
     const uint32_t *__restrict__ file32;     // the file as 4-byte words (16-byte aligned base, >= 64 bytes of slack behind it)
@@ -91,7 +70,6 @@ struct InflateArgs {
 #endif
 constexpr int IN_RING = TCMI_INFLATE_INRING;    // dwords of compressed input staged in LDS (two halves)
 
-__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Canonical Huffman decode (puff.c's loop) of a code that is known to be longer than `root` bits (the root table said so),
 // wave-uniform: the canonical decoder's state after `root` bits depends on the counts alone (`rs` = {first, index} at that point, left by build_table), and
@@ -115,13 +93,6 @@ __device__ inline int long_code(const uint16_t *cnt, const uint16_t *sym, const 
     return -1;
 }
 
-// Root-table entries (32 bits): code length in bits 0-3 (0: not in the root table — a longer code or none), kind in bits 8-10;
-// a literal in bits 16-23; a distance: extra bits in bits 4-7, base in bits 16-31; a length: see make_entry.  The hot loop needs
-// no arithmetic on symbols.
-constexpr uint32_t E_LIT = 1u << 8, E_BASE = 1u << 9, E_EOB = 1u << 10;
-enum { K_LITLEN = 0, K_DIST = 1, K_CODELEN = 2 };
-
-typedef uint32_t tab_t;             // (16-bit entries with base / extra bits computed per symbol: half the table LDS, measured slower)
 
 struct InflateLds {
     __attribute__((aligned(16))) uint8_t win[WIN];      // the most recent output
@@ -196,110 +167,6 @@ __device__ inline uint32_t take(Bits &b, int n)     // n <= 25, after a refill
     b.bb >>= n;
     b.bc -= n;
     return v;
-}
-
-
-__device__ inline uint32_t make_entry(int kind, int sym, int nbits)
-{
-    if (sym < 0) return 0u;
-    if (kind == K_CODELEN) return (uint32_t)nbits | ((uint32_t)sym << 16);
-    if (kind == K_LITLEN) {
-        if (sym < 256) return (uint32_t)nbits | E_LIT | ((uint32_t)sym << 16);
-        if (sym == 256) return (uint32_t)nbits | E_EOB;
-        const int s = sym - 257;
-        if (s > 28) return 0u;                                  // 286, 287: not a symbol
-        int eb = 0, base = 3 + s;
-        if (s == 28) base = 258;
-        else if (s >= 8) { eb = (s >> 2) - 1; base = 3 + ((4 + (s & 3)) << eb); }
-        // a LENGTH entry is laid out for the ISA loop: extra-bit count in bits 16-19 (with the code length in bits 0-3 that is an
-        // s_bfe_u32 operand: entry & 0x000F000F), code + extra bits in bits 11-15, base length in bits 20-28
-        return (uint32_t)nbits | ((uint32_t)(nbits + eb) << 11) | E_BASE | ((uint32_t)eb << 16) | ((uint32_t)base << 20);
-    }
-    if (sym > 29) return 0u;                                    // 30, 31: not a distance
-    int eb = 0, base = 1 + sym;
-    if (sym >= 4) { eb = (sym >> 1) - 1; base = 1 + ((2 + (sym & 1)) << eb); }
-    return (uint32_t)nbits | ((uint32_t)eb << 4) | E_BASE | ((uint32_t)base << 16);
-}
-
-// lens[0 .. n) -> cnt[1 .. 15], canonically ordered symbols, and the root table.  Returns false for an over-subscribed code.
-// The kernel is bound by instruction issue, and a quarter of its instructions were spent here: so the per-length counters,
-// offsets and first codes live in scalar registers (both loops over the 15 lengths are unrolled: the indices are constants),
-// no read-modify-write goes through LDS, and a table slot is decoded by nine compare-and-select steps against those scalars
-// instead of a bit-by-bit walk with an LDS read per bit.  MAXG: groups of 64 symbols (5 for the 286 literal/length codes).
-template <int MAXG, int ROOT>
-__device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, tab_t *tab, int kind, uint32_t *rs)
-{
-    const int lane = threadIdx.x;
-    __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
-    int l[MAXG];
-#pragma unroll
-    for (int g = 0; g < MAXG; ++g) l[g] = g * 64 + lane < n ? (int)lens[g * 64 + lane] : 0;
-    // histogram of the code lengths: one ballot per length and group (wave-uniform counters)
-    int c[16];
-#pragma unroll
-    for (int len = 0; len < 16; ++len) c[len] = 0;
-#pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
-#pragma unroll
-        for (int len = 1; len <= 15; ++len) c[len] += (int)__popcll(__ballot(l[g] == len));
-    }
-    // ... to LDS for the long-code walk (long_code(), slow_decode())
-    {
-        int mine = 0;
-#pragma unroll
-        for (int len = 1; len <= 15; ++len) mine = lane == len ? c[len] : mine;
-        if (lane < 16) cnt[lane] = (uint16_t)mine;
-    }
-    // offsets of each length in the sorted symbol array, first code of each length; over-subscription check
-    int off[16], first[16];
-    int left = 1, o = 0, f = 0;
-    bool ok = true;
-#pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-        left = (left << 1) - c[len];
-        if (left < 0) ok = false;
-        off[len] = o;
-        first[len] = f;
-        o += c[len];
-        f = (f + c[len]) << 1;
-        if (len == ROOT && lane == 0) { rs[0] = (uint32_t)f; rs[1] = (uint32_t)o; }    // long_code() starts here
-    }
-    // rank of every symbol among those of its length, in symbol order -> its slot in the sorted array
-    {
-        int nx[16];
-#pragma unroll
-        for (int len = 1; len <= 15; ++len) nx[len] = off[len];
-#pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
-#pragma unroll
-            for (int len = 1; len <= 15; ++len) {
-                const unsigned long long m = __ballot(l[g] == len);
-                if (m) {
-                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (l[g] == len) sym[nx[len] + below] = (uint16_t)(g * 64 + lane);
-                    nx[len] += (int)__popcll(m);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // root table: slot i holds the symbol whose code is a prefix of the bits of i (first stream bit = bit 0): the code of
-    // length len that the slot starts with is p = reverse(i)'s top len bits; it exists if first[len] <= p < first[len] + c[len]
-    // (for a prefix code at most one length answers)
-    for (int i = lane; i < (1 << ROOT); i += 64) {
-        const uint32_t r = __builtin_bitreverse32((uint32_t)i) >> (32 - ROOT);
-        int L = 0, si = 0;
-#pragma unroll
-        for (int len = 1; len <= ROOT; ++len) {
-            const uint32_t d = (r >> (ROOT - len)) - (uint32_t)first[len];
-            const bool hit = d < (uint32_t)c[len];
-            L = hit ? len : L;
-            si = hit ? off[len] + (int)d : si;
-        }
-        tab[i] = L ? make_entry(kind, (int)sym[si], L) : 0u;
-    }
-    __syncthreads();
-    return uni(ok ? 1u : 0u) != 0;
 }
 
 
@@ -866,520 +733,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate(InflateArgs a)
     }
 }
 
-// =============================================================================================================================
-// The two-kernel decoder: bgzf_symbols (Huffman symbols -> tokens, 64 lanes of a wavefront decoding ONE block speculatively in
-// parallel) and bgzf_copy (tokens -> bytes: the LZ77 copies through an LDS ring, the record chain, the flush).
-//
-// Why two kernels.  A deflate stream is serial twice over: the position of symbol k + 1 is known only when symbol k is decoded,
-// and a match may copy what the previous match produced.  The one-kernel decoder above walks both chains in one wavefront, one
-// symbol at a time, ~60 wave-instructions per symbol, all of them issued for a single useful lane.  Here the first chain is cut
-// into 64 pieces: lane c starts decoding at bit s_c = start + c * chunk — in the middle of nowhere, except for lane 0 — and
-// notes, in a window of WBITS bits behind s_c, every bit position on which it starts a symbol.  Huffman streams resynchronise:
-// after a few dozen bits a decoder that started on a wrong bit starts a symbol on a right one, and from there on it IS the
-// serial decoder.  A lane stops when a symbol of its own starts on a position that the lane in front of it has noted: from
-// there the two would decode the same (pass A).  Starting from lane 0 the chain of merge points says which lane holds the true
-// symbols of which bit range and how many they are; an exclusive sum gives every such lane its place in the block's token
-// array, and it decodes its range once more, for real (pass B).  Nothing in this depends on luck or timing: a lane that never
-// merges simply goes on to the block's end, and lane 0 alone is the serial decoder.  Measured on the bench files
-// (tools/spec_inflate_proto.py, the same scheme in Python): 1 600 symbols in 96 + 87 lock-step rounds, 6 900 in 298 + 291.
-//
-// Tokens (32 bits): literal 1<<31 | byte; match len (9 bits) | (dist - 1) << 9; raw 1<<30 | len << 17 | offset of the bytes from
-// the block's payload start (a stored deflate block, in pieces of <= 8 191 bytes).  bgzf_copy takes 64 tokens at a time: an
-// inclusive scan of the lengths gives every token its output position, all literals of a round go to the ring at once, the
-// matches one after the other (each copied by all 64 lanes).
-constexpr int WBITS = 256;                          // bits behind its start in which a lane notes the symbols it starts
-constexpr int MARK_W = WBITS / 32 + 1;              // (+1: odd stride, lanes c and c + 4 would share banks otherwise)
-constexpr int CWIN = 8192, CWMASK = CWIN - 1;       // bgzf_copy's ring of recent output
-constexpr int CSEG = 2048;
-// a round of bgzf_copy writes the literals of up to CSEG + 258 bytes ahead of the match it copies: what a match may still read
-// from the ring ends that much earlier; a source further back has been flushed (CWIN >= 2 CSEG + 522)
-constexpr int CNEAR = CWIN - CSEG - 264;
-static_assert(CWIN >= 2 * CSEG + 528 && (CWIN & (CWIN - 1)) == 0 && CWIN % CSEG == 0, "a far match must find its source flushed");
-constexpr uint32_t TOK_LIT = 1u << 31, TOK_RAW = 1u << 30;
-constexpr uint32_t RAW_PIECE = 8191;
-
-struct SymLds {
-    tab_t ll[1 << LL_ROOT];
-    tab_t dt[1 << D_ROOT];                          // (the code-length table borrows it)
-    uint32_t marks[64][MARK_W];
-    uint16_t sym_ll[288], sym_d[32], sym_cl[20];
-    uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
-    uint32_t rs[6];
-    uint8_t lens[320];
-    uint8_t cll[20];
-};
-
-struct SymArgs {
-    const uint32_t *__restrict__ file32;
-    const BlockDesc *blocks;
-    uint32_t *tokens;           // block b's tokens at tokens + blocks[b].tok
-    uint32_t *n_tok;            // [n_blocks]
-    uint32_t *status;           // [n_blocks]
-    int32_t n_blocks;
-    uint32_t pay_dwords;        // dwords of dynamic LDS behind SymLds: the largest block's payload + slack
-};
-
-// wave-uniform reads of the staged payload (header fields, code lengths): stateless, two LDS words per look
-__device__ inline uint32_t u_peek(const uint32_t *pay, uint32_t pos)      // 32 bits from bit `pos` on
-{
-    const uint32_t w = pos >> 5, sh = pos & 31u;
-    const uint64_t two = ((uint64_t)pay[w + 1] << 32) | pay[w];
-    return uni((uint32_t)(two >> sh));
-}
-
-// a lane's own bit reader over the staged payload
-struct LaneBits { uint64_t bb; int32_t bc; uint32_t wi, nx; };
-__device__ inline void lb_seek(LaneBits &b, const uint32_t *pay, uint32_t bit)
-{
-    const uint32_t w = bit >> 5, sh = bit & 31u;
-    b.bb = (uint64_t)(pay[w] >> sh);
-    b.bc = 32 - (int32_t)sh;
-    b.wi = w + 1;
-    b.nx = pay[b.wi];
-}
-__device__ inline void lb_refill(LaneBits &b, const uint32_t *pay)
-{
-    if (b.bc <= 32) {
-        b.bb |= (uint64_t)b.nx << b.bc;
-        b.bc += 32;
-        ++b.wi;
-        b.nx = pay[b.wi];
-    }
-}
-__device__ inline uint32_t lb_pos(const LaneBits &b) { return b.wi * 32u - (uint32_t)b.bc; }
-
-// long_code() for a lane of its own (no wave-uniform shortcuts)
-__device__ inline int long_code_lane(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, uint32_t v, int root)
-{
-    int first = (int)rs[0], index = (int)rs[1];
-    int code = (int)((__builtin_bitreverse32(v) >> (32 - root)) << 1);
-    v >>= root;
-    for (int len = root + 1; len <= 15; ++len) {
-        code |= (int)(v & 1u);
-        v >>= 1;
-        const int c = (int)cnt[len];
-        if (code - c < first) return (int)sym[index + (code - first)] | (len << 16);
-        index += c;
-        first = (first + c) << 1;
-        code <<= 1;
-    }
-    return -1;
-}
-
-// one literal / match / end-of-block symbol at the lane's position.  -> 0 literal, 1 match (tok set), 2 end of block, 3 no such code
-enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
-__device__ inline int sym_step(LaneBits &b, const SymLds &L, const uint32_t *pay, uint32_t &tok)
-{
-    lb_refill(b, pay);
-    uint32_t e = L.ll[(uint32_t)b.bb & ((1u << LL_ROOT) - 1u)];
-    if ((e & 15u) == 0) {
-        const int sl = long_code_lane(L.cnt_ll, L.sym_ll, L.rs, (uint32_t)b.bb, LL_ROOT);
-        e = sl < 0 ? 0u : make_entry(K_LITLEN, sl & 0xFFFF, sl >> 16);
-        if ((e & 15u) == 0) return SY_BAD;
-    }
-    const uint32_t nb = e & 15u;
-    b.bb >>= nb;
-    b.bc -= (int32_t)nb;
-    if (e & E_LIT) { tok = TOK_LIT | ((e >> 16) & 0xFFu); return SY_LIT; }
-    if (e & E_EOB) return SY_EOB;
-    const uint32_t eb = (e >> 16) & 15u;
-    const uint32_t len = ((e >> 20) & 0x1FFu) + ((uint32_t)b.bb & ((1u << eb) - 1u));
-    b.bb >>= eb;
-    b.bc -= (int32_t)eb;
-    lb_refill(b, pay);
-    uint32_t f = L.dt[(uint32_t)b.bb & ((1u << D_ROOT) - 1u)];
-    if ((f & 15u) == 0) {
-        const int sl = long_code_lane(L.cnt_d, L.sym_d, L.rs + 2, (uint32_t)b.bb, D_ROOT);
-        f = sl < 0 ? 0u : make_entry(K_DIST, sl & 0xFFFF, sl >> 16);
-        if ((f & 15u) == 0) return SY_BAD;
-    }
-    const uint32_t nd = f & 15u;
-    b.bb >>= nd;
-    b.bc -= (int32_t)nd;
-    const uint32_t eb2 = (f >> 4) & 15u;
-    const uint32_t dist = (f >> 16) + ((uint32_t)b.bb & ((1u << eb2) - 1u));
-    b.bb >>= eb2;
-    b.bc -= (int32_t)eb2;
-    tok = len | ((dist - 1u) << 9);
-    return SY_MATCH;
-}
-
-__global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
-{
-    __shared__ SymLds L;
-    extern __shared__ uint32_t pay[];               // the block's compressed payload, from the dword that holds its first byte on
-    const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
-    if (blk >= a.n_blocks) return;
-    const BlockDesc d = a.blocks[blk];
-    uint32_t *const toks = a.tokens + d.tok;
-    const uint32_t cap = d.tok_cap;
-    // ---- the payload into LDS (+ 4 dwords: a reader may look a few bytes past the end; the file buffer has the slack) ----
-    const uint32_t base_bit = (uint32_t)(d.cin & 3u) * 8u;
-    const uint32_t end = base_bit + d.clen * 8u;                    // first bit behind the payload
-    {
-        const uint32_t *src = a.file32 + (d.cin >> 2);
-        const uint32_t n = min(a.pay_dwords, (end + 31u) / 32u + 4u);
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay[i] = src[i];
-    }
-    __syncthreads();
-    uint32_t pos = base_bit;            // wave-uniform
-    uint32_t ntok = 0;
-    uint32_t err = ST_OK;
-    bool last = false;
-    while (!last && err == ST_OK) {
-        if (pos + 3u > end) { err = ST_BAD_STREAM; break; }
-        const uint32_t h = u_peek(pay, pos);
-        last = (h & 1u) != 0;
-        const uint32_t type = (h >> 1) & 3u;
-        pos += 3;
-        if (type == 0) {
-            // ---- stored block: byte-align, LEN / NLEN, LEN raw bytes -> raw tokens ------------------------------------------
-            pos = (pos + 7u) & ~7u;
-            if (pos + 32u > end) { err = ST_BAD_STREAM; break; }
-            const uint32_t v = u_peek(pay, pos);
-            const uint32_t len = v & 0xFFFFu;
-            if (((v >> 16) ^ len) != 0xFFFFu) { err = ST_BAD_STREAM; break; }
-            pos += 32;
-            if (pos + len * 8u > end) { err = ST_BAD_STREAM; break; }
-            const uint32_t off = (pos - base_bit) >> 3;
-            const uint32_t pieces = (len + RAW_PIECE - 1u) / RAW_PIECE;
-            if (ntok + pieces > cap) { err = ST_BAD_STREAM; break; }
-            if ((uint32_t)lane < pieces) {
-                const uint32_t o = (uint32_t)lane * RAW_PIECE;
-                toks[ntok + (uint32_t)lane] = TOK_RAW | (min(len - o, RAW_PIECE) << 17) | (off + o);
-            }
-            ntok += pieces;
-            pos += len * 8u;
-            continue;
-        }
-        if (type == 3) { err = ST_BAD_STREAM; break; }
-        // ---- code lengths, tables (as in bgzf_inflate) ------------------------------------------------------------------------
-        int nlen = 288, ndist = 32;
-        if (type == 1) {
-            __syncthreads();
-            for (int i = lane; i < 320; i += 64) L.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
-        } else {
-            if (pos + 14u > end) { err = ST_BAD_STREAM; break; }
-            const uint32_t hh = u_peek(pay, pos);
-            nlen = (int)(hh & 31u) + 257;
-            ndist = (int)((hh >> 5) & 31u) + 1;
-            const int ncode = (int)((hh >> 10) & 15u) + 4;
-            pos += 14;
-            if (nlen > 286 || ndist > 30) { err = ST_BAD_STREAM; break; }
-            __syncthreads();
-            if (lane < 19) L.cll[lane] = 0;
-            __syncthreads();
-            // (19 x 3 bits: three looks of up to 8 lengths each, lane k takes the k-th)
-            for (int i0 = 0; i0 < ncode; i0 += 8) {
-                const uint32_t v = u_peek(pay, pos + (uint32_t)i0 * 3u);
-                const int k = i0 + lane;
-                if (lane < 8 && k < ncode) L.cll[CL_ORDER[k]] = (uint8_t)((v >> (3 * lane)) & 7u);
-            }
-            pos += (uint32_t)ncode * 3u;
-            if (uni(build_table<1, CL_ROOT>(L.cll, 19, L.cnt_cl, L.sym_cl, L.dt, K_CODELEN, L.rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-            for (int i = lane; i < 320; i += 64) L.lens[i] = 0;
-            __syncthreads();
-            uint32_t got = 0, prev = 0;
-            const uint32_t total = (uint32_t)(nlen + ndist);
-            while (got < total) {
-                if (pos > end) { err = ST_BAD_STREAM; break; }
-                const uint32_t v = u_peek(pay, pos);
-                const uint32_t e = uni(L.dt[v & ((1u << CL_ROOT) - 1u)]);
-                const uint32_t nb = e & 15u, sym = e >> 16;
-                if (nb == 0) { err = ST_BAD_STREAM; break; }
-                pos += nb;
-                const uint32_t x = v >> nb;
-                uint32_t rep = 1, val = sym;
-                if (sym == 16) { if (got == 0) { err = ST_BAD_STREAM; break; } rep = 3 + (x & 3u); val = prev; pos += 2; }
-                else if (sym == 17) { rep = 3 + (x & 7u); val = 0; pos += 3; }
-                else if (sym == 18) { rep = 11 + (x & 127u); val = 0; pos += 7; }
-                if (got + rep > total) { err = ST_BAD_STREAM; break; }
-                if (val != 0) {
-                    if (rep == 1) { if (lane == 0) L.lens[got] = (uint8_t)val; }
-                    else if ((uint32_t)lane < rep) L.lens[got + (uint32_t)lane] = (uint8_t)val;
-                }
-                got += rep;
-                prev = val;
-            }
-            if (err != ST_OK) break;
-            __syncthreads();
-            if (uni(L.lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
-        }
-        if (uni(build_table<5, LL_ROOT>(L.lens, nlen, L.cnt_ll, L.sym_ll, L.ll, K_LITLEN, L.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table<1, D_ROOT>(L.lens + nlen, ndist, L.cnt_d, L.sym_d, L.dt, K_DIST, L.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (pos >= end) { err = ST_BAD_STREAM; break; }
-
-        // ---- pass A: every lane decodes from its own start until it meets the lane in front --------------------------------------
-        const uint32_t start = pos;
-        const uint32_t chunk = (end - start + 63u) / 64u;           // >= 1
-        const uint32_t s_c = start + (uint32_t)lane * chunk;
-        enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
-        uint32_t state = s_c < end ? RUN : DEAD;
-        uint32_t tgt = (uint32_t)lane + 1u, mpos = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < MARK_W; ++k) L.marks[lane][k] = 0;
-        LaneBits b;
-        lb_seek(b, pay, min(s_c, end));
-        __syncthreads();
-        while (__ballot(state == RUN)) {
-            const uint32_t p = lb_pos(b);
-            const uint32_t rel = p - s_c;
-            if (state == RUN && rel < (uint32_t)WBITS) L.marks[lane][rel >> 5] |= 1u << (rel & 31u);
-            __syncthreads();                        // (one wavefront: orders the notes before the looks)
-            if (state == RUN) {
-                while (tgt < 64u && p >= start + tgt * chunk + (uint32_t)WBITS) ++tgt;
-                if (tgt < 64u) {
-                    const uint32_t s_t = start + tgt * chunk;
-                    if (p >= s_t) {
-                        const uint32_t r = p - s_t;
-                        if ((L.marks[tgt][r >> 5] >> (r & 31u)) & 1u) { state = MERGED; mpos = p; }
-                    }
-                }
-            }
-            if (state == RUN) {
-                uint32_t tok;
-                const int k = p >= end ? SY_BAD : sym_step(b, L, pay, tok);
-                if (k == SY_BAD || lb_pos(b) > end) state = DEAD;
-                else {
-                    ++total;
-                    if (k == SY_EOB) state = EOB;
-                }
-            }
-        }
-        // ---- the chain of lanes that hold the true symbols: lane 0 from `start`, then whoever it met, ... ---------------------
-        uint32_t myP = start;
-        bool alive = lane == 0;
-        uint32_t eob_pos = 0;
-        {
-            uint32_t c = 0;
-            for (;;) {
-                const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)state, (int)c);
-                if (st == MERGED) {
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mpos, (int)c);
-                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tgt, (int)c);
-                    if ((uint32_t)lane == t) { alive = true; myP = m; }
-                    c = t;
-                } else {
-                    if (st == EOB) eob_pos = (uint32_t)__builtin_amdgcn_readlane((int)lb_pos(b), (int)c);
-                    else err = ST_BAD_STREAM;
-                    break;
-                }
-            }
-        }
-        if (err != ST_OK) break;
-        // symbols a lane decoded in front of its true start do not count (all of them are noted: the start lies in its window)
-        uint32_t cnt = 0;
-        if (alive) {
-            const uint32_t lim = myP - s_c;         // < WBITS for every lane but 0, where it is 0
-            uint32_t before = 0;
-#pragma unroll
-            for (int k = 0; k < WBITS / 32; ++k) {
-                const uint32_t w = L.marks[lane][k];
-                const uint32_t lo = (uint32_t)k * 32u;
-                const uint32_t m = lim >= lo + 32u ? 0xFFFFFFFFu : lim > lo ? (1u << (lim - lo)) - 1u : 0u;
-                before += (uint32_t)__popc(w & m);
-            }
-            cnt = total - before;
-            if (state == EOB) --cnt;                // (the end-of-block code is a symbol, not a token)
-        }
-        // exclusive sum over the lanes -> every lane's place in the token array
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, dlt, 64);
-            if (lane >= dlt) incl += up;
-        }
-        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (ntok + all > cap) { err = ST_BAD_STREAM; break; }
-        // ---- pass B: the true ranges once more, tokens out --------------------------------------------------------------------------
-        {
-            uint32_t *dst = toks + ntok + (incl - cnt);
-            if (alive) lb_seek(b, pay, myP);
-            uint32_t i = 0;
-            while (__ballot(alive && i < cnt)) {
-                if (alive && i < cnt) {
-                    uint32_t tok = 0;
-                    (void)sym_step(b, L, pay, tok);
-                    dst[i] = tok;
-                    ++i;
-                }
-            }
-        }
-        ntok += all;
-        pos = eob_pos;
-        __syncthreads();
-    }
-    if (lane == 0) {
-        a.n_tok[blk] = ntok;
-        a.status[blk] = err;
-    }
-}
-
-struct CopyArgs {
-    const uint8_t *file;        // compressed file (raw tokens copy from it)
-    const BlockDesc *blocks;
-    const uint32_t *tokens;
-    const uint32_t *n_tok;
-    uint8_t *out;
-    uint32_t *rec_slot;
-    uint32_t *n_rec;
-    int32_t *overshoot;
-    uint32_t *status;           // in: bgzf_symbols' verdict; out: the block's
-    int32_t n_blocks;
-};
-
-__global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[CWIN];
-    const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
-    if (blk >= a.n_blocks) return;
-    const BlockDesc d = a.blocks[blk];
-    const uint32_t ulen = d.ulen;
-    uint32_t err = uni(a.status[blk]);
-    const uint32_t ntok = err == ST_OK ? uni(a.n_tok[blk]) : 0u;
-    const uint32_t *toks = a.tokens + d.tok;
-    uint8_t *const out = a.out + d.uout;
-    const uint8_t *const payload = a.file + d.cin;
-    uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
-
-    uint32_t op = 0, flushed = 0;
-    uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
-    uint32_t n_rec = 0, bad_rec = 0, rec_buf = 0;
-    uint32_t next_evt = 0;
-    uint32_t bad = 0;
-
-    // list the record starts whose block_size field is complete, flush the segments that are complete (bgzf_inflate's housekeeping)
-    auto housekeeping = [&]() __attribute__((always_inline)) {
-        while (next_rec + 4 <= op) {
-            const uint32_t at = next_rec & CWMASK;
-            const uint32_t w = reinterpret_cast<const uint32_t *>(s_win)[((at >> 2) + (uint32_t)lane) & (CWIN / 4 - 1)];
-            const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
-            const uint32_t ubs = (uint32_t)(two >> ((at & 3u) * 8u));
-            if (__builtin_expect(ubs - 32u > (1u << 28) - 32u, 0)) { bad_rec = 1; break; }
-            rec_buf = (uint32_t)lane == (n_rec & 63u) ? next_rec : rec_buf;
-            if ((n_rec & 63u) == 63u) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
-            ++n_rec;
-            next_rec += 4u + ubs;
-        }
-        if (bad_rec) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; }
-        while (op - flushed >= CSEG) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & CWMASK));
-            uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
-#pragma unroll
-            for (int k = 0; k < CSEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
-            flushed += CSEG;
-        }
-        next_evt = flushed + (uint32_t)CSEG;
-    };
-    // a match: all lanes; with dist < len the pattern of the last `dist` bytes repeats
-    auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {
-        if (dist > at) { bad = 1; return; }                      // before the block's first byte
-        if (dist > (uint32_t)CNEAR) {
-            const uint8_t *src = out + (at - dist);             // flushed by this wavefront (see CNEAR)
-#pragma clang loop vectorize(disable) unroll(disable)
-            for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(at + i) & CWMASK] = src[i];
-        } else if (dist >= len) {
-#pragma clang loop vectorize(disable) unroll(disable)
-            for (uint32_t i = (uint32_t)lane; i < len; i += 64) s_win[(at + i) & CWMASK] = s_win[(at + i - dist) & CWMASK];
-        } else {
-            const float inv = 1.0f / (float)dist;
-#pragma clang loop vectorize(disable) unroll(disable)
-            for (int i = lane; i < (int)len; i += 64) {
-                int qd = (int)((float)i * inv);
-                int r = i - qd * (int)dist;
-                if (r < 0) r += (int)dist;
-                if (r >= (int)dist) r -= (int)dist;
-                s_win[(at + i) & CWMASK] = s_win[(at - dist + r) & CWMASK];
-            }
-        }
-    };
-    housekeeping();
-    for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
-        const uint32_t t = base + (uint32_t)lane < ntok ? toks[base + (uint32_t)lane] : 0u;
-        const bool is_lit = (t >> 31) != 0;
-        const bool is_raw = !is_lit && (t & TOK_RAW);
-        if (__ballot(is_raw)) {
-            // ---- a batch with stored bytes in it: token by token (rare: incompressible data, flush markers) --------------------
-            const uint32_t nb = min(64u, ntok - base);
-            for (uint32_t j = 0; j < nb && err == ST_OK && !bad; ++j) {
-                const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)j);
-                if (tj >> 31) {
-                    if (op + 1 > ulen) { err = ST_BAD_LENGTH; break; }
-                    s_win[op & CWMASK] = (uint8_t)tj;
-                    ++op;
-                } else if (tj & TOK_RAW) {
-                    uint32_t len = (tj >> 17) & 0x1FFFu;
-                    const uint8_t *src = payload + (tj & 0x1FFFFu);
-                    if (op + len > ulen) { err = ST_BAD_LENGTH; break; }
-                    while (len) {
-                        const uint32_t n = min(len, (uint32_t)CSEG - (op & (CSEG - 1)));
-#pragma clang loop vectorize(disable) unroll(disable)
-                        for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & CWMASK] = src[i];
-                        op += n; src += n; len -= n;
-                        if (op >= next_evt) { housekeeping(); if (err != ST_OK) break; }
-                    }
-                } else {
-                    const uint32_t len = tj & 511u, dist = ((tj >> 9) & 0x7FFFu) + 1u;
-                    if (op + len > ulen) { err = ST_BAD_LENGTH; break; }
-                    copy_match(op, len, dist);
-                    op += len;
-                }
-                if (op >= next_evt) housekeeping();
-            }
-            continue;
-        }
-        const uint32_t mylen = is_lit ? 1u : (t & 511u);
-        const uint32_t dist = ((t >> 9) & 0x7FFFu) + 1u;
-        uint32_t incl = mylen;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, dlt, 64);
-            if (lane >= dlt) incl += up;
-        }
-        const uint32_t dst = op + incl - mylen;                 // where this lane's token starts
-        const uint32_t batch_end = op + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (batch_end > ulen) { err = ST_BAD_LENGTH; break; }
-        uint32_t t_cur = 0;
-        while (t_cur < 64u) {
-            // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
-            const unsigned long long from = ~0ull << t_cur;
-            const unsigned long long ge = __ballot(dst >= next_evt) & from;
-            const uint32_t t_stop = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
-            const unsigned long long rng = t_stop < 64u ? from & ~(~0ull << t_stop) : from;
-            const bool mine = (rng >> lane) & 1ull;
-            if (mine && is_lit) s_win[dst & CWMASK] = (uint8_t)t;
-            unsigned long long mm = __ballot(mine && !is_lit && mylen != 0);
-            while (mm) {
-                const int j = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)dst, j);
-                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mylen, j);
-                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
-                copy_match(at, len, dj);
-            }
-            op = t_stop < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)t_stop) : batch_end;
-            t_cur = t_stop;
-            if (op >= next_evt) { housekeeping(); if (err != ST_OK) break; }
-            if (bad) break;
-        }
-    }
-    if (bad && err == ST_OK) err = ST_BAD_STREAM;
-    if (err == ST_OK && op != ulen) err = ST_BAD_LENGTH;
-    if (err == ST_OK) {
-        housekeeping();
-        const uint32_t rest = op - flushed;
-        for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & CWMASK];
-    }
-    if ((uint32_t)lane < (n_rec & 63u)) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
-    if (lane == 0) {
-        a.status[blk] = err;
-        a.n_rec[blk] = n_rec;
-        a.overshoot[blk] = d.entry >= 0 && next_rec < 0xFFFFFFF0u ? (int32_t)(next_rec - ulen) : 0;
-    }
-}
-
 // ---- bgzf_crc32: the CRC-32 of every block's inflated bytes against the value in the block's trailer (SAM spec §4.1; htslib
 // checks it on every block it reads).  One wavefront per block, four blocks per workgroup.  The block is read in rows of
 // 1 KiB, coalesced: lane l takes the 16 bytes at l * 16 of every row (the rows are cut from the block's END, so the short row
@@ -1686,7 +1039,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         b.tok_cap = std::min(b.ulen, 8u * b.clen) + b.clen / 2 + 8;
         b.tok = f->tok_total;
         f->tok_total += (b.tok_cap + 3u) & ~3u;
-        f->pay_dwords = std::max(f->pay_dwords, (uint32_t)(((b.cin & 3u) * 8u + b.clen * 8u + 31u) / 32u + 4u));
+        f->pay_dwords = std::max(f->pay_dwords, (uint32_t)(((b.cin & 3u) * 8u + b.clen * 8u + 31u) / 32u + 6u));
         uout += ((size_t)b.ulen + 15) & ~(size_t)15;            // every block's output starts 16-byte aligned on the device
         off += bsize;
         f->blocks.push_back(b);
@@ -1806,7 +1159,6 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     a.blocks = d_desc; a.out = d_out; a.rec_slot = d_slot; a.n_rec = d_nrec; a.overshoot = d_over; a.status = d_stat;
     a.n_blocks = (int32_t)nb;
     (void)hipGetLastError();
-    tcmi_prof_begin(ctx, TCMI_K_INFLATE);
     static const bool occ_once = [] {
         if (std::getenv("TCMI_INFLATE_OCCUPANCY")) {             // diagnostic: resident wavefronts of bgzf_inflate per CU
             int n = 0;
@@ -1817,29 +1169,16 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     }();
     (void)occ_once;
     if (legacy) {
+        tcmi_prof_begin(ctx, TCMI_K_INFLATE);
         hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
         tcmi_prof_end(ctx, TCMI_K_INFLATE);
         TCMI_HIP(ctx, hipGetLastError());
     } else {
-        SymArgs sa;
-        sa.file32 = a.file32; sa.blocks = d_desc; sa.tokens = d_tok; sa.n_tok = d_ntok; sa.status = d_stat; sa.n_blocks = (int32_t)nb;
-        sa.pay_dwords = f->pay_dwords;
-        const size_t dyn = (size_t)f->pay_dwords * 4;
-        static std::atomic<size_t> dyn_allowed{48 * 1024};
-        if (dyn > dyn_allowed.load()) {
-            TCMI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
-            dyn_allowed.store(80 * 1024);
-        }
-        hipLaunchKernelGGL(bgzf_symbols, dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
-        tcmi_prof_end(ctx, TCMI_K_INFLATE);
-        TCMI_HIP(ctx, hipGetLastError());
-        CopyArgs ca;
-        ca.file = d_file; ca.blocks = d_desc; ca.tokens = d_tok; ca.n_tok = d_ntok; ca.out = d_out; ca.rec_slot = d_slot; ca.n_rec = d_nrec;
-        ca.overshoot = d_over; ca.status = d_stat; ca.n_blocks = (int32_t)nb;
-        tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
-        hipLaunchKernelGGL(bgzf_copy, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
-        tcmi_prof_end(ctx, TCMI_K_INFLATE_COPY);
-        TCMI_HIP(ctx, hipGetLastError());
+        tcmi_bgzf_decode_args g;
+        g.d_file = d_file; g.d_desc = d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_out = d_out; g.d_slot = d_slot; g.d_nrec = d_nrec;
+        g.d_over = d_over; g.d_stat = d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
+        const int rc = tcmi_bgzf_decode_launch(ctx, g);
+        if (rc) return rc;
     }
     if (ctx->verify_crc) {
         static const CrcArgs proto = [] { CrcArgs c = {}; crc_zero_operators(c.zeros, c.zeros1k); return c; }();

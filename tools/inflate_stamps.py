@@ -9,16 +9,17 @@ subprocess.run([sys.executable, os.path.join(root, "tools/inflate_time.py"), kin
 a = np.fromfile(path, np.uint64).astype(np.int64)
 nb = a.size // 32
 s, c = a[:nb * 16].reshape(nb, 16), a[nb * 16:].reshape(nb, 16)
-ok = s[:, 6] > 0
-s = s[ok]
-print("blocks", nb, "with symbols", ok.sum(), "(s_memtime ticks; 100 MHz constant clock => 10 ns each)")
-names = ["stage payload", "header + code lengths", "tables", "pass A", "chain + scan", "pass B"]
-for k, nm in enumerate(names):
-    d = s[:, k + 1] - s[:, k]
+print("blocks", nb, "(s_memtime ticks = shader cycles)")
+own = s[s[:, 3] > 0]                  # every block: its own wavefront's header phases
+for k, nm in enumerate(["stage payload", "header + code lengths", "tables"]):
+    d = own[:, k + 1] - own[:, k]
     print("  symbols %-22s mean %8.1f  p50 %8.1f  max %8d" % (nm, d.mean(), np.median(d), d.max()))
-print("  symbols total               mean %8.1f" % (s[:, 6] - s[:, 0]).mean(), " rounds A %.1f B %.1f" % (s[:, 8].mean(), s[:, 9].mean()))
+grp = s[s[:, 6] > 0]                  # the first block of every workgroup: the decoding wavefront's phases (for all its blocks)
+for k, nm in ((3, "pass A (per workgroup)"), (4, "chain + scan"), (5, "tokens to their places")):
+    d = grp[:, k + 1] - grp[:, k]
+    print("  symbols %-22s mean %8.1f  p50 %8.1f  max %8d" % (nm, d.mean(), np.median(d), d.max()))
+print("  symbols workgroup total     mean %8.1f" % (grp[:, 6] - grp[:, 0]).mean(), " rounds A %.1f" % grp[:, 8].mean())
 print("  symbols kernel span (first start .. last end) %d ticks" % (s[:, 6].max() - s[:, 0].min()))
 c = c[c[:, 7] > 0]
 print("  copy total mean %.1f  prep %.1f  matches %.1f  housekeeping %.1f | tokens %.0f matches %.0f rounds %.0f" %
       ((c[:, 1] - c[:, 0]).mean(), c[:, 2].mean(), c[:, 3].mean(), c[:, 4].mean(), c[:, 7].mean(), c[:, 5].mean(), c[:, 6].mean()))
-print("  copy kernel span %d ticks" % (c[:, 1].max() - c[:, 0].min()))

@@ -1038,7 +1038,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         // deflate block takes >= 5 bytes)
         b.tok_cap = std::min(b.ulen, 8u * b.clen) + b.clen / 2 + 8;
         b.tok = f->tok_total;
-        f->tok_total += (b.tok_cap + 3u) & ~3u;
+        f->tok_total += (2u * b.tok_cap + 3u) & ~3u;        // (as many again behind them: bgzf_symbols' scratch)
         f->pay_dwords = std::max(f->pay_dwords, (uint32_t)(((b.cin & 3u) * 8u + b.clen * 8u + 31u) / 32u + 6u));
         uout += ((size_t)b.ulen + 15) & ~(size_t)15;            // every block's output starts 16-byte aligned on the device
         off += bsize;
@@ -1136,7 +1136,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
     static const bool legacy = std::getenv("TCMI_INFLATE_LEGACY") != nullptr;       // (A/B: the one-kernel decoder)
     const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
-                 b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 4 + al(nb * 8) + 256,
+                 b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 4 + al(nb * 8) + al(nb * 512) + 256,
                  b_tok = legacy ? 0 : al(f->tok_total * 4 + 256);
     const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 9 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
@@ -1150,6 +1150,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     uint64_t *d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
     unsigned long long *d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    uint32_t *d_seg = (uint32_t *)tcmi_arena_take(ctx, al(nb * 512));
     uint32_t *d_tok = legacy ? nullptr : (uint32_t *)tcmi_arena_take(ctx, b_tok);
 
     TCMI_HIP(ctx, hipMemcpyAsync(d_file, f->bytes, f->cap, hipMemcpyHostToDevice, ctx->stream));
@@ -1175,7 +1176,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
         TCMI_HIP(ctx, hipGetLastError());
     } else {
         tcmi_bgzf_decode_args g;
-        g.d_file = d_file; g.d_desc = d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_out = d_out; g.d_slot = d_slot; g.d_nrec = d_nrec;
+        g.d_file = d_file; g.d_desc = d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = d_out; g.d_slot = d_slot; g.d_nrec = d_nrec;
         g.d_over = d_over; g.d_stat = d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         const int rc = tcmi_bgzf_decode_launch(ctx, g);
         if (rc) return rc;

@@ -34,8 +34,6 @@
 
 namespace {
 
-constexpr int WBITS = 256;                          // bits behind its start in which a lane notes the symbols it starts
-constexpr int MARK_W = WBITS / 32 + 1;              // (+1: odd stride, lanes c and c + 4 would share banks otherwise)
 constexpr int CWIN = 8192, CWMASK = CWIN - 1;       // bgzf_copy's ring of recent output
 constexpr int CSEG = 2048;
 // a round of bgzf_copy writes the literals of up to CSEG + 258 bytes ahead of the match it copies: what a match may still read
@@ -45,36 +43,52 @@ static_assert(CWIN >= 2 * CSEG + 528 && (CWIN & (CWIN - 1)) == 0 && CWIN % CSEG 
 constexpr uint32_t TOK_LIT = 1u << 31, TOK_RAW = 1u << 30;
 constexpr uint32_t RAW_PIECE = 8191;
 constexpr int CL_SLAB = 496;                        // bit positions of the code-length stream looked up at a time
+// bgzf_symbols<NB>: NB BGZF blocks per workgroup — one wavefront each for header and tables, then wavefront 0 decodes all of
+// them, 64 / NB lanes per block.  NB = 4 (16 lanes: one row of the data-parallel moves) unless the payloads are too large for
+// four of them to share a compute unit's LDS; then NB = 1.
 
-struct SymLds {
-    tab_t ll[1 << LL_ROOT];                         // (first: the code-length stream's table of all positions, CL_SLAB entries)
+struct BlkTabs {                                    // per block
+    tab_t ll[1 << LL_ROOT];                         // (first: the code-length stream's table of all positions, CL_SLAB + 16 entries)
     tab_t dt[1 << D_ROOT];                          // (first: the code-length code's root table)
     tab_t long_ll[288], long_d[32];                 // entries of the codes longer than the root bits, in canonical order
-    union {
-        uint32_t marks[64][MARK_W];                 // pass A
-        struct {                                    // header and table building
-            uint8_t lens[320];
-            uint8_t cll[20];
-            uint16_t sym_ll[288], sym_d[32], sym_cl[20];
-            uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
-            uint32_t rs[6];
-        } h;
-    };
+    uint32_t fc_ll[15 - LL_ROOT], fc_d[15 - D_ROOT];// per such length: first code | count << 16
+    // header and table building
+    uint8_t lens[320];
+    uint8_t cll[20];
+    uint16_t sym_ll[288], sym_d[32], sym_cl[20];
+    uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
+    uint32_t rs[6];
+    // what the block's wavefront hands to the decoding wavefront and gets back
+    uint32_t pos;               // first symbol / behind the end-of-block code
+    uint32_t end;               // first bit behind the payload
+    uint32_t ntok;              // tokens so far
+    uint32_t err;               // ST_*
+    uint32_t go;                // 1: symbols to decode at pos
+    uint32_t last;              // 1: the stream's last deflate block
+    uint32_t seg;               // 1: the tokens are left in the lanes' scratch, in pieces (SymArgs::seg)
+};
+constexpr int RING = 8;
+template <int NB>
+struct SymLds {
+    BlkTabs b[NB];
+    uint2 ring[64][RING];       // pass A, per lane: {first symbol start in a stretch, symbols decoded before it}
+    uint2 rec[64];              // per lane: {state | target << 8, position}
 };
 static_assert((CL_SLAB + 16) * 4 <= sizeof(tab_t) * (1 << LL_ROOT), "the code-length position table borrows the literal/length table's LDS");
 
 struct SymArgs {
     const uint32_t *__restrict__ file32;
     const BlockDesc *blocks;
-    uint32_t *tokens;           // block b's tokens at tokens + blocks[b].tok
-    uint32_t *n_tok;            // [n_blocks]
+    uint32_t *tokens;           // block b's tokens at tokens + blocks[b].tok: tok_cap final ones, then tok_cap of scratch
+    uint32_t *n_tok;            // [n_blocks]: tokens | 1 << 31 when they are in pieces
+    uint32_t *seg;              // [n_blocks][128]: per piece its first token (offset from the block's tokens), per piece its tokens
     uint32_t *status;           // [n_blocks]
     int32_t n_blocks;
-    uint32_t pay_dwords;        // dwords of dynamic LDS behind SymLds: the largest block's payload + slack
+    uint32_t pay_dwords;        // dwords of dynamic LDS per block behind SymLds: the largest block's payload + slack
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
 };
-#define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if (threadIdx.x == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define TCMI_STAMP_ADD(buf_, blk_, k_, v_) do { if (buf_) { if (threadIdx.x == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] += (v_); } } while (0)
+#define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define TCMI_STAMP_ADD(buf_, blk_, k_, v_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] += (v_); } } while (0)
 
 // 32 bits of the staged payload from bit p on (any lane, any position)
 __device__ __forceinline__ uint32_t peek32(const uint32_t *pay, uint32_t p)
@@ -91,31 +105,36 @@ __device__ __forceinline__ void peek64(const uint32_t *pay, uint32_t p, uint32_t
     hi = __builtin_amdgcn_alignbit(w2, w1, p);
 }
 
-// The codes longer than the root bits: per length first code | count << 16 (wave-uniform, in scalar registers), and one
-// ready-made table entry per such code in canonical order.  A lane looks its code up by comparing the bit-reversed stream bits
-// with each length's code range — no walk through memory.
+// The codes longer than the root bits: per length first code | count << 16, and one ready-made table entry per such code in
+// canonical order.  A lane looks its code up by comparing the bit-reversed stream bits with each length's code range — no
+// walk through memory.
 template <int ROOT>
-struct LongCodes { uint32_t fc[15 - ROOT]; };
-
-template <int ROOT>
-__device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, int kind, tab_t *out, LongCodes<ROOT> &lc)
+__device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, int kind, tab_t *out, uint32_t *fc_out)
 {
+    const int lane = threadIdx.x & 63;
     uint32_t first = uni(rs[0]);
     const uint32_t at = uni(rs[1]);
     uint32_t n = 0;
+    uint32_t fc[15 - ROOT];
 #pragma unroll
     for (int len = ROOT + 1; len <= 15; ++len) {
         const uint32_t c = uni(cnt[len]);
-        lc.fc[len - ROOT - 1] = (first & 0xFFFFu) | (c << 16);
+        fc[len - ROOT - 1] = (first & 0xFFFFu) | (c << 16);
         first = (first + c) << 1;
         n += c;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+    if (lane < 15 - ROOT) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 15 - ROOT; ++k) mine = lane == k ? fc[k] : mine;
+        fc_out[lane] = mine;
+    }
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
         uint32_t base = 0;
         int mylen = 15;
 #pragma unroll
         for (int len = ROOT + 1; len <= 15; ++len) {
-            const uint32_t c = lc.fc[len - ROOT - 1] >> 16;
+            const uint32_t c = fc[len - ROOT - 1] >> 16;
             if (i >= base && i < base + c) mylen = len;
             base += c;
         }
@@ -124,52 +143,47 @@ __device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *
 }
 
 template <int ROOT>
-__device__ __forceinline__ uint32_t long_lookup(const LongCodes<ROOT> &lc, const tab_t *tab, uint32_t bits)
+__device__ __forceinline__ uint32_t long_lookup(const uint32_t *fcs, const tab_t *tab, uint32_t bits)
 {
     const uint32_t r = __builtin_bitreverse32(bits);
     uint32_t idx = 0xFFFFFFFFu, base = 0;
 #pragma unroll
     for (int len = ROOT + 1; len <= 15; ++len) {
-        const uint32_t fc = lc.fc[len - ROOT - 1];
+        const uint32_t fc = fcs[len - ROOT - 1];
         const uint32_t c = fc >> 16;
-        if (c) {                                            // (wave-uniform)
-            const uint32_t d = (r >> (32 - len)) - (fc & 0xFFFFu);
-            if (d < c) idx = base + d;
-            base += c;
-        }
+        const uint32_t d = (r >> (32 - len)) - (fc & 0xFFFFu);
+        if (d < c) idx = base + d;
+        base += c;
     }
     return idx != 0xFFFFFFFFu ? tab[idx] : 0u;
 }
 
+// an inclusive sum over each group of 64 / NB lanes (one block's lanes): rows of 16, pairs of rows, the wavefront
+template <int NB>
+__device__ __forceinline__ uint32_t group_scan_add(uint32_t v)
+{
+    v += dpp_shift<0x111, 0xF>(v);
+    v += dpp_shift<0x112, 0xF>(v);
+    v += dpp_shift<0x114, 0xF>(v);
+    v += dpp_shift<0x118, 0xF>(v);
+    if (NB <= 2) v += dpp_shift<0x142, 0xA>(v);
+    if (NB == 1) v += dpp_shift<0x143, 0xC>(v);
+    return v;
+}
+
 enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
 
-__global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
+// ---- header of one deflate block and its tables: one wavefront, the block's own (T, pay) ------------------------------------------
+// -> T.go = 1 and T.pos at the first symbol (a Huffman block), or the block's stream is finished / damaged (T.go = 0).  Stored
+// deflate blocks are turned into raw tokens here and the next header is taken at once.
+__device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
+                                             uint64_t *stamps, int blk)
 {
-    __shared__ SymLds L;
-    extern __shared__ uint32_t pay[];               // the block's compressed payload, from the dword that holds its first byte on
-    const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
-    if (blk >= a.n_blocks) return;
-    const BlockDesc d = a.blocks[blk];
-    uint32_t *const toks = a.tokens + d.tok;
-    const uint32_t cap = d.tok_cap;
-    // ---- the payload into LDS (+ 6 dwords: a lane looks up to 48 bits past the end; the file buffer has the slack) ----
-    const uint32_t base_bit = (uint32_t)(d.cin & 3u) * 8u;
-    const uint32_t end = base_bit + d.clen * 8u;                    // first bit behind the payload
-    if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
-    TCMI_STAMP(a.stamps, blk, 0);
-    {
-        const uint32_t *src = a.file32 + (d.cin >> 2);
-        const uint32_t n = min(a.pay_dwords, (end + 31u) / 32u + 6u);
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay[i] = src[i];
-    }
-    __syncthreads();
-    TCMI_STAMP(a.stamps, blk, 1);
-    uint32_t pos = base_bit;            // wave-uniform
-    uint32_t ntok = 0;
-    uint32_t err = ST_OK;
-    bool last = false;
-    while (!last && err == ST_OK) {
+    const int lane = threadIdx.x & 63;
+    uint32_t pos = uni(T.pos), ntok = uni(T.ntok), err = ST_OK;
+    const uint32_t end = uni(T.end);
+    bool go = false;
+    while (!last && err == ST_OK && !go) {
         if (pos + 3u > end) { err = ST_BAD_STREAM; break; }
         const uint32_t h = uni(peek32(pay, pos));
         last = (h & 1u) != 0;
@@ -198,9 +212,9 @@ __global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
         if (type == 3) { err = ST_BAD_STREAM; break; }
         // ---- code lengths -------------------------------------------------------------------------------------------------------
         int nlen = 288, ndist = 32;
-        __syncthreads();                            // (the header arrays share their LDS with pass A's notes)
+        wave_sync();
         if (type == 1) {
-            for (int i = lane; i < 320; i += 64) L.h.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+            for (int i = lane; i < 320; i += 64) T.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
         } else {
             if (pos + 14u > end) { err = ST_BAD_STREAM; break; }
             const uint32_t hh = uni(peek32(pay, pos));
@@ -209,46 +223,46 @@ __global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
             const int ncode = (int)((hh >> 10) & 15u) + 4;
             pos += 14;
             if (nlen > 286 || ndist > 30) { err = ST_BAD_STREAM; break; }
-            if (lane < 19) L.h.cll[lane] = 0;
-            __syncthreads();
+            if (lane < 19) T.cll[lane] = 0;
+            wave_sync();
             // (19 x 3 bits: three looks of up to 8 lengths each, lane k takes the k-th)
             for (int i0 = 0; i0 < ncode; i0 += 8) {
                 const uint32_t v = uni(peek32(pay, pos + (uint32_t)i0 * 3u));
                 const int k = i0 + lane;
-                if (lane < 8 && k < ncode) L.h.cll[CL_ORDER[k]] = (uint8_t)((v >> (3 * lane)) & 7u);
+                if (lane < 8 && k < ncode) T.cll[CL_ORDER[k]] = (uint8_t)((v >> (3 * lane)) & 7u);
             }
             pos += (uint32_t)ncode * 3u;
-            if (uni(build_table<1, CL_ROOT>(L.h.cll, 19, L.h.cnt_cl, L.h.sym_cl, L.dt, K_CODELEN, L.h.rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-            for (int i = lane; i < 320; i += 64) L.h.lens[i] = 0;
+            if (uni(build_table<1, CL_ROOT>(T.cll, 19, T.cnt_cl, T.sym_cl, T.dt, K_CODELEN, T.rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+            for (int i = lane; i < 320; i += 64) T.lens[i] = 0;
             // The code-length symbols (0 .. 15: a length; 16: the previous length 3 - 6 times; 17 / 18: 3 - 10 / 11 - 138 zeros) are
             // a serial chain too, but a short one over few bits.  Every bit position of a slab is looked up by some lane (what
             // symbol would start here, how many lengths would it give, how many bits would it take: step | rep << 4 | val << 12);
             // the chain is then followed through that table with one scalar look-up per symbol that only notes the entry
             // (lane j keeps the j-th of 64), and what the symbols mean is worked out for 64 of them at a time: a sum scan of
             // the repeat counts places them, a maximum scan finds for every "16" the last symbol in front that names a length.
-            uint32_t *const T = L.ll;
+            uint32_t *const P = T.ll;
             uint32_t got = 0, prev = 0;
             const uint32_t total = (uint32_t)(nlen + ndist);
             bool first = true;
             while (got < total && err == ST_OK) {
-                __syncthreads();
+                wave_sync();
 #pragma unroll 2
                 for (int o = lane; o < CL_SLAB + 16; o += 64) {
                     const uint32_t v = peek32(pay, pos + (uint32_t)o);
-                    const uint32_t e = L.dt[v & ((1u << CL_ROOT) - 1u)];
+                    const uint32_t e = T.dt[v & ((1u << CL_ROOT) - 1u)];
                     const uint32_t nb = e & 15u, sym = e >> 16;
                     const uint32_t x = v >> nb;
                     const uint32_t eb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
                     const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + (x & 127u) : 3u + (x & (sym == 16u ? 3u : 7u));
                     const uint32_t val = sym <= 16u ? sym : 0u;
-                    T[o] = nb && o < CL_SLAB ? (nb + eb) | (rep << 4) | (val << 12) : 0u;      // (0 behind the slab: the chain stops there)
+                    P[o] = nb && o < CL_SLAB ? (nb + eb) | (rep << 4) | (val << 12) : 0u;      // (0 behind the slab: the chain stops there)
                 }
-                __syncthreads();
+                wave_sync();
                 uint32_t o = 0;
                 while (got < total && err == ST_OK) {
                     uint32_t mine = 0, j = 0, g = got, e;
                     do {
-                        e = uni(T[o]);
+                        e = uni(P[o]);
                         if (e == 0) break;
                         asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mine) : "s"(e), "s"(j) : "m0");
                         g += (e >> 4) & 255u;
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
                     if (mine != 0 && val != 0) {
 #pragma unroll
                         for (uint32_t i = 0; i < 6; ++i)            // (zeros are not stored, so rep <= 6)
-                            if (i < rep) L.h.lens[at + i] = (uint8_t)val;
+                            if (i < rep) T.lens[at + i] = (uint8_t)val;
                     }
                     if (j) prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(j - 1u));
                     got = g;
@@ -277,155 +291,236 @@ __global__ __launch_bounds__(64) void bgzf_symbols(SymArgs a)
                 if (pos > end) err = ST_BAD_STREAM;
             }
             if (err != ST_OK) break;
-            __syncthreads();
-            if (uni(L.h.lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
+            wave_sync();
+            if (uni(T.lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
-        TCMI_STAMP(a.stamps, blk, 2);
+        TCMI_STAMP(stamps, blk, 2);
         // ---- tables: the root tables as in bgzf_inflate, the longer codes as ready-made entries ------------------------------------
-        LongCodes<LL_ROOT> lcl;
-        LongCodes<D_ROOT> lcd;
-        if (uni(build_table<5, LL_ROOT>(L.h.lens, nlen, L.h.cnt_ll, L.h.sym_ll, L.ll, K_LITLEN, L.h.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table<1, D_ROOT>(L.h.lens + nlen, ndist, L.h.cnt_d, L.h.sym_d, L.dt, K_DIST, L.h.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        build_long<LL_ROOT>(L.h.cnt_ll, L.h.sym_ll, L.h.rs, K_LITLEN, L.long_ll, lcl);
-        build_long<D_ROOT>(L.h.cnt_d, L.h.sym_d, L.h.rs + 2, K_DIST, L.long_d, lcd);
+        if (uni(build_table<5, LL_ROOT>(T.lens, nlen, T.cnt_ll, T.sym_ll, T.ll, K_LITLEN, T.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table<1, D_ROOT>(T.lens + nlen, ndist, T.cnt_d, T.sym_d, T.dt, K_DIST, T.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        build_long<LL_ROOT>(T.cnt_ll, T.sym_ll, T.rs, K_LITLEN, T.long_ll, T.fc_ll);
+        build_long<D_ROOT>(T.cnt_d, T.sym_d, T.rs + 2, K_DIST, T.long_d, T.fc_d);
         if (pos >= end) { err = ST_BAD_STREAM; break; }
-        __syncthreads();
-        TCMI_STAMP(a.stamps, blk, 3);
+        go = true;
+        TCMI_STAMP(stamps, blk, 3);
+    }
+    wave_sync();
+    if (lane == 0) { T.pos = pos; T.ntok = ntok; T.err = err; T.go = go && err == ST_OK ? 1u : 0u; T.last = last ? 1u : 0u; }
+}
 
-        // One literal / length / end-of-block code at bit p; a length is followed by its distance.  VALUES: the token is made
-        // (pass B); otherwise only the bits are counted (pass A).
-        auto symbol = [&](uint32_t &p, uint32_t &tok, const bool VALUES) __attribute__((always_inline)) -> int {
-            uint32_t lo, hi;
-            peek64(pay, p, lo, hi);
-            uint32_t e = L.ll[lo & ((1u << LL_ROOT) - 1u)];
-            if (__builtin_expect(__ballot((e & 15u) == 0) != 0, 0)) {
-                const uint32_t e2 = long_lookup<LL_ROOT>(lcl, L.long_ll, lo);
-                if ((e & 15u) == 0) e = e2;
-            }
-            if ((e & 15u) == 0) return SY_BAD;
-            if (e & E_LIT) { p += e & 15u; if (VALUES) tok = TOK_LIT | ((e >> 16) & 0xFFu); return SY_LIT; }
-            if (e & E_EOB) { p += e & 15u; return SY_EOB; }
-            const uint32_t k = (e >> 11) & 31u;                 // code + extra bits of the length
-            const uint32_t d32 = __builtin_amdgcn_alignbit(hi, lo, k);
-            uint32_t f = L.dt[d32 & ((1u << D_ROOT) - 1u)];
-            if (__builtin_expect(__ballot((f & 15u) == 0) != 0, 0)) {
-                const uint32_t f2 = long_lookup<D_ROOT>(lcd, L.long_d, d32);
-                if ((f & 15u) == 0) f = f2;
-            }
-            if ((f & 15u) == 0) return SY_BAD;
-            const uint32_t nd = f & 15u, eb2 = (f >> 4) & 15u;
-            p += k + nd + eb2;
-            if (VALUES) {
+template <int NB>
+__global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
+{
+    constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
+    static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
+    __shared__ SymLds<NB> L;
+    extern __shared__ uint32_t pay_all[];           // per block: its compressed payload, from the dword that holds its first byte on
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int blk0 = blockIdx.x * SYM_BLOCKS;
+    const int blk = blk0 + wave;                    // this wavefront's block (header, tables)
+    const bool have = blk < a.n_blocks;
+    BlkTabs &T = L.b[wave];
+    uint32_t *const pay = pay_all + (size_t)wave * a.pay_dwords;
+    BlockDesc d = {};
+    if (have) d = a.blocks[blk];
+    uint32_t *const toks = a.tokens + d.tok;
+    const uint32_t base_bit = (uint32_t)(d.cin & 3u) * 8u;
+    const uint32_t end = base_bit + d.clen * 8u;                    // first bit behind the payload
+    // ---- the payload into LDS (+ 6 dwords: a lane looks up to 48 bits past the end; the file buffer has the slack) ----
+    if (have) {
+        if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
+        TCMI_STAMP(a.stamps, blk, 0);
+        const uint32_t *src = a.file32 + (d.cin >> 2);
+        const uint32_t n = min(a.pay_dwords, (end + 31u) / 32u + 6u);
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay[i] = src[i];
+    }
+    if (lane == 0) { T.pos = base_bit; T.end = end; T.ntok = 0; T.err = ST_OK; T.go = 0; T.last = 0; T.seg = 0; }
+    wave_sync();
+    if (have) TCMI_STAMP(a.stamps, blk, 1);
+    bool last = !have;
+    for (;;) {
+        // ---- every wavefront: its block's next header and tables ------------------------------------------------------------------
+        if (have && uni(T.err) == ST_OK && !last) block_header(T, pay, base_bit, toks, d.tok_cap, last, a.stamps, blk);
+        else if (lane == 0) T.go = 0;
+        __syncthreads();
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) any |= L.b[k].go;
+        if (uni(any) == 0) break;                   // (all streams finished or failed)
+        if (wave == 0) {
+            // ---- wavefront 0: the symbols of all four blocks, 16 lanes each ------------------------------------------------------
+            const int b = lane / SYM_LANES, c = lane % SYM_LANES, lane0 = lane - c;       // block, lane in the block, the block's first lane
+            BlkTabs &B = L.b[b];
+            const uint32_t *const bp = pay_all + (size_t)b * a.pay_dwords;
+            const bool on = B.go != 0;
+            const uint32_t b_end = B.end, start = B.pos;
+            const BlockDesc bd = blk0 + b < a.n_blocks ? a.blocks[blk0 + b] : BlockDesc{};
+            uint32_t *const btok = a.tokens + bd.tok;
+            const uint32_t bcap = bd.tok_cap;
+            const uint32_t lane_cap = bcap / (uint32_t)SYM_LANES;                    // tokens a lane may park in the scratch half
+            uint32_t *const scratch = btok + bcap + (uint32_t)c * lane_cap;
+
+            // One literal / length / end-of-block code at bit p; a length is followed by its distance.
+            auto symbol = [&](uint32_t &p, uint32_t &tok) __attribute__((always_inline)) -> int {
+                uint32_t lo, hi;
+                peek64(bp, p, lo, hi);
+                uint32_t e = B.ll[lo & ((1u << LL_ROOT) - 1u)];
+                if (__builtin_expect(__ballot((e & 15u) == 0) != 0, 0)) {
+                    const uint32_t e2 = long_lookup<LL_ROOT>(B.fc_ll, B.long_ll, lo);
+                    if ((e & 15u) == 0) e = e2;
+                }
+                if ((e & 15u) == 0) return SY_BAD;
+                if (e & E_LIT) { p += e & 15u; tok = TOK_LIT | ((e >> 16) & 0xFFu); return SY_LIT; }
+                if (e & E_EOB) { p += e & 15u; return SY_EOB; }
+                const uint32_t k = (e >> 11) & 31u;                 // code + extra bits of the length
+                const uint32_t d32 = __builtin_amdgcn_alignbit(hi, lo, k);
+                uint32_t f = B.dt[d32 & ((1u << D_ROOT) - 1u)];
+                if (__builtin_expect(__ballot((f & 15u) == 0) != 0, 0)) {
+                    const uint32_t f2 = long_lookup<D_ROOT>(B.fc_d, B.long_d, d32);
+                    if ((f & 15u) == 0) f = f2;
+                }
+                if ((f & 15u) == 0) return SY_BAD;
+                const uint32_t nd = f & 15u, eb2 = (f >> 4) & 15u;
+                p += k + nd + eb2;
                 const uint32_t nb = e & 15u, eb = (e >> 16) & 15u;
                 const uint32_t len = ((e >> 20) & 0x1FFu) + ((lo >> nb) & ((1u << eb) - 1u));
                 const uint32_t dist = (f >> 16) + ((d32 >> nd) & ((1u << eb2) - 1u));
                 tok = len | ((dist - 1u) << 9);
-            }
-            return SY_MATCH;
-        };
+                return SY_MATCH;
+            };
 
-        // ---- pass A: every lane decodes from its own start until it meets a lane in front ----------------------------------------
-        const uint32_t start = pos;
-        const uint32_t chunk = (end - start + 63u) / 64u;           // >= 1
-        const uint32_t chunk_m = 0xFFFFFFFFu / chunk;               // (x * chunk_m) >> 32 = x / chunk or one less, for x < 2^20
-        const uint32_t s_c = start + (uint32_t)lane * chunk;
-        enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
-        uint32_t state = s_c < end ? RUN : DEAD;
-        uint32_t tgt = (uint32_t)lane + 1u, total = 0;
-        uint32_t p = min(s_c, end);
+            // ---- pass A: every lane decodes from its own start until it meets the lane in front; the tokens go to its scratch ----
+            // Meeting points are looked for where a lane's symbols cross into a new stretch of 2^shift bits: the lane notes its
+            // first symbol start p in the stretch (and how many symbols it had decoded by then) in a ring of its own, and looks
+            // p up in the ring of its target — the nearest lane in front that is still decoding, or the lane that one met.  Equal
+            // positions are one trajectory from there on: the lane stops, its target's symbols from that one on are the true ones.
+            const uint32_t chunk = on ? (b_end - start + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
+            // stretches of >= 64 bits (a symbol takes <= 48: none is skipped), about chunk / 4: a lane trails its target by about
+            // a chunk, RING stretches are kept
+            const uint32_t shift = max(6u, 30u - (uint32_t)__builtin_clz(chunk | 1u));
+            const uint32_t s_c = start + (uint32_t)c * chunk;
+            enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
+            uint32_t state = on && s_c < b_end ? RUN : DEAD;
+            uint32_t tgt = (uint32_t)c + 1u, total = 0, midx = 0;
+            uint32_t p = min(s_c, b_end);
+            uint32_t kprev = 0xFFFFFFFFu;
+            bool spilled = false;                   // more symbols than the scratch holds: pass B decodes this block again
 #pragma unroll
-        for (int k = 0; k < MARK_W; ++k) L.marks[lane][k] = 0;
-        __syncthreads();
-        while (__ballot(state == RUN)) {
-            if (state == RUN) {
-                const uint32_t rel = p - s_c;
-                if (rel < (uint32_t)WBITS) atomicOr(&L.marks[lane][rel >> 5], 1u << (rel & 31u));
-            }
-            __syncthreads();                        // (one wavefront: orders the notes before the looks)
-            if (state == RUN) {
-                // the nearest lane in front whose window still reaches p (the quotient may be one short: then r >= WBITS below and
-                // this round looks at nobody)
-                const uint32_t x = p - start;
-                const uint32_t q = x >= (uint32_t)WBITS ? __umulhi(x - (uint32_t)WBITS, chunk_m) + 1u : 0u;
-                tgt = max(tgt, q);
-                const uint32_t r = p - (start + tgt * chunk);
-                if (tgt < 64u && r < (uint32_t)WBITS && ((L.marks[tgt][r >> 5] >> (r & 31u)) & 1u)) state = MERGED;
-            }
-            if (state == RUN) {
-                uint32_t tok;
-                const int k = p >= end ? SY_BAD : symbol(p, tok, false);
-                if (k == SY_BAD || p > end) state = DEAD;
-                else {
-                    ++total;
-                    if (k == SY_EOB) state = EOB;
+            for (int k = 0; k < RING; ++k) L.ring[lane][k] = make_uint2(0xFFFFFFFFu, 0u);
+            L.rec[lane] = make_uint2(state, p);
+            wave_sync();
+            while (__ballot(state == RUN)) {
+                const uint32_t kk = p >> shift;
+                const bool cross = state == RUN && kk != kprev;
+                if (cross) L.ring[lane][kk & (RING - 1)] = make_uint2(p, total);
+                wave_sync();                        // (orders the notes before the looks)
+                if (cross) {
+                    kprev = kk;
+                    // a target that has stopped at or in front of p: on to the lane it met, or to the next one
+#pragma unroll 1
+                    for (int hop = 0; hop < 3 && tgt < (uint32_t)SYM_LANES; ++hop) {
+                        const uint2 r = L.rec[lane0 + (int)tgt];
+                        const uint32_t st = r.x & 3u;
+                        if (st == RUN || p < r.y) break;
+                        tgt = st == MERGED ? r.x >> 8 : tgt + 1u;
+                    }
+                    if (tgt < (uint32_t)SYM_LANES) {
+                        const uint2 e = L.ring[lane0 + (int)tgt][kk & (RING - 1)];
+                        if (e.x == p) { state = MERGED; midx = e.y; }
+                    }
                 }
-            }
-            TCMI_STAMP_ADD(a.stamps, blk, 8, 1);
-        }
-        TCMI_STAMP(a.stamps, blk, 4);
-        // ---- the chain of lanes that hold the true symbols: lane 0 from `start`, then whoever it met, ... ---------------------
-        uint32_t myP = start;
-        bool alive = lane == 0;
-        uint32_t eob_pos = 0;
-        {
-            uint32_t c = 0;
-            for (;;) {
-                const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)state, (int)c);
-                if (st == MERGED) {
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)c);
-                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tgt, (int)c);
-                    if ((uint32_t)lane == t) { alive = true; myP = m; }
-                    c = t;
-                } else {
-                    if (st == EOB) eob_pos = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)c);
-                    else err = ST_BAD_STREAM;
-                    break;
-                }
-            }
-        }
-        if (err != ST_OK) break;
-        // symbols a lane decoded in front of its true start do not count (all of them are noted: the start lies in its window)
-        uint32_t cnt = 0;
-        if (alive) {
-            const uint32_t lim = myP - s_c;         // < WBITS for every lane but 0, where it is 0
-            uint32_t before = 0;
-#pragma unroll
-            for (int k = 0; k < WBITS / 32; ++k) {
-                const uint32_t w = L.marks[lane][k];
-                const uint32_t lo = (uint32_t)k * 32u;
-                const uint32_t m = lim >= lo + 32u ? 0xFFFFFFFFu : lim > lo ? (1u << (lim - lo)) - 1u : 0u;
-                before += (uint32_t)__popc(w & m);
-            }
-            cnt = total - before;
-            if (state == EOB) --cnt;                // (the end-of-block code is a symbol, not a token)
-        }
-        // exclusive sum over the lanes -> every lane's place in the token array
-        const uint32_t incl = wave_scan_add(cnt);
-        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (ntok + all > cap) { err = ST_BAD_STREAM; break; }
-        TCMI_STAMP(a.stamps, blk, 5);
-        // ---- pass B: the true ranges once more, tokens out --------------------------------------------------------------------------
-        {
-            uint32_t *dst = toks + ntok + (incl - cnt);
-            uint32_t q = myP;
-            uint32_t i = 0;
-            while (__ballot(alive && i < cnt)) {
-                if (alive && i < cnt) {
+                if (state == RUN) {
                     uint32_t tok = 0;
-                    (void)symbol(q, tok, true);
-                    dst[i] = tok;
-                    ++i;
+                    const int k = p >= b_end ? SY_BAD : symbol(p, tok);
+                    if (k == SY_BAD || p > b_end) state = DEAD;
+                    else {
+                        if (k == SY_EOB) state = EOB;
+                        else if (total < lane_cap) scratch[total] = tok;
+                        else spilled = true;
+                        ++total;
+                    }
                 }
-                TCMI_STAMP_ADD(a.stamps, blk, 9, 1);
+                if (cross || state != RUN) L.rec[lane] = make_uint2(state | (tgt << 8), p);
+                TCMI_STAMP_ADD(a.stamps, blk0, 8, 1);
             }
+            TCMI_STAMP(a.stamps, blk0, 4);
+            // ---- per block the chain of lanes that hold the true symbols: lane 0 from `start`, then whoever it met, ... ----------
+            uint32_t before = 0;                    // symbols a lane decoded in front of its true start: they do not count
+            bool alive = on && c == 0;
+            uint32_t eob_pos = 0, berr = ST_OK;
+            for (int bb = 0; bb < SYM_BLOCKS; ++bb) {
+                if (uni(L.b[bb].go) == 0) continue;
+                uint32_t cc = (uint32_t)bb * SYM_LANES;
+                for (;;) {
+                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)state, (int)cc);
+                    if (st == MERGED) {
+                        const uint32_t t = (uint32_t)bb * SYM_LANES + (uint32_t)__builtin_amdgcn_readlane((int)tgt, (int)cc);
+                        const uint32_t mi = (uint32_t)__builtin_amdgcn_readlane((int)midx, (int)cc);
+                        if ((uint32_t)lane == t) { alive = true; before = mi; }
+                        cc = t;
+                    } else {
+                        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)cc);
+                        if (b == bb) { if (st == EOB) eob_pos = pp; else berr = ST_BAD_STREAM; }
+                        break;
+                    }
+                }
+            }
+            uint32_t cnt = 0;
+            if (alive) {
+                cnt = total - before;
+                if (state == EOB) --cnt;            // (the end-of-block code is a symbol, not a token)
+            }
+            // exclusive sum over the block's lanes -> every lane's place among the block's tokens
+            const uint32_t incl = group_scan_add<NB>(cnt);
+            const uint32_t all = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane0 + SYM_LANES - 1) << 2), (int)incl);
+            const uint32_t ntok0 = B.ntok;
+            if (on && berr == ST_OK && ntok0 + all > bcap) berr = ST_BAD_STREAM;
+            // a lane that parked more than its scratch holds: the whole block goes through pass B
+            const unsigned long long spill_mask = __ballot(alive && spilled);
+            const bool block_redo = ((spill_mask >> lane0) & (NB == 1 ? ~0ull : (1ull << (SYM_LANES & 63)) - 1ull)) != 0;
+            TCMI_STAMP(a.stamps, blk0, 5);
+            // The block's only deflate stream (the usual BGZF block): the tokens stay where they are parked and bgzf_copy gets the
+            // list of pieces.  Otherwise they are moved behind the tokens the block has already.
+            const bool pieces = on && berr == ST_OK && B.last != 0 && ntok0 == 0 && !block_redo;
+            if (on && blk0 + b < a.n_blocks) {
+                uint32_t *seg = a.seg + (size_t)(blk0 + b) * 128;
+                seg[c] = pieces ? bcap + (uint32_t)c * lane_cap + before : 0u;
+                seg[64 + c] = pieces ? cnt : 0u;
+#pragma unroll
+                for (int k = 1; k < NB; ++k) { seg[c + SYM_LANES * k] = 0; seg[64 + c + SYM_LANES * k] = 0; }
+            }
+            if (on && berr == ST_OK && !pieces) {
+                uint32_t *const dst = btok + ntok0 + (incl - cnt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the scratch stores are this lane's own)
+                if (!block_redo) {
+                    for (uint32_t i = 0; i < cnt; i += 4) {         // (four loads in flight: the loop is all latency)
+                        uint32_t t[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = i + k < cnt ? scratch[before + i + k] : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (i + k < cnt) dst[i + k] = t[k];
+                    }
+                } else {
+                    // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------
+                    // (the position of a lane's true start is not kept: decode from the lane's own start and drop `before` symbols)
+                    uint32_t pp = min(s_c, b_end);
+                    for (uint32_t i = 0; alive && i < before + cnt; ++i) {
+                        uint32_t tok = 0;
+                        (void)symbol(pp, tok);
+                        if (i >= before) dst[i - before] = tok;
+                    }
+                }
+            }
+            TCMI_STAMP(a.stamps, blk0, 6);
+            if (on && c == 0) B.seg = pieces ? 1u : 0u;
+            if (on && c == 0) { B.ntok = ntok0 + all; B.pos = eob_pos; B.err = berr; }
         }
-        TCMI_STAMP(a.stamps, blk, 6);
-        ntok += all;
-        pos = eob_pos;
+        __syncthreads();
     }
-    if (lane == 0) {
-        a.n_tok[blk] = ntok;
-        a.status[blk] = err;
+    if (have && lane == 0) {
+        a.n_tok[blk] = T.ntok | (T.seg << 31);
+        a.status[blk] = T.err;
     }
 }
 
@@ -434,6 +529,7 @@ struct CopyArgs {
     const BlockDesc *blocks;
     const uint32_t *tokens;
     const uint32_t *n_tok;
+    const uint32_t *seg;        // pieces of blocks whose n_tok has bit 31 set
     uint8_t *out;
     uint32_t *rec_slot;
     uint32_t *n_rec;
@@ -452,8 +548,16 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     const BlockDesc d = a.blocks[blk];
     const uint32_t ulen = d.ulen;
     uint32_t err = uni(a.status[blk]);
-    const uint32_t ntok = err == ST_OK ? uni(a.n_tok[blk]) : 0u;
+    const uint32_t ntok_raw = err == ST_OK ? uni(a.n_tok[blk]) : 0u;
+    const uint32_t ntok = ntok_raw & 0x7FFFFFFFu;
+    const bool pieces = (ntok_raw >> 31) != 0;      // the tokens lie where bgzf_symbols' lanes parked them: piece `lane` is mine to describe
     const uint32_t *toks = a.tokens + d.tok;
+    uint32_t p_off = 0, p_cnt = 0, p_pre = 0, p_cur = 0;
+    if (pieces) {
+        p_off = a.seg[(size_t)blk * 128 + lane];
+        p_cnt = a.seg[(size_t)blk * 128 + 64 + lane];
+        p_pre = wave_scan_add(p_cnt) - p_cnt;
+    }
     uint8_t *const out = a.out + d.uout;
     const uint8_t *const payload = a.file + d.cin;
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
@@ -515,7 +619,21 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     housekeeping();
     for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
         if (a.stamps) tk0 = __builtin_amdgcn_s_memtime();
-        const uint32_t t = base + (uint32_t)lane < ntok ? toks[base + (uint32_t)lane] : 0u;
+        uint32_t t = 0;
+        if (!pieces) {
+            if (base + (uint32_t)lane < ntok) t = toks[base + (uint32_t)lane];
+        } else {
+            const uint32_t g = base + (uint32_t)lane;
+            while (p_cur < 64u) {
+                const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)p_pre, (int)p_cur);
+                const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)p_cnt, (int)p_cur);
+                const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)p_off, (int)p_cur);
+                if (ps >= base + 64u) break;
+                if (g >= ps && g < ps + pc) t = toks[po + (g - ps)];
+                if (ps + pc > base + 64u) break;
+                ++p_cur;
+            }
+        }
         const bool is_lit = (t >> 31) != 0;
         const bool is_raw = !is_lit && (t & TOK_RAW);
         if (__ballot(is_raw)) {
@@ -614,20 +732,27 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.stamps = d_stamps;
     sa.file32 = reinterpret_cast<const uint32_t *>(g.d_file);
     sa.blocks = static_cast<const BlockDesc *>(g.d_desc);
-    sa.tokens = g.d_tok; sa.n_tok = g.d_ntok; sa.status = g.d_stat; sa.n_blocks = (int32_t)nb;
+    sa.tokens = g.d_tok; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)nb;
     sa.pay_dwords = g.pay_dwords;
-    const size_t dyn = (size_t)g.pay_dwords * 4;
-    static std::atomic<size_t> dyn_allowed{48 * 1024};
-    if (dyn > dyn_allowed.load()) {
-        TCMI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
-        dyn_allowed.store(80 * 1024);
-    }
+    // four blocks per workgroup while four payloads (+ 25 KiB of tables) leave room for two workgroups per compute unit
+    static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
+    const int per_wg = forced == 1 || forced == 2 || forced == 4 ? forced : (size_t)g.pay_dwords * 4 * 4 + sizeof(SymLds<4>) <= 80 * 1024 ? 4 : 1;
+    const size_t dyn = (size_t)g.pay_dwords * 4 * per_wg;
+    static const bool attr_once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<2>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<1>)));
+        return true;
+    }();
+    (void)attr_once;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE);
-    hipLaunchKernelGGL(bgzf_symbols, dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
+    if (per_wg == 4) hipLaunchKernelGGL(bgzf_symbols<4>, dim3((unsigned)((nb + 3) / 4)), dim3(256), dyn, ctx->stream, sa);
+    else if (per_wg == 2) hipLaunchKernelGGL(bgzf_symbols<2>, dim3((unsigned)((nb + 1) / 2)), dim3(128), dyn, ctx->stream, sa);
+    else hipLaunchKernelGGL(bgzf_symbols<1>, dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
     CopyArgs ca;
-    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = g.d_tok; ca.n_tok = g.d_ntok; ca.out = g.d_out; ca.rec_slot = g.d_slot;
+    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = g.d_tok; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
     ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.status = g.d_stat; ca.n_blocks = (int32_t)nb;
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);

@@ -32,6 +32,10 @@ enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_BAD_LENGTH = 2, ST_BAD_RECORD = 3, ST_BA
 static __constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// LDS written by some lanes of a wavefront and read by others of the same wavefront: the hardware keeps a wavefront's LDS
+// operations in order, so all this has to do is keep the compiler from moving them (no barrier: a workgroup may hold several
+// wavefronts that each work on a block of their own)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // Inclusive scans over the 64 lanes of a wavefront with data-parallel-primitive moves (no LDS, no waits): four shifts inside
 // the rows of 16 lanes, then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into the upper half.  Lanes shifted in
@@ -100,8 +104,8 @@ __device__ inline uint32_t make_entry(int kind, int sym, int nbits)
 template <int MAXG, int ROOT>
 __device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, tab_t *tab, int kind, uint32_t *rs)
 {
-    const int lane = threadIdx.x;
-    __syncthreads();                            // (one wavefront per workgroup: a compiler fence for the LDS hand-offs between lanes)
+    const int lane = threadIdx.x & 63;
+    wave_sync();                                // (LDS hand-offs between the lanes of this wavefront)
     int l[MAXG];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) l[g] = g * 64 + lane < n ? (int)lens[g * 64 + lane] : 0;
@@ -153,7 +157,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     // root table: slot i holds the symbol whose code is a prefix of the bits of i (first stream bit = bit 0): the code of
     // length len that the slot starts with is p = reverse(i)'s top len bits; it exists if first[len] <= p < first[len] + c[len]
     // (for a prefix code at most one length answers)
@@ -169,7 +173,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t
         }
         tab[i] = L ? make_entry(kind, (int)sym[si], L) : 0u;
     }
-    __syncthreads();
+    wave_sync();
     return uni(ok ? 1u : 0u) != 0;
 }
 
@@ -183,6 +187,7 @@ struct tcmi_bgzf_decode_args {
     const void *d_desc;             // BlockDesc [n_blocks]
     uint32_t *d_tok;                // token array (BlockDesc::tok / tok_cap)
     uint32_t *d_ntok;               // [n_blocks]
+    uint32_t *d_seg;                // [n_blocks][128]: where the pieces of a block's tokens lie
     uint8_t *d_out;                 // inflated stream (BlockDesc::uout)
     uint32_t *d_slot;               // [n_blocks][MAX_REC_PER_BLOCK] record starts
     uint32_t *d_nrec;               // [n_blocks]

@@ -541,7 +541,7 @@ struct CopyArgs {
 
 __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[CWIN];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[CWIN];        // (the kernel's only LDS object: ring index = LDS address)
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= a.n_blocks) return;
@@ -561,27 +561,46 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     uint8_t *const out = a.out + d.uout;
     const uint8_t *const payload = a.file + d.cin;
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
+    const uint32_t *const win32 = reinterpret_cast<const uint32_t *>(s_win);
 
     uint32_t op = 0, flushed = 0;
     uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
-    uint32_t n_rec = 0, bad_rec = 0, rec_buf = 0;
+    uint32_t rec_size = 0;              // 4 + block_size of the last record listed (0: none yet)
+    uint32_t n_rec = 0;
     uint32_t next_evt = 0;
     uint32_t bad = 0;
 
-    // list the record starts whose block_size field is complete, flush the segments that are complete
+    // List the record starts whose block_size field is complete, flush the segments that are complete.  The chain of records is
+    // serial (a record's start is known when its predecessor's size is), but the records of a BAM block mostly have one size: 16
+    // lanes look at where the next 16 records start if they all have the size of the last one, and the chain advances over all
+    // that do (at least one per step: the first candidate is a record start for sure).
     auto housekeeping = [&]() __attribute__((always_inline)) {
         while (next_rec + 4 <= op) {
-            const uint32_t at = next_rec & CWMASK;
-            const uint32_t w = reinterpret_cast<const uint32_t *>(s_win)[((at >> 2) + (uint32_t)lane) & (CWIN / 4 - 1)];
-            const uint64_t two = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
-            const uint32_t ubs = (uint32_t)(two >> ((at & 3u) * 8u));
-            if (__builtin_expect(ubs - 32u > (1u << 28) - 32u, 0)) { bad_rec = 1; break; }
-            rec_buf = (uint32_t)lane == (n_rec & 63u) ? next_rec : rec_buf;
-            if ((n_rec & 63u) == 63u) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
-            ++n_rec;
-            next_rec += 4u + ubs;
+            const uint32_t cand = next_rec + (uint32_t)lane * rec_size;
+            const bool look = lane < 16 && (lane == 0 || rec_size != 0) && cand + 4 <= op;
+            uint32_t bs = 0;
+            if (look) {
+                const uint32_t i = (cand & CWMASK) >> 2;
+                bs = __builtin_amdgcn_alignbit(win32[(i + 1) & (CWIN / 4 - 1)], win32[i], (cand & 3u) * 8u);
+            }
+            const uint32_t n_look = (uint32_t)__popcll(__ballot(look));                         // (a prefix of the lanes)
+            const uint32_t same = (uint32_t)__builtin_ctzll(~__ballot(look && bs + 4u == rec_size));  // leading candidates of the same size
+            uint32_t n_conf;
+            if (same < n_look) {
+                // candidate `same` starts a record of another size (or the first one at all)
+                const uint32_t ubs = (uint32_t)__builtin_amdgcn_readlane((int)bs, (int)same);
+                if (__builtin_expect(ubs - 32u > (1u << 28) - 32u, 0)) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
+                n_conf = same + 1u;
+                next_rec += same * rec_size + 4u + ubs;
+                rec_size = 4u + ubs;
+            } else {
+                n_conf = n_look;
+                next_rec += n_look * rec_size;
+            }
+            if (n_rec + n_conf > (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
+            if ((uint32_t)lane < n_conf) slots[n_rec + (uint32_t)lane] = cand;
+            n_rec += n_conf;
         }
-        if (bad_rec) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; }
         while (op - flushed >= CSEG) {
             const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & CWMASK));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
@@ -591,8 +610,8 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         }
         next_evt = flushed + (uint32_t)CSEG;
     };
-    // a match: all lanes; with dist < len the pattern of the last `dist` bytes repeats
-    auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {
+    // a match of any kind: all lanes; with dist < len the pattern of the last `dist` bytes repeats
+    auto copy_any = [&](uint32_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {
         if (dist > at) { bad = 1; return; }                      // before the block's first byte
         if (dist > (uint32_t)CNEAR) {
             const uint8_t *src = out + (at - dist);             // flushed by this wavefront (see CNEAR)
@@ -615,10 +634,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     };
     if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
     TCMI_STAMP(a.stamps, blk, 0);
-    uint64_t tk0 = 0, t_prep = 0, t_match = 0, t_house = 0, n_match = 0, n_round = 0;
+    uint32_t n_match = 0, n_slow = 0, n_round = 0;
     housekeeping();
     for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
-        if (a.stamps) tk0 = __builtin_amdgcn_s_memtime();
         uint32_t t = 0;
         if (!pieces) {
             if (base + (uint32_t)lane < ntok) t = toks[base + (uint32_t)lane];
@@ -636,7 +654,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         }
         const bool is_lit = (t >> 31) != 0;
         const bool is_raw = !is_lit && (t & TOK_RAW);
-        if (__ballot(is_raw)) {
+        if (__builtin_expect(__ballot(is_raw) != 0, 0)) {
             // ---- a batch with stored bytes in it: token by token (rare: incompressible data, flush markers) --------------------
             const uint32_t nb = min(64u, ntok - base);
             for (uint32_t j = 0; j < nb && err == ST_OK && !bad; ++j) {
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 } else {
                     const uint32_t len = tj & 511u, dist = ((tj >> 9) & 0x7FFFu) + 1u;
                     if (op + len > ulen) { err = ST_BAD_LENGTH; break; }
-                    copy_match(op, len, dist);
+                    copy_any(op, len, dist);
                     op += len;
                 }
                 if (op >= next_evt) housekeeping();
@@ -672,8 +690,14 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const uint32_t dst = op + incl - mylen;                 // where this lane's token starts
         const uint32_t batch_end = op + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (batch_end > ulen) { err = ST_BAD_LENGTH; break; }
+        // what the copy loop needs of a match, ready in two registers: ring addresses of its destination and source, its length, and
+        // whether it is one of the plain ones — source in the ring, no overlap with the destination closer than a round of 64
+        // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
+        const bool is_match = !is_lit && mylen != 0;
+        const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
+        const bool plain = dist <= (uint32_t)CNEAR && dist <= dst && (dist >= 64u || dist >= mylen) && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN;
+        const uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : 1u << 16);
         uint32_t t_cur = 0;
-        if (a.stamps) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_prep += now - tk0; tk0 = now; }
         while (t_cur < 64u) {
             // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
             const unsigned long long from = ~0ull << t_cur;
@@ -681,23 +705,39 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             const uint32_t t_stop = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
             const unsigned long long rng = t_stop < 64u ? from & ~(~0ull << t_stop) : from;
             const bool mine = (rng >> lane) & 1ull;
-            if (mine && is_lit) s_win[dst & CWMASK] = (uint8_t)t;
-            unsigned long long mm = __ballot(mine && !is_lit && mylen != 0);
+            if (mine && is_lit) s_win[dm] = (uint8_t)t;
+            unsigned long long mm = __ballot(mine && is_match);
+            n_match += (uint32_t)__popcll(mm);
             while (mm) {
                 const int j = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)dst, j);
-                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mylen, j);
-                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
-                copy_match(at, len, dj);
-                ++n_match;
+                const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)vB, j);
+                if (__builtin_expect(B >> 16, 0)) {
+                    copy_any((uint32_t)__builtin_amdgcn_readlane((int)dst, j), (uint32_t)__builtin_amdgcn_readlane((int)mylen, j),
+                             (uint32_t)__builtin_amdgcn_readlane((int)dist, j));
+                    ++n_slow;
+                    continue;
+                }
+                const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)vA, j);
+                const uint32_t len = A >> 16;
+                const uint8_t *const from8 = s_win + B + (uint32_t)lane;
+                uint8_t *const to8 = s_win + (A & 0xFFFFu) + (uint32_t)lane;
+                if ((uint32_t)lane < len) to8[0] = from8[0];
+                if (len > 64u) {                                // (rounds of 64 bytes, one after the other: right for dist >= 64 too)
+                    if ((uint32_t)lane + 64u < len) to8[64] = from8[64];
+                    if (len > 128u) {
+                        if ((uint32_t)lane + 128u < len) to8[128] = from8[128];
+                        if (len > 192u) {
+                            if ((uint32_t)lane + 192u < len) to8[192] = from8[192];
+                            if ((uint32_t)lane + 256u < len) to8[256] = from8[256];
+                        }
+                    }
+                }
             }
             op = t_stop < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)t_stop) : batch_end;
             t_cur = t_stop;
             ++n_round;
-            if (a.stamps) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_match += now - tk0; tk0 = now; }
             if (op >= next_evt) { housekeeping(); if (err != ST_OK) break; }
-            if (a.stamps) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_house += now - tk0; tk0 = now; }
             if (bad) break;
         }
     }
@@ -708,7 +748,6 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const uint32_t rest = op - flushed;
         for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & CWMASK];
     }
-    if ((uint32_t)lane < (n_rec & 63u)) slots[(n_rec & ~63u) + (uint32_t)lane] = rec_buf;
     if (lane == 0) {
         a.status[blk] = err;
         a.n_rec[blk] = n_rec;
@@ -716,7 +755,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     }
     if (a.stamps && lane == 0) {
         uint64_t *st = a.stamps + (size_t)blk * 16;
-        st[1] = __builtin_amdgcn_s_memtime(); st[2] = t_prep; st[3] = t_match; st[4] = t_house; st[5] = n_match; st[6] = n_round; st[7] = ntok;
+        st[1] = __builtin_amdgcn_s_memtime(); st[4] = n_slow; st[5] = n_match; st[6] = n_round; st[7] = ntok;
     }
 }
 
@@ -734,9 +773,11 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.blocks = static_cast<const BlockDesc *>(g.d_desc);
     sa.tokens = g.d_tok; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)nb;
     sa.pay_dwords = g.pay_dwords;
-    // four blocks per workgroup while four payloads (+ 25 KiB of tables) leave room for two workgroups per compute unit
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
-    const int per_wg = forced == 1 || forced == 2 || forced == 4 ? forced : (size_t)g.pay_dwords * 4 * 4 + sizeof(SymLds<4>) <= 80 * 1024 ? 4 : 1;
+    // (measured on one 4 187-block file, kernel alone: 4 blocks per workgroup 372 us, 2: 285 us, 1: 325 us; on the harder file —
+    //  4 611 blocks of 10.7 KB — 1 634 / 1 036 / 698 us: with larger payloads more lanes per block pay)
+    const size_t pay = (size_t)g.pay_dwords * 4;
+    const int per_wg = forced == 1 || forced == 2 || forced == 4 ? forced : pay <= 4096 ? 2 : 1;
     const size_t dyn = (size_t)g.pay_dwords * 4 * per_wg;
     static const bool attr_once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));

@@ -51,7 +51,9 @@ struct BlkTabs {                                    // per block
     tab_t ll[1 << LL_ROOT];                         // (first: the code-length stream's table of all positions, CL_SLAB + 16 entries)
     tab_t dt[1 << D_ROOT];                          // (first: the code-length code's root table)
     tab_t long_ll[288], long_d[32];                 // entries of the codes longer than the root bits, in canonical order
-    uint32_t fc_ll[15 - LL_ROOT], fc_d[15 - D_ROOT];// per such length: first code | count << 16
+    // per such length, for the look-up by range compare: the end of its codes, left-aligned in 15 bits (ascending: canonical codes are
+    // ordered by length), and first code | index of its first entry in long_* << 16
+    uint32_t lim_ll[16 - LL_ROOT], fb_ll[16 - LL_ROOT], lim_d[16 - D_ROOT], fb_d[16 - D_ROOT];
     // header and table building
     uint8_t lens[320];
     uint8_t cll[20];
@@ -67,6 +69,9 @@ struct BlkTabs {                                    // per block
     uint32_t last;              // 1: the stream's last deflate block
     uint32_t seg;               // 1: the tokens are left in the lanes' scratch, in pieces (SymArgs::seg)
 };
+#ifndef TCMI_SYM_ASM
+#define TCMI_SYM_ASM 1
+#endif
 constexpr int RING = 8;
 template <int NB>
 struct SymLds {
@@ -105,36 +110,34 @@ __device__ __forceinline__ void peek64(const uint32_t *pay, uint32_t p, uint32_t
     hi = __builtin_amdgcn_alignbit(w2, w1, p);
 }
 
-// The codes longer than the root bits: per length first code | count << 16, and one ready-made table entry per such code in
-// canonical order.  A lane looks its code up by comparing the bit-reversed stream bits with each length's code range — no
-// walk through memory.
+// The codes longer than the root bits: one ready-made table entry per such code, in canonical order.  A lane finds its code
+// without a walk through memory: canonical codes are ordered by length, so the code's first 15 bits, left-aligned, lie below the
+// end of exactly the lengths that are long enough — counting the ends at or below them gives the length.
 template <int ROOT>
-__device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, int kind, tab_t *out, uint32_t *fc_out)
+__device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *sym, const uint32_t *rs, int kind, tab_t *out, uint32_t *lim_out,
+                                           uint32_t *fb_out)
 {
     const int lane = threadIdx.x & 63;
     uint32_t first = uni(rs[0]);
     const uint32_t at = uni(rs[1]);
     uint32_t n = 0;
-    uint32_t fc[15 - ROOT];
+    uint32_t cs[15 - ROOT];
+    uint32_t my_lim = 0x10000u, my_fb = 0;                 // (entry 15 - ROOT: above every code)
 #pragma unroll
     for (int len = ROOT + 1; len <= 15; ++len) {
         const uint32_t c = uni(cnt[len]);
-        fc[len - ROOT - 1] = (first & 0xFFFFu) | (c << 16);
+        cs[len - ROOT - 1] = c;
+        if (lane == len - ROOT - 1) { my_lim = (first + c) << (15 - len); my_fb = (first & 0xFFFFu) | (n << 16); }
         first = (first + c) << 1;
         n += c;
     }
-    if (lane < 15 - ROOT) {
-        uint32_t mine = 0;
-#pragma unroll
-        for (int k = 0; k < 15 - ROOT; ++k) mine = lane == k ? fc[k] : mine;
-        fc_out[lane] = mine;
-    }
+    if (lane <= 15 - ROOT) { lim_out[lane] = my_lim; fb_out[lane] = my_fb; }
     for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
         uint32_t base = 0;
         int mylen = 15;
 #pragma unroll
         for (int len = ROOT + 1; len <= 15; ++len) {
-            const uint32_t c = fc[len - ROOT - 1] >> 16;
+            const uint32_t c = cs[len - ROOT - 1];
             if (i >= base && i < base + c) mylen = len;
             base += c;
         }
@@ -143,19 +146,17 @@ __device__ __forceinline__ void build_long(const uint16_t *cnt, const uint16_t *
 }
 
 template <int ROOT>
-__device__ __forceinline__ uint32_t long_lookup(const uint32_t *fcs, const tab_t *tab, uint32_t bits)
+__device__ __forceinline__ uint32_t long_lookup(const uint32_t *lim, const uint32_t *fb, const tab_t *tab, uint32_t bits)
 {
-    const uint32_t r = __builtin_bitreverse32(bits);
-    uint32_t idx = 0xFFFFFFFFu, base = 0;
+    const uint32_t r15 = __builtin_bitreverse32(bits) >> 17;
+    uint32_t n = 0;
 #pragma unroll
-    for (int len = ROOT + 1; len <= 15; ++len) {
-        const uint32_t fc = fcs[len - ROOT - 1];
-        const uint32_t c = fc >> 16;
-        const uint32_t d = (r >> (32 - len)) - (fc & 0xFFFFu);
-        if (d < c) idx = base + d;
-        base += c;
-    }
-    return idx != 0xFFFFFFFFu ? tab[idx] : 0u;
+    for (int k = 0; k < 15 - ROOT; ++k) n += r15 >= lim[k] ? 1u : 0u;
+    if (n >= (uint32_t)(15 - ROOT)) return 0u;
+    const uint32_t f = fb[n];
+    const uint32_t code = r15 >> (14 - ROOT - n);
+    if (code < (f & 0xFFFFu)) return 0u;                    // (a slot of the root table whose short code names no symbol)
+    return tab[(f >> 16) + (code - (f & 0xFFFFu))];
 }
 
 // an inclusive sum over each group of 64 / NB lanes (one block's lanes): rows of 16, pairs of rows, the wavefront
@@ -177,7 +178,7 @@ enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
 // -> T.go = 1 and T.pos at the first symbol (a Huffman block), or the block's stream is finished / damaged (T.go = 0).  Stored
 // deflate blocks are turned into raw tokens here and the next header is taken at once.
 __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
-                                             uint64_t *stamps, int blk)
+                                          uint64_t *stamps, int blk)
 {
     const int lane = threadIdx.x & 63;
     uint32_t pos = uni(T.pos), ntok = uni(T.ntok), err = ST_OK;
@@ -298,8 +299,8 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
         // ---- tables: the root tables as in bgzf_inflate, the longer codes as ready-made entries ------------------------------------
         if (uni(build_table<5, LL_ROOT>(T.lens, nlen, T.cnt_ll, T.sym_ll, T.ll, K_LITLEN, T.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
         if (uni(build_table<1, D_ROOT>(T.lens + nlen, ndist, T.cnt_d, T.sym_d, T.dt, K_DIST, T.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        build_long<LL_ROOT>(T.cnt_ll, T.sym_ll, T.rs, K_LITLEN, T.long_ll, T.fc_ll);
-        build_long<D_ROOT>(T.cnt_d, T.sym_d, T.rs + 2, K_DIST, T.long_d, T.fc_d);
+        build_long<LL_ROOT>(T.cnt_ll, T.sym_ll, T.rs, K_LITLEN, T.long_ll, T.lim_ll, T.fb_ll);
+        build_long<D_ROOT>(T.cnt_d, T.sym_d, T.rs + 2, K_DIST, T.long_d, T.lim_d, T.fb_d);
         if (pos >= end) { err = ST_BAD_STREAM; break; }
         go = true;
         TCMI_STAMP(stamps, blk, 3);
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                 peek64(bp, p, lo, hi);
                 uint32_t e = B.ll[lo & ((1u << LL_ROOT) - 1u)];
                 if (__builtin_expect(__ballot((e & 15u) == 0) != 0, 0)) {
-                    const uint32_t e2 = long_lookup<LL_ROOT>(B.fc_ll, B.long_ll, lo);
+                    const uint32_t e2 = long_lookup<LL_ROOT>(B.lim_ll, B.fb_ll, B.long_ll, lo);
                     if ((e & 15u) == 0) e = e2;
                 }
                 if ((e & 15u) == 0) return SY_BAD;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                 const uint32_t d32 = __builtin_amdgcn_alignbit(hi, lo, k);
                 uint32_t f = B.dt[d32 & ((1u << D_ROOT) - 1u)];
                 if (__builtin_expect(__ballot((f & 15u) == 0) != 0, 0)) {
-                    const uint32_t f2 = long_lookup<D_ROOT>(B.fc_d, B.long_d, d32);
+                    const uint32_t f2 = long_lookup<D_ROOT>(B.lim_d, B.fb_d, B.long_d, d32);
                     if ((f & 15u) == 0) f = f2;
                 }
                 if ((f & 15u) == 0) return SY_BAD;
@@ -406,10 +407,331 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
             uint32_t p = min(s_c, b_end);
             uint32_t kprev = 0xFFFFFFFFu;
             bool spilled = false;                   // more symbols than the scratch holds: pass B decodes this block again
+            uint32_t rounds = 0;
 #pragma unroll
             for (int k = 0; k < RING; ++k) L.ring[lane][k] = make_uint2(0xFFFFFFFFu, 0u);
             L.rec[lane] = make_uint2(state, p);
             wave_sync();
+#if TCMI_SYM_ASM
+            // The rounds, hand-scheduled (the compiler's version of the loop below takes ~180 instructions a round, half of them
+            // bookkeeping of which lanes are in which branch; this one ~85).  Differences to the C++ loop: a lane's look at its
+            // target's ring waits for the next round that is a multiple of four (the lane goes on decoding meanwhile; if it
+            // has met its target, it steps back to the meeting point), and a lane's target is kept as a lane of the wavefront.
+            {
+                uint32_t tgt_abs = (uint32_t)lane0 + tgt, room = lane_cap, crossp = 0xFFFFFFFFu, crosst = 0;
+                uint64_t sptr = reinterpret_cast<uint64_t>(scratch);
+                const uint32_t tabs = (uint32_t)reinterpret_cast<uintptr_t>(&B), payb = (uint32_t)reinterpret_cast<uintptr_t>(bp);
+                const uint32_t ringbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.ring[0][0]), recbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.rec[0]);
+                const uint32_t ringb = ringbase + (uint32_t)lane * (RING * 8), recb = recbase + (uint32_t)lane * 8u;
+                const uint32_t lim = (uint32_t)lane0 + (uint32_t)SYM_LANES;
+                unsigned long long run = __ballot(state == RUN);
+                static_assert(LL_ROOT == 9 && D_ROOT == 8 && RING == 8, "masks and counts below");
+                asm volatile(
+                    "s_mov_b64 s[92:93], exec\n"
+                    "LT%=:\n"
+                    "s_mov_b64 exec, %[run]\n"
+                    "s_cbranch_execz LX%=\n"
+                    // ---- a lane's symbols cross into a new stretch: note {p, total} in its ring
+                    "v_lshrrev_b32 v96, %[shift], %[p]\n"
+                    "v_cmp_ne_u32 vcc, v96, %[kprev]\n"
+                    "s_and_saveexec_b64 s[80:81], vcc\n"
+                    "s_cbranch_execz LA1%=\n"
+                    "v_mov_b32 %[kprev], v96\n"
+                    "v_and_b32 v97, 7, v96\n"
+                    "v_lshl_add_u32 v97, v97, 3, %[ringb]\n"
+                    "ds_write2_b32 v97, %[p], %[total] offset1:1\n"
+                    "v_mov_b32 %[crossp], %[p]\n"
+                    "v_mov_b32 %[crosst], %[total]\n"
+                    "LA1%=:\n"
+                    "s_mov_b64 exec, %[run]\n"
+                    // ---- every fourth round: the lanes that have crossed since look their position up in their target's ring
+                    "s_and_b32 s90, %[rounds], 3\n"
+                    "s_cmp_eq_u32 s90, 3\n"
+                    "s_cbranch_scc0 LC%=\n"
+                    "v_cmp_ne_u32 vcc, -1, %[crossp]\n"
+                    "s_and_saveexec_b64 s[80:81], vcc\n"
+                    "s_cbranch_execz LB9%=\n"
+                    "v_add_u32 v97, -1, %[lim]\n"
+                    "v_min_u32 v97, %[tgt], v97\n"
+                    "v_lshl_add_u32 v98, v97, 3, %[recbase]\n"
+                    "ds_read2_b32 v[100:101], v98 offset1:1\n"              // the target's {state | its target << 8, position}
+                    "v_lshrrev_b32 v96, %[shift], %[crossp]\n"
+                    "v_and_b32 v96, 7, v96\n"
+                    "v_lshlrev_b32 v96, 3, v96\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v99, 3, v100\n"
+                    "v_cmp_ne_u32 vcc, 0, v99\n"
+                    "v_cmp_ge_u32 s[86:87], %[crossp], v101\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"
+                    "v_cmp_lt_u32 s[86:87], %[tgt], %[lim]\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"
+                    "s_and_saveexec_b64 s[82:83], vcc\n"                    // a target that has stopped at or in front of the lane:
+                    "v_cmp_eq_u32 vcc, 1, v99\n"                            // on to the lane it met, or to the next one
+                    "v_add_u32 %[tgt], 1, %[tgt]\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "v_lshrrev_b32 %[tgt], 8, v100\n"
+                    "s_mov_b64 exec, s[82:83]\n"
+                    "v_cmp_lt_u32 vcc, %[tgt], %[lim]\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "s_cbranch_execz LB8%=\n"
+                    "v_lshl_add_u32 v98, %[tgt], 6, v96\n"
+                    "v_add_u32 v98, %[ringbase], v98\n"
+                    "ds_read2_b32 v[100:101], v98 offset1:1\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_cmp_eq_u32 vcc, v100, %[crossp]\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "s_cbranch_execz LB8%=\n"
+                    "v_mov_b32 %[midx], v101\n"                             // met: back to the meeting point, stop
+                    "v_mov_b32 %[state], 1\n"
+                    "v_mov_b32 %[p], %[crossp]\n"
+                    "v_mov_b32 %[total], %[crosst]\n"
+                    "v_lshl_or_b32 v99, %[tgt], 8, 1\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "LB8%=:\n"
+                    "s_mov_b64 exec, s[80:81]\n"
+                    "v_mov_b32 %[crossp], -1\n"
+                    "LB9%=:\n"
+                    "s_mov_b64 exec, %[run]\n"
+                    "s_cbranch_execz LX%=\n"
+                    "LC%=:\n"
+                    // ---- one symbol
+                    "v_cmp_lt_u32 vcc, %[p], %[end]\n"
+                    "s_xor_b64 s[86:87], vcc, exec\n"
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 LDend%=\n"
+                    "LC1%=:\n"
+                    "v_lshrrev_b32 v96, 5, %[p]\n"
+                    "v_lshl_add_u32 v96, v96, 2, %[pay]\n"
+                    "ds_read2_b32 v[100:101], v96 offset1:1\n"
+                    "ds_read_b32 v102, v96 offset:8\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_alignbit_b32 v103, v101, v100, %[p]\n"
+                    "v_alignbit_b32 v104, v102, v101, %[p]\n"
+                    "v_and_b32 v96, 0x1ff, v103\n"
+                    "v_lshl_add_u32 v96, v96, 2, %[tabs]\n"
+                    "ds_read_b32 v105, v96\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v106, 15, v105\n"
+                    "v_cmp_eq_u32 vcc, 0, v106\n"
+                    "s_cbranch_vccnz LLl%=\n"
+                    "LC2%=:\n"
+                    "v_bfe_u32 v97, v105, 8, 3\n"                            // 1 literal, 2 length, 4 end of block
+                    "v_cmp_eq_u32 vcc, 4, v97\n"
+                    "s_cbranch_vccnz LDeob%=\n"
+                    "LC3%=:\n"
+                    "v_bfe_u32 v107, v105, 16, 8\n"
+                    "v_or_b32 v107, 0x80000000, v107\n"
+                    "v_add_u32 v108, %[p], v106\n"
+                    "s_mov_b64 s[88:89], exec\n"
+                    "v_cmp_eq_u32 vcc, 2, v97\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "s_cbranch_execz LC5%=\n"
+                    "v_bfe_u32 v109, v105, 11, 5\n"                          // code + extra bits of the length
+                    "v_alignbit_b32 v110, v104, v103, v109\n"
+                    "v_and_b32 v96, 0xff, v110\n"
+                    "v_lshl_add_u32 v96, v96, 2, %[tabs]\n"
+                    "ds_read_b32 v111, v96 offset:%[odt]\n"
+                    "v_lshrrev_b32 v98, v106, v103\n"
+                    "v_bfe_u32 v99, v105, 16, 4\n"
+                    "v_bfe_u32 v98, v98, 0, v99\n"
+                    "v_bfe_u32 v99, v105, 20, 9\n"
+                    "v_add_u32 v112, v99, v98\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v113, 15, v111\n"
+                    "v_cmp_eq_u32 vcc, 0, v113\n"
+                    "s_cbranch_vccnz LLd%=\n"
+                    "LC4%=:\n"
+                    "v_bfe_u32 v99, v111, 4, 4\n"
+                    "v_lshrrev_b32 v98, v113, v110\n"
+                    "v_bfe_u32 v98, v98, 0, v99\n"
+                    "v_lshrrev_b32 v96, 16, v111\n"
+                    "v_add_u32 v98, v98, v96\n"
+                    "v_add_u32 v98, -1, v98\n"
+                    "v_lshl_or_b32 v107, v98, 9, v112\n"
+                    "v_add3_u32 v108, %[p], v109, v113\n"
+                    "v_add_u32 v108, v108, v99\n"
+                    "LC5%=:\n"
+                    "s_and_b64 exec, s[88:89], %[run]\n"
+                    "s_cbranch_execz LT%=\n"
+                    "v_mov_b32 %[p], v108\n"
+                    "v_cmp_gt_u32 vcc, %[p], %[end]\n"
+                    "s_cbranch_vccnz LDover%=\n"
+                    "LC6%=:\n"
+                    "s_mov_b64 s[80:81], exec\n"
+                    "v_cmp_ne_u32 vcc, 0, %[room]\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "global_store_dword %[sptr], v107, off\n"
+                    "v_add_u32 %[room], -1, %[room]\n"
+                    "v_lshl_add_u64 %[sptr], %[sptr], 0, 4\n"
+                    "s_mov_b64 exec, s[80:81]\n"
+                    "v_add_u32 %[total], 1, %[total]\n"
+                    "s_add_u32 %[rounds], %[rounds], 1\n"
+                    "s_branch LT%=\n"
+                    // ---- the rare ways out of a round
+                    "LDend%=:\n"                                              // s[86:87]: lanes at the end of the payload without an end-of-block code
+                    "s_mov_b64 s[82:83], exec\n"
+                    "s_mov_b64 exec, s[86:87]\n"
+                    "v_mov_b32 %[state], 3\n"
+                    "v_mov_b32 v99, 3\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "s_andn2_b64 exec, s[82:83], s[86:87]\n"
+                    "s_cbranch_execz LT%=\n"
+                    "s_branch LC1%=\n"
+                    "LDeob%=:\n"                                              // vcc: lanes at an end-of-block code
+                    "s_mov_b64 s[82:83], exec\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "v_add_u32 %[p], %[p], v106\n"
+                    "v_add_u32 %[total], 1, %[total]\n"
+                    "v_mov_b32 %[state], 2\n"
+                    "v_mov_b32 v99, 2\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "s_andn2_b64 exec, s[82:83], exec\n"
+                    "s_cbranch_execz LT%=\n"
+                    "s_branch LC3%=\n"
+                    "LDover%=:\n"                                             // vcc: lanes whose symbol runs over the end
+                    "s_mov_b64 s[82:83], exec\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "v_mov_b32 %[state], 3\n"
+                    "v_mov_b32 v99, 3\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "s_andn2_b64 exec, s[82:83], exec\n"
+                    "s_cbranch_execz LT%=\n"
+                    "s_branch LC6%=\n"
+                    // ---- a literal / length code longer than nine bits (vcc: the lanes that have one): the code's first 15 bits against the ends of the six longer lengths
+                    "LLl%=:\n"
+                    "s_mov_b64 s[84:85], exec\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "v_bfrev_b32 v96, v103\n"
+                    "v_lshrrev_b32 v96, 17, v96\n"
+                    "v_add_u32 v97, %[oliml], %[tabs]\n"
+                    "ds_read2_b32 v[114:115], v97 offset1:1\n"
+                    "ds_read2_b32 v[116:117], v97 offset0:2 offset1:3\n"
+                    "ds_read2_b32 v[118:119], v97 offset0:4 offset1:5\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_sub_u32 v114, v96, v114\n"
+                    "v_sub_u32 v115, v96, v115\n"
+                    "v_sub_u32 v116, v96, v116\n"
+                    "v_sub_u32 v117, v96, v117\n"
+                    "v_sub_u32 v118, v96, v118\n"
+                    "v_sub_u32 v119, v96, v119\n"
+                    "v_ashrrev_i32 v114, 31, v114\n"
+                    "v_ashrrev_i32 v115, 31, v115\n"
+                    "v_ashrrev_i32 v116, 31, v116\n"
+                    "v_ashrrev_i32 v117, 31, v117\n"
+                    "v_ashrrev_i32 v118, 31, v118\n"
+                    "v_ashrrev_i32 v119, 31, v119\n"
+                    "v_add3_u32 v114, v114, v115, v116\n"
+                    "v_add3_u32 v117, v117, v118, v119\n"
+                    "v_add3_u32 v98, v114, v117, 6\n"                        // lengths whose codes end at or below this one
+                    "v_min_u32 v97, 5, v98\n"
+                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
+                    "ds_read_b32 v99, v97 offset:%[ofbll]\n"                  // first code | index of its entry << 16
+                    "v_sub_u32 v97, 5, v98\n"
+                    "v_lshrrev_b32 v97, v97, v96\n"                           // the code, right-aligned
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v96, 0xffff, v99\n"
+                    "v_cmp_ge_u32 vcc, v97, v96\n"
+                    "v_cmp_gt_u32 s[86:87], 6, v98\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"                          // there is such a code
+                    "v_sub_u32 v97, v97, v96\n"
+                    "v_lshrrev_b32 v96, 16, v99\n"
+                    "v_add_u32 v97, v97, v96\n"
+                    "v_and_b32 v97, 0x1ff, v97\n"
+                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
+                    "ds_read_b32 v105, v97 offset:%[olongll]\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v106, 15, v105\n"
+                    "v_cmp_ne_u32 s[86:87], 0, v106\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"
+                    "s_andn2_b64 exec, exec, vcc\n"                           // the lanes without: dead
+                    "s_cbranch_execz LLl9%=\n"
+                    "v_mov_b32 %[state], 3\n"
+                    "v_mov_b32 v99, 3\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "LLl9%=:\n"
+                    "s_and_b64 exec, s[84:85], %[run]\n"
+                    "s_cbranch_execz LT%=\n"
+                    "s_branch LC2%=\n"
+                    // ---- ... a distance code longer than eight bits: seven lengths
+                    "LLd%=:\n"
+                    "s_mov_b64 s[84:85], exec\n"
+                    "s_and_b64 exec, exec, vcc\n"
+                    "v_bfrev_b32 v96, v110\n"
+                    "v_lshrrev_b32 v96, 17, v96\n"
+                    "v_add_u32 v97, %[olimd], %[tabs]\n"
+                    "ds_read2_b32 v[114:115], v97 offset1:1\n"
+                    "ds_read2_b32 v[116:117], v97 offset0:2 offset1:3\n"
+                    "ds_read2_b32 v[118:119], v97 offset0:4 offset1:5\n"
+                    "ds_read_b32 v98, v97 offset:24\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_sub_u32 v114, v96, v114\n"
+                    "v_sub_u32 v115, v96, v115\n"
+                    "v_sub_u32 v116, v96, v116\n"
+                    "v_sub_u32 v117, v96, v117\n"
+                    "v_sub_u32 v118, v96, v118\n"
+                    "v_sub_u32 v119, v96, v119\n"
+                    "v_sub_u32 v98, v96, v98\n"
+                    "v_ashrrev_i32 v114, 31, v114\n"
+                    "v_ashrrev_i32 v115, 31, v115\n"
+                    "v_ashrrev_i32 v116, 31, v116\n"
+                    "v_ashrrev_i32 v117, 31, v117\n"
+                    "v_ashrrev_i32 v118, 31, v118\n"
+                    "v_ashrrev_i32 v119, 31, v119\n"
+                    "v_ashrrev_i32 v98, 31, v98\n"
+                    "v_add3_u32 v114, v114, v115, v116\n"
+                    "v_add3_u32 v117, v117, v118, v119\n"
+                    "v_add3_u32 v98, v114, v117, v98\n"
+                    "v_add_u32 v98, 7, v98\n"
+                    "v_min_u32 v97, 6, v98\n"
+                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
+                    "ds_read_b32 v99, v97 offset:%[ofbd]\n"
+                    "v_sub_u32 v97, 6, v98\n"
+                    "v_lshrrev_b32 v97, v97, v96\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v96, 0xffff, v99\n"
+                    "v_cmp_ge_u32 vcc, v97, v96\n"
+                    "v_cmp_gt_u32 s[86:87], 7, v98\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"
+                    "v_sub_u32 v97, v97, v96\n"
+                    "v_lshrrev_b32 v96, 16, v99\n"
+                    "v_add_u32 v97, v97, v96\n"
+                    "v_and_b32 v97, 31, v97\n"
+                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
+                    "ds_read_b32 v111, v97 offset:%[olongd]\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_and_b32 v113, 15, v111\n"
+                    "v_cmp_ne_u32 s[86:87], 0, v113\n"
+                    "s_and_b64 vcc, vcc, s[86:87]\n"
+                    "s_andn2_b64 exec, exec, vcc\n"
+                    "s_cbranch_execz LLd9%=\n"
+                    "v_mov_b32 %[state], 3\n"
+                    "v_mov_b32 v99, 3\n"
+                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "s_andn2_b64 %[run], %[run], exec\n"
+                    "LLd9%=:\n"
+                    "s_and_b64 exec, s[84:85], %[run]\n"
+                    "s_cbranch_execz LC5%=\n"
+                    "s_branch LC4%=\n"
+                    "LX%=:\n"
+                    "s_mov_b64 exec, s[92:93]\n"
+                    : [p] "+v"(p), [total] "+v"(total), [tgt] "+v"(tgt_abs), [midx] "+v"(midx), [kprev] "+v"(kprev), [state] "+v"(state),
+                      [room] "+v"(room), [crossp] "+v"(crossp), [crosst] "+v"(crosst), [sptr] "+v"(sptr), [run] "+s"(run), [rounds] "+s"(rounds)
+                    : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim),
+                      [ringbase] "s"(ringbase), [recbase] "s"(recbase), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
+                      [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)),
+                      [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d))
+                    : "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
+                      "s88", "s89", "s90", "s92", "s93", "vcc", "scc", "memory");
+                tgt = tgt_abs - (uint32_t)lane0;
+                spilled = total > lane_cap;
+            }
+#else
             while (__ballot(state == RUN)) {
                 const uint32_t kk = p >> shift;
                 const bool cross = state == RUN && kk != kprev;
@@ -418,16 +740,13 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                 if (cross) {
                     kprev = kk;
                     // a target that has stopped at or in front of p: on to the lane it met, or to the next one
-#pragma unroll 1
-                    for (int hop = 0; hop < 3 && tgt < (uint32_t)SYM_LANES; ++hop) {
-                        const uint2 r = L.rec[lane0 + (int)tgt];
+                    {
+                        const uint2 r = L.rec[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)];
                         const uint32_t st = r.x & 3u;
-                        if (st == RUN || p < r.y) break;
-                        tgt = st == MERGED ? r.x >> 8 : tgt + 1u;
-                    }
-                    if (tgt < (uint32_t)SYM_LANES) {
-                        const uint2 e = L.ring[lane0 + (int)tgt][kk & (RING - 1)];
-                        if (e.x == p) { state = MERGED; midx = e.y; }
+                        const uint32_t nxt = st == MERGED ? r.x >> 8 : tgt + 1u;
+                        tgt = st != RUN && p >= r.y && tgt < (uint32_t)SYM_LANES ? nxt : tgt;      // (one step per stretch)
+                        const uint2 e = L.ring[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)][kk & (RING - 1)];
+                        if (tgt < (uint32_t)SYM_LANES && e.x == p) { state = MERGED; midx = e.y; }
                     }
                 }
                 if (state == RUN) {
@@ -442,9 +761,11 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     }
                 }
                 if (cross || state != RUN) L.rec[lane] = make_uint2(state | (tgt << 8), p);
-                TCMI_STAMP_ADD(a.stamps, blk0, 8, 1);
+                ++rounds;
             }
+#endif
             TCMI_STAMP(a.stamps, blk0, 4);
+            TCMI_STAMP_ADD(a.stamps, blk0, 8, rounds);
             // ---- per block the chain of lanes that hold the true symbols: lane 0 from `start`, then whoever it met, ... ----------
             uint32_t before = 0;                    // symbols a lane decoded in front of its true start: they do not count
             bool alive = on && c == 0;

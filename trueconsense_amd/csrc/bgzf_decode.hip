@@ -310,7 +310,7 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
 }
 
 template <int NB>
-__global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
+__global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_symbols(SymArgs a)
 {
     constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
     static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
@@ -432,14 +432,14 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "s_mov_b64 exec, %[run]\n"
                     "s_cbranch_execz LX%=\n"
                     // ---- a lane's symbols cross into a new stretch: note {p, total} in its ring
-                    "v_lshrrev_b32 v96, %[shift], %[p]\n"
-                    "v_cmp_ne_u32 vcc, v96, %[kprev]\n"
+                    "v_lshrrev_b32 v40, %[shift], %[p]\n"
+                    "v_cmp_ne_u32 vcc, v40, %[kprev]\n"
                     "s_and_saveexec_b64 s[80:81], vcc\n"
                     "s_cbranch_execz LA1%=\n"
-                    "v_mov_b32 %[kprev], v96\n"
-                    "v_and_b32 v97, 7, v96\n"
-                    "v_lshl_add_u32 v97, v97, 3, %[ringb]\n"
-                    "ds_write2_b32 v97, %[p], %[total] offset1:1\n"
+                    "v_mov_b32 %[kprev], v40\n"
+                    "v_and_b32 v41, 7, v40\n"
+                    "v_lshl_add_u32 v41, v41, 3, %[ringb]\n"
+                    "ds_write2_b32 v41, %[p], %[total] offset1:1\n"
                     "v_mov_b32 %[crossp], %[p]\n"
                     "v_mov_b32 %[crosst], %[total]\n"
                     "LA1%=:\n"
@@ -451,42 +451,42 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "v_cmp_ne_u32 vcc, -1, %[crossp]\n"
                     "s_and_saveexec_b64 s[80:81], vcc\n"
                     "s_cbranch_execz LB9%=\n"
-                    "v_add_u32 v97, -1, %[lim]\n"
-                    "v_min_u32 v97, %[tgt], v97\n"
-                    "v_lshl_add_u32 v98, v97, 3, %[recbase]\n"
-                    "ds_read2_b32 v[100:101], v98 offset1:1\n"              // the target's {state | its target << 8, position}
-                    "v_lshrrev_b32 v96, %[shift], %[crossp]\n"
-                    "v_and_b32 v96, 7, v96\n"
-                    "v_lshlrev_b32 v96, 3, v96\n"
+                    "v_add_u32 v41, -1, %[lim]\n"
+                    "v_min_u32 v41, %[tgt], v41\n"
+                    "v_lshl_add_u32 v42, v41, 3, %[recbase]\n"
+                    "ds_read2_b32 v[44:45], v42 offset1:1\n"              // the target's {state | its target << 8, position}
+                    "v_lshrrev_b32 v40, %[shift], %[crossp]\n"
+                    "v_and_b32 v40, 7, v40\n"
+                    "v_lshlrev_b32 v40, 3, v40\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v99, 3, v100\n"
-                    "v_cmp_ne_u32 vcc, 0, v99\n"
-                    "v_cmp_ge_u32 s[86:87], %[crossp], v101\n"
+                    "v_and_b32 v43, 3, v44\n"
+                    "v_cmp_ne_u32 vcc, 0, v43\n"
+                    "v_cmp_ge_u32 s[86:87], %[crossp], v45\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"
                     "v_cmp_lt_u32 s[86:87], %[tgt], %[lim]\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"
                     "s_and_saveexec_b64 s[82:83], vcc\n"                    // a target that has stopped at or in front of the lane:
-                    "v_cmp_eq_u32 vcc, 1, v99\n"                            // on to the lane it met, or to the next one
+                    "v_cmp_eq_u32 vcc, 1, v43\n"                            // on to the lane it met, or to the next one
                     "v_add_u32 %[tgt], 1, %[tgt]\n"
                     "s_and_b64 exec, exec, vcc\n"
-                    "v_lshrrev_b32 %[tgt], 8, v100\n"
+                    "v_lshrrev_b32 %[tgt], 8, v44\n"
                     "s_mov_b64 exec, s[82:83]\n"
                     "v_cmp_lt_u32 vcc, %[tgt], %[lim]\n"
                     "s_and_b64 exec, exec, vcc\n"
                     "s_cbranch_execz LB8%=\n"
-                    "v_lshl_add_u32 v98, %[tgt], 6, v96\n"
-                    "v_add_u32 v98, %[ringbase], v98\n"
-                    "ds_read2_b32 v[100:101], v98 offset1:1\n"
+                    "v_lshl_add_u32 v42, %[tgt], 6, v40\n"
+                    "v_add_u32 v42, %[ringbase], v42\n"
+                    "ds_read2_b32 v[44:45], v42 offset1:1\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_cmp_eq_u32 vcc, v100, %[crossp]\n"
+                    "v_cmp_eq_u32 vcc, v44, %[crossp]\n"
                     "s_and_b64 exec, exec, vcc\n"
                     "s_cbranch_execz LB8%=\n"
-                    "v_mov_b32 %[midx], v101\n"                             // met: back to the meeting point, stop
+                    "v_mov_b32 %[midx], v45\n"                             // met: back to the meeting point, stop
                     "v_mov_b32 %[state], 1\n"
                     "v_mov_b32 %[p], %[crossp]\n"
                     "v_mov_b32 %[total], %[crosst]\n"
-                    "v_lshl_or_b32 v99, %[tgt], 8, 1\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_lshl_or_b32 v43, %[tgt], 8, 1\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "LB8%=:\n"
                     "s_mov_b64 exec, s[80:81]\n"
@@ -501,67 +501,67 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "s_cmp_lg_u64 s[86:87], 0\n"
                     "s_cbranch_scc1 LDend%=\n"
                     "LC1%=:\n"
-                    "v_lshrrev_b32 v96, 5, %[p]\n"
-                    "v_lshl_add_u32 v96, v96, 2, %[pay]\n"
-                    "ds_read2_b32 v[100:101], v96 offset1:1\n"
-                    "ds_read_b32 v102, v96 offset:8\n"
+                    "v_lshrrev_b32 v40, 5, %[p]\n"
+                    "v_lshl_add_u32 v40, v40, 2, %[pay]\n"
+                    "ds_read2_b32 v[44:45], v40 offset1:1\n"
+                    "ds_read_b32 v46, v40 offset:8\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_alignbit_b32 v103, v101, v100, %[p]\n"
-                    "v_alignbit_b32 v104, v102, v101, %[p]\n"
-                    "v_and_b32 v96, 0x1ff, v103\n"
-                    "v_lshl_add_u32 v96, v96, 2, %[tabs]\n"
-                    "ds_read_b32 v105, v96\n"
+                    "v_alignbit_b32 v47, v45, v44, %[p]\n"
+                    "v_alignbit_b32 v48, v46, v45, %[p]\n"
+                    "v_and_b32 v40, 0x1ff, v47\n"
+                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n"
+                    "ds_read_b32 v49, v40\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v106, 15, v105\n"
-                    "v_cmp_eq_u32 vcc, 0, v106\n"
+                    "v_and_b32 v50, 15, v49\n"
+                    "v_cmp_eq_u32 vcc, 0, v50\n"
                     "s_cbranch_vccnz LLl%=\n"
                     "LC2%=:\n"
-                    "v_bfe_u32 v97, v105, 8, 3\n"                            // 1 literal, 2 length, 4 end of block
-                    "v_cmp_eq_u32 vcc, 4, v97\n"
+                    "v_bfe_u32 v41, v49, 8, 3\n"                            // 1 literal, 2 length, 4 end of block
+                    "v_cmp_eq_u32 vcc, 4, v41\n"
                     "s_cbranch_vccnz LDeob%=\n"
                     "LC3%=:\n"
-                    "v_bfe_u32 v107, v105, 16, 8\n"
-                    "v_or_b32 v107, 0x80000000, v107\n"
-                    "v_add_u32 v108, %[p], v106\n"
+                    "v_bfe_u32 v51, v49, 16, 8\n"
+                    "v_or_b32 v51, 0x80000000, v51\n"
+                    "v_add_u32 v52, %[p], v50\n"
                     "s_mov_b64 s[88:89], exec\n"
-                    "v_cmp_eq_u32 vcc, 2, v97\n"
+                    "v_cmp_eq_u32 vcc, 2, v41\n"
                     "s_and_b64 exec, exec, vcc\n"
                     "s_cbranch_execz LC5%=\n"
-                    "v_bfe_u32 v109, v105, 11, 5\n"                          // code + extra bits of the length
-                    "v_alignbit_b32 v110, v104, v103, v109\n"
-                    "v_and_b32 v96, 0xff, v110\n"
-                    "v_lshl_add_u32 v96, v96, 2, %[tabs]\n"
-                    "ds_read_b32 v111, v96 offset:%[odt]\n"
-                    "v_lshrrev_b32 v98, v106, v103\n"
-                    "v_bfe_u32 v99, v105, 16, 4\n"
-                    "v_bfe_u32 v98, v98, 0, v99\n"
-                    "v_bfe_u32 v99, v105, 20, 9\n"
-                    "v_add_u32 v112, v99, v98\n"
+                    "v_bfe_u32 v53, v49, 11, 5\n"                          // code + extra bits of the length
+                    "v_alignbit_b32 v54, v48, v47, v53\n"
+                    "v_and_b32 v40, 0xff, v54\n"
+                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n"
+                    "ds_read_b32 v55, v40 offset:%[odt]\n"
+                    "v_lshrrev_b32 v42, v50, v47\n"
+                    "v_bfe_u32 v43, v49, 16, 4\n"
+                    "v_bfe_u32 v42, v42, 0, v43\n"
+                    "v_bfe_u32 v43, v49, 20, 9\n"
+                    "v_add_u32 v56, v43, v42\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v113, 15, v111\n"
-                    "v_cmp_eq_u32 vcc, 0, v113\n"
+                    "v_and_b32 v57, 15, v55\n"
+                    "v_cmp_eq_u32 vcc, 0, v57\n"
                     "s_cbranch_vccnz LLd%=\n"
                     "LC4%=:\n"
-                    "v_bfe_u32 v99, v111, 4, 4\n"
-                    "v_lshrrev_b32 v98, v113, v110\n"
-                    "v_bfe_u32 v98, v98, 0, v99\n"
-                    "v_lshrrev_b32 v96, 16, v111\n"
-                    "v_add_u32 v98, v98, v96\n"
-                    "v_add_u32 v98, -1, v98\n"
-                    "v_lshl_or_b32 v107, v98, 9, v112\n"
-                    "v_add3_u32 v108, %[p], v109, v113\n"
-                    "v_add_u32 v108, v108, v99\n"
+                    "v_bfe_u32 v43, v55, 4, 4\n"
+                    "v_lshrrev_b32 v42, v57, v54\n"
+                    "v_bfe_u32 v42, v42, 0, v43\n"
+                    "v_lshrrev_b32 v40, 16, v55\n"
+                    "v_add_u32 v42, v42, v40\n"
+                    "v_add_u32 v42, -1, v42\n"
+                    "v_lshl_or_b32 v51, v42, 9, v56\n"
+                    "v_add3_u32 v52, %[p], v53, v57\n"
+                    "v_add_u32 v52, v52, v43\n"
                     "LC5%=:\n"
                     "s_and_b64 exec, s[88:89], %[run]\n"
                     "s_cbranch_execz LT%=\n"
-                    "v_mov_b32 %[p], v108\n"
+                    "v_mov_b32 %[p], v52\n"
                     "v_cmp_gt_u32 vcc, %[p], %[end]\n"
                     "s_cbranch_vccnz LDover%=\n"
                     "LC6%=:\n"
                     "s_mov_b64 s[80:81], exec\n"
                     "v_cmp_ne_u32 vcc, 0, %[room]\n"
                     "s_and_b64 exec, exec, vcc\n"
-                    "global_store_dword %[sptr], v107, off\n"
+                    "global_store_dword %[sptr], v51, off\n"
                     "v_add_u32 %[room], -1, %[room]\n"
                     "v_lshl_add_u64 %[sptr], %[sptr], 0, 4\n"
                     "s_mov_b64 exec, s[80:81]\n"
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "s_mov_b64 s[82:83], exec\n"
                     "s_mov_b64 exec, s[86:87]\n"
                     "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v99, 3\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_mov_b32 v43, 3\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "s_andn2_b64 exec, s[82:83], s[86:87]\n"
                     "s_cbranch_execz LT%=\n"
@@ -582,11 +582,11 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "LDeob%=:\n"                                              // vcc: lanes at an end-of-block code
                     "s_mov_b64 s[82:83], exec\n"
                     "s_and_b64 exec, exec, vcc\n"
-                    "v_add_u32 %[p], %[p], v106\n"
+                    "v_add_u32 %[p], %[p], v50\n"
                     "v_add_u32 %[total], 1, %[total]\n"
                     "v_mov_b32 %[state], 2\n"
-                    "v_mov_b32 v99, 2\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_mov_b32 v43, 2\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "s_andn2_b64 exec, s[82:83], exec\n"
                     "s_cbranch_execz LT%=\n"
@@ -595,8 +595,8 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "s_mov_b64 s[82:83], exec\n"
                     "s_and_b64 exec, exec, vcc\n"
                     "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v99, 3\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_mov_b32 v43, 3\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "s_andn2_b64 exec, s[82:83], exec\n"
                     "s_cbranch_execz LT%=\n"
@@ -605,53 +605,53 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "LLl%=:\n"
                     "s_mov_b64 s[84:85], exec\n"
                     "s_and_b64 exec, exec, vcc\n"
-                    "v_bfrev_b32 v96, v103\n"
-                    "v_lshrrev_b32 v96, 17, v96\n"
-                    "v_add_u32 v97, %[oliml], %[tabs]\n"
-                    "ds_read2_b32 v[114:115], v97 offset1:1\n"
-                    "ds_read2_b32 v[116:117], v97 offset0:2 offset1:3\n"
-                    "ds_read2_b32 v[118:119], v97 offset0:4 offset1:5\n"
+                    "v_bfrev_b32 v40, v47\n"
+                    "v_lshrrev_b32 v40, 17, v40\n"
+                    "v_add_u32 v41, %[oliml], %[tabs]\n"
+                    "ds_read2_b32 v[58:59], v41 offset1:1\n"
+                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n"
+                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_sub_u32 v114, v96, v114\n"
-                    "v_sub_u32 v115, v96, v115\n"
-                    "v_sub_u32 v116, v96, v116\n"
-                    "v_sub_u32 v117, v96, v117\n"
-                    "v_sub_u32 v118, v96, v118\n"
-                    "v_sub_u32 v119, v96, v119\n"
-                    "v_ashrrev_i32 v114, 31, v114\n"
-                    "v_ashrrev_i32 v115, 31, v115\n"
-                    "v_ashrrev_i32 v116, 31, v116\n"
-                    "v_ashrrev_i32 v117, 31, v117\n"
-                    "v_ashrrev_i32 v118, 31, v118\n"
-                    "v_ashrrev_i32 v119, 31, v119\n"
-                    "v_add3_u32 v114, v114, v115, v116\n"
-                    "v_add3_u32 v117, v117, v118, v119\n"
-                    "v_add3_u32 v98, v114, v117, 6\n"                        // lengths whose codes end at or below this one
-                    "v_min_u32 v97, 5, v98\n"
-                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
-                    "ds_read_b32 v99, v97 offset:%[ofbll]\n"                  // first code | index of its entry << 16
-                    "v_sub_u32 v97, 5, v98\n"
-                    "v_lshrrev_b32 v97, v97, v96\n"                           // the code, right-aligned
+                    "v_sub_u32 v58, v40, v58\n"
+                    "v_sub_u32 v59, v40, v59\n"
+                    "v_sub_u32 v60, v40, v60\n"
+                    "v_sub_u32 v61, v40, v61\n"
+                    "v_sub_u32 v62, v40, v62\n"
+                    "v_sub_u32 v63, v40, v63\n"
+                    "v_ashrrev_i32 v58, 31, v58\n"
+                    "v_ashrrev_i32 v59, 31, v59\n"
+                    "v_ashrrev_i32 v60, 31, v60\n"
+                    "v_ashrrev_i32 v61, 31, v61\n"
+                    "v_ashrrev_i32 v62, 31, v62\n"
+                    "v_ashrrev_i32 v63, 31, v63\n"
+                    "v_add3_u32 v58, v58, v59, v60\n"
+                    "v_add3_u32 v61, v61, v62, v63\n"
+                    "v_add3_u32 v42, v58, v61, 6\n"                        // lengths whose codes end at or below this one
+                    "v_min_u32 v41, 5, v42\n"
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
+                    "ds_read_b32 v43, v41 offset:%[ofbll]\n"                  // first code | index of its entry << 16
+                    "v_sub_u32 v41, 5, v42\n"
+                    "v_lshrrev_b32 v41, v41, v40\n"                           // the code, right-aligned
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v96, 0xffff, v99\n"
-                    "v_cmp_ge_u32 vcc, v97, v96\n"
-                    "v_cmp_gt_u32 s[86:87], 6, v98\n"
+                    "v_and_b32 v40, 0xffff, v43\n"
+                    "v_cmp_ge_u32 vcc, v41, v40\n"
+                    "v_cmp_gt_u32 s[86:87], 6, v42\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"                          // there is such a code
-                    "v_sub_u32 v97, v97, v96\n"
-                    "v_lshrrev_b32 v96, 16, v99\n"
-                    "v_add_u32 v97, v97, v96\n"
-                    "v_and_b32 v97, 0x1ff, v97\n"
-                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
-                    "ds_read_b32 v105, v97 offset:%[olongll]\n"
+                    "v_sub_u32 v41, v41, v40\n"
+                    "v_lshrrev_b32 v40, 16, v43\n"
+                    "v_add_u32 v41, v41, v40\n"
+                    "v_and_b32 v41, 0x1ff, v41\n"
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
+                    "ds_read_b32 v49, v41 offset:%[olongll]\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v106, 15, v105\n"
-                    "v_cmp_ne_u32 s[86:87], 0, v106\n"
+                    "v_and_b32 v50, 15, v49\n"
+                    "v_cmp_ne_u32 s[86:87], 0, v50\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"
                     "s_andn2_b64 exec, exec, vcc\n"                           // the lanes without: dead
                     "s_cbranch_execz LLl9%=\n"
                     "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v99, 3\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_mov_b32 v43, 3\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "LLl9%=:\n"
                     "s_and_b64 exec, s[84:85], %[run]\n"
@@ -661,57 +661,57 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                     "LLd%=:\n"
                     "s_mov_b64 s[84:85], exec\n"
                     "s_and_b64 exec, exec, vcc\n"
-                    "v_bfrev_b32 v96, v110\n"
-                    "v_lshrrev_b32 v96, 17, v96\n"
-                    "v_add_u32 v97, %[olimd], %[tabs]\n"
-                    "ds_read2_b32 v[114:115], v97 offset1:1\n"
-                    "ds_read2_b32 v[116:117], v97 offset0:2 offset1:3\n"
-                    "ds_read2_b32 v[118:119], v97 offset0:4 offset1:5\n"
-                    "ds_read_b32 v98, v97 offset:24\n"
+                    "v_bfrev_b32 v40, v54\n"
+                    "v_lshrrev_b32 v40, 17, v40\n"
+                    "v_add_u32 v41, %[olimd], %[tabs]\n"
+                    "ds_read2_b32 v[58:59], v41 offset1:1\n"
+                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n"
+                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n"
+                    "ds_read_b32 v42, v41 offset:24\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_sub_u32 v114, v96, v114\n"
-                    "v_sub_u32 v115, v96, v115\n"
-                    "v_sub_u32 v116, v96, v116\n"
-                    "v_sub_u32 v117, v96, v117\n"
-                    "v_sub_u32 v118, v96, v118\n"
-                    "v_sub_u32 v119, v96, v119\n"
-                    "v_sub_u32 v98, v96, v98\n"
-                    "v_ashrrev_i32 v114, 31, v114\n"
-                    "v_ashrrev_i32 v115, 31, v115\n"
-                    "v_ashrrev_i32 v116, 31, v116\n"
-                    "v_ashrrev_i32 v117, 31, v117\n"
-                    "v_ashrrev_i32 v118, 31, v118\n"
-                    "v_ashrrev_i32 v119, 31, v119\n"
-                    "v_ashrrev_i32 v98, 31, v98\n"
-                    "v_add3_u32 v114, v114, v115, v116\n"
-                    "v_add3_u32 v117, v117, v118, v119\n"
-                    "v_add3_u32 v98, v114, v117, v98\n"
-                    "v_add_u32 v98, 7, v98\n"
-                    "v_min_u32 v97, 6, v98\n"
-                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
-                    "ds_read_b32 v99, v97 offset:%[ofbd]\n"
-                    "v_sub_u32 v97, 6, v98\n"
-                    "v_lshrrev_b32 v97, v97, v96\n"
+                    "v_sub_u32 v58, v40, v58\n"
+                    "v_sub_u32 v59, v40, v59\n"
+                    "v_sub_u32 v60, v40, v60\n"
+                    "v_sub_u32 v61, v40, v61\n"
+                    "v_sub_u32 v62, v40, v62\n"
+                    "v_sub_u32 v63, v40, v63\n"
+                    "v_sub_u32 v42, v40, v42\n"
+                    "v_ashrrev_i32 v58, 31, v58\n"
+                    "v_ashrrev_i32 v59, 31, v59\n"
+                    "v_ashrrev_i32 v60, 31, v60\n"
+                    "v_ashrrev_i32 v61, 31, v61\n"
+                    "v_ashrrev_i32 v62, 31, v62\n"
+                    "v_ashrrev_i32 v63, 31, v63\n"
+                    "v_ashrrev_i32 v42, 31, v42\n"
+                    "v_add3_u32 v58, v58, v59, v60\n"
+                    "v_add3_u32 v61, v61, v62, v63\n"
+                    "v_add3_u32 v42, v58, v61, v42\n"
+                    "v_add_u32 v42, 7, v42\n"
+                    "v_min_u32 v41, 6, v42\n"
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
+                    "ds_read_b32 v43, v41 offset:%[ofbd]\n"
+                    "v_sub_u32 v41, 6, v42\n"
+                    "v_lshrrev_b32 v41, v41, v40\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v96, 0xffff, v99\n"
-                    "v_cmp_ge_u32 vcc, v97, v96\n"
-                    "v_cmp_gt_u32 s[86:87], 7, v98\n"
+                    "v_and_b32 v40, 0xffff, v43\n"
+                    "v_cmp_ge_u32 vcc, v41, v40\n"
+                    "v_cmp_gt_u32 s[86:87], 7, v42\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "v_sub_u32 v97, v97, v96\n"
-                    "v_lshrrev_b32 v96, 16, v99\n"
-                    "v_add_u32 v97, v97, v96\n"
-                    "v_and_b32 v97, 31, v97\n"
-                    "v_lshl_add_u32 v97, v97, 2, %[tabs]\n"
-                    "ds_read_b32 v111, v97 offset:%[olongd]\n"
+                    "v_sub_u32 v41, v41, v40\n"
+                    "v_lshrrev_b32 v40, 16, v43\n"
+                    "v_add_u32 v41, v41, v40\n"
+                    "v_and_b32 v41, 31, v41\n"
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
+                    "ds_read_b32 v55, v41 offset:%[olongd]\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v113, 15, v111\n"
-                    "v_cmp_ne_u32 s[86:87], 0, v113\n"
+                    "v_and_b32 v57, 15, v55\n"
+                    "v_cmp_ne_u32 s[86:87], 0, v57\n"
                     "s_and_b64 vcc, vcc, s[86:87]\n"
                     "s_andn2_b64 exec, exec, vcc\n"
                     "s_cbranch_execz LLd9%=\n"
                     "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v99, 3\n"
-                    "ds_write2_b32 %[recb], v99, %[p] offset1:1\n"
+                    "v_mov_b32 v43, 3\n"
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
                     "s_andn2_b64 %[run], %[run], exec\n"
                     "LLd9%=:\n"
                     "s_and_b64 exec, s[84:85], %[run]\n"
@@ -725,8 +725,8 @@ __global__ __launch_bounds__(64 * NB) void bgzf_symbols(SymArgs a)
                       [ringbase] "s"(ringbase), [recbase] "s"(recbase), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
                       [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)),
                       [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d))
-                    : "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-                      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                      "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
                       "s88", "s89", "s90", "s92", "s93", "vcc", "scc", "memory");
                 tgt = tgt_abs - (uint32_t)lane0;
                 spilled = total > lane_cap;
@@ -1030,30 +1030,80 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             unsigned long long mm = __ballot(mine && is_match);
             n_match += (uint32_t)__popcll(mm);
             while (mm) {
-                const int j = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)vB, j);
-                if (__builtin_expect(B >> 16, 0)) {
-                    copy_any((uint32_t)__builtin_amdgcn_readlane((int)dst, j), (uint32_t)__builtin_amdgcn_readlane((int)mylen, j),
-                             (uint32_t)__builtin_amdgcn_readlane((int)dist, j));
-                    ++n_slow;
-                    continue;
+                // the plain matches of the round, one after the other (hand-scheduled: 20 instructions for a match of up to 64 bytes;
+                // the compiler's loop took 29), until one of another kind comes up: j says which (-1: none left)
+                int j;
+                {
+                    uint32_t sa, sb, len, t0, t1, t2;
+                    asm volatile(
+                        "s_mov_b64 s[92:93], exec\n"
+                        "LM%=:\n"
+                        "s_ff1_i32_b64 %[j], %[mm]\n"
+                        "v_readlane_b32 %[sb], %[vB], %[j]\n"
+                        "v_readlane_b32 %[sa], %[vA], %[j]\n"
+                        "s_cmp_lt_u32 %[sb], 0x10000\n"
+                        "s_cbranch_scc0 LMx%=\n"
+                        "s_bitset0_b64 %[mm], %[j]\n"
+                        "s_lshr_b32 %[len], %[sa], 16\n"
+                        "s_and_b32 %[sa], %[sa], 0xffff\n"
+                        "v_add_u32 %[t0], %[sb], %[vlane]\n"
+                        "v_add_u32 %[t1], %[sa], %[vlane]\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_read_u8 %[t2], %[t0]\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2]\n"
+                        "s_cmp_gt_u32 %[len], 64\n"
+                        "s_cbranch_scc1 LM2%=\n"
+                        "LM1%=:\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        "s_cmp_lg_u64 %[mm], 0\n"
+                        "s_cbranch_scc1 LM%=\n"
+                        "s_mov_b32 %[j], -1\n"
+                        "s_branch LMx%=\n"
+                        "LM2%=:\n"                                  // rounds of 64 bytes, one after the other (right for dist >= 64 too)
+                        "s_sub_u32 %[len], %[len], 64\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_read_u8 %[t2], %[t0] offset:64\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2] offset:64\n"
+                        "s_cmp_gt_u32 %[len], 64\n"
+                        "s_cbranch_scc0 LM1%=\n"
+                        "s_sub_u32 %[len], %[len], 64\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_read_u8 %[t2], %[t0] offset:128\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2] offset:128\n"
+                        "s_cmp_gt_u32 %[len], 64\n"
+                        "s_cbranch_scc0 LM1%=\n"
+                        "s_sub_u32 %[len], %[len], 64\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_read_u8 %[t2], %[t0] offset:192\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2] offset:192\n"
+                        "s_cmp_gt_u32 %[len], 64\n"
+                        "s_cbranch_scc0 LM1%=\n"
+                        "s_sub_u32 %[len], %[len], 64\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_read_u8 %[t2], %[t0] offset:256\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2] offset:256\n"
+                        "s_branch LM1%=\n"
+                        "LMx%=:\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                        : [vA] "v"(vA), [vB] "v"(vB), [vlane] "v"(lane)
+                        : "s92", "s93", "vcc", "scc", "memory");
                 }
-                const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)vA, j);
-                const uint32_t len = A >> 16;
-                const uint8_t *const from8 = s_win + B + (uint32_t)lane;
-                uint8_t *const to8 = s_win + (A & 0xFFFFu) + (uint32_t)lane;
-                if ((uint32_t)lane < len) to8[0] = from8[0];
-                if (len > 64u) {                                // (rounds of 64 bytes, one after the other: right for dist >= 64 too)
-                    if ((uint32_t)lane + 64u < len) to8[64] = from8[64];
-                    if (len > 128u) {
-                        if ((uint32_t)lane + 128u < len) to8[128] = from8[128];
-                        if (len > 192u) {
-                            if ((uint32_t)lane + 192u < len) to8[192] = from8[192];
-                            if ((uint32_t)lane + 256u < len) to8[256] = from8[256];
-                        }
-                    }
-                }
+                if (j < 0) break;
+                mm &= ~(1ull << j);
+                copy_any((uint32_t)__builtin_amdgcn_readlane((int)dst, j), (uint32_t)__builtin_amdgcn_readlane((int)mylen, j),
+                         (uint32_t)__builtin_amdgcn_readlane((int)dist, j));
+                ++n_slow;
             }
             op = t_stop < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)t_stop) : batch_end;
             t_cur = t_stop;

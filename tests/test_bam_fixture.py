@@ -171,3 +171,54 @@ def test_cigar_in_cg_tag_is_refused(tmp_path):
             with pytest.raises(_ffi.TcmiError) as e:
                 engine.BamFile(p)
             assert e.value.code == _ffi.E_UNSUPPORTED and "CG tag" in str(e.value)
+
+
+def forged(path, what):
+    """A file whose CRC-32 and record chain are in order but whose second record lies about its variable-length fields."""
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:400\n"
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\0" + struct.pack("<i", 400)
+    good = rec(0, 5, "ok", 0, [(20, "M")], "ACGTACGTACGTACGTACGT", [30] * 20)
+    r = bytearray(rec(0, 9, "liar", 0, [(4, "S"), (16, "M")], "ACGTACGTACGTACGTACGT", [30] * 20))
+    if what == "l_seq":
+        struct.pack_into("<I", r, 4 + 16, 1 << 30)                  # bases that are not there (a large S or I op would walk off the stream)
+        struct.pack_into("<I", r, 4 + 32 + 5, ((1 << 28) - 1) << 4 | 1)      # 268435455I
+    elif what == "n_cigar":
+        struct.pack_into("<H", r, 4 + 12, 60000)                    # CIGAR operations that are really SEQ, QUAL and the next records
+    else:
+        r[4 + 8] = 0                                                # l_read_name = 0
+    tail = [rec(0, 30 + k, "t%d" % k, 0, [(20, "M")], "ACGTACGTACGTACGTACGT", [30] * 20) for k in range(40)]
+    with open(path, "wb") as fh:
+        fh.write(bgzf(head))
+        fh.write(bgzf(good + bytes(r) + b"".join(tail)))
+        fh.write(EOF_BLOCK)
+
+
+@pytest.mark.parametrize("what", ["l_seq", "n_cigar", "l_read_name"])
+def test_record_fields_that_overrun_block_size_host(tmp_path, what):
+    from trueconsense_amd import _ffi
+    p = str(tmp_path / "forged.bam")
+    forged(p, what)
+    with pytest.raises(_ffi.TcmiError) as e:
+        engine.BamFile(p)
+    assert e.value.code == _ffi.E_FORMAT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["l_seq", "n_cigar", "l_read_name"])
+def test_record_fields_that_overrun_block_size_device(tmp_path, what):
+    """The device decoder checks every record's l_read_name / n_cigar_op / l_seq against its block_size before any kernel follows
+    them (the CRC-32 cannot tell: the file is intact, it just is not a BAM file): refused, with the CRC check on and off."""
+    from trueconsense_amd import _ffi, _state
+    ctx = _state.default_context()
+    p = str(tmp_path / "forged.bam")
+    forged(p, what)
+    try:
+        for crc in (1, 0):
+            ctx.set_option("verify_crc", crc)
+            d = engine.DeviceBam(p)
+            with pytest.raises(_ffi.TcmiError) as e:
+                ctx.upload_bamfile(d)
+            assert e.value.code in (_ffi.E_UNSUPPORTED, _ffi.E_FORMAT)
+            d.close()
+    finally:
+        ctx.set_option("verify_crc", 1)

@@ -214,6 +214,7 @@ int tcmi_bam_load(const char *path, int n_threads, tcmi_bam **out)
         const uint8_t *r = p + o + 4;
         const size_t l_name = r[8], n_c = rd16(r + 12), l_seq = rd32(r + 16);
         if (32 + l_name + 4 * n_c + (l_seq + 1) / 2 + l_seq > bs) return fail("alignment record fields overrun block_size");
+        if (l_name == 0) return fail("alignment record without a read name (l_read_name = 0; htslib refuses it too)");
         rec_at.push_back(o);
         bam->cigar_off.push_back(co); bam->seq_off.push_back(so); qual_off.push_back(qo); bam->name_off.push_back(no);
         co += n_c; so += (l_seq + 1) / 2; qo += l_seq; no += l_name ? l_name - 1 : 0;

@@ -39,6 +39,7 @@ struct ReadView {
     const uint8_t *cigar;       // n_cigar little-endian words, not necessarily aligned
     const uint8_t *seq;         // ceil(l_seq / 2) bytes
     bool bad;                   // inconsistent offsets / lengths
+    bool broken;                // ... of a BAM record (any record, mapped or not: the file is not a BAM file then)
 };
 
 __device__ inline uint32_t ld_u32(const uint8_t *p)
@@ -56,6 +57,7 @@ __device__ inline ReadView view(const PackSrc &s, int64_t i)
 {
     ReadView v;
     v.bad = false;
+    v.broken = false;
     if (s.mode == 0) {
         v.tid = s.tid ? s.tid[i] : 0;
         v.pos = s.pos[i];
@@ -75,9 +77,16 @@ __device__ inline ReadView view(const PackSrc &s, int64_t i)
         v.n_cigar = w3 & 0xFFFFu;
         v.flag = w3 >> 16;
         v.l_seq = (int32_t)ld_u32(r + 16);
+        // The record walk only checked block_size itself: the variable-length fields must fit into it (what bam_reader.cpp's
+        // "alignment record fields overrun block_size" refuses) — a forged l_seq or n_cigar_op would otherwise send the kernels
+        // that follow the CIGAR and the bases far behind the record, or behind the stream.
+        const uint32_t block_size = ld_u32(r - 4);
+        const uint64_t need = 32ull + l_name + 4ull * v.n_cigar + ((uint64_t)(uint32_t)v.l_seq + 1) / 2 + (uint64_t)(uint32_t)v.l_seq;
+        v.bad = v.l_seq < 0 || l_name == 0 || need > block_size;
+        v.broken = v.bad;
+        if (v.bad) v.n_cigar = 0;
         v.cigar = r + 32 + l_name;
         v.seq = v.cigar + 4 * (size_t)v.n_cigar;
-        v.bad = v.l_seq < 0;                                    // (the record walk has checked the fields against block_size)
     }
     return v;
 }
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     if (i < s.n) {
         const ReadView v = view(s, i);
         bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
-        if (v.bad && !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
+        if (v.broken || (v.bad && !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0)) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
         if (!(v.flag & 0x4u) && v.tid > 0) atomicOr(&tot->flags, (uint32_t)PKF_MULTIREF);   // (the host packer words the error)
         if (kept) {
             // one walk over the CIGAR: reference span, and is it [H]*[S]* (M|=|X)+ [S]*[H]* ?

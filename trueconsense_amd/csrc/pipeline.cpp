@@ -439,8 +439,10 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                     rc = tcmi_readset_from_bamfile(ctx, it.file, &rs, nullptr);
                     it.on_device = rc == TCMI_OK;
                 }
+                std::string host_err;
                 if (rc == TCMI_E_UNSUPPORTED) {                  // the host reader takes it
                     rc = tcmi_bam_load(paths[i], r->host_threads, &hb);
+                    if (rc) host_err = tcmi_last_error(nullptr); // (its words: it failed without a context)
                     if (!rc) {
                         tcmi_reads reads;
                         tcmi_bam_reads(hb, &reads);
@@ -491,7 +493,7 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                     }
                 }
                 t_step = seconds_since(t1);
-                if (rc) { it.rc = rc; it.err = tcmi_last_error(ctx); }
+                if (rc) { it.rc = rc; it.err = host_err.empty() ? tcmi_last_error(ctx) : host_err; }
                 if (rs) tcmi_readset_free(ctx, rs);
                 if (hb) tcmi_bam_free(hb);
             }

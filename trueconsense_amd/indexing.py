@@ -56,11 +56,16 @@ def build_counts(bamfile, ref, ctx=None):
             d.close()
         if rs is not None:
             try:
+                build_counts.last_reads = int(rs.n_reads)
                 return ctx.step(rs, max(ref_length, rs.max_end, 1), 0, True, want_counts=True)[3]
             finally:
                 rs.free()
         bamfile = bamfile.get() if isinstance(bamfile, LazyBam) else BamFile(path)
+    build_counts.last_reads = int(bamfile.n_reads)
     return ctx.tally(bamfile, ref_len=ref_length)
+
+
+build_counts.last_reads = 0         # alignment records of the file the last call read (the command line's --stats)
 
 
 def BuildIndex(bamfile, ref):

@@ -165,8 +165,10 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
     L = len(ref)
     ld = (L + 255) // 256 * 256
     tile = L - 150 + 1
-    reads = sy.make_reads(ref, a.reads, seed=7000 + rank, start_range=(tile * rank // world, tile * (rank + 1) // world))
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)     # tally, collective and call on torch's stream
+    if a.from_file:
+        return run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs, ctx, tile)
+    reads = sy.make_reads(ref, a.reads, seed=7000 + rank, start_range=(tile * rank // world, tile * (rank + 1) // world))
     rs = ctx.upload(reads)
     counts = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
     rec = torch.zeros((3, ld), dtype=torch.uint8).pin_memory()                     # the call kernel stores across PCIe
@@ -227,6 +229,115 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
         dist.destroy_process_group()
 
 
+def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs, ctx, tile):
+    """configs[4] from ONE FILE: rank 0 writes one BAM of world x --reads reads (outside the clock); every rank maps it and, per
+    step, sends the compressed bytes of ITS contiguous range of BGZF blocks to its GPU, inflates them, indexes and packs the records
+    that start there, tallies; ONE reduce (sum) of the int32 [7][ld] matrix to rank 0, which calls and walks.  Nothing of the
+    file is decoded on the host, and no rank decodes another rank's blocks (one block at a range's end excepted: the last
+    record may run into it)."""
+    from trueconsense_amd import _ffi
+    from trueconsense_amd import distributed as td
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.engine import DeviceBam, Walker
+    from trueconsense_amd.io import bamwriter
+    import numpy as np
+    L = len(ref)
+    ld = (L + 255) // 256 * 256
+    tmp = a.tmp or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    path = os.path.join(tmp, "tcmi_split_%s.bam" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    t_gen = time.perf_counter()
+    want_counts = None
+    if rank == 0:
+        from oracle import c_oracle
+        want_counts = np.zeros((L, 7), np.int64)
+        for r in range(world):                                       # tile by tile: the file is coordinate-sorted
+            reads = sy.make_reads(ref, a.reads, seed=7000 + r, start_range=(tile * r // world, tile * (r + 1) // world))
+            bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(a.reads, -1), 150, "MN908947.3", L, level=a.level,
+                                     part=(r == 0, r == world - 1), first_id=r * a.reads)
+            want_counts += c_oracle.tally(reads, L)                  # (the checker: outside the clock)
+            del reads
+    t_gen = time.perf_counter() - t_gen
+    if dist is not None:
+        dist.barrier()
+    d = DeviceBam(path)
+    first, count = td.block_range(d.n_blocks, rank, world)
+    counts = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
+    rec = torch.zeros((3, ld), dtype=torch.uint8).pin_memory()
+    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
+    rec_np = rec.numpy()
+    n_mine = [0]
+
+    def step():
+        rs = ctx.upload_bamfile(d, blocks=(first, count))            # H2D of the range's compressed bytes, inflate, index, pack
+        n_mine[0] = rs.n_reads
+        counts.zero_()
+        if rs.n_piled:
+            ctx.tally_dev(rs, L, ld, counts.data_ptr(), zero=False)
+        td.reduce_counts(counts, dst=0)                              # ONE exchange: int32 sum of 7 x ld, to rank 0 only
+        out = None
+        if rank == 0:
+            ctx.call_dev(counts.data_ptr(), L, ld, a.mincov, True, rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr())
+            torch.cuda.current_stream().synchronize()
+            out = walker(rec_np[0, :L], rec_np[1, :L], rec_np[2, :L])[0]
+        else:
+            torch.cuda.current_stream().synchronize()                # (the read set's memory goes back to the pool below)
+        rs.free()
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cons = step()
+    fence()
+    dt_mine = time.perf_counter() - t0
+    dt = dt_mine
+    per_rank = [dt_mine]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        g = [None] * world
+        dist.all_gather_object(g, (dt_mine, int(n_mine[0]), int(count)))
+        per_rank = g
+    else:
+        per_rank = [(dt_mine, int(n_mine[0]), int(count))]
+    if rank == 0:
+        from oracle import tc_oracle as orc
+        got = np.ascontiguousarray(counts[:, :L].T.cpu().numpy()).astype(np.int64)
+        has, ins = orc.list_inserts(want_counts, a.mincov, lambda pos1: [])
+        want, _ = orc.build_consensus(a.mincov, want_counts, [dict(o) for o in orfs], True, ins if has else None, True)
+        print(json.dumps({
+            "metric": "reference positions/sec (ONE BAM FILE of %d reads, %d GPU(s) each decoding its range of the file's BGZF blocks -> consensus)" % (a.reads * world, world),
+            "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_per_rank": [1e3 * x[0] / a.steps for x in per_rank],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, ONE BAM file of %d x %d synthetic 150-bp reads (%d bytes, %d BGZF blocks, "
+                                   "zlib level %d); per step every rank sends the compressed bytes of its contiguous block range to its GPU, "
+                                   "inflates / indexes / packs / tallies there, ONE reduce (sum) of the int32 [7][%d] matrix (%d bytes) to rank 0, "
+                                   "call kernel + walk on rank 0" % (world, a.reads, d.file_bytes, d.n_blocks, a.level, ld, 28 * ld),
+                       "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL reduce" if world > 1 else "none"),
+                       "blocks_per_rank": [x[2] for x in per_rank], "reads_per_rank": [x[1] for x in per_rank],
+                       "input_generation_seconds_outside_clock": t_gen},
+            "counts_bit_exact": bool(np.array_equal(got, want_counts)), "fasta_bit_exact": bool(cons == want),
+            "consensus_len": len(cons), "coverage_sum": int(got[:, 0].sum()), "coverage_sum_expected": 150 * a.reads * world}))
+    d.close()
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            os.remove(path)
+        dist.destroy_process_group()
+    elif rank == 0:
+        os.remove(path)
+
+
 # ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -254,6 +365,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8)
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT", help="tcmi_ctx_set_option (diagnostic)")
     ap.add_argument("--tmp", default=None, help="directory for the synthetic BAM files (default: /dev/shm or $TMPDIR)")
+    ap.add_argument("--from-file", action="store_true", help="with --split-bam: ONE BAM file, every rank decodes its range of the file's BGZF blocks on its GPU")
     ap.add_argument("--split-bam", action="store_true",
                     help="BASELINE configs[4]: ONE BAM of gpus x --reads reads, each rank tallies its contiguous read range, "
                          "one reduce (RCCL) of the count matrix per step, base calling on rank 0")

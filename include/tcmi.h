@@ -308,6 +308,11 @@ int  tcmi_bamfile_info(const tcmi_bamfile *f, int64_t *file_bytes, int64_t *infl
                        const char **ref0_name, int64_t *ref0_len);
 const char *tcmi_bamfile_text(const tcmi_bamfile *f);
 int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads);
+/* ... of the alignment records that START in BGZF blocks [first_block, first_block + n_blocks) only (n_blocks < 0: to the end of the
+ * file).  Ranks that share ONE BAM file (BASELINE configs[4]) each decode a contiguous range of its blocks and nothing else; the
+ * count matrices of the ranges add up to the file's (what indexing.py:96-100 piles up in one pass). */
+int  tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out,
+                                      int64_t *n_reads);
 /* Events.ExtractInserts for a read set the DEVICE decoded (tcmi_readset_from_bamfile): same arguments and results as
  * tcmi_modal_tokens, but the reads of every candidate column are examined by a HIP kernel where they lie (the inflated
  * stream stays resident on the context until its next upload) and only a few thousand 48-byte entries per column reach

@@ -198,23 +198,39 @@ def test_file_to_counts_all_on_device(ctx, tmp_path):
     check_counts(ctx, p, int(engine.reads_extent(fuzz, 3000)))
 
 
-def test_files_the_device_decoder_leaves_to_the_host(ctx, tmp_path):
+def test_records_that_straddle_bgzf_blocks_are_decoded_on_the_device(ctx, tmp_path):
+    """Writers other than htslib (htsjdk: Picard, GATK) fill every BGZF block to the brim: records — and their block_size fields —
+    run from one block into the next.  Every block finds the first record start in its own bytes, the host checks that the
+    chain closes (bam_device.hip); stream, record index and counts as from a file cut on record boundaries."""
     ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
     reads = sy.make_reads(ref, 4000, seed=1)
     p = str(tmp_path / "split.bam")
     bamwriter.write_bam(p, reads, "r", len(ref), split_records=True)      # records straddle BGZF blocks
-    d = engine.DeviceBam(p)
-    with pytest.raises(_ffi.TcmiError) as e:
-        ctx.upload_bamfile(d)
-    assert e.value.code == _ffi.E_UNSUPPORTED and "straddles" in str(e.value)
-    d.close()
-    # ... and the file runner then takes the host reader for it, with the same result
+    check_decode(ctx, p).close()
+    check_counts(ctx, p, len(ref))
+    # names of different lengths, indel carriers, small blocks: starts and size fields fall on every offset of a block's end
+    rng = np.random.default_rng(23)
+    fuzz = fz.random_reads(rng, 6000, 3000)
+    for block in (0xFF00, 4099, 1021):
+        p = str(tmp_path / ("split%d.bam" % block))
+        bamwriter.write_bam(p, fuzz, "ref", 3000, level=6, block=block, split_records=True)
+        check_decode(ctx, p).close()
+        check_counts(ctx, p, int(engine.reads_extent(fuzz, 3000)))
+    # the file runner takes the device for both kinds
     runner = engine.FileRunner(ctx, [{"start": 10, "end": 600, "strand": "+"}], 30)
+    p = str(tmp_path / "split.bam")
     p2 = str(tmp_path / "whole.bam")
     bamwriter.write_bam(p2, reads, "r", len(ref))
     a, b = runner.run([p, p2], names=["S", "S"], ref_len=len(ref))
     assert a == b and len(a.split("\n")[1]) == len(ref)
-    assert runner.decoded_on == {"device": 1, "host": 1}
+    assert runner.decoded_on == {"device": 2, "host": 0}
+
+
+def test_a_damaged_stream_is_an_error(ctx, tmp_path):
+    ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
+    reads = sy.make_reads(ref, 4000, seed=1)
+    p2 = str(tmp_path / "whole.bam")
+    bamwriter.write_bam(p2, reads, "r", len(ref))
     # a damaged deflate stream is an error, not a hang and not a wrong answer
     raw = bytearray(open(p2, "rb").read())
     raw[len(raw) // 2] ^= 0x55

@@ -141,13 +141,15 @@ def test_hand_assembled_bam_on_the_device(tmp_path):
     # ... and the host reader's arrays through the device packer give the same matrix
     b = engine.BamFile(p)
     assert np.array_equal(ctx.tally(b, L=510), want)
-    # the straddling variant is left to the host reader
+    # the straddling variant (blocks cut through block_size fields and record bodies): on the device as well
     p2 = str(tmp_path / "hand2.bam")
     build(p2, straddle=True)
     d2 = engine.DeviceBam(p2)
-    with pytest.raises(_ffi.TcmiError) as e:
-        ctx.upload_bamfile(d2)
-    assert e.value.code == _ffi.E_UNSUPPORTED
+    stream2, rec2 = d2.decode_to_host(ctx)
+    assert np.array_equal(stream2, stream) and np.array_equal(rec2, rec_off)
+    rs2 = ctx.upload_bamfile(d2)
+    assert rs2.n_reads == 9 and np.array_equal(ctx.step(rs2, 510, 1, True)[3], want)
+    rs2.free()
     d2.close()
     assert np.array_equal(ctx.tally(engine.BamFile(p2), L=510), want)
 

@@ -53,7 +53,22 @@ def _work(rank, world, use_gpu, q, td, sy, c_oracle):
         if rank == 0:
             ok = ok and bool(np.array_equal(part.numpy().T, want))
         else:
-            ok = ok and bool(torch.equal(part, mine) or True)      # (gloo leaves the non-root buffers unspecified)
+            del mine                                             # (gloo leaves the non-root buffers unspecified)
+        if use_gpu:
+            # ... and from ONE FILE: every rank decodes only the records that start in its range of the file's BGZF blocks
+            import tempfile
+            from trueconsense_amd.io import bamwriter
+            path = os.path.join(tempfile.gettempdir(), "tcmi_split_%d.bam" % os.getppid())
+            for split in (False, True):                          # blocks cut on record boundaries / filled to the brim
+                if rank == 0:
+                    bamwriter.write_bam(path, reads, "r", L, level=6, block=4000, split_records=split)
+                import torch.distributed as dist
+                dist.barrier()
+                both = td.tally_split_bamfile(path, L, rank, world, device=0)
+                ok = ok and bool(np.array_equal(both, want))
+                dist.barrier()
+            if rank == 0:
+                os.remove(path)
         q.put((rank, ok, int(got[:, 0].sum())))
 
 
@@ -82,6 +97,10 @@ def test_shard_bookkeeping():
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[k][1] == edges[k + 1][0] for k in range(world - 1))
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
+    for nb in (0, 1, 5, 4187):
+        for world in (1, 2, 8):
+            r = [td.block_range(nb, k, world) for k in range(world)]
+            assert r[0][0] == 0 and sum(c for _, c in r) == nb and all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(world - 1))
     assert td.shard_items(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((td.shard_items(512, r, 8) for r in range(8)), [])) == list(range(512))
 
@@ -128,6 +147,13 @@ def test_bench_many_bam_shard_two_ranks_rehearsal():
     d = _bench_ranks(["--steps", "3", "--warmup", "1", "--reads", "40000", "--files", "2", "--no-cpu-baseline", "--no-resident"])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
     assert d["value"] > 0 and d["unit"] == "positions/s" and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_bench_split_bam_from_one_file_two_ranks_rehearsal():
+    d = _bench_ranks(["--split-bam", "--from-file", "--steps", "3", "--warmup", "1", "--reads", "40000"])
+    assert d["n_gpus"] == 2 and d["coverage_sum"] == d["coverage_sum_expected"] == 150 * 40000 * 2
+    assert d["consensus_len"] == 29903 and d["config"]["blocks_per_rank"][0] > 0 and d["fasta_bit_exact"] is True
 
 
 @pytest.mark.gpu

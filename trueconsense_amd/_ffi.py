@@ -91,6 +91,7 @@ _SIGS = {
     "tcmi_bamfile_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i32), _P(C.c_char_p), _P(_i64)]),
     "tcmi_bamfile_text": (C.c_char_p, [_vp]),
     "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
+    "tcmi_readset_from_bamfile_blocks": (_int, [_vp, _vp, _i64, _i64, _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
     "tcmi_bamfile_decode_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _P(_i64)]),
     "tcmi_filerunner_create": (_int, [_int, _int, _int, _int, _int, _P(_vp)]),

@@ -71,14 +71,43 @@ __global__ __launch_bounds__(256) void bgzf_crc32(CrcArgs a)
     if (blk >= a.n_blocks) return;
     if (a.status[blk] != ST_OK) return;
     const BlockDesc d = a.blocks[blk];
-    const uint8_t *p = a.out + d.uout;                      // 16-byte aligned (the host pads every block's output)
-    const int32_t body = (int32_t)(d.ulen & ~15u);          // whole 16-byte pieces; the last ulen % 16 bytes follow at the end
+    // The blocks' outputs follow each other without gaps (a record may run from one into the next), so a block starts at any byte:
+    // the rows are cut on 16-byte boundaries of the STREAM.  In the linear form below zero bytes in front of a message leave the
+    // register at zero: the head of the first piece (the previous block's last bytes) is simply masked out.
+    const uint32_t head = (uint32_t)(d.uout & 15u);
+    const uint8_t *p = a.out + (d.uout - head);             // 16-byte aligned; the block's bytes are p[head .. head + ulen)
+    if (d.ulen < 64u) {                                     // (short blocks — the end-of-file marker's is empty — byte by byte)
+        if (lane == 0) {
+            uint32_t t = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < d.ulen; ++i) t = s_tab[(t ^ p[head + i]) & 0xFFu] ^ (t >> 8);
+            t = ~t;
+            const uint8_t *e = a.file + d.cin + d.clen;
+            const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+            if (t != want) a.status[blk] = ST_BAD_CRC;
+        }
+        return;
+    }
+    const uint32_t vlen = head + d.ulen;
+    const int32_t body = (int32_t)(vlen & ~15u);            // whole 16-byte pieces; the last vlen % 16 bytes follow at the end
     const int32_t rows = (body + 1023) >> 10;
     // All of it in the CRC's LINEAR form (register starts at 0, no final inversion: then crc(A || B) = later(crc(A), |B|) ^ crc(B)
     // and pieces may be taken in any order); the standard's all-ones start is the same as inverting the block's first four bytes.
     auto crc16 = [&](uint4 v, int32_t at) {
-        uint32_t c = at == 0 ? 0xFFFFFFFFu : 0u;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t c = 0u;
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (at < 32) {                                      // the piece(s) with the block's first bytes: bytes in front of them are
+#pragma unroll                                              // not the block's, its first four are inverted (the all-ones start)
+            for (int k = 0; k < 4; ++k) {
+                uint32_t keep = 0, inv = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t vi = (uint32_t)at + 4u * k + b;
+                    if (vi >= head) keep |= 0xFFu << (8 * b);
+                    if (vi >= head && vi < head + 4u) inv |= 0xFFu << (8 * b);
+                }
+                w[k] = (w[k] & keep) ^ inv;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             c ^= w[k];
@@ -113,8 +142,8 @@ __global__ __launch_bounds__(256) void bgzf_crc32(CrcArgs a)
         c = m ^ right;
     }
     if (lane == 0) {
-        uint32_t t = body ? c : 0xFFFFFFFFu;                // the register after the body; the last ulen % 16 bytes one by one
-        for (uint32_t i = (uint32_t)body; i < d.ulen; ++i) t = s_tab[(t ^ p[i]) & 0xFFu] ^ (t >> 8);
+        uint32_t t = c;                                     // the register after the body; the last vlen % 16 bytes one by one
+        for (uint32_t i = (uint32_t)body; i < vlen; ++i) t = s_tab[(t ^ p[i]) & 0xFFu] ^ (t >> 8);
         t = ~t;
         const uint8_t *e = a.file + d.cin + d.clen;         // the block's trailer: CRC32, ISIZE (little endian)
         const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
@@ -140,13 +169,26 @@ static void crc_zero_operators(uint32_t zeros[6][32], uint32_t zeros1k[32])
 }
 
 // per-block record lists -> dense offsets into the stream; base[b] = exclusive scan of n_rec (done by one workgroup first)
-__global__ __launch_bounds__(1024) void rec_scan(const uint32_t *n_rec, uint64_t *base, int32_t n_blocks, unsigned long long *total)
+// A block whose last record starts within its last three bytes could not read that record's size: it is read here, from the stream
+// (`overshoot` = TAIL_UNKNOWN on entry: the record's start is the block's last listed one).
+constexpr int32_t TAIL_UNKNOWN = 0x7FFFFFFF;
+__global__ __launch_bounds__(1024) void rec_scan(uint32_t *n_rec, uint64_t *base, int32_t n_blocks, int32_t n_own, unsigned long long *total,
+                                                 const BlockDesc *blocks, const uint32_t *rec_slot, const uint8_t *out, int32_t *overshoot)
 {
     __shared__ unsigned long long s[1024];
     const int t = threadIdx.x;
     const int per = (n_blocks + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blocks);
     unsigned long long sum = 0;
-    for (int b = b0; b < b1; ++b) sum += n_rec[b];
+    for (int b = b0; b < b1; ++b) {
+        if (b >= n_own) n_rec[b] = 0;                           // (a block taken along for the tail of the last record: its records are not ours)
+        sum += n_rec[b];
+        if (overshoot[b] == TAIL_UNKNOWN && n_rec[b]) {
+            const uint32_t at = rec_slot[(size_t)b * MAX_REC_PER_BLOCK + n_rec[b] - 1];
+            const uint8_t *q = out + blocks[b].uout + at;
+            const uint32_t bs = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            overshoot[b] = bs - 32u > (1u << 28) - 32u ? -1 : (int32_t)(at + 4u + bs - blocks[b].ulen);     // (-1: no such record)
+        }
+    }
     s[t] = sum;
     __syncthreads();
     for (int dd = 1; dd < 1024; dd <<= 1) {
@@ -328,7 +370,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         b.clen = (uint32_t)(bsize - 12 - xlen - 8);
         b.ulen = rd32(h + bsize - 4);
         b.uout = uout;
-        b.entry = 0;
+        b.entry = -2;                                           // (-2: the block's first record starts where the device finds it)
         if (b.ulen > 65536) return bail(TCMI_E_FORMAT, "BGZF block inflates to more than 64 KiB", off);
         // tokens: one per literal / match (each gives >= 1 byte and takes >= 1 bit), one per <= 8 191 stored bytes (a stored
         // deflate block takes >= 5 bytes)
@@ -336,7 +378,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         b.tok = f->tok_total;
         f->tok_total += (2u * b.tok_cap + 3u) & ~3u;        // (as many again behind them: bgzf_symbols' scratch)
         f->pay_dwords = std::max(f->pay_dwords, (uint32_t)(((b.cin & 3u) * 8u + b.clen * 8u + 31u) / 32u + 6u));
-        uout += ((size_t)b.ulen + 15) & ~(size_t)15;            // every block's output starts 16-byte aligned on the device
+        uout += (size_t)b.ulen;                                 // the blocks' outputs follow each other without gaps: the stream as it inflates
         off += bsize;
         f->blocks.push_back(b);
     }
@@ -421,17 +463,46 @@ const char *tcmi_bamfile_text(const tcmi_bamfile *f) { return f ? f->text.c_str(
 namespace {
 struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; };
 
-int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
+// blocks [first, first + count) of the file (count < 0: to the end): the records that START in them.  A range that does not end
+// with the file takes one block more along — the last record may run into it — whose own records are left out.
+int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int64_t first_blk = 0, int64_t count = -1)
 {
-    const size_t nb = f->blocks.size();
-    if (nb == 0) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: no BGZF blocks", f->path.c_str());
+    if (whole->blocks.empty()) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: no BGZF blocks", whole->path.c_str());
+    const int64_t all = (int64_t)whole->blocks.size();
+    if (first_blk < 0 || first_blk > all) return tcmi_fail(ctx, TCMI_E_ARG, "block range starts at %lld, the file has %lld blocks", (long long)first_blk, (long long)all);
+    const int64_t own = count < 0 ? all - first_blk : std::min<int64_t>(count, all - first_blk);
+    const bool ranged = first_blk != 0 || own != all;
+    // the range as a file of its own: the blocks' places in the stream and in the token array start at 0
+    tcmi_bamfile part;
+    const tcmi_bamfile *f = whole;
+    if (ranged) {
+        const int64_t extra = first_blk + own < all ? 1 : 0;
+        part.path = whole->path; part.ref_name = whole->ref_name; part.ref_len = whole->ref_len;
+        part.blocks.assign(whole->blocks.begin() + first_blk, whole->blocks.begin() + first_blk + own + extra);
+        part.pay_dwords = whole->pay_dwords;
+        // (only the range's bytes cross PCIe: from the 16-byte boundary in front of its first payload to behind its last trailer)
+        const size_t lo = part.blocks.empty() ? 0 : (size_t)part.blocks.front().cin & ~(size_t)15;
+        const size_t hi = part.blocks.empty() ? 0 : (size_t)part.blocks.back().cin + part.blocks.back().clen + 8;
+        part.bytes = whole->bytes + lo; part.n_bytes = hi - lo; part.cap = std::min(whole->cap - lo, ((hi - lo) + 4096 + 15) & ~(size_t)15);
+        size_t uout = 0;
+        for (BlockDesc &b : part.blocks) {
+            b.cin -= lo;
+            b.uout = uout; uout += b.ulen;
+            b.tok = part.tok_total; part.tok_total += (2u * b.tok_cap + 3u) & ~3u;
+        }
+        part.inflated = uout;
+        f = &part;
+    }
+    struct Unown { tcmi_bamfile *p; ~Unown() { if (p) p->bytes = nullptr; } } unown{ranged ? &part : nullptr};    // (the bytes are the whole file's)
+    const size_t nb = f->blocks.size(), nb_own = ranged ? (size_t)own : nb;
+    if (nb == 0) { D->d_out = nullptr; D->d_rec = nullptr; D->d_desc = nullptr; D->n = 0; return TCMI_OK; }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // bounds on the records for the arena: a record takes at least 36 bytes of the stream; reserve for records of >= 64 bytes
     // (block_size + 32 fixed bytes + name + CIGAR + SEQ + QUAL of a 15-base read) — the arena cannot grow under live data
     const size_t max_rec = f->inflated / 36 + 16;
     const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
     const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
-                 b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 4 + al(nb * 8) + al(nb * 512) + 256,
+                 b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 5 + al(nb * 8) + al(nb * 512) + 256,
                  b_tok = al(f->tok_total * 4 + 256);
     const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 9 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
@@ -442,6 +513,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     uint32_t *d_nrec = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
     int32_t *d_over = (int32_t *)tcmi_arena_take(ctx, al(nb * 4));
     uint32_t *d_stat = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    uint32_t *d_first = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
     uint64_t *d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
     unsigned long long *d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
@@ -454,7 +526,8 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     {
         tcmi_bgzf_decode_args g;
         g.d_file = d_file; g.d_desc = d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = d_out; g.d_slot = d_slot; g.d_nrec = d_nrec;
-        g.d_over = d_over; g.d_stat = d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
+        g.d_over = d_over; g.d_first = d_first; g.d_stat = d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
+        g.n_ref = (uint32_t)f->ref_name.size();
         const int rc = tcmi_bgzf_decode_launch(ctx, g);
         if (rc) return rc;
     }
@@ -467,13 +540,15 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
         tcmi_prof_end(ctx, TCMI_K_CRC);
         TCMI_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, d_total);
+    hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, (int32_t)nb_own, d_total, d_desc, d_slot, d_out, d_over);
     TCMI_HIP(ctx, hipGetLastError());
     // the verdict of every block comes back to the host: a few bytes per block
     std::vector<uint32_t> stat(nb);
     std::vector<int32_t> over(nb);
+    std::vector<uint32_t> first(nb);
     unsigned long long total = 0;
     TCMI_HIP(ctx, hipMemcpyAsync(stat.data(), d_stat, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(first.data(), d_first, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipMemcpyAsync(over.data(), d_over, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -483,15 +558,39 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
     for (size_t b = 0; b < nb; ++b)
         if (stat[b] == ST_BAD_CRC)
             return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: CRC32 mismatch in BGZF block %zu", f->path.c_str(), b);
-    // The record chain: every block was walked from offset 0 on the assumption that its predecessor ends on a record
-    // boundary.  In block order that assumption holds by induction up to the first block that runs over, so a bad
-    // record before that point is real, and anything after it is not to be trusted.
-    for (size_t b = 0; b < nb; ++b) {
-        if (stat[b] == ST_BAD_RECORD)
-            return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: alignment record with an impossible block_size in BGZF block %zu", f->path.c_str(), b);
-        if (over[b] != 0)
-            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: a record straddles BGZF blocks %zu / %zu (the file was not written the htslib way): host reader",
-                             f->path.c_str(), b, b + 1);
+    // The record chain.  Every block found the first record start in its own bytes by itself — where the header says (the first
+    // record), or the first offset at which a plausible record starts (htslib cuts its blocks on record boundaries: offset 0;
+    // other writers fill them to the brim) — and followed the chain of block_size fields from there.  In block order: if every
+    // block's find is where its predecessor's last record ends, all of them are record starts, by induction from the header.
+    {
+        int64_t expect = -1;                                    // offset in the next block at which a record must start
+        bool open = ranged;                                     // (a range: wherever its first block found one)
+        for (size_t b = 0; b < nb_own; ++b) {
+            const BlockDesc &d = f->blocks[b];
+            if (d.entry == -1) continue;                        // header only
+            if (open && first[b] != 0xFFFFFFFFu) { expect = first[b]; open = false; }
+            if (open) continue;
+            if (stat[b] == ST_BAD_RECORD)
+                return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: alignment record with an impossible block_size in BGZF block %zu", f->path.c_str(), b);
+            if (d.entry >= 0) expect = d.entry;
+            if (first[b] == 0xFFFFFFFFu) {                      // no record starts in this block: it lies inside one, or is empty
+                if (expect < (int64_t)d.ulen)
+                    return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: no alignment record found where one must start in BGZF block %zu: host reader", f->path.c_str(), b);
+                expect -= d.ulen;
+                continue;
+            }
+            if ((int64_t)first[b] != expect || over[b] < 0)
+                return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the chain of alignment records does not close at BGZF block %zu (found a start at %u, expected %lld): host reader",
+                                 f->path.c_str(), b, first[b], (long long)expect);
+            expect = over[b];
+        }
+        if (nb_own < nb) {                                      // the range's last record must end in the block taken along
+            if (expect > (int64_t)f->blocks[nb_own].ulen)
+                return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: a record longer than a BGZF block at the end of a block range: host reader", f->path.c_str());
+            expect = 0;
+        }
+        if (expect > 0)
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the last alignment record runs %lld bytes past the end of the file: host reader", f->path.c_str(), (long long)expect);
     }
     if (total > max_rec) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: impossible record count", f->path.c_str());
     const size_t n = (size_t)total;
@@ -500,7 +599,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *f, DeviceBam *D)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: %zu very short records need more device scratch than was reserved: host reader", f->path.c_str(), n);
     uint64_t *d_rec = (uint64_t *)tcmi_arena_take(ctx, al(n * 8 + 8));
     tcmi_prof_begin(ctx, TCMI_K_RECORDS);
-    if (n) hipLaunchKernelGGL(rec_compact, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_desc, d_slot, d_nrec, d_base, d_rec);
+    if (n) hipLaunchKernelGGL(rec_compact, dim3((unsigned)nb_own), dim3(256), 0, ctx->stream, d_desc, d_slot, d_nrec, d_base, d_rec);
     tcmi_prof_end(ctx, TCMI_K_RECORDS);
     TCMI_HIP(ctx, hipGetLastError());
     D->d_out = d_out; D->d_rec = d_rec; D->d_desc = d_desc; D->n = n;
@@ -515,13 +614,21 @@ extern "C" {
 // longer than 512 positions, ...): the caller falls back to tcmi_bam_load + tcmi_readset_upload.
 int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads_out)
 {
+    return tcmi_readset_from_bamfile_blocks(ctx, f, 0, -1, out, n_reads_out);
+}
+
+// ... of the records that start in BGZF blocks [first_block, first_block + n_blocks) only (n_blocks < 0: to the end of the file): ranks
+// that share ONE file each take a contiguous range of its blocks (tcmi_bamfile_info says how many there are) and decode nothing
+// else; their count matrices add up to the file's (BASELINE configs[4]; indexing.py:96).
+int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out)
+{
     if (!ctx || !f || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     *out = nullptr;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     static const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     DeviceBam D;
-    int rc = decode_on_device(ctx, f, &D);
+    int rc = decode_on_device(ctx, f, &D, first_block, n_blocks);
     if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     if (n_reads_out) *n_reads_out = (int64_t)D.n;
@@ -563,24 +670,12 @@ int tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *s
     if (rc) return rc;
     *n_rec = (int64_t)D.n;
     if ((int64_t)D.n > rec_cap && rec_off) return tcmi_fail(ctx, TCMI_E_ARG, "rec_off holds %lld entries, the file has %zu records", (long long)rec_cap, D.n);
-    int64_t at = 0;
-    std::vector<uint64_t> rec(D.n);
-    if (D.n) TCMI_HIP(ctx, hipMemcpyAsync(rec.data(), D.d_rec, D.n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    for (const BlockDesc &b : f->blocks) {      // the device keeps every block's output 16-byte aligned: close the gaps
-        if (at + (int64_t)b.ulen > stream_cap) return tcmi_fail(ctx, TCMI_E_ARG, "stream buffer too small");
-        if (b.ulen) TCMI_HIP(ctx, hipMemcpyAsync(stream + at, D.d_out + b.uout, b.ulen, hipMemcpyDeviceToHost, ctx->stream));
-        at += b.ulen;
-    }
+    int64_t inflated = 0;
+    for (const BlockDesc &b : f->blocks) inflated += b.ulen;
+    if (inflated > stream_cap) return tcmi_fail(ctx, TCMI_E_ARG, "stream buffer too small");
+    if (inflated) TCMI_HIP(ctx, hipMemcpyAsync(stream, D.d_out, (size_t)inflated, hipMemcpyDeviceToHost, ctx->stream));
+    if (rec_off && D.n) TCMI_HIP(ctx, hipMemcpyAsync(rec_off, D.d_rec, D.n * 8, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (rec_off) {
-        // device offsets are in the padded layout: map them back to offsets in the contiguous stream
-        size_t k = 0;
-        int64_t contiguous = 0;
-        for (size_t i = 0; i < D.n; ++i) {
-            while (k + 1 < f->blocks.size() && rec[i] >= f->blocks[k].uout + (((uint64_t)f->blocks[k].ulen + 15) & ~15ull)) { contiguous += f->blocks[k].ulen; ++k; }
-            rec_off[i] = (uint64_t)contiguous + (rec[i] - f->blocks[k].uout);
-        }
-    }
     return TCMI_OK;
 }
 

@@ -854,9 +854,11 @@ struct CopyArgs {
     uint8_t *out;
     uint32_t *rec_slot;
     uint32_t *n_rec;
-    int32_t *overshoot;
+    int32_t *overshoot;         // bytes by which the block's last record runs into the next blocks (0x7FFFFFFF: its size field does)
+    uint32_t *first_rec;        // offset of the first record start found in the block (0xFFFFFFFF: none)
     uint32_t *status;           // in: bgzf_symbols' verdict; out: the block's
     int32_t n_blocks;
+    uint32_t n_ref;             // reference sequences of the BAM header
     uint64_t *stamps;           // diagnostic, as SymArgs::stamps
 };
 
@@ -879,23 +881,69 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         p_cnt = a.seg[(size_t)blk * 128 + 64 + lane];
         p_pre = wave_scan_add(p_cnt) - p_cnt;
     }
-    uint8_t *const out = a.out + d.uout;
+    // The blocks' outputs follow each other in the stream without gaps, so this block's starts at any byte.  Positions in this
+    // kernel count from the 16-byte boundary in front of it (`a0` bytes of the previous block come first and are never touched):
+    // ring index and stream address of a byte are then equal modulo 16 and the flush can use 16-byte rows.
+    const uint32_t a0 = (uint32_t)(d.uout & 15u);
+    uint8_t *const out = a.out + (d.uout - a0);
+    const uint32_t vend = a0 + ulen;    // the block's end
     const uint8_t *const payload = a.file + d.cin;
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
     const uint32_t *const win32 = reinterpret_cast<const uint32_t *>(s_win);
 
-    uint32_t op = 0, flushed = 0;
-    uint32_t next_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFF0u;
+    uint32_t op = a0, flushed = 0;
+    uint32_t next_rec = d.entry >= 0 ? a0 + (uint32_t)d.entry : 0xFFFFFFF0u;
+    bool searching = d.entry == -2;     // the block's first record start is still to be found, from `search_pos` on
+    uint32_t search_pos = a0;
+    uint32_t first_rec = d.entry >= 0 ? (uint32_t)d.entry : 0xFFFFFFFFu;
     uint32_t rec_size = 0;              // 4 + block_size of the last record listed (0: none yet)
     uint32_t n_rec = 0;
     uint32_t next_evt = 0;
     uint32_t bad = 0;
+    bool tail_unknown = false;
+
+    // four bytes of the ring at any position
+    auto ring_u32 = [&](uint32_t x) __attribute__((always_inline)) {
+        const uint32_t i = (x & CWMASK) >> 2;
+        return __builtin_amdgcn_alignbit(win32[(i + 1) & (CWIN / 4 - 1)], win32[i], (x & 3u) * 8u);
+    };
+    // Could an alignment record start at c (its first 40 bytes are in the ring)?  block_size, refID, pos, l_read_name, the variable
+    // lengths against block_size, next_refID — what BAM readers that must find a record in the middle of a file test.  A wrong yes
+    // is caught by the host: the chain of records through all blocks must close.
+    // (`avail`: bytes of the candidate that lie in this block — at the block's end fewer than the 36 of the fixed fields; what
+    // is not there is not tested)
+    auto plausible = [&](uint32_t c, uint32_t avail) __attribute__((always_inline)) {
+        const uint32_t bs = ring_u32(c), refid = ring_u32(c + 4), pos = ring_u32(c + 8), w2 = ring_u32(c + 12), w3 = ring_u32(c + 16);
+        const uint32_t l_seq = ring_u32(c + 20), nref = ring_u32(c + 24), npos = ring_u32(c + 28);
+        const uint32_t l_name = w2 & 0xFFu, n_cig = w3 & 0xFFFFu;
+        const uint64_t need = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq;
+        bool ok = avail >= 4u && bs >= 33u && bs < (1u << 24);
+        if (avail >= 8u) ok = ok && refid + 1u <= a.n_ref;
+        if (avail >= 12u) ok = ok && (int32_t)pos >= -1;
+        if (avail >= 13u) ok = ok && l_name >= 1u;
+        if (avail >= 24u) ok = ok && l_seq < (1u << 28) && need <= bs;
+        if (avail >= 28u) ok = ok && nref + 1u <= a.n_ref;
+        if (avail >= 32u) ok = ok && (int32_t)npos >= -1;
+        return ok;
+    };
 
     // List the record starts whose block_size field is complete, flush the segments that are complete.  The chain of records is
     // serial (a record's start is known when its predecessor's size is), but the records of a BAM block mostly have one size: 16
     // lanes look at where the next 16 records start if they all have the size of the last one, and the chain advances over all
     // that do (at least one per step: the first candidate is a record start for sure).
     auto housekeeping = [&]() __attribute__((always_inline)) {
+        while (searching && search_pos + 40u <= op) {            // 64 candidates at a time
+            const uint32_t c = search_pos + (uint32_t)lane;
+            const unsigned long long hit = __ballot(c + 40u <= op && c < vend && plausible(c, 40u));
+            if (hit) {
+                next_rec = search_pos + (uint32_t)__builtin_ctzll(hit);
+                first_rec = next_rec - a0;
+                searching = false;
+            } else {
+                search_pos = min(search_pos + 64u, op - 39u);
+                if (search_pos >= vend) searching = false;
+            }
+        }
         while (next_rec + 4 <= op) {
             const uint32_t cand = next_rec + (uint32_t)lane * rec_size;
             const bool look = lane < 16 && (lane == 0 || rec_size != 0) && cand + 4 <= op;
@@ -919,21 +967,25 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 next_rec += n_look * rec_size;
             }
             if (n_rec + n_conf > (uint32_t)MAX_REC_PER_BLOCK) { err = ST_BAD_RECORD; next_rec = 0xFFFFFFF0u; break; }
-            if ((uint32_t)lane < n_conf) slots[n_rec + (uint32_t)lane] = cand;
+            if ((uint32_t)lane < n_conf) slots[n_rec + (uint32_t)lane] = cand - a0;
             n_rec += n_conf;
         }
         while (op - flushed >= CSEG) {
             const uint4 *src = reinterpret_cast<const uint4 *>(s_win + (flushed & CWMASK));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
+            if (flushed == 0 && a0 != 0) {                       // the block's first row: its first bytes are the previous block's
+                if (lane == 0) { for (uint32_t i = a0; i < 16u; ++i) out[i] = s_win[i]; }
+                else dst[lane] = src[lane];
+            } else dst[lane] = src[lane];
 #pragma unroll
-            for (int k = 0; k < CSEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+            for (int k = 1; k < CSEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
             flushed += CSEG;
         }
         next_evt = flushed + (uint32_t)CSEG;
     };
     // a match of any kind: all lanes; with dist < len the pattern of the last `dist` bytes repeats
     auto copy_any = [&](uint32_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {
-        if (dist > at) { bad = 1; return; }                      // before the block's first byte
+        if (dist + a0 > at) { bad = 1; return; }                 // before the block's first byte
         if (dist > (uint32_t)CNEAR) {
             const uint8_t *src = out + (at - dist);             // flushed by this wavefront (see CNEAR)
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -981,13 +1033,13 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             for (uint32_t j = 0; j < nb && err == ST_OK && !bad; ++j) {
                 const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)j);
                 if (tj >> 31) {
-                    if (op + 1 > ulen) { err = ST_BAD_LENGTH; break; }
+                    if (op + 1 > vend) { err = ST_BAD_LENGTH; break; }
                     s_win[op & CWMASK] = (uint8_t)tj;
                     ++op;
                 } else if (tj & TOK_RAW) {
                     uint32_t len = (tj >> 17) & 0x1FFFu;
                     const uint8_t *src = payload + (tj & 0x1FFFFu);
-                    if (op + len > ulen) { err = ST_BAD_LENGTH; break; }
+                    if (op + len > vend) { err = ST_BAD_LENGTH; break; }
                     while (len) {
                         const uint32_t n = min(len, (uint32_t)CSEG - (op & (CSEG - 1)));
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -997,7 +1049,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                     }
                 } else {
                     const uint32_t len = tj & 511u, dist = ((tj >> 9) & 0x7FFFu) + 1u;
-                    if (op + len > ulen) { err = ST_BAD_LENGTH; break; }
+                    if (op + len > vend) { err = ST_BAD_LENGTH; break; }
                     copy_any(op, len, dist);
                     op += len;
                 }
@@ -1010,13 +1062,13 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const uint32_t incl = wave_scan_add(mylen);
         const uint32_t dst = op + incl - mylen;                 // where this lane's token starts
         const uint32_t batch_end = op + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (batch_end > ulen) { err = ST_BAD_LENGTH; break; }
+        if (batch_end > vend) { err = ST_BAD_LENGTH; break; }
         // what the copy loop needs of a match, ready in two registers: ring addresses of its destination and source, its length, and
         // whether it is one of the plain ones — source in the ring, no overlap with the destination closer than a round of 64
         // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
         const bool is_match = !is_lit && mylen != 0;
         const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
-        const bool plain = dist <= (uint32_t)CNEAR && dist <= dst && (dist >= 64u || dist >= mylen) && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN;
+        const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && (dist >= 64u || dist >= mylen) && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN;
         const uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : 1u << 16);
         uint32_t t_cur = 0;
         while (t_cur < 64u) {
@@ -1113,16 +1165,31 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         }
     }
     if (bad && err == ST_OK) err = ST_BAD_STREAM;
-    if (err == ST_OK && op != ulen) err = ST_BAD_LENGTH;
+    if (err == ST_OK && op != vend) err = ST_BAD_LENGTH;
     if (err == ST_OK) {
         housekeeping();
-        const uint32_t rest = op - flushed;
-        for (uint32_t i = lane; i < rest; i += 64) out[flushed + i] = s_win[(flushed + i) & CWMASK];
+        while (searching && search_pos + 4u <= vend) {           // the block's last 39 bytes: what there is of a record's fixed fields
+            const uint32_t c = search_pos + (uint32_t)lane;
+            const unsigned long long hit = __ballot(c + 4u <= vend && plausible(c, vend - c));
+            if (hit) {
+                next_rec = search_pos + (uint32_t)__builtin_ctzll(hit);
+                first_rec = next_rec - a0;
+                searching = false;
+                housekeeping();                                 // (its chain, as far as the block goes)
+            } else search_pos += 64u;
+        }
+        // a record that starts within the block's last three bytes: its start is listed, its size is read from the stream later
+        if (next_rec < vend && next_rec + 4 > vend) {
+            if (n_rec < (uint32_t)MAX_REC_PER_BLOCK) { if (lane == 0) slots[n_rec] = next_rec - a0; ++n_rec; tail_unknown = true; }
+            else err = ST_BAD_RECORD;
+        }
+        for (uint32_t i = max(flushed, a0) + (uint32_t)lane; i < op; i += 64) out[i] = s_win[i & CWMASK];
     }
     if (lane == 0) {
         a.status[blk] = err;
         a.n_rec[blk] = n_rec;
-        a.overshoot[blk] = d.entry >= 0 && next_rec < 0xFFFFFFF0u ? (int32_t)(next_rec - ulen) : 0;
+        a.first_rec[blk] = first_rec;
+        a.overshoot[blk] = tail_unknown ? 0x7FFFFFFF : first_rec != 0xFFFFFFFFu && next_rec < 0xFFFFFFF0u ? (int32_t)(next_rec - vend) : 0;
     }
     if (a.stamps && lane == 0) {
         uint64_t *st = a.stamps + (size_t)blk * 16;
@@ -1165,7 +1232,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     TCMI_HIP(ctx, hipGetLastError());
     CopyArgs ca;
     ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = g.d_tok; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
-    ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.status = g.d_stat; ca.n_blocks = (int32_t)nb;
+    ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)nb; ca.n_ref = g.n_ref;
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
     hipLaunchKernelGGL(bgzf_copy, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);

@@ -191,9 +191,11 @@ struct tcmi_bgzf_decode_args {
     uint8_t *d_out;                 // inflated stream (BlockDesc::uout)
     uint32_t *d_slot;               // [n_blocks][MAX_REC_PER_BLOCK] record starts
     uint32_t *d_nrec;               // [n_blocks]
-    int32_t *d_over;                // [n_blocks] bytes by which a block's last record runs into the next block
+    int32_t *d_over;                // [n_blocks] bytes by which a block's last record runs into the next blocks
+    uint32_t *d_first;              // [n_blocks] offset of the first record start the block found in itself (0xFFFFFFFF: none)
     uint32_t *d_stat;               // [n_blocks] ST_*
     size_t n_blocks;
     uint32_t pay_dwords;            // the largest block's payload in dwords + slack
+    uint32_t n_ref;                 // reference sequences of the BAM header (a record's refID must be one of them)
 };
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &a);

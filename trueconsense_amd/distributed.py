@@ -3,11 +3,13 @@
 Two shard shapes (BASELINE.json configs[3] and [4]):
 
 * many BAMs  — independent objects: rank r takes BAMs r, r+world, ...; NO data-path collective.
-* one BAM    — the tally is a commutative integer sum: the coordinate-sorted reads are cut into
-               `world` contiguous ranges, every rank tallies its range into a full-length
-               int32 [7][ld] matrix in HBM and ONE exchange of that matrix (837 284 B at L = 29 903):
-               a reduce to the rank that calls and walks (reduce_counts), or an all-reduce when every
-               rank wants the whole matrix (allreduce_counts).
+* one BAM    — the tally is a commutative integer sum: every rank takes a contiguous range of the FILE's
+               BGZF blocks (tally_split_bamfile: it maps the same file, sends only its range's compressed
+               bytes to its GPU, decodes and packs the records that start in those blocks there) — or, for
+               reads already decoded, a contiguous range of the read arrays (tally_split_bam) —, tallies
+               it into a full-length int32 [7][ld] matrix in HBM, and ONE exchange of that matrix
+               (837 284 B at L = 29 903) follows: a reduce to the rank that calls and walks
+               (reduce_counts), or an all-reduce when every rank wants the whole matrix (allreduce_counts).
 """
 from __future__ import annotations
 
@@ -28,6 +30,13 @@ def read_range(n_reads, rank, world):
     base, rem = divmod(int(n_reads), int(world))
     a = rank * base + min(rank, rem)
     return a, a + base + (1 if rank < rem else 0)
+
+
+def block_range(n_blocks, rank, world):
+    """BGZF blocks [first, first + count) of rank `rank`: contiguous, the ranges partition the file.  (Header and end-of-file
+    blocks are simply part of some range: they hold no records.)"""
+    a, b = read_range(n_blocks, rank, world)
+    return a, b - a
 
 
 def shard_reads(reads, rank, world):
@@ -105,4 +114,39 @@ def tally_split_bam(reads, L, rank, world, device=0, group=None, tally_fn=None):
     counts = np.ascontiguousarray(t[:, :L].T.cpu().numpy())
     rs.free()
     ctx.close()
+    return counts
+
+
+def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to_root=False):
+    """BASELINE configs[4] from ONE FILE: every rank opens the same BAM, decodes on its GPU only the alignment records that start
+    in its contiguous range of BGZF blocks (engine.Context.upload_bamfile(blocks=...): inflate, record index, pack), tallies
+    them into a full-length int32 [7][ld] matrix and the matrices are summed — to every rank, or (to_root) to rank 0 only.
+    -> int [L,7] (None on the other ranks with to_root).  No rank ever holds the file's reads, decoded or not."""
+    import torch
+    from .engine import Context, DeviceBam
+    L = int(L)
+    ld = (L + 255) // 256 * 256
+    torch.cuda.set_device(device)
+    own = ctx is None
+    if own:
+        ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)         # tally and collective on torch's stream
+    d = DeviceBam(path)
+    try:
+        first, count = block_range(d.n_blocks, rank, world)
+        rs = ctx.upload_bamfile(d, blocks=(first, count))
+        t = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
+        if rs.n_piled:
+            check(lib().tcmi_tally_dev(ctx.handle, rs.handle, L, ld, C.c_void_p(t.data_ptr()), 0), ctx.handle)
+        if to_root:
+            reduce_counts(t, 0, group)
+        else:
+            allreduce_counts(t, group)
+        import torch.distributed as dist
+        mine = not to_root or not dist.is_initialized() or dist.get_rank(group) == 0
+        counts = np.ascontiguousarray(t[:, :L].T.cpu().numpy()) if mine else None
+        rs.free()
+    finally:
+        d.close()
+        if own:
+            ctx.close()
     return counts

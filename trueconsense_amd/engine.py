@@ -110,10 +110,12 @@ class Context:
         check(lib().tcmi_readset_upload_batch(self.handle, arr, len(structs), int(stride), C.byref(h)), self.handle)
         return ReadSet(self, h, (keep, structs))
 
-    def upload_bamfile(self, dbam):
-        """DeviceBam -> ReadSet: BGZF inflate, record index and packing all on the device."""
+    def upload_bamfile(self, dbam, blocks=None):
+        """DeviceBam -> ReadSet: BGZF inflate, record index and packing all on the device.  blocks = (first, count): only the
+        records that start in that range of the file's BGZF blocks (ranks that share one file take a range each)."""
         h, n = C.c_void_p(), C.c_int64(0)
-        check(lib().tcmi_readset_from_bamfile(self.handle, dbam.handle, C.byref(h), C.byref(n)), self.handle)
+        first, count = (0, -1) if blocks is None else blocks
+        check(lib().tcmi_readset_from_bamfile_blocks(self.handle, dbam.handle, int(first), int(count), C.byref(h), C.byref(n)), self.handle)
         rs = ReadSet(self, h, None)
         return rs
 

@@ -101,9 +101,10 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
         fh.write(_EOF)
 
 
-def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_len=0, level=1, qual=30):
+def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_len=0, level=1, qual=30, part=(True, True), first_id=0):
     """Vectorised writer for the bench workload: n reads, all `read_len`M, flags from `flag`,
-    seq_packed uint8 [n, ceil(read_len/2)] in BAM nibble order, constant quality."""
+    seq_packed uint8 [n, ceil(read_len/2)] in BAM nibble order, constant quality.  part = (first, last): a large file is written
+    in several calls, slice by slice (the header goes with the first, the end-of-file block with the last); first_id numbers the names."""
     n = len(pos)
     nb = (read_len + 1) // 2
     name_len = 8                                   # fixed-width names: 7 chars + NUL
@@ -132,7 +133,7 @@ def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_le
     put(24, np.full(n, -1), "<i4")
     put(28, np.full(n, -1), "<i4")
     put(32, np.zeros(n), "<i4")
-    ids = np.arange(n) % 10000000
+    ids = (np.arange(n) + first_id) % 10000000
     digits = np.zeros((n, 7), np.uint8)
     for k in range(7):
         digits[:, 6 - k] = 48 + (ids // 10 ** k) % 10
@@ -147,11 +148,13 @@ def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_le
             struct.pack("<i", ref_len))
     block = 0xFF00
     per = max(1, block // (4 + rec_len))            # whole records per block, as htslib cuts them
-    with open(path, "wb") as fh:
-        for o in range(0, len(head), block):
-            fh.write(_bgzf_block(head[o:o + block], level))
+    with open(path, "wb" if part[0] else "ab") as fh:
+        if part[0]:
+            for o in range(0, len(head), block):
+                fh.write(_bgzf_block(head[o:o + block], level))
         flat = rec.reshape(-1)
         step = per * (4 + rec_len)
         for o in range(0, flat.size, step):
             fh.write(_bgzf_block(flat[o:o + step].tobytes(), level))
-        fh.write(_EOF)
+        if part[1]:
+            fh.write(_EOF)

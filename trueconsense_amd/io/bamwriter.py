@@ -101,13 +101,14 @@ def write_bam(path, reads, ref_name="ref", ref_len=0, level=1, sam_text=None, bl
         fh.write(_EOF)
 
 
-def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_len=0, level=1, qual=30, part=(True, True), first_id=0):
+def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_len=0, level=1, qual=30, part=(True, True), first_id=0, names=None):
     """Vectorised writer for the bench workload: n reads, all `read_len`M, flags from `flag`,
     seq_packed uint8 [n, ceil(read_len/2)] in BAM nibble order, constant quality.  part = (first, last): a large file is written
-    in several calls, slice by slice (the header goes with the first, the end-of-file block with the last); first_id numbers the names."""
+    in several calls, slice by slice (the header goes with the first, the end-of-file block with the last); first_id numbers the names.
+    qual: one value, or uint8 [n, read_len]; names: uint8 [n, k] (k characters each, no NUL) instead of the seven-digit numbers."""
     n = len(pos)
     nb = (read_len + 1) // 2
-    name_len = 8                                   # fixed-width names: 7 chars + NUL
+    name_len = 8 if names is None else names.shape[1] + 1     # fixed-width names: 7 digits (or the caller's characters) + NUL
     rec_len = 32 + name_len + 4 + nb + read_len
     rec = np.zeros((n, 4 + rec_len), np.uint8)
     def put(col, arr, dt):
@@ -133,11 +134,14 @@ def write_bam_fast(path, pos, flag, seq_packed, read_len, ref_name="ref", ref_le
     put(24, np.full(n, -1), "<i4")
     put(28, np.full(n, -1), "<i4")
     put(32, np.zeros(n), "<i4")
-    ids = (np.arange(n) + first_id) % 10000000
-    digits = np.zeros((n, 7), np.uint8)
-    for k in range(7):
-        digits[:, 6 - k] = 48 + (ids // 10 ** k) % 10
-    rec[:, 36:43] = digits
+    if names is None:
+        ids = (np.arange(n) + first_id) % 10000000
+        digits = np.zeros((n, 7), np.uint8)
+        for k in range(7):
+            digits[:, 6 - k] = 48 + (ids // 10 ** k) % 10
+        rec[:, 36:43] = digits
+    else:
+        rec[:, 36:36 + names.shape[1]] = names
     put(36 + name_len, np.full(n, (read_len << 4) | 0), "<u4")
     s0 = 36 + name_len + 4
     rec[:, s0:s0 + nb] = seq_packed

@@ -341,6 +341,16 @@ tcmi_ctx *tcmi_filerunner_ctx(tcmi_filerunner *r, int k);
 int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
                         int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
                         int32_t *status, double *stage_seconds, int64_t *decoded_on);
+/* The command line's other three outputs for many samples (Outputs.py:13-71, 104-180; Coverage.py:1-16), written by the runner's
+ * walker threads.  tcmi_filerunner_set_outputs: the reference (id and sequence of its first FASTA record), the complete VCF header
+ * text (Outputs.py:115-127), the GFF header text and per GFF row (the rows of tcmi_filerunner_set_orfs, same order) six strings:
+ * source, type, score, strand, phase, attributes.  tcmi_filerunner_run_files: per sample the paths of its FASTA and (optionally;
+ * an array or an entry may be NULL) VCF, corrected GFF and coverage TSV. */
+int tcmi_filerunner_set_outputs(tcmi_filerunner *r, const char *ref_id, const char *ref_seq, const char *vcf_head, const char *gff_head,
+                                int32_t n_rows, const char *const *row_cols);
+int tcmi_filerunner_run_files(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, const char *const *fasta,
+                              const char *const *vcf, const char *const *gff, const char *const *doc, int64_t ref_len, int32_t mincov,
+                              int include_ambig, int device_decode, int32_t *status, double *stage_seconds, int64_t *decoded_on);
 
 #ifdef __cplusplus
 }

@@ -431,6 +431,52 @@ def test_cli_bam_to_outputs_matches_reference(ctx, tmp_path, monkeypatch):
     assert n_done >= 20 and n_over >= 10
 
 
+def test_cli_batch_writes_the_same_four_files(ctx, tmp_path, monkeypatch):
+    """--batch MANIFEST: many samples through the native file runner, whose walker threads write FASTA, VCF, corrected GFF and
+    coverage TSV themselves (csrc/pipeline.cpp) — byte for byte the reference's text (the golden files of the single-sample
+    command line above), for two manifest lines at a time."""
+    from trueconsense_amd import TrueConsense as cli
+    monkeypatch.chdir(tmp_path)
+    n_done = n_raise = 0
+    for case in load("outputs"):
+        spec = case["spec"]
+        reads = ss.reads_from_spec(spec)
+        bamwriter.write_bam("in.bam", reads, "refid", len(spec["ref"]))
+        with open("ref.fa", "w") as fh:
+            fh.write(">refid some description\n")
+            for o in range(0, len(spec["ref"]), 60):
+                fh.write(spec["ref"][o:o + 60] + "\n")
+        with open("f.gff", "w") as fh:
+            fh.write("##gff-version 3\n")
+            for k, o in enumerate(spec["orfs"]):
+                fh.write("S\tx\tCDS\t%d\t%d\t.\t%s\t0\tID=o%d;Name=orf%d\n" % (o["start"], o["end"], o["strand"], k, k))
+        with open("m.tsv", "w") as fh:
+            fh.write("# BAM, name, FASTA, VCF, GFF, TSV\n")
+            fh.write("in.bam\tSAMPLE\ta.fa\ta.vcf\ta.gff\ta.tsv\n")
+            fh.write("in.bam\tSAMPLE\tb.fa\t-\tb.gff\n")                    # (no VCF, no TSV for the second)
+        for key, run in case["runs"].items():
+            argv = ["--batch", "m.tsv", "-ref", "ref.fa", "-gff", "f.gff", "-cov", str(spec["mincov"])] + (["-noambig"] if key == "amb0" else [])
+            monkeypatch.setattr(sys, "argv", ["TrueConsense", "ARGS"])
+            for f in ("a.fa", "a.vcf", "a.gff", "a.tsv", "b.fa", "b.gff", "b.vcf"):
+                if os.path.exists(f):
+                    os.remove(f)
+            if "raises" in run:
+                with pytest.raises((KeyError, ZeroDivisionError, IndexError)):
+                    cli.main(argv)
+                n_raise += 1
+                continue
+            cli.main(argv)
+            assert open("a.fa").read() == open("b.fa").read() == run["fa"], case["name"]
+            assert open("a.tsv").read() == run["tsv"]
+            lines = open("a.vcf").read().split("\n")
+            lines[1] = "##fileDate=DATE"
+            assert "\n".join(lines) == run["vcf"], case["name"]
+            assert open("a.gff").read() == open("b.gff").read() == run["gff_cli"], case["name"]
+            assert not os.path.exists("b.vcf")
+            n_done += 1
+    assert n_done >= 20
+
+
 def test_self_cleaning_steps_and_pipeline(ctx):
     """Steps that do not fetch the counts leave the matrix zeroed by the call kernel (no memset
     between them); the native pipeline must give what the step-by-step path gives, inserts included."""

@@ -7,7 +7,7 @@ timeout -k 10 400 python -m pytest tests/test_bam_device.py tests/test_bam_fixtu
 tail -3 gpurun_out/inf/tests.log
 for kind in headline hard; do
   timeout -k 10 300 python3 tools/inflate_stamps.py $kind 1000000 2>&1 | grep -v amdgpu.ids | tee gpurun_out/inf/new_$kind.log || exit 1
-  if [ "$1" = legacy ]; then
+  if false; then
     TCMI_INFLATE_LEGACY=1 timeout -k 10 300 python3 tools/inflate_time.py $kind 1000000 2>&1 | grep -v amdgpu.ids | tee gpurun_out/inf/legacy_$kind.log || exit 1
   fi
 done

@@ -22,9 +22,10 @@ from .Sequences import consensus_from_records
 _FIXED = [c for c in GFF3_COLUMNS if c != "attributes"]
 
 
-def _gff_line(row):
-    """One GFF row dict -> its text line: the eight fixed columns, then every other key folded into the attributes column
-    (keys lower-cased; the parsed pairs of an `attributes` entry take its place in the row's key order)."""
+def _gff_columns(row):
+    """One GFF row dict -> ({fixed column: text} in canonical order, attributes text): the eight fixed columns, every other key
+    folded into the attributes column (keys lower-cased; the parsed pairs of an `attributes` entry take its place in the row's
+    key order)."""
     fixed, attrs = {}, {}
     for key, value in row.items():
         k = str(key).lower()
@@ -37,7 +38,25 @@ def _gff_line(row):
         else:
             attrs[k] = str(value)
     assert list(fixed) == _FIXED                        # upstream insists on the canonical column order, too
-    return "\t".join(list(fixed.values()) + [";".join("%s=%s" % kv for kv in attrs.items())]) + "\n"
+    return fixed, ";".join("%s=%s" % kv for kv in attrs.items())
+
+
+def _gff_line(row):
+    """One GFF row dict -> its text line."""
+    fixed, attrs = _gff_columns(row)
+    return "\t".join(list(fixed.values()) + [attrs]) + "\n"
+
+
+def gff_row_columns(row):
+    """-> [source, type, score, strand, phase, attributes] of a row: what the native batch writer (csrc/pipeline.cpp) puts around the
+    sample's name and the corrected start / end."""
+    fixed, attrs = _gff_columns(row)
+    return [fixed["source"], fixed["type"], fixed["score"], fixed["strand"], fixed["phase"], attrs]
+
+
+def vcf_header(today, argv, ref, refID):
+    """The VCF's header lines (Outputs.py:115-127)."""
+    return _VCF_HEAD.format(date=today, argv=" ".join(argv), ref=ref, contig=refID)
 
 
 def WriteGFF(gffheader, gffdict, output_gff, name):
@@ -61,7 +80,7 @@ def vcf_text(today, argv, ref, refID, reflist, consensus_noinsert, iDict, mincov
     2), POS of indel records one less than their index + 1, IndexError when a deletion run reaches the end."""
     cons = consensus_noinsert.upper()
     ins = insertpositions if hasinserts is True else {}
-    lines = [_VCF_HEAD.format(date=today, argv=" ".join(argv), ref=ref, contig=refID)]
+    lines = [vcf_header(today, argv, ref, refID)]
     i, n = 0, len(reflist)
     while i < n:
         here = cons[i]

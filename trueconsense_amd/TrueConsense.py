@@ -3,7 +3,14 @@
     python -m trueconsense_amd.TrueConsense -i x.bam -ref r.fa -gff r.gff -cov 30 -name S -o out.fa
         [-vcf out.vcf] [-doc cov.tsv] [-ogff out.gff] [-t N] [-noambig] [--index-override f.csv.gz]
 
-Additive flags (not in the reference): --device N (GPU ordinal), --stats FILE (JSON timings).
+Additive flags (not in the reference): --device N (GPU ordinal), --stats FILE (JSON timings), and
+
+    python -m trueconsense_amd.TrueConsense --batch MANIFEST -ref r.fa -gff r.gff -cov 30 [-noambig] [-t N]
+
+for many samples against one reference in one process: MANIFEST holds one sample per line, tab-separated:
+input BAM, sample name, consensus FASTA and — optional, "-" or empty for "not wanted" — VCF, corrected GFF, coverage TSV
+(the -i / -name / -o / -vcf / -ogff / -doc of the single-sample form).  The samples go through the native file runner
+(csrc/pipeline.cpp): reading, GPU work and the host walk of consecutive samples overlap, all four outputs are written natively.
 """
 from __future__ import annotations
 
@@ -77,14 +84,65 @@ def GetArgs(givenargs):
         (("--device",), dict(type=int, default=None, metavar="N", help="GPU ordinal (default: 0)")),
         (("--stats",), dict(type=str, default=None, metavar="File", help="write stage timings as JSON")),
     ]
+    additive.append((("--batch",), dict(type=str, default=None, metavar="File",
+                                        help="many samples: a tab-separated manifest (BAM, name, FASTA[, VCF, GFF, TSV] per line)\n"
+                                             "instead of -i / -name / -o / -vcf / -ogff / -doc")))
+    batch = "--batch" in givenargs
     for title, rows, req in (("Required arguments", required, True), ("Optional arguments", optional, False),
                              ("MI355X arguments (additive)", additive, False)):
         group = parser.add_argument_group(title)
         for flags, kw in rows:
             if req:
-                kw["required"] = True
+                kw["required"] = not (batch and flags[0] in ("--input", "--output", "--samplename"))
             group.add_argument(*flags, **kw)
     return parser.parse_args(givenargs)
+
+
+def run_batch(a):
+    """--batch: the manifest's samples through the native file runner, four output files each."""
+    from datetime import date
+    from .engine import FileRunner
+    from .io import fasta
+    from .Outputs import gff_row_columns, vcf_header
+    if a.index_override:
+        print("--index-override goes with a single sample (-i), not with --batch. Exiting...")
+        sys.exit(1)
+    rows = []
+    with open(a.batch) as fh:
+        for ln, line in enumerate(fh, 1):
+            line = line.rstrip("\n")
+            if not line or line.startswith("#"):
+                continue
+            f = line.split("\t")
+            if len(f) < 3:
+                print(f'{a.batch}:{ln}: need at least "BAM<TAB>name<TAB>FASTA". Exiting...')
+                sys.exit(1)
+            f += [""] * (6 - len(f))
+            if not os.path.isfile(f[0]):
+                print(f'"{f[0]}" is not a file. Exiting...')
+                sys.exit(-1)
+            rows.append([f[0], f[1], f[2]] + [None if x in ("", "-") else x for x in f[3:6]])
+    IndexGff = Gffindex(a.features)
+    gffdf = IndexGff.df
+    gffdf["seqid"] = "S"                                         # (the runner puts each sample's name there: TrueConsense.py:240)
+    gffrows = list(gffdf.to_dict("index").values())
+    refID, refseq = fasta.read_first_record(a.reference)
+    t0 = time.perf_counter()
+    cores = max(1, min(int(a.threads), os.cpu_count() or 1))
+    runner = FileRunner(int(os.environ.get("TCMI_DEVICE", "0")), gffrows, a.coverage_level, a.noambiguity is False,
+                        decoders=min(4, max(1, cores // 4)), decode_threads=max(1, cores // 2), walkers=min(4, max(1, cores // 4)),
+                        gpu_streams=3 if len(rows) > 2 else 1)
+    runner.set_outputs(refID, refseq, vcf_header(date.today().strftime("%Y%m%d"), sys.argv[1:], a.reference, refID), IndexGff.header.raw_text,
+                       [gff_row_columns(r) for r in gffrows])
+    try:
+        runner.run_files([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
+                         [r[5] for r in rows], ref_len=len(refseq))
+    finally:
+        if a.stats:
+            with open(a.stats, "w") as fh:
+                json.dump({"seconds": {"batch": time.perf_counter() - t0}, "samples": len(rows), "stage_busy_seconds": runner.seconds,
+                           "decoded_on": runner.decoded_on, "status": [int(x) for x in getattr(runner, "last_status", [])]}, fh)
+        runner.close()
 
 
 def main(args=None):
@@ -98,6 +156,8 @@ def main(args=None):
     a = GetArgs(args)
     if a.device is not None:
         os.environ["TCMI_DEVICE"] = str(a.device)
+    if a.batch:
+        return run_batch(a)
     t = {"start": time.perf_counter()}
 
     from .engine import LazyBam

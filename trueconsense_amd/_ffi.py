@@ -99,6 +99,8 @@ _SIGS = {
     "tcmi_filerunner_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "tcmi_filerunner_ctx": (_vp, [_vp, _int]),
     "tcmi_filerunner_run": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tcmi_filerunner_set_outputs": (_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, _i32, _vp]),
+    "tcmi_filerunner_run_files": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _int, _int, _vp, _vp, _vp]),
 }
 
 _lib = None

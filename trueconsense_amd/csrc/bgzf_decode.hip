@@ -40,6 +40,7 @@ constexpr int CSEG = 2048;
 // from the ring ends that much earlier; a source further back has been flushed (CWIN >= 2 CSEG + 522)
 constexpr int CNEAR = CWIN - CSEG - 264;
 static_assert(CWIN >= 2 * CSEG + 528 && (CWIN & (CWIN - 1)) == 0 && CWIN % CSEG == 0, "a far match must find its source flushed");
+constexpr int FAR_WORDS = 128;                      // bgzf_copy: words of LDS in which the sources of a batch's far matches are parked
 constexpr uint32_t TOK_LIT = 1u << 31, TOK_RAW = 1u << 30;
 constexpr uint32_t RAW_PIECE = 8191;
 constexpr int CL_SLAB = 496;                        // bit positions of the code-length stream looked up at a time
@@ -864,7 +865,8 @@ struct CopyArgs {
 
 __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[CWIN];        // (the kernel's only LDS object: ring index = LDS address)
+    __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; } s_lds;     // (the ring first: ring index = LDS address)
+    uint8_t *const s_win = s_lds.win;
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= a.n_blocks) return;
@@ -1069,7 +1071,38 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const bool is_match = !is_lit && mylen != 0;
         const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
         const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && (dist >= 64u || dist >= mylen) && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN;
-        const uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : 1u << 16);
+        const bool far_ok = dist > (uint32_t)CNEAR && dist + a0 <= dst && dm + mylen <= (uint32_t)CWIN;      // (its source is flushed when its turn comes: CNEAR)
+        uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : far_ok ? 1u << 16 : 2u << 16);
+        const uint32_t vC = dst - dist;                         // a far match's source, as a position
+        // A match that reaches back further than the ring holds reads what this wavefront flushed long ago — from HBM, a microsecond
+        // away if it is fetched when the match comes up.  So the far matches of the batch whose sources are flushed already (all of
+        // them, unless the batch is several KB of output long) are fetched NOW, every lane its own match's bytes, into a few
+        // hundred bytes of LDS next to the ring; to the copy loop below they are plain matches whose source lies there.
+        {
+            const uint32_t src = dst - dist;                    // (position of the source's first byte)
+            const bool fetch = is_match && far_ok && mylen <= 64u && src + mylen <= flushed;     // (longer ones: 64 bytes an instruction in the loop)
+            if (__ballot(fetch)) {
+                const uint32_t words = fetch ? (mylen + 3u) >> 2 : 0u;
+                const uint32_t end_w = wave_scan_add(words);
+                const bool take = fetch && end_w <= (uint32_t)FAR_WORDS;
+                if (__ballot(take)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wavefront's own flush stores)
+                    const uint32_t *g = reinterpret_cast<const uint32_t *>(out + (src & ~3u));
+                    const uint32_t sh = (src & 3u) * 8u;
+                    uint32_t *park = s_lds.far + (end_w - words);
+                    const uint32_t n = take ? words : 0u;
+                    for (uint32_t k = 0; __ballot(k < n); k += 4) {           // four words a turn: five loads in flight
+                        uint32_t w[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) w[i] = k + i <= n && k < n ? g[k + i] : 0u;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (k + i < n) park[k + i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+                    }
+                    if (take) vB = (uint32_t)CWIN + 4u * (end_w - words);
+                }
+            }
+        }
         uint32_t t_cur = 0;
         while (t_cur < 64u) {
             // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
@@ -1094,7 +1127,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                         "v_readlane_b32 %[sb], %[vB], %[j]\n"
                         "v_readlane_b32 %[sa], %[vA], %[j]\n"
                         "s_cmp_lt_u32 %[sb], 0x10000\n"
-                        "s_cbranch_scc0 LMx%=\n"
+                        "s_cbranch_scc0 LMf%=\n"
                         "s_bitset0_b64 %[mm], %[j]\n"
                         "s_lshr_b32 %[len], %[sa], 16\n"
                         "s_and_b32 %[sa], %[sa], 0xffff\n"
@@ -1145,10 +1178,32 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                         "s_waitcnt lgkmcnt(0)\n"
                         "ds_write_b8 %[t1], %[t2] offset:256\n"
                         "s_branch LM1%=\n"
+                        "LMf%=:\n"                                  // a far match: 64 bytes a round straight from the flushed output
+                        "s_cmp_lt_u32 %[sb], 0x20000\n"
+                        "s_cbranch_scc0 LMx%=\n"
+                        "s_bitset0_b64 %[mm], %[j]\n"
+                        "v_readlane_b32 %[sb], %[vC], %[j]\n"
+                        "s_lshr_b32 %[len], %[sa], 16\n"
+                        "s_and_b32 %[sa], %[sa], 0xffff\n"
+                        "v_add_u32 %[t1], %[sa], %[vlane]\n"
+                        "v_add_u32 %[t0], %[sb], %[vlane]\n"
+                        "LMg%=:\n"
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "global_load_ubyte %[t2], %[t0], %[outp]\n"
+                        "s_waitcnt vmcnt(0)\n"
+                        "ds_write_b8 %[t1], %[t2]\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        "s_cmp_gt_u32 %[len], 64\n"
+                        "s_cbranch_scc0 LM1%=\n"
+                        "s_sub_u32 %[len], %[len], 64\n"
+                        "v_add_u32 %[t0], 64, %[t0]\n"
+                        "v_add_u32 %[t1], 64, %[t1]\n"
+                        "s_branch LMg%=\n"
                         "LMx%=:\n"
                         "s_mov_b64 exec, s[92:93]\n"
                         : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                        : [vA] "v"(vA), [vB] "v"(vB), [vlane] "v"(lane)
+                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [outp] "s"(out)
                         : "s92", "s93", "vcc", "scc", "memory");
                 }
                 if (j < 0) break;

@@ -68,10 +68,17 @@ bool parse_token(const char *t, int64_t n, int *size_digit, const char **bases, 
 // call records of one BAM -> consensus: insert candidates -> modal tokens (Events.py:5-82), then the sequential walk
 // modal tokens of the candidate columns resolved beforehand (on the device: tcmi_readset_modal_tokens)
 struct PreTokens { std::vector<int64_t> cand, off, cnt; std::vector<char> toks; bool valid = false; };
+// what the other writers (VCF, corrected GFF) take from the walk besides the consensus
+struct WalkExtra {
+    std::vector<int64_t> new_start, new_end;        // corrected GFF coordinates per row (of the walk WITH inserts: Outputs.py:95-98)
+    std::vector<int64_t> ins_pos, ins_off;          // accepted inserts: 1-based positions, bases at ins_seq[ins_off[k] .. ins_off[k + 1])
+    std::string ins_seq;
+    std::string cons_noinsert;                      // the second walk (includeINS = False)
+};
 
 int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags, int64_t L, const tcmi_reads *reads, bool reads_known,
                  const std::vector<int64_t> &orf_start, const std::vector<int64_t> &orf_end, const std::vector<uint8_t> &orf_plus,
-                 char *out, int64_t cap, int64_t *out_len, long long item, const PreTokens *pre = nullptr)
+                 char *out, int64_t cap, int64_t *out_len, long long item, const PreTokens *pre = nullptr, WalkExtra *extra = nullptr)
 {
     // insert candidates (Events.py:29-36 evaluated by the call kernel) -> accepted inserts
     std::vector<int64_t> cand;
@@ -119,9 +126,115 @@ int walk_records(const uint8_t *plain, const uint8_t *alt, const uint8_t *flags,
     const int32_t n_orf = (int32_t)orf_start.size();
     std::vector<int64_t> ns((size_t)n_orf), ne((size_t)n_orf);
     int64_t err_pos = 0;
-    return tcmi_consensus_walk(plain, alt, flags, L, n_orf, orf_start.data(), orf_end.data(), orf_plus.data(),
-                               (int32_t)ins_pos.size(), ins_pos.data(), ins_shift.data(), ins_seq.c_str(), ins_off.data(), 1,
-                               out, cap, out_len, ns.data(), ne.data(), &err_pos);
+    int rc = tcmi_consensus_walk(plain, alt, flags, L, n_orf, orf_start.data(), orf_end.data(), orf_plus.data(),
+                                 (int32_t)ins_pos.size(), ins_pos.data(), ins_shift.data(), ins_seq.c_str(), ins_off.data(), 1,
+                                 out, cap, out_len, ns.data(), ne.data(), &err_pos);
+    if (rc || !extra) return rc;
+    // the insert-free consensus the VCF is made from: a second walk (Outputs.py:98), whose ORF corrections are discarded
+    extra->cons_noinsert.resize((size_t)L + 1);
+    int64_t len2 = 0;
+    std::vector<int64_t> ns2((size_t)n_orf), ne2((size_t)n_orf);
+    rc = tcmi_consensus_walk(plain, alt, flags, L, n_orf, orf_start.data(), orf_end.data(), orf_plus.data(),
+                             (int32_t)ins_pos.size(), ins_pos.data(), ins_shift.data(), ins_seq.c_str(), ins_off.data(), 0,
+                             &extra->cons_noinsert[0], (int64_t)extra->cons_noinsert.size(), &len2, ns2.data(), ne2.data(), &err_pos);
+    if (rc) return rc;
+    extra->cons_noinsert.resize((size_t)len2);
+    extra->new_start = ns; extra->new_end = ne;
+    extra->ins_pos = ins_pos; extra->ins_off = ins_off; extra->ins_seq = ins_seq;
+    return TCMI_OK;
+}
+
+// ---- the other three outputs of the command line, as text (Outputs.py:13-71, 104-180; Coverage.py:1-16) ----------------------------
+void put_int(std::string &o, long long v)
+{
+    char b[24];
+    int n = 0;
+    const bool neg = v < 0;
+    unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) o.push_back('-');
+    while (n) o.push_back(b[--n]);
+}
+
+// Coverage.BuildCoverage: "{pos}\t{coverage}\n" for every position of the index
+void coverage_tsv_text(const int32_t *cov, int64_t L, std::string &o)
+{
+    o.clear();
+    o.reserve((size_t)L * 12);
+    for (int64_t i = 0; i < L; ++i) { put_int(o, i + 1); o.push_back('\t'); put_int(o, cov[i]); o.push_back('\n'); }
+}
+
+// Outputs.WriteGFF: the header text verbatim, then one line per row — seqid = the sample's name (TrueConsense.py:240), start / end as
+// the walk corrected them, the other columns as the caller folded them (Outputs.py:32-58)
+void gff_text(const std::string &head, const std::vector<std::string> &row_cols, const char *name, const std::vector<int64_t> &ns,
+              const std::vector<int64_t> &ne, std::string &o)
+{
+    o = head;
+    for (size_t k = 0; k < ns.size(); ++k) {
+        const std::string *c = &row_cols[6 * k];            // source, type, score, strand, phase, attributes
+        o += name; o.push_back('\t'); o += c[0]; o.push_back('\t'); o += c[1]; o.push_back('\t');
+        put_int(o, ns[k]); o.push_back('\t'); put_int(o, ne[k]); o.push_back('\t');
+        o += c[2]; o.push_back('\t'); o += c[3]; o.push_back('\t'); o += c[4]; o.push_back('\t'); o += c[5]; o.push_back('\n');
+    }
+}
+
+// Outputs.py:115-180 as one left-to-right scan (the Python twin: trueconsense_amd/Outputs.py vcf_text).  The quirks are upstream's
+// (SURVEY §8-Q10): raw reference characters against the upper-cased insert-free consensus, DP from the FOLLOWING position,
+// POS of indel records one less than their index + 1, an insert matched by 0-based index == its 1-based position, Python's
+// index -1 (the last element) for a deletion at the very first position.  -> TCMI_E_KEYERROR where upstream raises (a deletion
+// run that reaches the end of the consensus: IndexError; a coverage look-up beyond the index: KeyError).
+int vcf_text(const std::string &head, const std::string &ref_id, const std::string &ref, const std::string &cons_in, const int32_t *cov,
+             int64_t L, int32_t mincov, const WalkExtra &x, std::string &o)
+{
+    std::string cons = cons_in;
+    for (char &c : cons) c = (char)std::toupper((unsigned char)c);
+    const int64_t n = (int64_t)ref.size(), nc = (int64_t)cons.size();
+    o = head;
+    auto coverage = [&](int64_t pos1, long long *out) { if (pos1 < 1 || pos1 > L) return false; *out = cov[pos1 - 1]; return true; };
+    size_t next_ins = 0;
+    int64_t i = 0;
+    while (i < n) {
+        if (i >= nc) return tcmi_fail(nullptr, TCMI_E_KEYERROR, "VCF: the consensus ends at %lld, the reference at %lld (IndexError upstream)", (long long)nc, (long long)n);
+        const char here = cons[(size_t)i];
+        int64_t step = 1;
+        long long dp = 0;
+        if (here == '-') {
+            int64_t j = i;
+            while (j < nc && cons[(size_t)j] == '-') ++j;
+            if (j >= nc) return tcmi_fail(nullptr, TCMI_E_KEYERROR, "VCF: a deletion runs to the end of the consensus (IndexError upstream)");
+            if (!coverage(i + 1, &dp)) return tcmi_fail(nullptr, TCMI_E_KEYERROR, "VCF: no coverage for position %lld (KeyError upstream)", (long long)(i + 1));
+            o += ref_id; o.push_back('\t'); put_int(o, i); o += "\t.\t";
+            o.push_back(ref[(size_t)((i - 1 + n) % n)]);
+            o.append(ref, (size_t)i, (size_t)(std::min(j, n) - i));         // (a Python slice: cut at the reference's end)
+            o.push_back('\t'); o.push_back(cons[(size_t)((i - 1 + nc) % nc)]);
+            o += "\t.\tPASS\tDP="; put_int(o, dp); o += ";INDEL\n";
+            step = j - i;
+        } else if (here != ref[(size_t)i]) {
+            if (!coverage(std::max<int64_t>(i, 1) + 1, &dp)) return tcmi_fail(nullptr, TCMI_E_KEYERROR, "VCF: no coverage for position %lld (KeyError upstream)", (long long)(std::max<int64_t>(i, 1) + 1));
+            o += ref_id; o.push_back('\t'); put_int(o, i + 1); o += "\t.\t"; o.push_back(ref[(size_t)i]); o.push_back('\t'); o.push_back(here);
+            o += "\t.\tPASS\tDP="; put_int(o, dp); o.push_back('\n');
+        }
+        while (next_ins < x.ins_pos.size() && x.ins_pos[next_ins] < i) ++next_ins;
+        if (next_ins < x.ins_pos.size() && x.ins_pos[next_ins] == i) {
+            if (!coverage(i + 1, &dp)) return tcmi_fail(nullptr, TCMI_E_KEYERROR, "VCF: no coverage for position %lld (KeyError upstream)", (long long)(i + 1));
+            if (dp > mincov) {
+                o += ref_id; o.push_back('\t'); put_int(o, i); o += "\t.\t"; o.push_back(ref[(size_t)i]); o.push_back('\t'); o.push_back(here);
+                o.append(x.ins_seq, (size_t)x.ins_off[next_ins], (size_t)(x.ins_off[next_ins + 1] - x.ins_off[next_ins]));
+                o += "\t.\tPASS\tDP="; put_int(o, dp); o += ";INDEL\n";
+            }
+        }
+        i += step;
+    }
+    return TCMI_OK;
+}
+
+int write_file(const char *path, const std::string &text)
+{
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return tcmi_fail(nullptr, TCMI_E_IO, "cannot write %s", path);
+    const size_t w = std::fwrite(text.data(), 1, text.size(), fp);
+    if (std::fclose(fp) != 0 || w != text.size()) return tcmi_fail(nullptr, TCMI_E_IO, "short write to %s", path);
+    return TCMI_OK;
 }
 
 int walk_item(tcmi_pipeline *p, int slot, int64_t item_in, int b)
@@ -316,6 +429,9 @@ struct tcmi_filerunner {
     std::vector<tcmi_ctx *> ctxs;
     std::vector<int64_t> orf_start, orf_end;
     std::vector<uint8_t> orf_plus;
+    // what the VCF / GFF writers of tcmi_filerunner_run_files need besides the walk (tcmi_filerunner_set_outputs)
+    std::string ref_id, ref_seq, vcf_head, gff_head;
+    std::vector<std::string> gff_cols;              // per GFF row: source, type, score, strand, phase, attributes
 };
 
 namespace {
@@ -329,6 +445,7 @@ struct FileItem {
     std::string err;
     bool on_device = false;
     PreTokens pre;                      // insert tokens resolved on the device while the decoded stream was still resident
+    std::vector<int32_t> cov;           // files mode: the coverage column (VCF, coverage TSV)
 };
 
 double seconds_since(std::chrono::steady_clock::time_point t0)
@@ -383,11 +500,18 @@ tcmi_ctx *tcmi_filerunner_ctx(tcmi_filerunner *r, int k) { return (r && k >= 0 &
 // out_text: n * stride bytes, text i at out_text + i * stride, out_len[i] bytes (stride >= ref_len + inserted bases + name + 32)
 // stage_seconds[4]: busy seconds summed over the items: read, upload (decode + pack), step, walk
 // decoded_on[2]: items decoded on the device / by the host reader
-int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
-                        int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
-                        int32_t *status, double *stage_seconds, int64_t *decoded_on)
+} // extern "C"
+
+namespace {
+struct OutFiles { const char *const *fasta, *const *vcf, *const *gff, *const *doc; };     // per item; an entry may be NULL (not wanted)
+
+int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
+                    int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
+                    int32_t *status, double *stage_seconds, int64_t *decoded_on, const OutFiles *files)
 {
-    if (!r || n < 0 || (n > 0 && (!paths || !out_text || !out_len || !status))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    if (!r || n < 0 || (n > 0 && (!paths || !status || (!files && (!out_text || !out_len))))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    std::vector<int64_t> len_store;
+    if (!out_len) { len_store.assign((size_t)n, 0); out_len = len_store.data(); }
     std::vector<FileItem> items((size_t)n);
     std::mutex mu;
     std::condition_variable cv;
@@ -456,10 +580,13 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                     tcmi_readset_info(rs, nullptr, nullptr, nullptr, nullptr, &max_end);
                     const int64_t L = std::max<int64_t>({ref_len, max_end, 1});
                     const uint8_t *pl, *al, *fl;
+                    const int32_t *planes = nullptr;
                     int64_t ld = 0;
-                    rc = tcmi_step(ctx, rs, L, mincov, include_ambig, &pl, &al, &fl, nullptr, &ld);
+                    const bool want_cov = files && ((files->vcf && files->vcf[i]) || (files->doc && files->doc[i]));
+                    rc = tcmi_step(ctx, rs, L, mincov, include_ambig, &pl, &al, &fl, want_cov ? &planes : nullptr, &ld);
                     if (!rc) {
                         it.L = L;
+                        if (want_cov) it.cov.assign(planes + (size_t)TCMI_COV * ld, planes + (size_t)TCMI_COV * ld + L);
                         it.rec.resize((size_t)L * 3);
                         std::memcpy(it.rec.data(), pl, (size_t)L);
                         std::memcpy(it.rec.data() + L, al, (size_t)L);
@@ -531,14 +658,32 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
                     rc = tcmi_bam_load(paths[i], r->host_threads, &hb);
                     if (!rc) tcmi_bam_reads(hb, &reads);
                 }
-                char *dst = out_text + i * stride;
-                const int head = std::snprintf(dst, (size_t)stride, ">%s mincov=%d\n", names && names[i] ? names[i] : "sample", (int)mincov);
+                const char *nm = names && names[i] ? names[i] : "sample";
+                std::string own;                                 // files mode: the FASTA text lives here
+                int64_t room = stride;
+                char *dst = out_text ? out_text + i * stride : nullptr;
+                if (files) { room = L + (int64_t)std::strlen(nm) + (1 << 16); own.resize((size_t)room); dst = &own[0]; }
+                const int head = std::snprintf(dst, (size_t)room, ">%s mincov=%d\n", nm, (int)mincov);
                 int64_t len = 0;
-                if (!rc && (head < 0 || head + 2 >= stride)) rc = tcmi_fail(nullptr, TCMI_E_ARG, "output stride too small");
+                WalkExtra extra;
+                const bool want_extra = files && ((files->vcf && files->vcf[i]) || (files->gff && files->gff[i]));
+                if (!rc && (head < 0 || head + 2 >= room)) rc = tcmi_fail(nullptr, TCMI_E_ARG, "output stride too small");
                 if (!rc) rc = walk_records(pl, al, fl, L, cand ? &reads : nullptr, true, r->orf_start, r->orf_end, r->orf_plus, dst + head,
-                                           stride - head - 1, &len, (long long)i, &it.pre);
+                                           room - head - 1, &len, (long long)i, &it.pre, want_extra ? &extra : nullptr);
                 if (!rc) { dst[head + len] = '\n'; out_len[i] = head + len + 1; }
-                else { it.rc = rc; it.err = tcmi_last_error(nullptr); }
+                if (!rc && files) {
+                    // the four writers of Outputs.WriteOutputs / Coverage.BuildCoverage, in the reference's order: coverage TSV
+                    // (TrueConsense.py:243-245), corrected GFF, VCF, FASTA
+                    std::string text;
+                    if (files->doc && files->doc[i]) { coverage_tsv_text(it.cov.data(), L, text); rc = write_file(files->doc[i], text); }
+                    if (!rc && files->gff && files->gff[i]) { gff_text(r->gff_head, r->gff_cols, nm, extra.new_start, extra.new_end, text); rc = write_file(files->gff[i], text); }
+                    if (!rc && files->vcf && files->vcf[i]) {
+                        rc = vcf_text(r->vcf_head, r->ref_id, r->ref_seq, extra.cons_noinsert, it.cov.data(), L, mincov, extra, text);
+                        if (!rc) rc = write_file(files->vcf[i], text);
+                    }
+                    if (!rc && files->fasta && files->fasta[i]) { own.resize((size_t)out_len[i]); rc = write_file(files->fasta[i], own); }
+                }
+                if (rc) { it.rc = rc; it.err = tcmi_last_error(nullptr); }
                 if (hb) tcmi_bam_free(hb);
                 std::vector<uint8_t>().swap(it.rec);
             }
@@ -563,6 +708,45 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
     for (int64_t i = 0; i < n; ++i)
         if (items[(size_t)i].rc) return tcmi_fail(nullptr, items[(size_t)i].rc, "%s: %s", paths[i], items[(size_t)i].err.c_str());
     return TCMI_OK;
+}
+} // namespace
+
+extern "C" {
+
+int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
+                        int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
+                        int32_t *status, double *stage_seconds, int64_t *decoded_on)
+{
+    return filerunner_core(r, n, paths, names, ref_len, mincov, include_ambig, device_decode, out_text, stride, out_len, status, stage_seconds,
+                           decoded_on, nullptr);
+}
+
+// What the VCF and GFF writers need besides a sample's walk: the reference (first FASTA record: id and sequence, Outputs.py:108-113),
+// the complete VCF header text (Outputs.py:115-127: date, command line and reference path are the caller's), the GFF header text
+// and, per GFF row, its columns other than seqid / start / end: source, type, score, strand, phase, attributes (6 strings per row,
+// the attributes folded as Outputs.py:32-58 folds them).
+int tcmi_filerunner_set_outputs(tcmi_filerunner *r, const char *ref_id, const char *ref_seq, const char *vcf_head, const char *gff_head,
+                                int32_t n_rows, const char *const *row_cols)
+{
+    if (!r || !ref_id || !ref_seq || !vcf_head || !gff_head || n_rows < 0 || (n_rows > 0 && !row_cols)) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    if ((size_t)n_rows != r->orf_start.size()) return tcmi_fail(nullptr, TCMI_E_ARG, "%d GFF rows, %zu ORFs set", (int)n_rows, r->orf_start.size());
+    r->ref_id = ref_id; r->ref_seq = ref_seq; r->vcf_head = vcf_head; r->gff_head = gff_head;
+    r->gff_cols.clear();
+    for (int32_t k = 0; k < 6 * n_rows; ++k) r->gff_cols.emplace_back(row_cols[k] ? row_cols[k] : "");
+    return TCMI_OK;
+}
+
+// BAM files -> the command line's four output FILES per sample (TrueConsense.py:212-264 with -o, -vcf, -ogff, -doc), same stages
+// and overlap as tcmi_filerunner_run; the walker threads also write the VCF, the corrected GFF and the coverage TSV (no Python
+// per sample).  Any of vcf / gff / doc, or single entries of them, may be NULL.  tcmi_filerunner_set_outputs first.
+int tcmi_filerunner_run_files(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, const char *const *fasta,
+                              const char *const *vcf, const char *const *gff, const char *const *doc, int64_t ref_len, int32_t mincov,
+                              int include_ambig, int device_decode, int32_t *status, double *stage_seconds, int64_t *decoded_on)
+{
+    if (!r || !fasta) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    if ((vcf || gff) && r->gff_cols.size() != 6 * r->orf_start.size()) return tcmi_fail(nullptr, TCMI_E_ARG, "tcmi_filerunner_set_outputs first");
+    const OutFiles f = {fasta, vcf, gff, doc};
+    return filerunner_core(r, n, paths, names, ref_len, mincov, include_ambig, device_decode, nullptr, 0, nullptr, status, stage_seconds, decoded_on, &f);
 }
 
 } // extern "C"

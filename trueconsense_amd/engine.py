@@ -569,6 +569,41 @@ class FileRunner:
         check(rc)
         return [out[i * stride:i * stride + int(lens[i])].tobytes().decode("ascii") for i in range(n)]
 
+    def set_outputs(self, ref_id, ref_seq, vcf_head, gff_head, gff_row_columns):
+        """What the native VCF / GFF writers need besides a sample's walk (run_files): the reference's first record, the complete
+        VCF header text, the GFF header text, and per GFF row [source, type, score, strand, phase, attributes]."""
+        flat = [str(c).encode() for row in gff_row_columns for c in row]
+        arr = (C.c_char_p * max(1, len(flat)))(*flat)
+        check(lib().tcmi_filerunner_set_outputs(self.handle, str(ref_id).encode(), str(ref_seq).encode(), str(vcf_head).encode(),
+                                                str(gff_head).encode(), len(gff_row_columns), arr))
+
+    def run_files(self, paths, names, fasta, vcf=None, gff=None, doc=None, ref_len=0):
+        """BAM files -> per sample its consensus FASTA and (lists, entries may be None) VCF, corrected GFF, coverage TSV, all written
+        by the native runner's walker threads.  Raises what the reference raises (KeyError, ZeroDivisionError) for the first
+        sample that fails; last_status has every sample's code."""
+        n = len(paths)
+        if n == 0:
+            return
+        def arr(xs):
+            if xs is None:
+                return None
+            return (C.c_char_p * n)(*[None if x is None else str(x).encode() for x in xs])
+        status = np.zeros(n, np.int32)
+        sec = (C.c_double * 4)()
+        on = (C.c_int64 * 2)()
+        rc = lib().tcmi_filerunner_run_files(self.handle, n, arr(paths), arr(names), arr(fasta), arr(vcf), arr(gff), arr(doc), int(ref_len),
+                                             self.mincov, int(self.amb), int(bool(self.device_decode)), ptr(status), sec, on)
+        self.last_status = status
+        for k, v in zip(("decode", "upload", "step", "walk"), sec):
+            self.seconds[k] += v
+        self.decoded_on["device"] += on[0]
+        self.decoded_on["host"] += on[1]
+        if rc == _ffi.E_KEYERROR:
+            raise KeyError((lib().tcmi_last_error(None) or b"").decode("utf-8", "replace"))
+        if rc == _ffi.E_ZERODIV:
+            raise ZeroDivisionError("division by zero")
+        check(rc)
+
     def close(self):
         if self.handle:
             lib().tcmi_filerunner_destroy(self.handle)

@@ -33,7 +33,8 @@ def random_cigar(rng, long_reads=False):
     return pre + core + post
 
 
-def random_reads(rng, n, L, long_reads=False, sort=True):
+def random_specs(rng, n, L, long_reads=False):
+    """-> list of read dicts (synth_small.reads_from_spec's input), unsorted."""
     reads = []
     for _ in range(n):
         cig = random_cigar(rng, long_reads)
@@ -53,6 +54,11 @@ def random_reads(rng, n, L, long_reads=False, sort=True):
         flag = int(rng.choice([0, 16, 0, 16, 4, 0x100, 0x400, 1, 3, 0x10 | 0x200]))
         reads.append({"pos": pos, "flag": flag, "cigar": "".join("%d%s" % t for t in cig), "seq": seq,
                       "qual": int(rng.integers(0, 41)), "tid": -1 if rng.random() < 0.01 else 0})
+    return reads
+
+
+def random_reads(rng, n, L, long_reads=False, sort=True):
+    reads = random_specs(rng, n, L, long_reads)
     if sort:
         reads.sort(key=lambda r: r["pos"])
     return ss.reads_from_spec({"reads": reads})

@@ -226,6 +226,31 @@ def test_records_that_straddle_bgzf_blocks_are_decoded_on_the_device(ctx, tmp_pa
     assert runner.decoded_on == {"device": 2, "host": 0}
 
 
+def test_long_reads_stay_on_the_device(ctx, tmp_path):
+    """Reads that span more reference positions than a chunk of the packed set holds (long-read platforms: 2 kb amplicon reads
+    among short ones, every CIGAR operation in them) no longer send the whole file to the host reader: they are walked in
+    the inflated stream by tally_stream_kernel.  Counts against the oracle; the file runner reports a device decode."""
+    ref, _ = sy.make_reference(L=12000, cds=[(10, 600)])
+    L = len(ref)
+    rng = np.random.default_rng(31)
+    specs = fz.random_specs(rng, 40_000, L) + fz.random_specs(rng, 800, L, long_reads=True)    # 2 %: up to a few kb each, indels / skips / clips
+    specs.sort(key=lambda r: r["pos"])
+    both = ss.reads_from_spec({"reads": specs})
+    p = str(tmp_path / "mixed.bam")
+    bamwriter.write_bam(p, both, "r", L, level=6)
+    Lx = int(max(L, engine.reads_extent(both, L)))
+    d = engine.DeviceBam(p)
+    rs = ctx.upload_bamfile(d)
+    want = c_oracle.tally(both, Lx)
+    got = ctx.step(rs, Lx, 30, True)[3]
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    rs.free()
+    d.close()
+    runner = engine.FileRunner(ctx, [{"start": 10, "end": 600, "strand": "+"}], 30)
+    runner.run([p], names=["S"], ref_len=L)
+    assert runner.decoded_on == {"device": 1, "host": 0}
+
+
 def test_a_damaged_stream_is_an_error(ctx, tmp_path):
     ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
     reads = sy.make_reads(ref, 4000, seed=1)

@@ -504,7 +504,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     const size_t b_file = al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
                  b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 5 + al(nb * 8) + al(nb * 512) + 256,
                  b_tok = al(f->tok_total * 4 + 256);
-    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 9 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
+    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 10 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
     uint8_t *d_file = (uint8_t *)tcmi_arena_take(ctx, b_file);
     BlockDesc *d_desc = (BlockDesc *)tcmi_arena_take(ctx, b_desc);
@@ -594,7 +594,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     }
     if (total > max_rec) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: impossible record count", f->path.c_str());
     const size_t n = (size_t)total;
-    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 9 + al((n / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
+    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 10 + al((n / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
     if (need_rest > b_rest)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: %zu very short records need more device scratch than was reserved: host reader", f->path.c_str(), n);
     uint64_t *d_rec = (uint64_t *)tcmi_arena_take(ctx, al(n * 8 + 8));

@@ -141,7 +141,7 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t n_chunks, n_events, n_runs;
     uint32_t word_cursor;
     uint32_t max_len;               // longest reference span of a kept read
-    uint32_t pad_;
+    uint32_t n_gen;                 // reads left to the stream-walking tally kernel (longer than TCMI_D_MAXLEN positions)
 };
 
 __device__ inline uint32_t words_of(uint32_t len) { return 2u * ((len + 31u) >> 5) + 2u; }
@@ -166,7 +166,7 @@ __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */
 
 // ---- 1: classify ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *rd_seq, uint2 *blk_sum, unsigned long long *blk_alg,
-                                                  int32_t *blk_end, PackTotals *tot)
+                                                  int32_t *blk_end, PackTotals *tot, uint32_t *gen_idx)
 {
     __shared__ uint2 s_w[PB / 64];
     __shared__ unsigned long long s_alg[PB / 64];
@@ -208,7 +208,17 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
                 const int64_t end = (int64_t)v.pos + s.pos_shift + span;
                 const int64_t len = simple ? m : span;
                 if (end >= (int64_t)TCMI_F_EVPOS) { atomicOr(&tot->flags, (uint32_t)PKF_FARPOS); kept = false; }
-                else if (len > TCMI_D_MAXLEN) { atomicOr(&tot->flags, (uint32_t)PKF_LONG); kept = false; }
+                else if (len > TCMI_D_MAXLEN) {
+                    // A read that spans more positions than a chunk's window (long-read platforms).  From the flat arrays: the host
+                    // packer cuts it into pieces.  In a device-decoded stream: it stays out of the packed set and is walked where it
+                    // lies, CIGAR op by CIGAR op, by tally_stream_kernel (one wavefront per such read).
+                    if (s.mode == 1 && gen_idx) {
+                        gen_idx[atomicAdd(&tot->n_gen, 1u)] = (uint32_t)i;
+                        my_alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
+                        my_end = (int32_t)end;
+                    } else atomicOr(&tot->flags, (uint32_t)PKF_LONG);
+                    kept = false;
+                }
                 else {
                     word = (uint32_t)len | (simple ? 0u : INFO_PROJ) | INFO_KEPT | (simple ? (uint32_t)y0 << 12 : 0u);
                     nwords = words_of((uint32_t)len);
@@ -876,13 +886,14 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
     int32_t *blk_end = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 4);
     PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
+    uint32_t *gen_idx = src.mode == 1 ? (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4) : nullptr;
     PackTotals tot;
     std::memset(&tot, 0, sizeof tot);
     TCMI_HIP(ctx, hipMemsetAsync(d_tot, 0, sizeof(PackTotals), ctx->stream));
     if (n > 0) {
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
-        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, blk_alg, blk_end, d_tot);
+        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, blk_alg, blk_end, d_tot, gen_idx);
         hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, blk_alg, blk_end, n_blk, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
         TCMI_HIP(ctx, hipGetLastError());
@@ -891,8 +902,12 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tot.flags) { *why = tot.flags; return TCMI_E_UNSUPPORTED; }
     const int64_t nf = (int64_t)tot.n_kept;
-    rs->n_piled = nf; rs->f_reads = nf; rs->alg_bytes = (int64_t)tot.alg_bytes; rs->max_end = tot.max_end; rs->max_len = (int32_t)tot.max_len;
+    rs->n_piled = nf + (int64_t)tot.n_gen; rs->f_reads = nf; rs->alg_bytes = (int64_t)tot.alg_bytes; rs->max_end = tot.max_end; rs->max_len = (int32_t)tot.max_len;
     rs->packed_on_device = 1;
+    if (tot.n_gen) {                        // long reads: tallied from the stream, which stays in the arena until this context's next upload
+        rs->d_stream = src.stream; rs->d_rec_off = src.rec_off; rs->d_gen_idx = gen_idx; rs->s_reads = (int64_t)tot.n_gen;
+        rs->arena_epoch = ctx->arena_epoch;
+    }
     if (nf == 0) return TCMI_OK;
     if (tot.n_words > 0xF0000000ull) { *why = PKF_WORD_OVF; return TCMI_E_UNSUPPORTED; }
 
@@ -980,6 +995,84 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     }
 }
 
+// ---- tally_stream_kernel: the reads the packer left out (spans above TCMI_D_MAXLEN), straight from the inflated BAM stream -------
+// One wavefront per read.  The CIGAR is walked op by op (wave-uniform), the lanes take the positions of an op 64 at a time and add
+// each token to the count matrix with a global atomic — the token rules of tally.hip's tally_read_general: a
+// matched base counts by its letter, a deleted position counts X unless an insertion follows the deletion's last base ("*+.."),
+// the last reference base in front of an insertion counts I, every position from pos to the end counts coverage (M, =, X, D, N).
+namespace {
+__device__ inline bool st_ins_after(const uint8_t *cg, int n, int k)        // htslib resolve_cigar2's peek at the last base of op k
+{
+    if (k + 1 >= n) return false;
+    const uint32_t op2 = ld_u32(cg + 4 * (size_t)(k + 1)) & 0xFu;
+    int64_t tot = 0;
+    if (op2 == 1) {
+        tot = ld_u32(cg + 4 * (size_t)(k + 1)) >> 4;
+        for (int j = k + 2; j < n; ++j) {
+            const uint32_t c = ld_u32(cg + 4 * (size_t)j), o = c & 0xFu;
+            if (o == 1) tot += c >> 4;
+            else if (o != 6) break;
+        }
+    } else if (op2 == 6 && k + 2 < n) {
+        for (int j = k + 2; j < n; ++j) {
+            const uint32_t c = ld_u32(cg + 4 * (size_t)j), o = c & 0xFu;
+            if (o == 1) tot += c >> 4;
+            else if (consumes_ref(o)) break;
+        }
+    }
+    return tot > 0;
+}
+
+__global__ __launch_bounds__(256) void tally_stream_kernel(PackSrc s, const uint32_t *gen_idx, uint32_t n_gen, int32_t *counts, int64_t ld, int32_t L)
+{
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= n_gen) return;
+    const ReadView v = view(s, (int64_t)gen_idx[w]);
+    auto add = [&](int col, int32_t p) { if ((uint32_t)p < (uint32_t)L) atomicAdd(&counts[(int64_t)col * ld + p], 1); };
+    int32_t x = v.pos + s.pos_shift, y = 0;
+    const int32_t x0 = x;
+    for (uint32_t k = 0; k < v.n_cigar; ++k) {
+        const uint32_t c = ld_u32(v.cigar + 4 * (size_t)k), op = c & 0xFu;
+        const int32_t len = (int32_t)(c >> 4);
+        if (consumes_ref(op)) {
+            const bool ins = len > 0 && st_ins_after(v.cigar, (int)v.n_cigar, (int)k);
+            if (is_match(op)) {
+                for (int32_t j = lane; j < len; j += 64) {
+                    const int32_t q = y + j;
+                    const uint32_t nib = q < v.l_seq ? nib_at(v.seq, q) : 15u;          // past SEQ -> 'N'
+                    if (__popc(nib) == 1) { const int b = __ffs(nib) - 1; add(b == 0 ? TCMI_A : b == 1 ? TCMI_C : b == 2 ? TCMI_G : TCMI_T, x + j); }
+                }
+            } else if (op == 2) {
+                const int32_t nx = ins ? len - 1 : len;                              // "*+.." does not count X
+                for (int32_t j = lane; j < nx; j += 64) add(TCMI_X, x + j);
+            }
+            if (ins && lane == 0) add(TCMI_I, x + len - 1);
+            x += len;
+        }
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) y += len;
+    }
+    for (int32_t p = x0 + lane; p < x; p += 64) add(TCMI_COV, p);
+}
+} // namespace
+
+// the long reads of a device-decoded read set into the count matrix (tcmi_launch_tally calls it behind the packed set's kernel)
+int tcmi_launch_tally_stream(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
+{
+    if (rs->s_reads <= 0) return TCMI_OK;
+    if (!rs->d_stream || rs->arena_epoch != ctx->arena_epoch || rs->device != ctx->device)
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "the read set's long reads lie in a decoded stream that is gone (another upload on this context): upload it again");
+    PackSrc s = {};
+    s.stream = rs->d_stream; s.rec_off = rs->d_rec_off; s.mode = 1; s.n = rs->n_reads; s.pos_shift = 0;
+    (void)hipGetLastError();
+    tcmi_prof_begin(ctx, TCMI_K_TALLY_GENERAL);
+    hipLaunchKernelGGL(tally_stream_kernel, dim3((unsigned)((rs->s_reads + 3) / 4)), dim3(256), 0, ctx->stream, s, rs->d_gen_idx, (uint32_t)rs->s_reads,
+                       d_counts, ld, (int32_t)L);
+    tcmi_prof_end(ctx, TCMI_K_TALLY_GENERAL);
+    TCMI_HIP(ctx, hipGetLastError());
+    return TCMI_OK;
+}
+
 // the flat arrays of struct tcmi_reads -> device (one arena block) -> tcmi_pack_on_device
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why)
 {
@@ -1019,6 +1112,8 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
 {
     if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
         return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (rs->s_reads > 0)
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "long reads lie outside the packed set: their tokens are not looked at here (host sweep)");
     if (!rs->d_stream || rs->arena_epoch != ctx->arena_epoch || rs->device != ctx->device)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "the read set's decoded stream is no longer (or never was) resident on this context: host sweep");
     for (int32_t k = 1; k < n_pos; ++k)

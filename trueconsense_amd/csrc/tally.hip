@@ -216,6 +216,10 @@ int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t 
         const int rc = tcmi_launch_tally_fast(ctx, rs, L, ld, d_counts);
         if (rc) return rc;
     }
+    if (rs->s_reads > 0) {                                    // long reads of a device-decoded stream (pack_device.hip)
+        const int rc = tcmi_launch_tally_stream(ctx, rs, L, ld, d_counts);
+        if (rc) return rc;
+    }
     if (rs->g_reads == 0) return TCMI_OK;
     TallyArgs a;
     a.pos = rs->d_pos; a.meta = rs->d_meta; a.lseq = rs->d_lseq; a.cigar = rs->d_cigar; a.seq = rs->d_seq;

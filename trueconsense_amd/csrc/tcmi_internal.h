@@ -97,6 +97,8 @@ struct tcmi_readset {
     const uint64_t *d_rec_off = nullptr;
     const uint32_t *d_cidx = nullptr;
     const int32_t *d_cpos = nullptr;
+    const uint32_t *d_gen_idx = nullptr;   // records of reads too long for the packed set (s_reads of them): tally_stream_kernel walks them in the stream
+    int64_t s_reads = 0;
     uint64_t arena_epoch = 0;
     char *d_blob = nullptr;     // one allocation holding d_flenoff | d_fseq | d_fchunk | d_fcovrun | d_fevent
     size_t blob_bytes = 0;
@@ -236,6 +238,7 @@ void *tcmi_arena_take(tcmi_ctx *ctx, size_t bytes);
 // kernels (tally.hip / call.hip)
 int tcmi_launch_tally(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
+int tcmi_launch_tally_stream(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts);
 // pipeline-internal: a step whose call kernel rides in the NEXT step's tally launch (api.cpp)
 int tcmi_step_begin_deferred(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_t mincov, int include_ambig, tcmi_ctx *prev);
 int tcmi_step_flush(tcmi_ctx *ctx);

@@ -9,6 +9,7 @@ import pytest
 
 from oracle import c_oracle
 from tests import fuzz_reads as fz
+from tests import synth_small as ss
 from trueconsense_amd import _ffi, _state, engine
 from trueconsense_amd import synthetic as sy
 from trueconsense_amd.io import bamwriter

@@ -307,6 +307,11 @@ int  tcmi_bamfile_free(tcmi_bamfile *f);
 int  tcmi_bamfile_info(const tcmi_bamfile *f, int64_t *file_bytes, int64_t *inflated_bytes, int64_t *n_blocks, int32_t *n_ref,
                        const char **ref0_name, int64_t *ref0_len);
 const char *tcmi_bamfile_text(const tcmi_bamfile *f);
+const char *tcmi_bamfile_path(const tcmi_bamfile *f);
+/* The file's compressed bytes into HBM, to stay until tcmi_bamfile_free: tcmi_readset_from_bamfile[_blocks] on that device then
+ * start from device memory, no PCIe copy per call (a file a peer GPU, a NIC or a storage engine delivered into HBM looks like
+ * this; bench.py's headline times this form: "inputs resident in HBM when the timed region starts"). */
+int  tcmi_bamfile_to_device(tcmi_ctx *ctx, tcmi_bamfile *f);
 int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset **out, int64_t *n_reads);
 /* ... of the alignment records that START in BGZF blocks [first_block, first_block + n_blocks) only (n_blocks < 0: to the end of the
  * file).  Ranks that share ONE BAM file (BASELINE configs[4]) each decode a contiguous range of its blocks and nothing else; the
@@ -341,6 +346,11 @@ tcmi_ctx *tcmi_filerunner_ctx(tcmi_filerunner *r, int k);
 int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
                         int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
                         int32_t *status, double *stage_seconds, int64_t *decoded_on);
+/* ... of files read before (tcmi_bamfile_read; they stay the caller's): the read stage has nothing to do, and with
+ * tcmi_bamfile_to_device the GPU stage starts from HBM.  Everything else as tcmi_filerunner_run. */
+int tcmi_filerunner_run_resident(tcmi_filerunner *r, int64_t n, tcmi_bamfile *const *files, const char *const *names, int64_t ref_len,
+                                 int32_t mincov, int include_ambig, char *out_text, int64_t stride, int64_t *out_len, int32_t *status,
+                                 double *stage_seconds, int64_t *decoded_on);
 /* The command line's other three outputs for many samples (Outputs.py:13-71, 104-180; Coverage.py:1-16), written by the runner's
  * walker threads.  tcmi_filerunner_set_outputs: the reference (id and sequence of its first FASTA record), the complete VCF header
  * text (Outputs.py:115-127), the GFF header text and per GFF row (the rows of tcmi_filerunner_set_orfs, same order) six strings:

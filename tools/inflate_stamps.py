@@ -21,5 +21,5 @@ for k, nm in ((3, "pass A (per workgroup)"), (4, "chain + scan"), (5, "tokens to
 print("  symbols workgroup total     mean %8.1f" % (grp[:, 6] - grp[:, 0]).mean(), " rounds A %.1f" % grp[:, 8].mean())
 print("  symbols kernel span (first start .. last end) %d ticks" % (s[:, 6].max() - s[:, 0].min()))
 c = c[c[:, 7] > 0]
-print("  copy total mean %.1f | tokens %.0f matches %.0f (not plain: %.0f) rounds %.0f" %
-      ((c[:, 1] - c[:, 0]).mean(), c[:, 7].mean(), c[:, 5].mean(), c[:, 4].mean(), c[:, 6].mean()))
+print("  copy total mean %.1f max %d | tokens %.0f matches %.0f (not plain: %.0f) rounds %.0f team rounds %.0f (matches in them %.0f)" %
+      ((c[:, 1] - c[:, 0]).mean(), (c[:, 1] - c[:, 0]).max(), c[:, 7].mean(), c[:, 5].mean(), c[:, 4].mean(), c[:, 6].mean(), c[:, 8].mean(), c[:, 9].mean()))

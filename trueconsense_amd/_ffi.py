@@ -90,6 +90,8 @@ _SIGS = {
     "tcmi_bamfile_free": (_int, [_vp]),
     "tcmi_bamfile_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i32), _P(C.c_char_p), _P(_i64)]),
     "tcmi_bamfile_text": (C.c_char_p, [_vp]),
+    "tcmi_bamfile_path": (C.c_char_p, [_vp]),
+    "tcmi_bamfile_to_device": (_int, [_vp, _vp]),
     "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
     "tcmi_readset_from_bamfile_blocks": (_int, [_vp, _vp, _i64, _i64, _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
@@ -99,6 +101,7 @@ _SIGS = {
     "tcmi_filerunner_set_orfs": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "tcmi_filerunner_ctx": (_vp, [_vp, _int]),
     "tcmi_filerunner_run": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tcmi_filerunner_run_resident": (_int, [_vp, _i64, _vp, _vp, _i64, _i32, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tcmi_filerunner_set_outputs": (_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, _i32, _vp]),
     "tcmi_filerunner_run_files": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _int, _int, _vp, _vp, _vp]),
 }

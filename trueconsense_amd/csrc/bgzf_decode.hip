@@ -40,7 +40,11 @@ constexpr int CSEG = 2048;
 // from the ring ends that much earlier; a source further back has been flushed (CWIN >= 2 CSEG + 522)
 constexpr int CNEAR = CWIN - CSEG - 264;
 static_assert(CWIN >= 2 * CSEG + 528 && (CWIN & (CWIN - 1)) == 0 && CWIN % CSEG == 0, "a far match must find its source flushed");
-constexpr int FAR_WORDS = 128;                      // bgzf_copy: words of LDS in which the sources of a batch's far matches are parked
+#ifndef TCMI_COPY_TEAMS
+#define TCMI_COPY_TEAMS 1
+#endif
+constexpr int FAR_WORDS = 128;
+constexpr int TEAM_BATCH_BYTES = 1536;               // bgzf_copy: a batch of 64 tokens this short (<= 24 bytes a token) copies its matches in teams                      // bgzf_copy: words of LDS in which the sources of a batch's far matches are parked
 constexpr uint32_t TOK_LIT = 1u << 31, TOK_RAW = 1u << 30;
 constexpr uint32_t RAW_PIECE = 8191;
 constexpr int CL_SLAB = 496;                        // bit positions of the code-length stream looked up at a time
@@ -861,11 +865,102 @@ struct CopyArgs {
     int32_t n_blocks;
     uint32_t n_ref;             // reference sequences of the BAM header
     uint64_t *stamps;           // diagnostic, as SymArgs::stamps
+    uint32_t team_bytes;        // a batch of 64 tokens with at most this many bytes of output copies its matches in teams
 };
 
+// the copy loop of the plain (and the far) matches, hand-scheduled; LOOPBACK: the two lines that go on with the next match (or nothing: one match a call)
+#define TCMI_LM_ASM(LOOPBACK) \
+                    asm volatile( \
+                        "s_mov_b64 s[92:93], exec\n" \
+                        "LM%=:\n" \
+                        "s_ff1_i32_b64 %[j], %[mm]\n" \
+                        "v_readlane_b32 %[sb], %[vB], %[j]\n" \
+                        "v_readlane_b32 %[sa], %[vA], %[j]\n" \
+                        "s_cmp_lt_u32 %[sb], 0x10000\n" \
+                        "s_cbranch_scc0 LMf%=\n" \
+                        "s_bitset0_b64 %[mm], %[j]\n" \
+                        "s_lshr_b32 %[len], %[sa], 16\n" \
+                        "s_and_b32 %[sa], %[sa], 0xffff\n" \
+                        "v_add_u32 %[t0], %[sb], %[vlane]\n" \
+                        "v_add_u32 %[t1], %[sa], %[vlane]\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "ds_read_u8 %[t2], %[t0]\n" \
+                        "s_waitcnt lgkmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2]\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc1 LM2%=\n" \
+                        "LM1%=:\n" \
+                        "s_mov_b64 exec, s[92:93]\n" \
+                        LOOPBACK \
+                        "s_mov_b32 %[j], -1\n" \
+                        "s_branch LMx%=\n" \
+                        "LM2%=:\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "ds_read_u8 %[t2], %[t0] offset:64\n" \
+                        "s_waitcnt lgkmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2] offset:64\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc0 LM1%=\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "ds_read_u8 %[t2], %[t0] offset:128\n" \
+                        "s_waitcnt lgkmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2] offset:128\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc0 LM1%=\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "ds_read_u8 %[t2], %[t0] offset:192\n" \
+                        "s_waitcnt lgkmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2] offset:192\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc0 LM1%=\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "ds_read_u8 %[t2], %[t0] offset:256\n" \
+                        "s_waitcnt lgkmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2] offset:256\n" \
+                        "s_branch LM1%=\n" \
+                        "LMf%=:\n" \
+                        "s_cmp_lt_u32 %[sb], 0x20000\n" \
+                        "s_cbranch_scc0 LMx%=\n" \
+                        "s_bitset0_b64 %[mm], %[j]\n" \
+                        "v_readlane_b32 %[sb], %[vC], %[j]\n" \
+                        "s_lshr_b32 %[len], %[sa], 16\n" \
+                        "s_and_b32 %[sa], %[sa], 0xffff\n" \
+                        "v_add_u32 %[t1], %[sa], %[vlane]\n" \
+                        "v_add_u32 %[t0], %[sb], %[vlane]\n" \
+                        "LMg%=:\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "global_load_ubyte %[t2], %[t0], %[outp]\n" \
+                        "s_waitcnt vmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2]\n" \
+                        "s_mov_b64 exec, s[92:93]\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc0 LM1%=\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_add_u32 %[t0], 64, %[t0]\n" \
+                        "v_add_u32 %[t1], 64, %[t1]\n" \
+                        "s_branch LMg%=\n" \
+                        "LMx%=:\n" \
+                        "s_mov_b64 exec, s[92:93]\n" \
+                        : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) \
+                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [outp] "s"(out) \
+                        : "s92", "s93", "vcc", "scc", "memory");
+
+// TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
+// both are right for any input — the lean one is 4 % faster where no batch would use teams)
+template <bool TEAMS>
 __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 {
-    __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; } s_lds;     // (the ring first: ring index = LDS address)
+    __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; } s_lds;     // (the ring first: ring index = LDS address)
     uint8_t *const s_win = s_lds.win;
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -892,6 +987,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     const uint8_t *const payload = a.file + d.cin;
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
     const uint32_t *const win32 = reinterpret_cast<const uint32_t *>(s_win);
+    // (teams of eight lanes: lane l belongs to team l / 8 and takes that team's piece l % 8)
+    const uint32_t team_of = (uint32_t)lane >> 3, team_sub = (uint32_t)lane & 7u, team_sub8 = team_sub * 8u;
+    const uint32_t team_base = (uint32_t)(CWIN + FAR_WORDS * 4), team_slot = team_base + team_of * 8u;     // s_lds.team, as LDS addresses
 
     uint32_t op = a0, flushed = 0;
     uint32_t next_rec = d.entry >= 0 ? a0 + (uint32_t)d.entry : 0xFFFFFFF0u;
@@ -1010,6 +1108,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
     TCMI_STAMP(a.stamps, blk, 0);
     uint32_t n_match = 0, n_slow = 0, n_round = 0;
+    const uint32_t n_team = 0, n_teamed = 0;
     housekeeping();
     for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
         uint32_t t = 0;
@@ -1103,6 +1202,15 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 }
             }
         }
+        // Matches whose source lies wholly in front of the first match still to be copied do not depend on it: up to eight of them are
+        // copied at a time, by a TEAM of eight lanes each (eight bytes a lane and step).  `srcend`: the position behind a match's source
+        // (a parked one's lies in flushed output: 0, always ready; one that is not plain never joins a team).
+        // (Worth it where tokens are short: a round of teams costs about three single matches' instructions, and in a batch of long
+        // matches — the same record 289 bytes back, say — only two or three matches at a time are independent.)
+        const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
+        const bool teamable = is_match && (vB >> 16) == 0u;
+        const uint32_t srcend = teamable ? (vB >= (uint32_t)CWIN ? 0u : dst - dist + mylen) : 0xFFFFFFFFu;
+        const unsigned long long team_mask = __ballot(teamable);
         uint32_t t_cur = 0;
         while (t_cur < 64u) {
             // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
@@ -1115,98 +1223,102 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             unsigned long long mm = __ballot(mine && is_match);
             n_match += (uint32_t)__popcll(mm);
             while (mm) {
+                if (use_teams) {
+                    // Rounds of teams, hand-scheduled (about 50 instructions a round + 10 per further 64 bytes of the longest match; the
+                    // compiler's version of the same took ~90): r = the matches whose source ends in front of F, where the first match
+                    // still to be copied starts (+ that one itself, if it is plain: its steps of 64 bytes come in order); the first eight
+                    // of them leave {vA, vB} in a slot each, every lane reads its team's slot; a match of up to 8 bytes is copied byte by
+                    // byte (lane s of the team: byte s), a longer one in 8-byte pieces at min(8 s + 64 k, len - 8).  Leaves when fewer
+                    // than two matches are ready (the single-match loop below takes the first one).
+                    uint32_t f_, F_, n_;
+                    asm volatile(
+                        "s_mov_b64 s[92:93], exec\n"
+                        "TL%=:\n"
+                        "s_ff1_i32_b64 %[f], %[mm]\n"
+                        "v_readlane_b32 %[F], %[vdst], %[f]\n"
+                        "s_lshl_b64 s[84:85], 1, %[f]\n"
+                        "s_and_b64 s[84:85], s[84:85], %[tmask]\n"
+                        "v_cmp_ge_u32 vcc, %[F], %[vsrcend]\n"
+                        "s_or_b64 s[80:81], vcc, s[84:85]\n"
+                        "s_and_b64 s[80:81], s[80:81], %[mm]\n"
+                        "s_bcnt1_i32_b64 %[n], s[80:81]\n"
+                        "s_cmp_lt_u32 %[n], 2\n"
+                        "s_cbranch_scc1 TX%=\n"
+                        "v_mbcnt_lo_u32_b32 v48, s80, 0\n"
+                        "v_mbcnt_hi_u32_b32 v48, s81, v48\n"
+                        "v_cmp_gt_u32 vcc, 8, v48\n"
+                        "s_and_b64 s[82:83], vcc, s[80:81]\n"
+                        "s_mov_b64 exec, s[82:83]\n"
+                        "v_lshl_add_u32 v49, v48, 3, %[sK]\n"
+                        "ds_write2_b32 v49, %[vA], %[vB] offset1:1\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        "s_bcnt1_i32_b64 %[n], s[82:83]\n"
+                        "s_andn2_b64 %[mm], %[mm], s[82:83]\n"
+                        "ds_read2_b32 v[56:57], %[vslot] offset1:1\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "v_lshrrev_b32 v58, 16, v56\n"
+                        "v_and_b32 v59, 0xffff, v56\n"
+                        "v_cmp_gt_u32 vcc, %[n], %[vT]\n"
+                        "v_cmp_gt_u32 s[84:85], 9, v58\n"
+                        "v_cmp_gt_u32 s[86:87], v58, %[vsub]\n"
+                        "v_cmp_gt_u32 s[88:89], v58, %[vsub8]\n"
+                        "s_and_b64 s[86:87], s[86:87], s[84:85]\n"
+                        "s_andn2_b64 s[88:89], s[88:89], s[84:85]\n"
+                        "s_and_b64 s[86:87], s[86:87], vcc\n"
+                        "s_and_b64 s[88:89], s[88:89], vcc\n"
+                        "s_mov_b64 exec, s[86:87]\n"
+                        "v_add_u32 v60, v57, %[vsub]\n"
+                        "v_add_u32 v61, v59, %[vsub]\n"
+                        "ds_read_u8 v62, v60\n"
+                        "s_mov_b64 exec, s[88:89]\n"
+                        "v_subrev_u32 v50, 8, v58\n"
+                        "v_min_u32 v51, v50, %[vsub8]\n"
+                        "v_add_u32 v52, v57, v51\n"
+                        "v_add_u32 v53, v59, v51\n"
+                        "ds_read_b64 v[54:55], v52\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b64 v53, v[54:55]\n"
+                        "s_mov_b64 exec, s[86:87]\n"
+                        "ds_write_b8 v61, v62\n"
+                        "s_mov_b64 exec, s[88:89]\n"
+                        "v_mov_b32 v60, %[vsub8]\n"
+                        "TW%=:\n"
+                        "v_add_u32 v60, 64, v60\n"
+                        "v_cmp_gt_u32 vcc, v58, v60\n"
+                        "s_and_b64 exec, exec, vcc\n"
+                        "s_cbranch_scc0 TE%=\n"
+                        "v_min_u32 v51, v50, v60\n"
+                        "v_add_u32 v52, v57, v51\n"
+                        "v_add_u32 v53, v59, v51\n"
+                        "ds_read_b64 v[54:55], v52\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "ds_write_b64 v53, v[54:55]\n"
+                        "s_branch TW%=\n"
+                        "TE%=:\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        "s_cmp_lg_u64 %[mm], 0\n"
+                        "s_cbranch_scc1 TL%=\n"
+                        "TX%=:\n"
+                        "s_mov_b64 exec, s[92:93]\n"
+                        : [mm] "+s"(mm), [f] "=&s"(f_), [F] "=&s"(F_), [n] "=&s"(n_)
+                        : [vA] "v"(vA), [vB] "v"(vB), [vdst] "v"(dst), [vsrcend] "v"(srcend), [tmask] "s"(team_mask), [vT] "v"(team_of), [vsub] "v"(team_sub),
+                          [vsub8] "v"(team_sub8), [vslot] "v"(team_slot), [sK] "s"(team_base)
+                        : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s92", "s93", "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52",
+                          "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
+                    if (!mm) break;
+                }
                 // the plain matches of the round, one after the other (hand-scheduled: 20 instructions for a match of up to 64 bytes;
-                // the compiler's loop took 29), until one of another kind comes up: j says which (-1: none left)
+                // the compiler's loop took 29), until one of another kind comes up: j says which (-1: none left).  (With teams: one.)
                 int j;
                 {
                     uint32_t sa, sb, len, t0, t1, t2;
-                    asm volatile(
-                        "s_mov_b64 s[92:93], exec\n"
-                        "LM%=:\n"
-                        "s_ff1_i32_b64 %[j], %[mm]\n"
-                        "v_readlane_b32 %[sb], %[vB], %[j]\n"
-                        "v_readlane_b32 %[sa], %[vA], %[j]\n"
-                        "s_cmp_lt_u32 %[sb], 0x10000\n"
-                        "s_cbranch_scc0 LMf%=\n"
-                        "s_bitset0_b64 %[mm], %[j]\n"
-                        "s_lshr_b32 %[len], %[sa], 16\n"
-                        "s_and_b32 %[sa], %[sa], 0xffff\n"
-                        "v_add_u32 %[t0], %[sb], %[vlane]\n"
-                        "v_add_u32 %[t1], %[sa], %[vlane]\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "ds_read_u8 %[t2], %[t0]\n"
-                        "s_waitcnt lgkmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2]\n"
-                        "s_cmp_gt_u32 %[len], 64\n"
-                        "s_cbranch_scc1 LM2%=\n"
-                        "LM1%=:\n"
-                        "s_mov_b64 exec, s[92:93]\n"
-                        "s_cmp_lg_u64 %[mm], 0\n"
-                        "s_cbranch_scc1 LM%=\n"
-                        "s_mov_b32 %[j], -1\n"
-                        "s_branch LMx%=\n"
-                        "LM2%=:\n"                                  // rounds of 64 bytes, one after the other (right for dist >= 64 too)
-                        "s_sub_u32 %[len], %[len], 64\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "ds_read_u8 %[t2], %[t0] offset:64\n"
-                        "s_waitcnt lgkmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2] offset:64\n"
-                        "s_cmp_gt_u32 %[len], 64\n"
-                        "s_cbranch_scc0 LM1%=\n"
-                        "s_sub_u32 %[len], %[len], 64\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "ds_read_u8 %[t2], %[t0] offset:128\n"
-                        "s_waitcnt lgkmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2] offset:128\n"
-                        "s_cmp_gt_u32 %[len], 64\n"
-                        "s_cbranch_scc0 LM1%=\n"
-                        "s_sub_u32 %[len], %[len], 64\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "ds_read_u8 %[t2], %[t0] offset:192\n"
-                        "s_waitcnt lgkmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2] offset:192\n"
-                        "s_cmp_gt_u32 %[len], 64\n"
-                        "s_cbranch_scc0 LM1%=\n"
-                        "s_sub_u32 %[len], %[len], 64\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "ds_read_u8 %[t2], %[t0] offset:256\n"
-                        "s_waitcnt lgkmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2] offset:256\n"
-                        "s_branch LM1%=\n"
-                        "LMf%=:\n"                                  // a far match: 64 bytes a round straight from the flushed output
-                        "s_cmp_lt_u32 %[sb], 0x20000\n"
-                        "s_cbranch_scc0 LMx%=\n"
-                        "s_bitset0_b64 %[mm], %[j]\n"
-                        "v_readlane_b32 %[sb], %[vC], %[j]\n"
-                        "s_lshr_b32 %[len], %[sa], 16\n"
-                        "s_and_b32 %[sa], %[sa], 0xffff\n"
-                        "v_add_u32 %[t1], %[sa], %[vlane]\n"
-                        "v_add_u32 %[t0], %[sb], %[vlane]\n"
-                        "LMg%=:\n"
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n"
-                        "s_mov_b64 exec, vcc\n"
-                        "global_load_ubyte %[t2], %[t0], %[outp]\n"
-                        "s_waitcnt vmcnt(0)\n"
-                        "ds_write_b8 %[t1], %[t2]\n"
-                        "s_mov_b64 exec, s[92:93]\n"
-                        "s_cmp_gt_u32 %[len], 64\n"
-                        "s_cbranch_scc0 LM1%=\n"
-                        "s_sub_u32 %[len], %[len], 64\n"
-                        "v_add_u32 %[t0], 64, %[t0]\n"
-                        "v_add_u32 %[t1], 64, %[t1]\n"
-                        "s_branch LMg%=\n"
-                        "LMx%=:\n"
-                        "s_mov_b64 exec, s[92:93]\n"
-                        : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [outp] "s"(out)
-                        : "s92", "s93", "vcc", "scc", "memory");
+                    // (with teams: this match only — the loop is handed a set of one)
+                    const unsigned long long rest = use_teams ? mm & (mm - 1ull) : 0ull;
+                    mm ^= rest;
+                    TCMI_LM_ASM("s_cmp_lg_u64 %[mm], 0\n" "s_cbranch_scc1 LM%=\n")
+                    mm |= rest;
                 }
-                if (j < 0) break;
+                if (j < 0) { if (use_teams) continue; break; }
                 mm &= ~(1ull << j);
                 copy_any((uint32_t)__builtin_amdgcn_readlane((int)dst, j), (uint32_t)__builtin_amdgcn_readlane((int)mylen, j),
                          (uint32_t)__builtin_amdgcn_readlane((int)dist, j));
@@ -1248,7 +1360,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     }
     if (a.stamps && lane == 0) {
         uint64_t *st = a.stamps + (size_t)blk * 16;
-        st[1] = __builtin_amdgcn_s_memtime(); st[4] = n_slow; st[5] = n_match; st[6] = n_round; st[7] = ntok;
+        st[1] = __builtin_amdgcn_s_memtime(); st[4] = n_slow; st[5] = n_match; st[6] = n_round; st[7] = ntok; st[8] = n_team; st[9] = n_teamed;
     }
 }
 
@@ -1289,8 +1401,11 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = g.d_tok; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
     ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)nb; ca.n_ref = g.n_ref;
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
+    static const int team_env = std::getenv("TCMI_TEAM_BYTES") ? std::atoi(std::getenv("TCMI_TEAM_BYTES")) : -1;      // (A/B measurements)
+    ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
-    hipLaunchKernelGGL(bgzf_copy, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL(bgzf_copy<true>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    else hipLaunchKernelGGL(bgzf_copy<false>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
     tcmi_prof_end(ctx, TCMI_K_INFLATE_COPY);
     TCMI_HIP(ctx, hipGetLastError());
     if (d_stamps) {

@@ -28,7 +28,6 @@ namespace {
 
 constexpr int PB = 256;                          // lanes per workgroup of every kernel here
 constexpr int PK_CMAX = 1024;                    // most reads one pk_pack workgroup takes
-constexpr int PK_OUTW = 4096;                    // words of packed planes staged in LDS before they go out as one contiguous run
 constexpr uint32_t NIB = 0x11111111u;
 
 using PackSrc = tcmi_pack_src;
@@ -44,13 +43,9 @@ struct ReadView {
 
 __device__ inline uint32_t ld_u32(const uint8_t *p)
 {
-    // aligned dword loads + funnel shift (the record fields of a BAM stream sit at any byte offset)
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3) * 8u;
-    // (both words always: a conditional second load would wait for the first one — two memory round trips instead of one;
-    //  the word behind an aligned field is still inside the stream's allocation)
-    return __builtin_amdgcn_alignbit(q[1], q[0], sh);
+    uint32_t w;                                 // (the record fields of a BAM stream sit at any byte offset: one unaligned dword load)
+    __builtin_memcpy(&w, p, 4);
+    return w;
 }
 
 __device__ inline ReadView view(const PackSrc &s, int64_t i)
@@ -70,17 +65,22 @@ __device__ inline ReadView view(const PackSrc &s, int64_t i)
         v.seq = s.seq + q0;
     } else {
         const uint8_t *r = s.stream + s.rec_off[i] + 4;        // behind block_size
-        v.tid = (int32_t)ld_u32(r);
-        v.pos = (int32_t)ld_u32(r + 4);
-        const uint32_t w2 = ld_u32(r + 8), w3 = ld_u32(r + 12);
+        // the fixed fields in two loads at the record's own (any) byte address — unaligned access mode; twelve aligned dword loads
+        // and funnel shifts kept the kernel waiting on the address unit: every lane's record lies in a cache line of its own
+        uint32_t h[6];                                         // block_size, refID, pos, l_read_name|mapq|bin, n_cigar_op|flag, l_seq
+        __builtin_memcpy(h, r - 4, 16);
+        __builtin_memcpy(h + 4, r + 12, 8);
+        v.tid = (int32_t)h[1];
+        v.pos = (int32_t)h[2];
+        const uint32_t w2 = h[3], w3 = h[4];
         const uint32_t l_name = w2 & 0xFFu;
         v.n_cigar = w3 & 0xFFFFu;
         v.flag = w3 >> 16;
-        v.l_seq = (int32_t)ld_u32(r + 16);
+        v.l_seq = (int32_t)h[5];
         // The record walk only checked block_size itself: the variable-length fields must fit into it (what bam_reader.cpp's
         // "alignment record fields overrun block_size" refuses) — a forged l_seq or n_cigar_op would otherwise send the kernels
         // that follow the CIGAR and the bases far behind the record, or behind the stream.
-        const uint32_t block_size = ld_u32(r - 4);
+        const uint32_t block_size = h[0];
         const uint64_t need = 32ull + l_name + 4ull * v.n_cigar + ((uint64_t)(uint32_t)v.l_seq + 1) / 2 + (uint64_t)(uint32_t)v.l_seq;
         v.bad = v.l_seq < 0 || l_name == 0 || need > block_size;
         v.broken = v.bad;
@@ -165,7 +165,7 @@ __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */
 }
 
 // ---- 1: classify ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *rd_seq, uint2 *blk_sum, unsigned long long *blk_alg,
+__global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *rd_seq, int32_t *rd_pos, uint2 *blk_sum, unsigned long long *blk_alg,
                                                   int32_t *blk_end, PackTotals *tot, uint32_t *gen_idx)
 {
     __shared__ uint2 s_w[PB / 64];
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
         // pk_pack goes straight there instead of chasing record offset -> header -> CIGAR -> SEQ through four dependent loads
         const unsigned long long so = (unsigned long long)(v.seq - (s.mode == 0 ? s.seq : s.stream));
         rd_seq[i] = make_uint2((uint32_t)so, ((uint32_t)(so >> 32) & 0xFFu) | ((uint32_t)min(v.l_seq, 0xFFFFFF) << 8));
+        rd_pos[i] = v.pos;                      // (pk_scatter's copy: it need not go back to the record)
     }
     const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
     if (threadIdx.x == PB - 1) blk_sum[blockIdx.x] = incl;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned l
 }
 
 // ---- 3: scatter: compacted index + word offset of every kept read -----------------------------------------------------
-__global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info, const uint2 *rd_seq, const uint2 *blk_base, uint32_t *c_idx,
+__global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info, const uint2 *rd_seq, const int32_t *rd_pos, const uint2 *blk_base, uint32_t *c_idx,
                                                  int32_t *c_pos, uint32_t *c_info, uint32_t *c_woff, uint2 *c_seq)
 {
     __shared__ uint2 s_w[PB / 64];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(PB) void pk_scatter(PackSrc s, const uint32_t *info
         const uint2 base = blk_base[blockIdx.x];
         const uint32_t j = base.x + incl.x - 1u;
         c_idx[j] = (uint32_t)i;
-        c_pos[j] = (s.mode == 0 ? s.pos[i] : (int32_t)ld_u32(s.stream + s.rec_off[i] + 8)) + s.pos_shift;
+        c_pos[j] = rd_pos[i] + s.pos_shift;
         c_info[j] = w;
         c_woff[j] = base.y + incl.y - mine.y;
         c_seq[j] = rd_seq[i];
@@ -397,62 +398,36 @@ __device__ inline bool ins_after(const uint8_t *cg, uint32_t n, uint32_t k)
     return tot > 0;
 }
 
-// one read -> its plane pairs (out: 2 * ceil(len / 32) words, then the zero pair) and its event words
-__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, uint2 where, int32_t gpos,
-                                 uint32_t *out)
+// 32 consecutive bases of a read that lies on the reference as it is ([H][S]M[S][H]): one unaligned 16-byte load (+ the byte behind
+// it for a read whose first aligned base sits in a low nibble) -> the pair {C|T, G|T} and the "is A/C/G/T" plane.
+// p: the byte that holds base y (= y0 + 32 q), odd: y is odd, have: bases of the pair the read really has (< 32: masked)
+__device__ inline void pair_planes(const uint8_t *p, bool odd, int have, uint32_t &lo, uint32_t &hi, uint32_t &ok)
+{
+    uint32_t d[5];
+    __builtin_memcpy(d, p, 16);                                 // (any byte address: unaligned access mode, one global_load_dwordx4)
+    d[4] = p[16];                                               // (what lies behind a read's SEQ — its QUAL, the arrays' slack — is masked below)
+    uint32_t w[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) w[k] = ((d[k] & 0x0F0F0F0Fu) << 4) | ((d[k] >> 4) & 0x0F0F0F0Fu);   // BAM keeps the first base of a byte in the high nibble
+    lo = hi = ok = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t n = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 4) : w[k];
+        uint32_t l, h, v;
+        classify8(n, l, h, v);
+        lo |= squeeze8(l) << (8 * k);
+        hi |= squeeze8(h) << (8 * k);
+        ok |= squeeze8(v) << (8 * k);
+    }
+    const uint32_t mask = have >= 32 ? 0xFFFFFFFFu : have > 0 ? ((1u << have) - 1u) : 0u;
+    lo &= mask; hi &= mask; ok &= mask;
+}
+
+// one PROJECTED read (anything but [H][S]M[S][H]) -> its plane pairs (out: 2 * ceil(len / 32) words, then the zero pair) and its event words
+__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, int32_t gpos, uint32_t *out)
 {
     const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
-    if (!(info & INFO_PROJ)) {
-        const uint8_t *seq = (src.mode == 0 ? src.seq : src.stream) + (((unsigned long long)(where.y & 0xFFu) << 32) | where.x);
-        const int l_seq = (int)(where.y >> 8);
-        const int y0 = (int)(info >> 12);
-        // 160 bases (five pairs, 80 bytes) per round: ALL of the round's words are requested before the first is used — one
-        // memory round trip per round instead of one per pair (a 150-base read: one instead of five)
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(seq + (y0 >> 1));
-        const uint32_t *qw = reinterpret_cast<const uint32_t *>(a0 & ~(uintptr_t)3);       // (generic-pointer loads: telling the compiler
-                                                                                         //  "global" made this kernel slower, 194 vs 123 us)
-        const uint32_t sh = (uint32_t)(a0 & 3) * 8u;
-        const bool odd = y0 & 1;
-        const int avail = min(len, l_seq - y0);                 // bases the read really has (the rest count as "not A/C/G/T")
-        for (int g = 0; g < npair; g += 5) {
-            uint32_t d[22];
-#pragma unroll
-            for (int k = 0; k < 22; ++k) d[k] = qw[4 * g + k];      // (unguarded: a guard per word costs more than the words; what lies behind
-                                                                    //  the read's SEQ — its QUAL, the next record, the arrays' 128 bytes of slack — is masked below)
-            uint32_t w[21];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) {
-                const uint32_t b = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
-                w[k] = ((b & 0x0F0F0F0Fu) << 4) | ((b >> 4) & 0x0F0F0F0Fu);   // BAM keeps the first base of a byte in the high nibble
-            }
-#pragma unroll
-            for (int p5 = 0; p5 < 5; ++p5) {
-                const int q = g + p5;
-                if (q < npair) {
-                    const int nb = min(32, len - 32 * q), have = min(nb, avail - 32 * q);
-                    uint32_t lo = 0, hi = 0, ok = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t n = odd ? __builtin_amdgcn_alignbit(w[4 * p5 + k + 1], w[4 * p5 + k], 4) : w[4 * p5 + k];
-                        uint32_t l, h, v;
-                        classify8(n, l, h, v);
-                        lo |= squeeze8(l) << (8 * k);
-                        hi |= squeeze8(h) << (8 * k);
-                        ok |= squeeze8(v) << (8 * k);
-                    }
-                    const uint32_t mask = have >= 32 ? 0xFFFFFFFFu : have > 0 ? ((1u << have) - 1u) : 0u;
-                    lo &= mask; hi &= mask; ok &= mask;
-                    *reinterpret_cast<uint2 *>(out + 2 * q) = make_uint2(lo, hi);
-                    uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
-                    while (miss) {
-                        const int b = __builtin_ctz(miss);
-                        push_event(o, tot, (uint32_t)(gpos + 32 * q + b) | TCMI_F_EV_OTHER);
-                        miss &= miss - 1;
-                    }
-                }
-            }
-        }
-    } else {
+    {
         const ReadView v = view(src, i);
         // Walk the CIGAR: matched bases land on their reference offset (bit-field copies into the pair being built), D / N
         // leave empty positions, and the tokens that are not plain bases become events: X for a deleted base
@@ -503,9 +478,8 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
     *reinterpret_cast<uint2 *>(out + 2 * npair) = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint32_t *c_idx, const int32_t *c_pos, const uint32_t *c_info,
-                                              const uint32_t *c_woff, const uint2 *c_seq, uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages,
-                                              int stage_cap, PackTotals *tot)
+__global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, const uint32_t *c_info, const uint32_t *c_woff, uint32_t *r_word,
+                                              uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages, int stage_cap, PackTotals *tot)
 {
     __shared__ int32_t s_pos[PK_CMAX];
     __shared__ uint32_t s_woff[PK_CMAX + 1];
@@ -514,7 +488,6 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
     __shared__ int s_red[3][PB / 64];
     __shared__ int s_scan[PB / 64];
     __shared__ uint32_t s_slot[2];
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[PK_OUTW + 40];   // (+ the longest read: 2 * 16 pairs + the zero pair)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
     const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
@@ -608,34 +581,80 @@ __global__ __launch_bounds__(PB) void pk_pack(PackSrc src, PackOut o, const uint
                 o.seq[w0] = 0u; o.seq[w0 + 1] = 0u;              // the zero pair in front of the first read
                 for (uint32_t g = 2u + words_c; g < ((2u + words_c + 3u) & ~3u); ++g) o.seq[w0 + g] = 0u;
             }
-            // ---- per read: header word, planes, events.  The planes of up to 256 consecutive reads are built in LDS (one lane
-            //      per read) and leave as ONE contiguous run of 8-byte-per-lane stores: a read's 52 bytes written by its own
-            //      lane (8-byte stores at a 48-byte stride) reached HBM as partial lines, 3.4 x the bytes. -------------------
-            for (int t0 = 0; t0 < nc;) {
-                int nb = min(PB, nc - t0);
-                while (s_woff[cur + t0 + nb] - s_woff[cur + t0] > (uint32_t)PK_OUTW) --nb;   // (a read is at most 34 words: nb >= 120)
-                const uint32_t wb0 = s_woff[cur + t0], wbn = s_woff[cur + t0 + nb] - wb0;
-                if (tid < nb) {
-                    const int t = t0 + tid, j = cur + t, st = t / sub;
-                    const uint32_t base = 2u + s_woff[j] - s_woff[cur];                          // words from word0
-                    const uint32_t sb = st == 0 ? 0u : s_woff[cur + st * sub] - s_woff[cur];     // the stage starts on the zero pair in front of its first read
-                    const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
+        }
+        // ---- per read: the header word, and where its planes go (pk_planes writes them, one lane per 32 bases) ----------------
+        {
+            const uint32_t g0 = r0 + (uint32_t)cur;
+            for (int t = tid; t < nc; t += PB) {
+                const int j = cur + t, st = t / sub;
+                const uint32_t base = 2u + s_woff[j] - s_woff[cur];                          // words from word0
+                const uint32_t sb = st == 0 ? 0u : s_woff[cur + st * sub] - s_woff[cur];     // the stage starts on the zero pair in front of its first read
+                const uint32_t rel = (uint32_t)(s_pos[j] - P0), len = s_len[j], poff = (base - sb) >> 1;
+                if (fits) {
                     if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
                     o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
-                    pack_read(src, o, tot, c_idx[g0 + t], c_info[g0 + t], c_seq[g0 + t], s_pos[j], s_out + (s_woff[j] - wb0));
                 }
-                __syncthreads();
-                {
-                    const uint2 *from = reinterpret_cast<const uint2 *>(s_out);
-                    uint2 *to = reinterpret_cast<uint2 *>(o.seq + w0 + 2u + (wb0 - s_woff[cur]));   // (even word offsets: 8-byte aligned)
-                    for (uint32_t k = tid; k < wbn / 2; k += PB) to[k] = from[k];
-                }
-                __syncthreads();
-                t0 += nb;
+                r_word[g0 + t] = fits ? w0 + base : 0xFFFFFFFFu;
             }
         }
         cur += nc;
         __syncthreads();
+    }
+}
+
+// ---- 5: planes: one lane per 32 bases --------------------------------------------------------------------------------------
+// A workgroup takes PB consecutive kept reads.  Every read's lane notes, for each of the read's pairs (and the zero pair behind
+// them), "read t, pair q" in an LDS list indexed by the pair's place in the workgroup's stretch of the word stream; then the
+// lanes take the places of that list in order: a lane loads ITS 16 bytes of SEQ, makes its pair and stores it — consecutive
+// lanes read consecutive 16-byte pieces of a read and store consecutive 8-byte pairs (a read per lane, five pairs one after
+// the other, kept 22 uncoalesced dword loads per lane in flight and the kernel at 16 waves a CU waiting for them).
+// Reads that need their CIGAR walked (INFO_PROJ) are packed by their own lane, as before, straight to where they go.
+constexpr int PL_SLOTS = PB * (TCMI_D_MAXLEN / 32 + 1);
+__global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const uint32_t *c_idx, const int32_t *c_pos, const uint32_t *c_info,
+                                                const uint32_t *c_woff, const uint2 *c_seq, const uint32_t *r_word, uint32_t n_kept, uint32_t n_words,
+                                                PackTotals *tot)
+{
+    __shared__ uint32_t s_info[PB], s_word[PB];
+    __shared__ int32_t s_pos[PB];
+    __shared__ uint2 s_seq[PB];
+    __shared__ uint16_t s_owner[PL_SLOTS];
+    const int tid = threadIdx.x;
+    const uint32_t r0 = (uint32_t)blockIdx.x * PB;
+    const int n = (int)min((uint32_t)PB, n_kept - r0);
+    const uint32_t w_first = c_woff[r0], w_end = r0 + (uint32_t)n < n_kept ? c_woff[r0 + n] : n_words;
+    if (tid < n) {
+        const uint32_t g = r0 + (uint32_t)tid, info = c_info[g], word = r_word[g];
+        const int32_t pos = c_pos[g];
+        const int npair = (int)((info & 1023u) + 31u) >> 5;
+        const uint32_t slot0 = (c_woff[g] - w_first) >> 1;
+        const bool own = (info & INFO_PROJ) || word == 0xFFFFFFFFu;     // (no room for the chunk: pk_pack has raised the flag)
+        s_info[tid] = info; s_word[tid] = word; s_pos[tid] = pos; s_seq[tid] = c_seq[g];
+        for (int q = 0; q <= npair; ++q) s_owner[slot0 + q] = own ? (uint16_t)0xFFFFu : (uint16_t)(tid | (q << 8));
+        if ((info & INFO_PROJ) && word != 0xFFFFFFFFu) pack_read(src, o, tot, c_idx[g], info, pos, o.seq + word);
+    }
+    __syncthreads();
+    const uint8_t *bytes = src.mode == 0 ? src.seq : src.stream;
+    const uint32_t n_slots = (w_end - w_first) >> 1;
+    for (uint32_t k = tid; k < n_slots; k += PB) {
+        const uint32_t ow = s_owner[k];
+        if (ow == 0xFFFFu) continue;
+        const int t = (int)(ow & 255u), q = (int)(ow >> 8);
+        const uint32_t info = s_info[t];
+        const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
+        uint2 *dst = reinterpret_cast<uint2 *>(o.seq + s_word[t]) + q;                  // (even word offsets: 8-byte aligned)
+        if (q == npair) { *dst = make_uint2(0u, 0u); continue; }
+        const uint2 where = s_seq[t];
+        const int l_seq = (int)(where.y >> 8), y = (int)(info >> 12) + 32 * q;
+        const int nb = min(32, len - 32 * q), have = min(nb, l_seq - y);
+        uint32_t lo, hi, ok;
+        pair_planes(bytes + ((((unsigned long long)(where.y & 0xFFu) << 32) | where.x) + (uint32_t)(y >> 1)), y & 1, have, lo, hi, ok);
+        *dst = make_uint2(lo, hi);
+        uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
+        while (miss) {
+            const int b = __builtin_ctz(miss);
+            push_event(o, tot, (uint32_t)(s_pos[t] + 32 * q + b) | TCMI_F_EV_OTHER);
+            miss &= miss - 1;
+        }
     }
 }
 
@@ -882,6 +901,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     const int64_t n_blk = (n + PB - 1) / PB;
     uint32_t *info = (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4);
     uint2 *rd_seq = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 8);
+    int32_t *rd_pos = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4);
     uint2 *blk_sum = (uint2 *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
     unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 8);
     int32_t *blk_end = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 4);
@@ -893,7 +913,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     if (n > 0) {
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
-        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, blk_alg, blk_end, d_tot, gen_idx);
+        hipLaunchKernelGGL(pk_classify, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, rd_pos, blk_sum, blk_alg, blk_end, d_tot, gen_idx);
         hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_sum, blk_alg, blk_end, n_blk, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
         TCMI_HIP(ctx, hipGetLastError());
@@ -930,6 +950,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     uint32_t *c_info = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     uint32_t *c_woff = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     uint2 *c_seq = (uint2 *)arena_take(ctx, (size_t)nf * 8);
+    uint32_t *r_word = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     if (ctx->dev_arena->used > ctx->dev_arena->cap) { return tcmi_fail(ctx, TCMI_E_NOMEM, "internal: pack scratch under-reserved"); }
 
     uint32_t event_cap = (uint32_t)std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(1 << 20, nf / 2));
@@ -965,9 +986,11 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK);
         if (attempt == 0)
-            hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, blk_sum, c_idx, c_pos, c_info, c_woff, c_seq);
-        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq, (uint32_t)nf,
+            hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, rd_pos, blk_sum, c_idx, c_pos, c_info, c_woff, c_seq);
+        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, c_pos, c_info, c_woff, r_word, (uint32_t)nf,
                            (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot);
+        hipLaunchKernelGGL(pk_planes, dim3((unsigned)((nf + PB - 1) / PB)), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq, r_word,
+                           (uint32_t)nf, (uint32_t)tot.n_words, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK);
         TCMI_HIP(ctx, hipGetLastError());
         TCMI_HIP(ctx, hipMemcpyAsync(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
@@ -1084,7 +1107,7 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
                           al(n_cig * 4 + 64), al((size_t)(n + 1) * 8), al(n_seq + 128)};
     size_t src_bytes = 0;
     for (size_t b : sz) src_bytes += b + 256;
-    const size_t tmp_bytes = al((size_t)n * 4) * 9 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 16 * 256;
+    const size_t tmp_bytes = al((size_t)n * 4) * 11 + al((size_t)((n + PB - 1) / PB + 1) * 8) * 3 + 4096 + 16 * 256;
     int rc = arena_reserve(ctx, src_bytes + tmp_bytes);
     if (rc) return rc;
     PackSrc s = {};

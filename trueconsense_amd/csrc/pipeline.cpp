@@ -507,9 +507,17 @@ struct OutFiles { const char *const *fasta, *const *vcf, *const *gff, *const *do
 
 int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, const char *const *names, int64_t ref_len,
                     int32_t mincov, int include_ambig, int device_decode, char *out_text, int64_t stride, int64_t *out_len,
-                    int32_t *status, double *stage_seconds, int64_t *decoded_on, const OutFiles *files)
+                    int32_t *status, double *stage_seconds, int64_t *decoded_on, const OutFiles *files, tcmi_bamfile *const *resident = nullptr)
 {
-    if (!r || n < 0 || (n > 0 && (!paths || !status || (!files && (!out_text || !out_len))))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    if (!r || n < 0 || (n > 0 && ((!paths && !resident) || !status || (!files && (!out_text || !out_len))))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    std::vector<const char *> own_paths;
+    if (resident) {                                             // files already read (and, with tcmi_bamfile_to_device, already in HBM)
+        for (int64_t i = 0; i < n; ++i) {
+            if (!resident[i]) return tcmi_fail(nullptr, TCMI_E_ARG, "null file");
+            own_paths.push_back(tcmi_bamfile_path(resident[i]));
+        }
+        paths = own_paths.data();
+    }
     std::vector<int64_t> len_store;
     if (!out_len) { len_store.assign((size_t)n, 0); out_len = len_store.data(); }
     std::vector<FileItem> items((size_t)n);
@@ -531,7 +539,8 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
             }
             const auto t0 = std::chrono::steady_clock::now();
             FileItem &it = items[(size_t)i];
-            if (device_decode) {
+            if (resident) it.file = resident[i];
+            else if (device_decode) {
                 it.rc = tcmi_bamfile_read_threads(paths[i], r->n_readers > 1 ? 1 : 0, &it.file);
                 if (it.rc) it.err = tcmi_last_error(nullptr);
             }
@@ -624,7 +633,8 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
                 if (rs) tcmi_readset_free(ctx, rs);
                 if (hb) tcmi_bam_free(hb);
             }
-            if (it.file) { tcmi_bamfile_free(it.file); it.file = nullptr; }
+            if (it.file && !resident) tcmi_bamfile_free(it.file);
+            it.file = nullptr;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 it.state = 2;
@@ -719,6 +729,17 @@ int tcmi_filerunner_run(tcmi_filerunner *r, int64_t n, const char *const *paths,
 {
     return filerunner_core(r, n, paths, names, ref_len, mincov, include_ambig, device_decode, out_text, stride, out_len, status, stage_seconds,
                            decoded_on, nullptr);
+}
+
+// ... of files that were read before (tcmi_bamfile_read) and stay the caller's: the read stage has nothing to do.  With their bytes
+// in HBM (tcmi_bamfile_to_device) the GPU stage starts from device memory — no PCIe copy inside the run.
+int tcmi_filerunner_run_resident(tcmi_filerunner *r, int64_t n, tcmi_bamfile *const *files, const char *const *names, int64_t ref_len,
+                                 int32_t mincov, int include_ambig, char *out_text, int64_t stride, int64_t *out_len, int32_t *status,
+                                 double *stage_seconds, int64_t *decoded_on)
+{
+    if (!files && n > 0) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    return filerunner_core(r, n, nullptr, names, ref_len, mincov, include_ambig, 1, out_text, stride, out_len, status, stage_seconds, decoded_on,
+                           nullptr, files);
 }
 
 // What the VCF and GFF writers need besides a sample's walk: the reference (first FASTA record: id and sequence, Outputs.py:108-113),

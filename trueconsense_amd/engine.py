@@ -484,6 +484,11 @@ class DeviceBam:
         self.lengths = (ln.value,) if n_ref.value else ()
         self.text = (lib().tcmi_bamfile_text(h) or b"").decode("utf-8", "replace")
 
+    def to_device(self, ctx):
+        """The compressed bytes into HBM, to stay (tcmi_bamfile_to_device): uploads of this file then start from device memory."""
+        check(lib().tcmi_bamfile_to_device(ctx.handle, self.handle), ctx.handle)
+        return self
+
     def decode_to_host(self, ctx):
         """(for tests / tools) -> (inflated stream uint8, record offsets uint64), both produced by the device."""
         stream = np.empty(max(1, self.inflated_bytes), np.uint8)
@@ -561,6 +566,31 @@ class FileRunner:
         on = (C.c_int64 * 2)()
         rc = lib().tcmi_filerunner_run(self.handle, n, c_paths, c_names, int(ref_len), self.mincov, int(self.amb), int(bool(self.device_decode)),
                                        ptr(out), stride, ptr(lens), ptr(status), sec, on)
+        self.last_status = status
+        for k, v in zip(("decode", "upload", "step", "walk"), sec):
+            self.seconds[k] += v
+        self.decoded_on["device"] += on[0]
+        self.decoded_on["host"] += on[1]
+        check(rc)
+        return [out[i * stride:i * stride + int(lens[i])].tobytes().decode("ascii") for i in range(n)]
+
+    def run_resident(self, dbams, names=None, ref_len=0, max_inserted=4096):
+        """... of DeviceBam objects read before (and, after DeviceBam.to_device, resident in HBM): no read stage, no PCIe copy of
+        the file inside the run.  -> list of FASTA texts, in input order."""
+        n = len(dbams)
+        names = names or ["S%d" % i for i in range(n)]
+        if n == 0:
+            return []
+        c_files = (C.c_void_p * n)(*[d.handle for d in dbams])
+        c_names = (C.c_char_p * n)(*[str(x).encode() for x in names])
+        stride = int(ref_len) + int(max_inserted) + max(len(x) for x in names) + 64
+        out = np.empty(n * stride, np.uint8)
+        lens = np.zeros(n, np.int64)
+        status = np.zeros(n, np.int32)
+        sec = (C.c_double * 4)()
+        on = (C.c_int64 * 2)()
+        rc = lib().tcmi_filerunner_run_resident(self.handle, n, c_files, c_names, int(ref_len), self.mincov, int(self.amb), ptr(out), stride,
+                                                ptr(lens), ptr(status), sec, on)
         self.last_status = status
         for k, v in zip(("decode", "upload", "step", "walk"), sec):
             self.seconds[k] += v

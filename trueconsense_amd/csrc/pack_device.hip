@@ -144,7 +144,11 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t n_gen;                 // reads left to the stream-walking tally kernel (longer than TCMI_D_MAXLEN positions)
 };
 
-__device__ inline uint32_t words_of(uint32_t len) { return 2u * ((len + 31u) >> 5) + 2u; }
+// words a read takes in the plane stream: its pairs, the zero pair behind them, and — for an even number of pairs — one more zero pair,
+// so that every read ends on a 16-byte boundary: the reads then lie in ONE contiguous run (a read's place is 2 + the scanned sum of
+// the words in front of it, known before any chunk is cut), and the zero pair that closes a read is the one a chunk that starts with
+// the next read needs in front of it — 16-byte aligned, as the tally kernel's loads want a chunk's first word.
+__device__ inline uint32_t words_of(uint32_t len) { return (2u * ((len + 31u) >> 5) + 2u + 3u) & ~3u; }
 
 // inclusive scan of a pair over the workgroup (PB lanes)
 __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */)
@@ -478,7 +482,7 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
     *reinterpret_cast<uint2 *>(out + 2 * npair) = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, const uint32_t *c_info, const uint32_t *c_woff, uint32_t *r_word,
+__global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, const uint32_t *c_info, const uint32_t *c_woff,
                                               uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages, int stage_cap, PackTotals *tot)
 {
     __shared__ int32_t s_pos[PK_CMAX];
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
     __shared__ uint16_t s_run[PK_CMAX + 1];     // chunk-relative index of every run's first read
     __shared__ int s_red[3][PB / 64];
     __shared__ int s_scan[PB / 64];
-    __shared__ uint32_t s_slot[2];
+    __shared__ uint32_t s_slot[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
     const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
@@ -536,11 +540,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
         if (sub > cap) sub = max(S, cap / S * S);
         const int whole = max(sub, min(((1 << TCMI_P_NPL) - 1) * S, n_stages * sub) / sub * sub);
         const int nc = min(e1 - cur, whole);
-        const uint32_t words_c = s_woff[cur + nc] - s_woff[cur];
-        if (tid == 0) {
-            s_slot[0] = atomicAdd(&tot->n_chunks, 1u);
-            s_slot[1] = atomicAdd(&tot->word_cursor, (2u + words_c + 3u) & ~3u);
-        }
+        if (tid == 0) s_slot[0] = atomicAdd(&tot->n_chunks, 1u);
         // ---- coverage runs: reads of equal (position, length) follow each other in a sorted BAM ---------------------
         int n_runs = 0;
         for (int t0 = 0; t0 < nc; t0 += PB) {
@@ -559,9 +559,10 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
         static_assert(PB / 64 == 4, "run count sums four wave totals");
         if (tid == 0) s_run[n_runs] = (uint16_t)nc;
         __syncthreads();
-        const uint32_t ci = s_slot[0], w0 = s_slot[1];
-        const bool fits = ci < o.chunk_cap && (unsigned long long)w0 + ((2u + words_c + 3u) & ~3u) <= o.word_cap;
-        if (!fits && tid == 0) atomicOr(&tot->flags, (uint32_t)(ci >= o.chunk_cap ? PKF_CHUNK_OVF : PKF_WORD_OVF));
+        // the chunk's words: from the zero pair that closes the read in front of its first one (the stream's own first pair for read 0)
+        const uint32_t ci = s_slot[0], w0 = s_woff[cur];
+        const bool fits = ci < o.chunk_cap;
+        if (!fits && tid == 0) atomicOr(&tot->flags, (uint32_t)PKF_CHUNK_OVF);
         if (fits) {
             const uint32_t g0 = r0 + (uint32_t)cur;             // compacted index of the chunk's first read
             for (int k = tid; k < n_runs; k += PB) {
@@ -578,8 +579,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
                 c.run0 = g0; c.n_runs = n_runs; c.reserved_ = 0;
                 o.chunks[ci] = c;
                 atomicAdd(&tot->n_runs, (uint32_t)n_runs);
-                o.seq[w0] = 0u; o.seq[w0 + 1] = 0u;              // the zero pair in front of the first read
-                for (uint32_t g = 2u + words_c; g < ((2u + words_c + 3u) & ~3u); ++g) o.seq[w0 + g] = 0u;
+                if (w0 == 0u) { o.seq[0] = 0u; o.seq[1] = 0u; }  // the zero pair in front of the very first read (the others: pk_planes)
             }
         }
         // ---- per read: the header word, and where its planes go (pk_planes writes them, one lane per 32 bases) ----------------
@@ -594,7 +594,6 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
                     if (rel > 1023u || len > 1023u || poff > 4095u) atomicOr(&tot->flags, (uint32_t)PKF_HEADER_OVF);
                     o.lenoff[g0 + t] = rel | (len << 10) | (poff << 20);
                 }
-                r_word[g0 + t] = fits ? w0 + base : 0xFFFFFFFFu;
             }
         }
         cur += nc;
@@ -609,9 +608,9 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
 // lanes read consecutive 16-byte pieces of a read and store consecutive 8-byte pairs (a read per lane, five pairs one after
 // the other, kept 22 uncoalesced dword loads per lane in flight and the kernel at 16 waves a CU waiting for them).
 // Reads that need their CIGAR walked (INFO_PROJ) are packed by their own lane, as before, straight to where they go.
-constexpr int PL_SLOTS = PB * (TCMI_D_MAXLEN / 32 + 1);
+constexpr int PL_SLOTS = PB * (TCMI_D_MAXLEN / 32 + 2);      // a read's pairs, its zero pair, and the second one that ends it on 16 bytes
 __global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const uint32_t *c_idx, const int32_t *c_pos, const uint32_t *c_info,
-                                                const uint32_t *c_woff, const uint2 *c_seq, const uint32_t *r_word, uint32_t n_kept, uint32_t n_words,
+                                                const uint32_t *c_woff, const uint2 *c_seq, uint32_t n_kept, uint32_t n_words,
                                                 PackTotals *tot)
 {
     __shared__ uint32_t s_info[PB], s_word[PB];
@@ -623,14 +622,15 @@ __global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const ui
     const int n = (int)min((uint32_t)PB, n_kept - r0);
     const uint32_t w_first = c_woff[r0], w_end = r0 + (uint32_t)n < n_kept ? c_woff[r0 + n] : n_words;
     if (tid < n) {
-        const uint32_t g = r0 + (uint32_t)tid, info = c_info[g], word = r_word[g];
+        const uint32_t g = r0 + (uint32_t)tid, info = c_info[g], word = 2u + c_woff[g];      // (the read's place in the plane stream)
         const int32_t pos = c_pos[g];
         const int npair = (int)((info & 1023u) + 31u) >> 5;
         const uint32_t slot0 = (c_woff[g] - w_first) >> 1;
-        const bool own = (info & INFO_PROJ) || word == 0xFFFFFFFFu;     // (no room for the chunk: pk_pack has raised the flag)
+        const bool own = (info & INFO_PROJ) != 0;                       // (its lane writes its pairs and the zero pair behind them)
+        const int n_slot = (int)(words_of(info & 1023u) >> 1);
         s_info[tid] = info; s_word[tid] = word; s_pos[tid] = pos; s_seq[tid] = c_seq[g];
-        for (int q = 0; q <= npair; ++q) s_owner[slot0 + q] = own ? (uint16_t)0xFFFFu : (uint16_t)(tid | (q << 8));
-        if ((info & INFO_PROJ) && word != 0xFFFFFFFFu) pack_read(src, o, tot, c_idx[g], info, pos, o.seq + word);
+        for (int q = 0; q < n_slot; ++q) s_owner[slot0 + q] = own && q <= npair ? (uint16_t)0xFFFFu : (uint16_t)(tid | (q << 8));
+        if (own) pack_read(src, o, tot, c_idx[g], info, pos, o.seq + word);
     }
     __syncthreads();
     const uint8_t *bytes = src.mode == 0 ? src.seq : src.stream;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const ui
         const uint32_t info = s_info[t];
         const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
         uint2 *dst = reinterpret_cast<uint2 *>(o.seq + s_word[t]) + q;                  // (even word offsets: 8-byte aligned)
-        if (q == npair) { *dst = make_uint2(0u, 0u); continue; }
+        if (q >= npair) { *dst = make_uint2(0u, 0u); continue; }
         const uint2 where = s_seq[t];
         const int l_seq = (int)(where.y >> 8), y = (int)(info >> 12) + 32 * q;
         const int nb = min(32, len - 32 * q), have = min(nb, l_seq - y);
@@ -943,14 +943,13 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     const int64_t n_wg = (nf + C - 1) / C;
     // every workgroup opens at least one chunk; more when a window or a lane's 255-read budget runs out
     const uint32_t chunk_cap = (uint32_t)std::min<int64_t>(nf, 4 * n_wg + (int64_t)tot.max_end / 128 + 64);
-    const uint32_t word_cap = (uint32_t)std::min<unsigned long long>(0xFFFFFFF0ull, tot.n_words + 8ull * chunk_cap + 16);
+    const uint32_t word_cap = (uint32_t)(tot.n_words + 2 + 16);        // the zero pair in front, the reads, slack for the last 16-byte load
 
     uint32_t *c_idx = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     int32_t *c_pos = (int32_t *)arena_take(ctx, (size_t)nf * 4);
     uint32_t *c_info = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     uint32_t *c_woff = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     uint2 *c_seq = (uint2 *)arena_take(ctx, (size_t)nf * 8);
-    uint32_t *r_word = (uint32_t *)arena_take(ctx, (size_t)nf * 4);
     if (ctx->dev_arena->used > ctx->dev_arena->cap) { return tcmi_fail(ctx, TCMI_E_NOMEM, "internal: pack scratch under-reserved"); }
 
     uint32_t event_cap = (uint32_t)std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(1 << 20, nf / 2));
@@ -983,13 +982,14 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         o.word_cap = word_cap; o.chunk_cap = chunk_cap; o.event_cap = event_cap;
         TCMI_HIP(ctx, hipMemsetAsync(blob + b_len + b_seq + b_chk + b_run + b_ev, 0, 256, ctx->stream));   // slack behind the last array
         TCMI_HIP(ctx, hipMemsetAsync(&d_tot->n_chunks, 0, 4 * sizeof(uint32_t), ctx->stream));              // n_chunks, n_events, n_runs, word_cursor
+        TCMI_HIP(ctx, hipMemsetAsync(o.seq + 2 + tot.n_words, 0, 16 * sizeof(uint32_t), ctx->stream));      // (what the last stage's last 16-byte load takes along)
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK);
         if (attempt == 0)
             hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, rd_pos, blk_sum, c_idx, c_pos, c_info, c_woff, c_seq);
-        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, c_pos, c_info, c_woff, r_word, (uint32_t)nf,
+        hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, c_pos, c_info, c_woff, (uint32_t)nf,
                            (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot);
-        hipLaunchKernelGGL(pk_planes, dim3((unsigned)((nf + PB - 1) / PB)), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq, r_word,
+        hipLaunchKernelGGL(pk_planes, dim3((unsigned)((nf + PB - 1) / PB)), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq,
                            (uint32_t)nf, (uint32_t)tot.n_words, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK);
         TCMI_HIP(ctx, hipGetLastError());
@@ -1011,8 +1011,8 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
             rs->d_stream = src.stream; rs->d_rec_off = src.rec_off; rs->d_cidx = c_idx; rs->d_cpos = c_pos;
             rs->arena_epoch = ctx->arena_epoch;
         }
-        rs->f_chunks = tot.n_chunks; rs->f_words = tot.word_cursor; rs->f_events = tot.n_events;
-        rs->dev_bytes = nf * 4 + (int64_t)tot.word_cursor * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) +
+        rs->f_chunks = tot.n_chunks; rs->f_words = (int64_t)tot.n_words + 4; rs->f_events = tot.n_events;
+        rs->dev_bytes = nf * 4 + ((int64_t)tot.n_words + 4) * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) +
                         (int64_t)tot.n_runs * 4 + (int64_t)tot.n_events * 4;
         return TCMI_OK;
     }

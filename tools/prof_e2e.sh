@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/prof_e2e.sh OUTDIR [bench args...] — rocprofv3 --kernel-trace --stats over a short file -> FASTA bench leg (every kernel
-# of the cold path: bgzf_inflate, rec_*, pk_*, tally_planes_kernel, call_kernel); the stats CSV lands in OUTDIR.
+# of the cold path: bgzf_symbols, bgzf_copy, bgzf_crc32, rec_*, pk_*, tally_planes_kernel, call_kernel); the stats CSV lands in OUTDIR.
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out

@@ -59,12 +59,6 @@ struct BlkTabs {                                    // per block
     // per such length, for the look-up by range compare: the end of its codes, left-aligned in 15 bits (ascending: canonical codes are
     // ordered by length), and first code | index of its first entry in long_* << 16
     uint32_t lim_ll[16 - LL_ROOT], fb_ll[16 - LL_ROOT], lim_d[16 - D_ROOT], fb_d[16 - D_ROOT];
-    // header and table building
-    uint8_t lens[320];
-    uint8_t cll[20];
-    uint16_t sym_ll[288], sym_d[32], sym_cl[20];
-    uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
-    uint32_t rs[6];
     // what the block's wavefront hands to the decoding wavefront and gets back
     uint32_t pos;               // first symbol / behind the end-of-block code
     uint32_t end;               // first bit behind the payload
@@ -74,15 +68,33 @@ struct BlkTabs {                                    // per block
     uint32_t last;              // 1: the stream's last deflate block
     uint32_t seg;               // 1: the tokens are left in the lanes' scratch, in pieces (SymArgs::seg)
 };
+struct HdrScratch {                                 // per block, while its header is decoded and its tables are built
+    uint8_t lens[320];
+    uint8_t cll[20];
+    uint16_t sym_ll[288], sym_d[32], sym_cl[20];
+    uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
+    uint32_t rs[6];
+};
 #ifndef TCMI_SYM_ASM
 #define TCMI_SYM_ASM 1
 #endif
+#ifndef TCMI_SYM_WAVES
+#define TCMI_SYM_WAVES 4                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (4: 128 VGPRs)
+#endif
 constexpr int RING = 8;
+struct PassALds {
+    uint2 ring[64][RING];       // pass A, per lane: {first symbol start in a stretch, symbols decoded before it}
+    uint2 rec[64];              // per lane: {state | target << 8, position}
+};
+// The header scratch and pass A's notes share their LDS: a workgroup barrier separates the two phases, and with 2.3 KB less a
+// workgroup of two blocks stays under the 18.2 KB at which nine of them fit a compute unit.
 template <int NB>
 struct SymLds {
     BlkTabs b[NB];
-    uint2 ring[64][RING];       // pass A, per lane: {first symbol start in a stretch, symbols decoded before it}
-    uint2 rec[64];              // per lane: {state | target << 8, position}
+    union {
+        HdrScratch h[NB];
+        PassALds a;
+    };
 };
 static_assert((CL_SLAB + 16) * 4 <= sizeof(tab_t) * (1 << LL_ROOT), "the code-length position table borrows the literal/length table's LDS");
 
@@ -182,7 +194,7 @@ enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
 // ---- header of one deflate block and its tables: one wavefront, the block's own (T, pay) ------------------------------------------
 // -> T.go = 1 and T.pos at the first symbol (a Huffman block), or the block's stream is finished / damaged (T.go = 0).  Stored
 // deflate blocks are turned into raw tokens here and the next header is taken at once.
-__device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
+__device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
                                           uint64_t *stamps, int blk)
 {
     const int lane = threadIdx.x & 63;
@@ -220,7 +232,7 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
         int nlen = 288, ndist = 32;
         wave_sync();
         if (type == 1) {
-            for (int i = lane; i < 320; i += 64) T.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+            for (int i = lane; i < 320; i += 64) H.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
         } else {
             if (pos + 14u > end) { err = ST_BAD_STREAM; break; }
             const uint32_t hh = uni(peek32(pay, pos));
@@ -229,17 +241,17 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
             const int ncode = (int)((hh >> 10) & 15u) + 4;
             pos += 14;
             if (nlen > 286 || ndist > 30) { err = ST_BAD_STREAM; break; }
-            if (lane < 19) T.cll[lane] = 0;
+            if (lane < 19) H.cll[lane] = 0;
             wave_sync();
             // (19 x 3 bits: three looks of up to 8 lengths each, lane k takes the k-th)
             for (int i0 = 0; i0 < ncode; i0 += 8) {
                 const uint32_t v = uni(peek32(pay, pos + (uint32_t)i0 * 3u));
                 const int k = i0 + lane;
-                if (lane < 8 && k < ncode) T.cll[CL_ORDER[k]] = (uint8_t)((v >> (3 * lane)) & 7u);
+                if (lane < 8 && k < ncode) H.cll[CL_ORDER[k]] = (uint8_t)((v >> (3 * lane)) & 7u);
             }
             pos += (uint32_t)ncode * 3u;
-            if (uni(build_table<1, CL_ROOT>(T.cll, 19, T.cnt_cl, T.sym_cl, T.dt, K_CODELEN, T.rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-            for (int i = lane; i < 320; i += 64) T.lens[i] = 0;
+            if (uni(build_table<1, CL_ROOT>(H.cll, 19, H.cnt_cl, H.sym_cl, T.dt, K_CODELEN, H.rs + 4) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+            for (int i = lane; i < 320; i += 64) H.lens[i] = 0;
             // The code-length symbols (0 .. 15: a length; 16: the previous length 3 - 6 times; 17 / 18: 3 - 10 / 11 - 138 zeros) are
             // a serial chain too, but a short one over few bits.  Every bit position of a slab is looked up by some lane (what
             // symbol would start here, how many lengths would it give, how many bits would it take: step | rep << 4 | val << 12);
@@ -286,7 +298,7 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
                     if (mine != 0 && val != 0) {
 #pragma unroll
                         for (uint32_t i = 0; i < 6; ++i)            // (zeros are not stored, so rep <= 6)
-                            if (i < rep) T.lens[at + i] = (uint8_t)val;
+                            if (i < rep) H.lens[at + i] = (uint8_t)val;
                     }
                     if (j) prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(j - 1u));
                     got = g;
@@ -298,14 +310,14 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
             }
             if (err != ST_OK) break;
             wave_sync();
-            if (uni(T.lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
+            if (uni(H.lens[256]) == 0) { err = ST_BAD_STREAM; break; }    // no end-of-block code
         }
         TCMI_STAMP(stamps, blk, 2);
         // ---- tables: the root tables as in bgzf_inflate, the longer codes as ready-made entries ------------------------------------
-        if (uni(build_table<5, LL_ROOT>(T.lens, nlen, T.cnt_ll, T.sym_ll, T.ll, K_LITLEN, T.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        if (uni(build_table<1, D_ROOT>(T.lens + nlen, ndist, T.cnt_d, T.sym_d, T.dt, K_DIST, T.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
-        build_long<LL_ROOT>(T.cnt_ll, T.sym_ll, T.rs, K_LITLEN, T.long_ll, T.lim_ll, T.fb_ll);
-        build_long<D_ROOT>(T.cnt_d, T.sym_d, T.rs + 2, K_DIST, T.long_d, T.lim_d, T.fb_d);
+        if (uni(build_table<5, LL_ROOT>(H.lens, nlen, H.cnt_ll, H.sym_ll, T.ll, K_LITLEN, H.rs) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        if (uni(build_table<1, D_ROOT>(H.lens + nlen, ndist, H.cnt_d, H.sym_d, T.dt, K_DIST, H.rs + 2) ? 1u : 0u) == 0u) { err = ST_BAD_STREAM; break; }
+        build_long<LL_ROOT>(H.cnt_ll, H.sym_ll, H.rs, K_LITLEN, T.long_ll, T.lim_ll, T.fb_ll);
+        build_long<D_ROOT>(H.cnt_d, H.sym_d, H.rs + 2, K_DIST, T.long_d, T.lim_d, T.fb_d);
         if (pos >= end) { err = ST_BAD_STREAM; break; }
         go = true;
         TCMI_STAMP(stamps, blk, 3);
@@ -315,7 +327,7 @@ __device__ __forceinline__ void block_header(BlkTabs &T, const uint32_t *pay, ui
 }
 
 template <int NB>
-__global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_symbols(SymArgs a)
+__global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SYM_WAVES, TCMI_SYM_WAVES))) void bgzf_symbols(SymArgs a)
 {
     constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
     static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4)))
     bool last = !have;
     for (;;) {
         // ---- every wavefront: its block's next header and tables ------------------------------------------------------------------
-        if (have && uni(T.err) == ST_OK && !last) block_header(T, pay, base_bit, toks, d.tok_cap, last, a.stamps, blk);
+        if (have && uni(T.err) == ST_OK && !last) block_header(T, L.h[wave], pay, base_bit, toks, d.tok_cap, last, a.stamps, blk);
         else if (lane == 0) T.go = 0;
         __syncthreads();
         uint32_t any = 0;
@@ -414,8 +426,8 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4)))
             bool spilled = false;                   // more symbols than the scratch holds: pass B decodes this block again
             uint32_t rounds = 0;
 #pragma unroll
-            for (int k = 0; k < RING; ++k) L.ring[lane][k] = make_uint2(0xFFFFFFFFu, 0u);
-            L.rec[lane] = make_uint2(state, p);
+            for (int k = 0; k < RING; ++k) L.a.ring[lane][k] = make_uint2(0xFFFFFFFFu, 0u);
+            L.a.rec[lane] = make_uint2(state, p);
             wave_sync();
 #if TCMI_SYM_ASM
             // The rounds, hand-scheduled (the compiler's version of the loop below takes ~180 instructions a round, half of them
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 uint32_t tgt_abs = (uint32_t)lane0 + tgt, room = lane_cap, crossp = 0xFFFFFFFFu, crosst = 0;
                 uint64_t sptr = reinterpret_cast<uint64_t>(scratch);
                 const uint32_t tabs = (uint32_t)reinterpret_cast<uintptr_t>(&B), payb = (uint32_t)reinterpret_cast<uintptr_t>(bp);
-                const uint32_t ringbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.ring[0][0]), recbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.rec[0]);
+                const uint32_t ringbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.a.ring[0][0]), recbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.a.rec[0]);
                 const uint32_t ringb = ringbase + (uint32_t)lane * (RING * 8), recb = recbase + (uint32_t)lane * 8u;
                 const uint32_t lim = (uint32_t)lane0 + (uint32_t)SYM_LANES;
                 unsigned long long run = __ballot(state == RUN);
@@ -740,17 +752,17 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4)))
             while (__ballot(state == RUN)) {
                 const uint32_t kk = p >> shift;
                 const bool cross = state == RUN && kk != kprev;
-                if (cross) L.ring[lane][kk & (RING - 1)] = make_uint2(p, total);
+                if (cross) L.a.ring[lane][kk & (RING - 1)] = make_uint2(p, total);
                 wave_sync();                        // (orders the notes before the looks)
                 if (cross) {
                     kprev = kk;
                     // a target that has stopped at or in front of p: on to the lane it met, or to the next one
                     {
-                        const uint2 r = L.rec[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)];
+                        const uint2 r = L.a.rec[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)];
                         const uint32_t st = r.x & 3u;
                         const uint32_t nxt = st == MERGED ? r.x >> 8 : tgt + 1u;
                         tgt = st != RUN && p >= r.y && tgt < (uint32_t)SYM_LANES ? nxt : tgt;      // (one step per stretch)
-                        const uint2 e = L.ring[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)][kk & (RING - 1)];
+                        const uint2 e = L.a.ring[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)][kk & (RING - 1)];
                         if (tgt < (uint32_t)SYM_LANES && e.x == p) { state = MERGED; midx = e.y; }
                     }
                 }
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         ++total;
                     }
                 }
-                if (cross || state != RUN) L.rec[lane] = make_uint2(state | (tgt << 8), p);
+                if (cross || state != RUN) L.a.rec[lane] = make_uint2(state | (tgt << 8), p);
                 ++rounds;
             }
 #endif
@@ -1391,6 +1403,14 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
         return true;
     }();
     (void)attr_once;
+    if (stamp_path) {                           // (diagnostic) how many workgroups of each kernel a compute unit really holds
+        int occ_s = 0, occ_c = 0;
+        if (per_wg == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<2>), 128, dyn);
+        else if (per_wg == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1>), 64, dyn);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false>), 64, 0);
+        std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
+                     nb, pay, per_wg, dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
+    }
     tcmi_prof_begin(ctx, TCMI_K_INFLATE);
     if (per_wg == 4) hipLaunchKernelGGL(bgzf_symbols<4>, dim3((unsigned)((nb + 3) / 4)), dim3(256), dyn, ctx->stream, sa);
     else if (per_wg == 2) hipLaunchKernelGGL(bgzf_symbols<2>, dim3((unsigned)((nb + 1) / 2)), dim3(128), dyn, ctx->stream, sa);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
 __global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned long long *blk_alg, const int32_t *blk_end, int64_t n_blk,
                                                 PackTotals *tot)
 {
-    __shared__ unsigned long long s_x[1024], s_y[1024];
+    __shared__ unsigned long long s_x[16], s_y[16];
     const int t = threadIdx.x;
     const int64_t per = (n_blk + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, n_blk);
     unsigned long long sx = 0, sy = 0, alg = 0;
@@ -278,21 +278,24 @@ __global__ __launch_bounds__(1024) void pk_scan(uint2 *blk_sum, const unsigned l
     if (alg) atomicAdd(&tot->alg_bytes, alg);                  // (at most 1024 of these)
     if (mlen) atomicMax(&tot->max_len, mlen);
     if (mend) atomicMax(&tot->max_end, mend);
-    s_x[t] = sx; s_y[t] = sy;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                    // Hillis-Steele over the 1024 partials
-        const unsigned long long ax = t >= d ? s_x[t - d] : 0, ay = t >= d ? s_y[t - d] : 0;
-        __syncthreads();
-        s_x[t] += ax; s_y[t] += ay;
-        __syncthreads();
+    // inclusive scan of the 1024 partials: within the wavefronts by shuffles, then the sixteen wavefront totals (two barriers;
+    // ten rounds of Hillis-Steele through LDS cost twenty, and this kernel is one workgroup's latency from end to end)
+    unsigned long long ix = sx, iy = sy;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long ox = (unsigned long long)__shfl_up((long long)ix, d, 64), oy = (unsigned long long)__shfl_up((long long)iy, d, 64);
+        if ((t & 63) >= d) { ix += ox; iy += oy; }
     }
-    unsigned long long bx = s_x[t] - sx, by = s_y[t] - sy;  // exclusive base of this lane's range
+    if ((t & 63) == 63) { s_x[t >> 6] = ix; s_y[t >> 6] = iy; }
+    __syncthreads();
+    for (int w = 0; w < (t >> 6); ++w) { ix += s_x[w]; iy += s_y[w]; }
+    unsigned long long bx = ix - sx, by = iy - sy;          // exclusive base of this lane's range
     for (int64_t b = b0; b < b1; ++b) {
         const uint2 v = blk_sum[b];
         blk_sum[b] = make_uint2((uint32_t)bx, (uint32_t)by);
         bx += v.x; by += v.y;
     }
-    if (t == 1023) { tot->n_kept = s_x[1023]; tot->n_words = s_y[1023]; }
+    if (t == 1023) { tot->n_kept = ix; tot->n_words = iy; tot->n_chunks = 0; tot->n_events = 0; tot->n_runs = 0; tot->word_cursor = 0; }   // (the counters pk_pack / pk_planes take from)
 }
 
 // ---- 3: scatter: compacted index + word offset of every kept read -----------------------------------------------------
@@ -323,6 +326,7 @@ struct PackOut {
     uint32_t *covrun;               // [n_kept]: the runs of a chunk start at its first read's index
     uint32_t *events;               // [event_cap]
     uint32_t word_cap, chunk_cap, event_cap;
+    uint32_t *slack;                // 64 words behind the last array
 };
 
 __device__ inline void push_event(const PackOut &o, PackTotals *tot, uint32_t w)
@@ -493,6 +497,10 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
     __shared__ int s_scan[PB / 64];
     __shared__ uint32_t s_slot[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid < 64) {                          // what the last stage's last 16-byte load takes along, and the blob's slack
+        if (tid < 16) o.seq[2u + n_words + tid] = 0u;
+        o.slack[tid] = 0u;
+    }
     const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
     const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
     for (int t = tid; t < n; t += PB) {
@@ -980,9 +988,8 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         o.covrun = (uint32_t *)(blob + b_len + b_seq + b_chk);
         o.events = (uint32_t *)(blob + b_len + b_seq + b_chk + b_run);
         o.word_cap = word_cap; o.chunk_cap = chunk_cap; o.event_cap = event_cap;
-        TCMI_HIP(ctx, hipMemsetAsync(blob + b_len + b_seq + b_chk + b_run + b_ev, 0, 256, ctx->stream));   // slack behind the last array
-        TCMI_HIP(ctx, hipMemsetAsync(&d_tot->n_chunks, 0, 4 * sizeof(uint32_t), ctx->stream));              // n_chunks, n_events, n_runs, word_cursor
-        TCMI_HIP(ctx, hipMemsetAsync(o.seq + 2 + tot.n_words, 0, 16 * sizeof(uint32_t), ctx->stream));      // (what the last stage's last 16-byte load takes along)
+        o.slack = reinterpret_cast<uint32_t *>(blob + b_len + b_seq + b_chk + b_run + b_ev);                // 256 bytes behind the last array: pk_pack zeroes them
+        if (attempt > 0) TCMI_HIP(ctx, hipMemsetAsync(&d_tot->n_chunks, 0, 4 * sizeof(uint32_t), ctx->stream));    // n_chunks, n_events, n_runs, word_cursor (the first time: pk_scan)
         (void)hipGetLastError();
         tcmi_prof_begin(ctx, TCMI_K_PACK);
         if (attempt == 0)

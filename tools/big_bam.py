@@ -26,6 +26,15 @@ rs = ctx.upload_bamfile(d)
 got = ctx.step(rs, L, 30, True)[3]
 print("reads %d piled %d decode + pack + tally %.1f ms (first call: allocations included)" % (rs.n_reads, rs.n_piled, 1e3 * (time.time() - t1)))
 print("counts equal the oracle's:", bool(np.array_equal(got, want)), "coverage sum", int(got[:, 0].sum()), "expected", 150 * n * m)
+rs.free()
+ctx.profile(True)
+t1 = time.time()
+rs = ctx.upload_bamfile(d)
+ctx.step(rs, L, 30, True, want_counts=False)
+print("second call: decode + pack + tally %.1f ms" % (1e3 * (time.time() - t1)), {k: round(ctx.profile_get(v)[0] * 1e3) for k, v in
+      (("symbols_us", engine._ffi.K_INFLATE), ("copy_us", engine._ffi.K_INFLATE_COPY), ("crc_us", engine._ffi.K_CRC), ("classify_us", engine._ffi.K_PACK_CLASSIFY),
+       ("pack_us", engine._ffi.K_PACK), ("tally_us", engine._ffi.K_TALLY))})
+ctx.profile(False)
 # ... and the same file as two block ranges, each decoded on its own (what two ranks would do)
 rs.free()
 acc = np.zeros_like(got)

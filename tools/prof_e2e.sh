@@ -4,7 +4,7 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-resident --no-cpu-baseline --steps 16 --warmup 2 "$@" > $out/bench_under_rocprof.json 2> $out/rocprof.err || { tail -5 $out/rocprof.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-resident --no-cpu-baseline --no-cli-batch --no-hard-bam --steps 16 --warmup 2 "$@" > $out/bench_under_rocprof.json 2> $out/rocprof.err || { tail -5 $out/rocprof.err; exit 1; }
 f=$(ls $out/stats/*/*kernel_stats.csv | head -1)
 cp $f $out/kernel_stats.csv
 cat $out/kernel_stats.csv

@@ -21,5 +21,7 @@ echo "resident stats done"
 python3 bench.py --no-cpu-baseline --no-resident --indels --steps 8 --warmup 2 > $out/bench_indels.json 2> $out/bench_indels.err
 echo "indels done"
 python3 bench.py --split-bam --steps 100 --warmup 10 > $out/bench_split.json 2> $out/bench_split.err
+python3 bench.py --split-bam --from-file --reads 4000000 --steps 20 --warmup 3 > $out/bench_split_from_file.json 2> $out/bench_split_from_file.err
+echo "split done"
 python3 bench.py --host-decode --no-cpu-baseline --no-resident --steps 16 > $out/bench_host_decode.json 2> $out/bench_host_decode.err
 echo done

@@ -79,7 +79,8 @@ struct HdrScratch {                                 // per block, while its head
 #define TCMI_SYM_ASM 1
 #endif
 #ifndef TCMI_SYM_WAVES
-#define TCMI_SYM_WAVES 4                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (4: 128 VGPRs)
+#define TCMI_SYM_WAVES 5                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (5: 96 VGPRs; with 4 — 128 —
+                                                    // a BAM's 2 094 workgroups fill every CU's register file: 182 us instead of 173)
 #endif
 constexpr int RING = 8;
 struct PassALds {
@@ -891,16 +892,14 @@ struct CopyArgs {
                         "s_cmp_lt_u32 %[sb], 0x10000\n" \
                         "s_cbranch_scc0 LMf%=\n" \
                         "s_bitset0_b64 %[mm], %[j]\n" \
-                        "s_lshr_b32 %[len], %[sa], 16\n" \
-                        "s_and_b32 %[sa], %[sa], 0xffff\n" \
+                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
+                        "s_and_b32 %[len], %[sa], 0xffff\n" \
                         "v_add_u32 %[t0], %[sb], %[vlane]\n" \
-                        "v_add_u32 %[t1], %[sa], %[vlane]\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
+                        "v_add_u32 %[t1], %[len], %[vlane]\n" \
                         "ds_read_u8 %[t2], %[t0]\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2]\n" \
-                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
                         "s_cbranch_scc1 LM2%=\n" \
                         "LM1%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
@@ -908,33 +907,29 @@ struct CopyArgs {
                         "s_mov_b32 %[j], -1\n" \
                         "s_branch LMx%=\n" \
                         "LM2%=:\n" \
-                        "s_sub_u32 %[len], %[len], 64\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
+                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
+                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
                         "ds_read_u8 %[t2], %[t0] offset:64\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2] offset:64\n" \
-                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
                         "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[len], %[len], 64\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
+                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
+                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
                         "ds_read_u8 %[t2], %[t0] offset:128\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2] offset:128\n" \
-                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
                         "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[len], %[len], 64\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
+                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
+                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
                         "ds_read_u8 %[t2], %[t0] offset:192\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2] offset:192\n" \
-                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
                         "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[len], %[len], 64\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
+                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
+                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
                         "ds_read_u8 %[t2], %[t0] offset:256\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2] offset:256\n" \
@@ -964,7 +959,7 @@ struct CopyArgs {
                         "LMx%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
                         : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) \
-                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [outp] "s"(out) \
+                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [outp] "s"(out) \
                         : "s92", "s93", "vcc", "scc", "memory");
 
 // TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
@@ -999,6 +994,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     const uint8_t *const payload = a.file + d.cin;
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
     const uint32_t *const win32 = reinterpret_cast<const uint32_t *>(s_win);
+    const uint32_t lane_hi = ((uint32_t)lane << 16) | 0xFFFFu;  // (len << 16 | anything) > lane_hi  <=>  len > lane: the copy round's lane mask from the packed operand
     // (teams of eight lanes: lane l belongs to team l / 8 and takes that team's piece l % 8)
     const uint32_t team_of = (uint32_t)lane >> 3, team_sub = (uint32_t)lane & 7u, team_sub8 = team_sub * 8u;
     const uint32_t team_base = (uint32_t)(CWIN + FAR_WORDS * 4), team_slot = team_base + team_of * 8u;     // s_lds.team, as LDS addresses
@@ -1319,7 +1315,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                           "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
                     if (!mm) break;
                 }
-                // the plain matches of the round, one after the other (hand-scheduled: 20 instructions for a match of up to 64 bytes;
+                // the plain matches of the round, one after the other (hand-scheduled: 18 instructions for a match of up to 64 bytes, 7 per further 64;
                 // the compiler's loop took 29), until one of another kind comes up: j says which (-1: none left).  (With teams: one.)
                 int j;
                 {

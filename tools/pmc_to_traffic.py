@@ -1,0 +1,33 @@
+"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round3" block of profiles/traffic.json that
+bench.py's roofline blocks quote.   python3 tools/pmc_to_traffic.py gpurun_out/TAG/pmc_e2e_summary.txt profiles/TAG_pmc_e2e.txt"""
+import ast, json, os, re, sys
+
+src, committed_as = sys.argv[1], sys.argv[2]
+k = {}
+for line in open(src):
+    m = re.match(r"^([\w<>]+) (\{.*\}) n= (\d+)$", line.strip())
+    if not m:
+        continue
+    name = re.sub(r"<.*>", "", m.group(1))
+    k.setdefault(name, {}).update(ast.literal_eval(m.group(2)))
+# FETCH_SIZE: KiB as reported; gfx950 tallies the 128-byte requests of a wide coalesced stream (16 bytes per lane, consecutive lanes) at
+# 64 bytes (MI355X_MICROARCH.md): doubled for the kernels that read that way
+wide = {"bgzf_crc32", "tally_planes_kernel"}
+out = {}
+for name, c in k.items():
+    if "FETCH_SIZE" not in c:
+        continue
+    insts = {x: round(c.get("SQ_INSTS_" + x.upper(), 0)) for x in ("valu", "salu", "lds", "smem")}
+    insts["vmem"] = round(c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0))
+    out[name] = {"fetch_kib": c["FETCH_SIZE"], "fetch_doubled": name in wide, "write_kib": c.get("WRITE_SIZE", 0.0),
+                 "hbm_bytes": round((c["FETCH_SIZE"] * (2 if name in wide else 1) + c.get("WRITE_SIZE", 0.0)) * 1024),
+                 "wave_insts": insts, "wave_insts_total": sum(insts.values()), "waves": round(c.get("SQ_WAVES", 0)),
+                 "lds_bank_conflict_cycles": round(c.get("SQ_LDS_BANK_CONFLICT", 0))}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tp = os.path.join(root, "profiles", "traffic.json")
+t = json.load(open(tp))
+t["round3"] = {"source": committed_as + " (tools/pmc_e2e.sh: one --pmc set per pass, kernel trace only; one 1M-read BAM per launch, single stream)",
+               "kernels": out, "wave_insts_per_bam": sum(v["wave_insts_total"] for v in out.values()),
+               "hbm_bytes_per_bam": sum(v["hbm_bytes"] for v in out.values())}
+json.dump(t, open(tp, "w"), indent=1)
+print(json.dumps(t["round3"], indent=1)[:1500])

@@ -321,8 +321,9 @@ int  tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int6
 /* Events.ExtractInserts for a read set the DEVICE decoded (tcmi_readset_from_bamfile): same arguments and results as
  * tcmi_modal_tokens, but the reads of every candidate column are examined by a HIP kernel where they lie (the inflated
  * stream stays resident on the context until its next upload) and only a few thousand 48-byte entries per column reach
- * the host.  TCMI_E_UNSUPPORTED when the stream is gone (another upload happened on the context), the read set was not
- * decoded on the device, or an insertion of more than 12 bases sits on a column: use tcmi_bam_load + tcmi_modal_tokens. */
+ * the host (+ the bases of insertions too long for an entry's 64-bit token key, from a 4 MB text buffer).  TCMI_E_UNSUPPORTED when the
+ * stream is gone (another upload happened on the context), the read set was not decoded on the device, or that text buffer
+ * overflows: use tcmi_bam_load + tcmi_modal_tokens. */
 int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions,
                                int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
                                int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,

@@ -316,6 +316,43 @@ def test_crc32_of_every_block_is_checked_on_the_device(ctx, tmp_path):
     d.close()
 
 
+def test_long_insertions_on_a_candidate_column_stay_on_the_device(ctx, tmp_path):
+    """An insertion of more than 12 bases does not fit the device entry's 64-bit token key (round 2 sent such a file to a host
+    decode): the kernel leaves its bases in a text buffer, the host builds the token text from there.  Against the host sweep and the
+    pileup emulator (Events.py:63-80: the modal token of the column, in upper case)."""
+    from tests import synth_small as ss
+    from oracle import tc_oracle as orc
+    rng = np.random.default_rng(8)
+    ins_a = "ACGTTGCAAGGCTTAACCGGT"                       # 21 bases
+    ins_b = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 57))
+    reads = []
+    for k in range(900):
+        kind = k % 3
+        if kind == 0:
+            reads.append({"pos": 100 + k % 7, "flag": 16 if k % 2 else 0, "cigar": "%dM21I%dM" % (20 - k % 7, 20 + k % 7), "qual": 30, "name": "a%d" % k,
+                          "seq": "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 20 - k % 7)) + ins_a + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 20 + k % 7))})
+        elif kind == 1:
+            reads.append({"pos": 150 + k % 5, "flag": 0, "cigar": "%dM57I%dM" % (30 - k % 5, 10 + k % 5), "qual": 25, "name": "b%d" % k,
+                          "seq": "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 30 - k % 5)) + (ins_b if k % 9 else ins_b[:-1] + "N") + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 10 + k % 5))})
+        else:
+            reads.append({"pos": 95 + k % 11, "flag": 0, "cigar": "90M", "qual": 30, "name": "c%d" % k, "seq": "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 90))})
+    reads.sort(key=lambda r: r["pos"])
+    rd = ss.reads_from_spec({"reads": reads})
+    p = str(tmp_path / "longins.bam")
+    bamwriter.write_bam(p, rd, "r", 400)
+    d = engine.DeviceBam(p)
+    rs = ctx.upload_bamfile(d)
+    assert rs.packed_on_device
+    cols = [119, 120, 179, 180]                            # (1-based: the last base in front of each insertion, and the one behind)
+    got = ctx.readset_modal_tokens(rs, cols)
+    assert got == engine.modal_tokens(engine.BamFile(p), cols)
+    for c in cols:
+        want = orc.region_tokens(rd, c)
+        assert got[c][1] == len(want) and got[c][0] == orc.Counter(t.upper() for t in want).most_common(1)[0][0], c
+    assert got[120][0].endswith("+21" + ins_a) and got[180][0].endswith("+57" + ins_b)
+    rs.free(); d.close()
+
+
 def test_insert_tokens_resolved_on_the_device(ctx, tmp_path):
     """Events.ExtractInserts (Events.py:47-82) for a BAM the device decoded: the HIP kernel's entries + the host vote against
     the host sweep over the host-decoded file and against the oracle — indel sites of the configs[2] kind, a column deeper than

@@ -297,9 +297,12 @@ int emit_modal(std::vector<std::vector<Entry>> &entries, const std::vector<std::
 // Entries produced on the device (pack_device.hip, ins_entries_kernel) -> the same finalisation as the host sweep.
 int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
                                 int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
-                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags)
+                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags, const uint8_t *long_text,
+                                size_t long_bytes)
 {
     std::vector<std::vector<Entry>> entries((size_t)n_pos);
+    std::vector<std::string> long_tokens;                      // the text of insertions of more than 12 bases (as the host sweep builds it)
+    std::string tok;
     int32_t status = 0;
     for (int32_t k = 0; k < n_pos; ++k) {
         // the entries of a column arrive in file order, one slot per read that could reach it; key 0: no token there
@@ -310,9 +313,25 @@ int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const
         auto &E = entries[(size_t)k];
         E.reserve(order.size());
         for (const tcmi_dev_entry *d : order) {
-            if (d->bits & 0x40) return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED, "an insertion of more than 12 bases on a candidate column: host sweep");
             Entry e;
-            e.key = d->key; e.name_hash = d->name_hash; e.end = d->end; e.pos = d->pos; e.tid = 0;
+            e.key = d->key;
+            if (d->bits & 0x40) {
+                const uint64_t at = (d->key >> 8) & 0xFFFFFFFFull, n = (d->key >> 40) & 0x7FFFFFull;
+                if ((d->bits & 0x80) || !long_text || at + n > long_bytes)
+                    return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED, "the insertions of more than 12 bases on the candidate columns exceed the device's text buffer: host sweep");
+                const bool rev = (d->flag & 0x10) != 0;
+                tok.clear();
+                tok.push_back((char)(d->key & 0xFF));
+                tok.push_back('+');
+                append_number(tok, (int64_t)n);
+                for (uint64_t t = 0; t < n; ++t) {
+                    const char ch = NT16[long_text[at + t] & 15u];
+                    tok.push_back(ch == '=' ? (rev ? ',' : '.') : ch);
+                }
+                e.key = 0;
+                e.tok = (int32_t)long_tokens.size();
+                long_tokens.push_back(tok);
+            } e.name_hash = d->name_hash; e.end = d->end; e.pos = d->pos; e.tid = 0;
             e.mtid = (d->bits & 0x20) ? 1 : 0;                 // only "same reference or not" matters
             e.mpos = d->mpos; e.isize = d->isize; e.l_qseq = d->l_qseq; e.flag = d->flag; e.qual = d->qual;
             e.base = d->bits & 0xF; e.on_base = (d->bits & 0x10) != 0;
@@ -320,8 +339,7 @@ int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const
             E.push_back(std::move(e));
         }
     }
-    const std::vector<std::string> no_long_tokens;             // (the device declines insertions that do not fit the key)
-    const int rc = emit_modal(entries, no_long_tokens, min_base_quality, max_depth, ignore_overlaps, prober, tokens, tokens_cap, token_off, n_tokens, &status);
+    const int rc = emit_modal(entries, long_tokens, min_base_quality, max_depth, ignore_overlaps, prober, tokens, tokens_cap, token_off, n_tokens, &status);
     if (status_flags) *status_flags = status;
     return rc;
 }

@@ -691,6 +691,10 @@ struct InsArgs {
     int32_t n_cand;
     uint32_t flag_filter;
     int32_t ignore_orphans;
+    // insertions of more than 12 bases do not fit the entry's key: their bases (one 4-bit code per byte) go here, the key says where
+    uint8_t *long_text;
+    uint32_t *long_cursor;          // bytes taken
+    uint32_t long_cap;
 };
 
 
@@ -753,8 +757,19 @@ __global__ __launch_bounds__(PB) void ins_entries_kernel(InsArgs a)
                     }
                 }
                 uint64_t key = (1ull << 63) | (uint8_t)first;
-                if (indel > 12) e.bits |= 0x40;                   // does not fit the key: the host sweep takes the BAM
-                else if (indel > 0) {
+                if (indel > 12) {
+                    // does not fit the key: bits 8-39 where its bases start in the text buffer, bits 40-62 how many (bits |= 0x40;
+                    // 0x80: the buffer is full or the insertion absurdly long — the host sweep takes the BAM)
+                    e.bits |= 0x40;
+                    const uint32_t slot = indel < (1 << 23) ? atomicAdd(a.long_cursor, (uint32_t)indel) : a.long_cap;
+                    if (indel < (1 << 23) && (uint64_t)slot + (uint64_t)indel <= a.long_cap) {
+                        for (int64_t t = 1; t <= indel; ++t) {
+                            const int64_t q2 = qpos + t;
+                            a.long_text[slot + (uint32_t)(t - 1)] = (uint8_t)(q2 >= lq ? 15u : nib_at(v.seq, (int32_t)q2));
+                        }
+                        key |= ((uint64_t)slot << 8) | ((uint64_t)indel << 40);
+                    } else e.bits |= 0x80;
+                } else if (indel > 0) {
                     key |= (1ull << 8) | ((uint64_t)indel << 10);
                     bool any_eq = false;
                     for (int64_t t = 1; t <= indel; ++t) {
@@ -1209,9 +1224,11 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
     std::vector<int32_t> cnt((size_t)n_pos, 0);
     for (int32_t k = 0; k < n_pos; ++k) cnt[(size_t)k] = (int32_t)(off[(size_t)k + 1] - off[(size_t)k]);
     const tcmi_dev_entry *ents = nullptr;
+    std::vector<uint8_t> long_text;
+    constexpr size_t LONG_TEXT_CAP = 4u << 20;                  // bases of insertions longer than 12 on the candidate columns of one call
     if (total > 0) {
         const size_t b_head = b_cols + 2 * b_lo + b_off, b_ent = al((size_t)total * sizeof(tcmi_dev_entry));
-        const int rc = scratch(b_head + b_ent, std::max(2 * b_lo, b_ent));
+        const int rc = scratch(b_head + b_ent + 256 + LONG_TEXT_CAP, std::max(2 * b_lo, b_ent));
         if (rc) return rc;
         // (a regrown device buffer lost the columns and ranges: they are sent again — all tiny)
         d_cols = (int32_t *)ctx->tok_dev;
@@ -1223,6 +1240,8 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
         a.out = (tcmi_dev_entry *)(ctx->tok_dev + b_head);
         a.cols = d_cols; a.lo = d_lo; a.off = d_off;
         a.n_cand = n_pos; a.flag_filter = flag_filter; a.ignore_orphans = ignore_orphans;
+        a.long_cursor = (uint32_t *)(ctx->tok_dev + b_head + b_ent); a.long_text = (uint8_t *)(ctx->tok_dev + b_head + b_ent + 256); a.long_cap = (uint32_t)LONG_TEXT_CAP;
+        TCMI_HIP(ctx, hipMemsetAsync(a.long_cursor, 0, 4, ctx->stream));
         TCMI_HIP(ctx, hipMemcpyAsync(d_cols, cols.data(), (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
         TCMI_HIP(ctx, hipMemcpyAsync(d_lo, lo_v.data(), (size_t)n_pos * 8, hipMemcpyHostToDevice, ctx->stream));
         TCMI_HIP(ctx, hipMemcpyAsync(d_off, off.data(), ((size_t)n_pos + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1230,8 +1249,14 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
         hipLaunchKernelGGL(ins_entries_kernel, dim3((unsigned)((total + PB - 1) / PB)), dim3(PB), 0, ctx->stream, a);
         TCMI_HIP(ctx, hipGetLastError());
         TCMI_HIP(ctx, hipMemcpyAsync(ctx->tok_host, a.out, (size_t)total * sizeof(tcmi_dev_entry), hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t long_used = 0;
+        TCMI_HIP(ctx, hipMemcpyAsync(&long_used, a.long_cursor, 4, hipMemcpyDeviceToHost, ctx->stream));
         TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (lo_v / off / cols were pageable: their copies are done)
         ents = (const tcmi_dev_entry *)ctx->tok_host;
+        if (long_used) {                                        // (rare: a long insertion on a candidate column) its bases
+            long_text.resize(std::min<size_t>(long_used, LONG_TEXT_CAP));
+            TCMI_HIP(ctx, hipMemcpy(long_text.data(), a.long_text, long_text.size(), hipMemcpyDeviceToHost));
+        }
     }
     // the other mate of an overlapping pair, looked at on one reference position (rare: a pair with a deletion on a candidate column)
     const tcmi_prober prober = [&](const std::vector<tcmi_probe_req> &req, std::vector<tcmi_probe_res> &res) -> int {
@@ -1266,5 +1291,5 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
         return TCMI_OK;
     };
     return tcmi_modal_from_dev_entries(n_pos, ents, off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, &prober, tokens,
-                                       tokens_cap, token_off, n_tokens, status_flags);
+                                       tokens_cap, token_off, n_tokens, status_flags, long_text.data(), long_text.size());
 }

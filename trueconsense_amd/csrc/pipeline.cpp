@@ -621,8 +621,8 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
                                     }
                                     break;
                                 }
-                                // (anything the device path declines — a long insertion, overlapping mates with a deletion on the
-                                // column — is left to the walker's host sweep, which words the refusal if it is one)
+                                // (anything the device path declines — megabytes of long insertions, an overlap it cannot resolve —
+                                // is left to the walker's host sweep, which words the refusal if it is one)
                                 it.pre.valid = rt == TCMI_OK && !(st & TCMI_TOKENS_OVERLAP_UNKNOWN);
                             }
                         }

@@ -217,7 +217,8 @@ struct tcmi_dev_entry {
     int32_t pos, end, mpos, isize, l_qseq;
     uint16_t flag;
     uint8_t qual;
-    uint8_t bits;               // base code | on_base << 4 | mate on another reference << 5 | insertion too long for the key << 6
+    uint8_t bits;               // base code | on_base << 4 | mate on another reference << 5 | insertion too long for the key << 6 (its bases lie in
+                                // the call's text buffer: key bits 8-39 where, bits 40-62 how many) | << 7: that buffer was full
     int32_t qref;               // deletion / ref-skip token: reference position of the matched base whose quality is tested, or -1
 };
 // "does read `idx` have a matched base on reference position `ref`, which, with what quality?" — asked for the other mate of an
@@ -227,7 +228,8 @@ struct tcmi_probe_res { uint8_t matched, base, qual; };
 typedef std::function<int(const std::vector<tcmi_probe_req> &, std::vector<tcmi_probe_res> &)> tcmi_prober;
 int tcmi_modal_from_dev_entries(int32_t n_pos, const tcmi_dev_entry *ents, const int64_t *ent_off, const int32_t *ent_cnt,
                                 int32_t min_base_quality, int64_t max_depth, int ignore_overlaps, const tcmi_prober *prober, char *tokens,
-                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
+                                int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens, int32_t *status_flags, const uint8_t *long_text = nullptr,
+                                size_t long_bytes = 0);
 extern "C" int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile **out);   // (bam_device.hip; 0 = by size)
 // device packer (pack_device.hip): struct tcmi_reads -> device -> packed read set; TCMI_E_UNSUPPORTED + *why when the
 // input needs the host packer

@@ -34,8 +34,14 @@
 
 namespace {
 
-constexpr int CWIN = 8192, CWMASK = CWIN - 1;       // bgzf_copy's ring of recent output
-constexpr int CSEG = 2048;
+#ifndef TCMI_COPY_RING
+#define TCMI_COPY_RING 8192
+#endif
+#ifndef TCMI_COPY_SEG
+#define TCMI_COPY_SEG 2048
+#endif
+constexpr int CWIN = TCMI_COPY_RING, CWMASK = CWIN - 1;       // bgzf_copy's ring of recent output
+constexpr int CSEG = TCMI_COPY_SEG;
 // a round of bgzf_copy writes the literals of up to CSEG + 258 bytes ahead of the match it copies: what a match may still read
 // from the ring ends that much earlier; a source further back has been flushed (CWIN >= 2 CSEG + 522)
 constexpr int CNEAR = CWIN - CSEG - 264;

@@ -887,17 +887,34 @@ struct CopyArgs {
     uint32_t team_bytes;        // a batch of 64 tokens with at most this many bytes of output copies its matches in teams
 };
 
-// the copy loop of the plain (and the far) matches, hand-scheduled; LOOPBACK: the two lines that go on with the next match (or nothing: one match a call)
-#define TCMI_LM_ASM(LOOPBACK) \
+// The copy loop of the matches of a stretch, hand-scheduled.  mm: the matches still to be copied; pm: those of them that are plain
+// (source in the ring or parked next to it, no overlap closer than 64 bytes).  Outer loop: the plain matches in front of the first
+// other one are copied without asking what they are — 16 instructions for up to 64 bytes, 7 per further 64; the lane mask of a
+// round comes from one v_cmpx on the packed operand (len << 16 | address > lane << 16 | 0xffff  <=>  len > lane) —; then the other
+// one: a far match (source flushed to HBM long ago) is copied here too, 64 bytes a load; anything else leaves with its lane in j
+// (C++ copies it: short periods, ranges across the ring's end) — or j = -1: all done.
+#define TCMI_LM_ASM() \
                     asm volatile( \
                         "s_mov_b64 s[92:93], exec\n" \
+                        "LO%=:\n" \
+                        "s_andn2_b64 s[80:81], %[mm], %[pm]\n" \
+                        "s_ff1_i32_b64 %[j], s[80:81]\n" \
+                        "s_mov_b64 s[82:83], %[mm]\n" \
+                        "s_cmp_lt_i32 %[j], 0\n" \
+                        "s_cbranch_scc1 LR%=\n" \
+                        "s_lshl_b64 s[82:83], 1, %[j]\n" \
+                        "s_sub_u32 s82, s82, 1\n" \
+                        "s_subb_u32 s83, s83, 0\n" \
+                        "s_and_b64 s[82:83], s[82:83], %[mm]\n" \
+                        "LR%=:\n" \
+                        "s_andn2_b64 %[mm], %[mm], s[82:83]\n" \
+                        "s_cmp_eq_u64 s[82:83], 0\n" \
+                        "s_cbranch_scc1 LN%=\n" \
                         "LM%=:\n" \
-                        "s_ff1_i32_b64 %[j], %[mm]\n" \
-                        "v_readlane_b32 %[sb], %[vB], %[j]\n" \
-                        "v_readlane_b32 %[sa], %[vA], %[j]\n" \
-                        "s_cmp_lt_u32 %[sb], 0x10000\n" \
-                        "s_cbranch_scc0 LMf%=\n" \
-                        "s_bitset0_b64 %[mm], %[j]\n" \
+                        "s_ff1_i32_b64 s84, s[82:83]\n" \
+                        "v_readlane_b32 %[sa], %[vA], s84\n" \
+                        "v_readlane_b32 %[sb], %[vB], s84\n" \
+                        "s_bitset0_b64 s[82:83], s84\n" \
                         "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
                         "s_and_b32 %[len], %[sa], 0xffff\n" \
                         "v_add_u32 %[t0], %[sb], %[vlane]\n" \
@@ -909,8 +926,38 @@ struct CopyArgs {
                         "s_cbranch_scc1 LM2%=\n" \
                         "LM1%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
-                        LOOPBACK \
+                        "s_cmp_lg_u64 s[82:83], 0\n" \
+                        "s_cbranch_scc1 LM%=\n" \
+                        "LN%=:\n" \
+                        "s_cmp_lt_i32 %[j], 0\n" \
+                        "s_cbranch_scc1 LMx%=\n" \
+                        "v_readlane_b32 %[sb], %[vB], %[j]\n" \
+                        "v_readlane_b32 %[sa], %[vA], %[j]\n" \
+                        "s_cmp_lt_u32 %[sb], 0x20000\n" \
+                        "s_cbranch_scc0 LMx%=\n" \
+                        "s_bitset0_b64 %[mm], %[j]\n" \
+                        "v_readlane_b32 %[sb], %[vC], %[j]\n" \
+                        "s_lshr_b32 %[len], %[sa], 16\n" \
+                        "s_and_b32 %[sa], %[sa], 0xffff\n" \
+                        "v_add_u32 %[t1], %[sa], %[vlane]\n" \
+                        "v_add_u32 %[t0], %[sb], %[vlane]\n" \
+                        "LMg%=:\n" \
+                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
+                        "s_mov_b64 exec, vcc\n" \
+                        "global_load_ubyte %[t2], %[t0], %[outp]\n" \
+                        "s_waitcnt vmcnt(0)\n" \
+                        "ds_write_b8 %[t1], %[t2]\n" \
+                        "s_mov_b64 exec, s[92:93]\n" \
+                        "s_cmp_gt_u32 %[len], 64\n" \
+                        "s_cbranch_scc0 LF1%=\n" \
+                        "s_sub_u32 %[len], %[len], 64\n" \
+                        "v_add_u32 %[t0], 64, %[t0]\n" \
+                        "v_add_u32 %[t1], 64, %[t1]\n" \
+                        "s_branch LMg%=\n" \
+                        "LF1%=:\n" \
                         "s_mov_b32 %[j], -1\n" \
+                        "s_cmp_lg_u64 %[mm], 0\n" \
+                        "s_cbranch_scc1 LO%=\n" \
                         "s_branch LMx%=\n" \
                         "LM2%=:\n" \
                         "s_sub_u32 %[sa], %[sa], 0x400000\n" \
@@ -940,33 +987,11 @@ struct CopyArgs {
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2] offset:256\n" \
                         "s_branch LM1%=\n" \
-                        "LMf%=:\n" \
-                        "s_cmp_lt_u32 %[sb], 0x20000\n" \
-                        "s_cbranch_scc0 LMx%=\n" \
-                        "s_bitset0_b64 %[mm], %[j]\n" \
-                        "v_readlane_b32 %[sb], %[vC], %[j]\n" \
-                        "s_lshr_b32 %[len], %[sa], 16\n" \
-                        "s_and_b32 %[sa], %[sa], 0xffff\n" \
-                        "v_add_u32 %[t1], %[sa], %[vlane]\n" \
-                        "v_add_u32 %[t0], %[sb], %[vlane]\n" \
-                        "LMg%=:\n" \
-                        "v_cmp_gt_u32 vcc, %[len], %[vlane]\n" \
-                        "s_mov_b64 exec, vcc\n" \
-                        "global_load_ubyte %[t2], %[t0], %[outp]\n" \
-                        "s_waitcnt vmcnt(0)\n" \
-                        "ds_write_b8 %[t1], %[t2]\n" \
-                        "s_mov_b64 exec, s[92:93]\n" \
-                        "s_cmp_gt_u32 %[len], 64\n" \
-                        "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[len], %[len], 64\n" \
-                        "v_add_u32 %[t0], 64, %[t0]\n" \
-                        "v_add_u32 %[t1], 64, %[t1]\n" \
-                        "s_branch LMg%=\n" \
                         "LMx%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
                         : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) \
-                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [outp] "s"(out) \
-                        : "s92", "s93", "vcc", "scc", "memory");
+                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [outp] "s"(out), [pm] "s"(plain_mask) \
+                        : "s80", "s81", "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
 
 // TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
 // both are right for any input — the lean one is 4 % faster where no batch would use teams)
@@ -1223,8 +1248,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // matches — the same record 289 bytes back, say — only two or three matches at a time are independent.)
         const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
         const bool teamable = is_match && (vB >> 16) == 0u;
+        const unsigned long long plain_mask = __ballot(teamable);  // (plain matches, parked far ones included: what the copy loop takes unasked)
         const uint32_t srcend = teamable ? (vB >= (uint32_t)CWIN ? 0u : dst - dist + mylen) : 0xFFFFFFFFu;
-        const unsigned long long team_mask = __ballot(teamable);
+        const unsigned long long team_mask = plain_mask;
         uint32_t t_cur = 0;
         while (t_cur < 64u) {
             // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
@@ -1321,15 +1347,15 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                           "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
                     if (!mm) break;
                 }
-                // the plain matches of the round, one after the other (hand-scheduled: 18 instructions for a match of up to 64 bytes, 7 per further 64;
-                // the compiler's loop took 29), until one of another kind comes up: j says which (-1: none left).  (With teams: one.)
+                // the matches of the stretch, one after the other (TCMI_LM_ASM), until one comes up that C++ copies: j says which (-1: none
+                // left).  (With teams: one.)
                 int j;
                 {
                     uint32_t sa, sb, len, t0, t1, t2;
                     // (with teams: this match only — the loop is handed a set of one)
                     const unsigned long long rest = use_teams ? mm & (mm - 1ull) : 0ull;
                     mm ^= rest;
-                    TCMI_LM_ASM("s_cmp_lg_u64 %[mm], 0\n" "s_cbranch_scc1 LM%=\n")
+                    TCMI_LM_ASM()
                     mm |= rest;
                 }
                 if (j < 0) { if (use_teams) continue; break; }

@@ -9,6 +9,17 @@
 
 static thread_local std::string g_err;
 
+void *tcmi_ctx_pinned(tcmi_ctx *ctx, size_t bytes)
+{
+    if (ctx->h_pin_cap < bytes) {
+        if (ctx->h_pin) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; ctx->h_pin_cap = 0; }
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc((void **)&ctx->h_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_pin = nullptr; return nullptr; }
+        ctx->h_pin_cap = want;
+    }
+    return ctx->h_pin;
+}
+
 int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -131,6 +142,7 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     c->blob_pool.clear();
     if (c->tok_dev) (void)hipFree(c->tok_dev);
     if (c->tok_host) (void)hipHostFree(c->tok_host);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

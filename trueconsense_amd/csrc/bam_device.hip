@@ -594,15 +594,16 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, (int32_t)nb_own, d_total, d_desc, d_slot, d_out, d_over);
     TCMI_HIP(ctx, hipGetLastError());
     // the verdict of every block comes back to the host: a few bytes per block
-    std::vector<uint32_t> stat(nb);
-    std::vector<int32_t> over(nb);
-    std::vector<uint32_t> first(nb);
-    unsigned long long total = 0;
-    TCMI_HIP(ctx, hipMemcpyAsync(stat.data(), d_stat, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TCMI_HIP(ctx, hipMemcpyAsync(first.data(), d_first, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TCMI_HIP(ctx, hipMemcpyAsync(over.data(), d_over, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TCMI_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    char *pin = (char *)tcmi_ctx_pinned(ctx, nb * 12 + 16);
+    if (!pin) return tcmi_fail(ctx, TCMI_E_NOMEM, "pinned scratch for %zu block verdicts", nb);
+    const uint32_t *stat = (const uint32_t *)(pin + 16), *first = stat + nb;
+    const int32_t *over = (const int32_t *)(first + nb);
+    TCMI_HIP(ctx, hipMemcpyAsync((void *)stat, d_stat, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync((void *)first, d_first, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync((void *)over, d_over, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(pin, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long total = *(const unsigned long long *)pin;
     for (size_t b = 0; b < nb; ++b)
         if (stat[b] == ST_BAD_STREAM || stat[b] == ST_BAD_LENGTH)
             return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: BGZF block %zu failed to inflate (deflate stream or ISIZE damaged)", f->path.c_str(), b);

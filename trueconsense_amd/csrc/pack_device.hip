@@ -938,8 +938,10 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
     int32_t *blk_end = (int32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n_blk, 1) * 4);
     PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
     uint32_t *gen_idx = src.mode == 1 ? (uint32_t *)arena_take(ctx, (size_t)std::max<int64_t>(n, 1) * 4) : nullptr;
-    PackTotals tot;
-    std::memset(&tot, 0, sizeof tot);
+    PackTotals *h_tot = (PackTotals *)tcmi_ctx_pinned(ctx, sizeof(PackTotals));     // (pinned: the two read-backs below)
+    if (!h_tot) return tcmi_fail(ctx, TCMI_E_NOMEM, "pinned scratch for the packer's totals");
+    std::memset(h_tot, 0, sizeof *h_tot);
+    PackTotals &tot = *h_tot;
     TCMI_HIP(ctx, hipMemsetAsync(d_tot, 0, sizeof(PackTotals), ctx->stream));
     if (n > 0) {
         (void)hipGetLastError();
@@ -949,7 +951,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
         TCMI_HIP(ctx, hipGetLastError());
     }
-    TCMI_HIP(ctx, hipMemcpyAsync(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+    TCMI_HIP(ctx, hipMemcpyAsync(h_tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tot.flags) { *why = tot.flags; return TCMI_E_UNSUPPORTED; }
     const int64_t nf = (int64_t)tot.n_kept;
@@ -1023,7 +1025,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
                            (uint32_t)nf, (uint32_t)tot.n_words, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK);
         TCMI_HIP(ctx, hipGetLastError());
-        TCMI_HIP(ctx, hipMemcpyAsync(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+        TCMI_HIP(ctx, hipMemcpyAsync(h_tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
         TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (tot.n_events > event_cap && attempt == 0) {          // rare: a read set full of N / indel tokens — once more with room for all
             (void)hipFree(blob);

@@ -141,6 +141,10 @@ struct tcmi_ctx {
     // scratch of tcmi_readset_modal_tokens (columns, ranges, entries): device + pinned host, grow-only
     char *tok_dev = nullptr, *tok_host = nullptr;
     size_t tok_dev_cap = 0, tok_host_cap = 0;
+    // small read-backs of the cold path (block verdicts, packer totals) land in pinned memory of the context: a copy into pageable
+    // memory makes the runtime pin and unpin the destination's pages on every call
+    char *h_pin = nullptr;
+    size_t h_pin_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
@@ -187,6 +191,7 @@ struct tcmi_ctx {
 };
 
 int tcmi_fail(tcmi_ctx *ctx, int code, const char *fmt, ...);
+void *tcmi_ctx_pinned(tcmi_ctx *ctx, size_t bytes);             // >= bytes of the context's pinned scratch (grow-only; nullptr: no memory)
 #define TCMI_HIP(ctx, call)                                                                   \
     do {                                                                                      \
         hipError_t e__ = (call);                                                              \

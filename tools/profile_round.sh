@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/profile_round.sh TAG — the evidence set of a round, written under gpurun_out/TAG (copy what is to be judged into
 # profiles/): the default bench, the driver's shape (--steps 20 --warmup 5), the file -> FASTA leg under rocprofv3
-# --kernel-trace --stats, its PMC passes, the HBM-resident leg under rocprofv3 (tally kernel), the configs[2] / [4] shapes.
+# --kernel-trace --stats, its PMC passes, the HBM-resident leg under rocprofv3 (tally kernel), the configs[2] / [4] shapes, the
+# kernels alone on the GPU.  (tools/gpu_round_evidence.sh TAG: the > 4 GiB single-file run, a call of its own.)
 tag=$1
 out=gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -18,10 +19,13 @@ echo "e2e pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_resident -- python3 bench.py --only-resident > $out/bench_resident_under_rocprof.json 2> $out/rocprof_resident.err
 cp $(ls $out/stats_resident/*/*kernel_stats.csv | head -1) $out/resident_kernel_stats.csv
 echo "resident stats done"
-python3 bench.py --no-cpu-baseline --no-resident --indels --steps 8 --warmup 2 > $out/bench_indels.json 2> $out/bench_indels.err
+python3 bench.py --no-cpu-baseline --no-resident --no-cli-batch --indels --steps 8 --warmup 2 > $out/bench_indels.json 2> $out/bench_indels.err
 echo "indels done"
 python3 bench.py --split-bam --steps 100 --warmup 10 > $out/bench_split.json 2> $out/bench_split.err
 python3 bench.py --split-bam --from-file --reads 4000000 --steps 20 --warmup 3 > $out/bench_split_from_file.json 2> $out/bench_split_from_file.err
 echo "split done"
 python3 bench.py --host-decode --no-cpu-baseline --no-resident --steps 16 > $out/bench_host_decode.json 2> $out/bench_host_decode.err
+echo "host decode done"
+# the kernels with nothing else on the GPU (one context, one reader)
+bash tools/prof_e2e.sh $out/single --gpu-streams 1 --decoders 1 --steps 8 --min-seconds 0.1 > $out/single.log 2>&1
 echo done

@@ -6,7 +6,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT)
 import bench                                                     # noqa: E402
 from trueconsense_amd import synthetic as sy                     # noqa: E402
-from trueconsense_amd.engine import Context, FileRunner          # noqa: E402
+from trueconsense_amd.engine import Context, DeviceBam, FileRunner   # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 ref, orfs = sy.make_reference()
@@ -16,12 +16,16 @@ paths, _ = bench.write_inputs(tmp, ref, orfs, 8, 1_000_000, 0, False, 6)
 hard, _ = bench.write_inputs(tmp + "_i", ref, orfs, 4, 300_000, 1, True, 6) if os.makedirs(tmp + "_i", exist_ok=True) is None else (None, None)
 paths = paths + hard
 ctx = Context(0)
-runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=2, decode_threads=8, walkers=2, gpu_streams=3)
+runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=3, decode_threads=8, walkers=2, gpu_streams=5)
 want = runner.run(paths, names=["S"] * len(paths), ref_len=L)
-t0, n, bad = time.time(), 0, 0
+dbams = [DeviceBam(p).to_device(ctx) for p in paths]             # ... and the same files with their bytes resident in HBM, turn about
+t0, n, bad, turn = time.time(), 0, 0, 0
 while time.time() - t0 < seconds:
-    files = [paths[i % len(paths)] for i in range(96)]
-    got = runner.run(files, names=["S"] * len(files), ref_len=L)
+    turn += 1
+    if turn % 2:
+        got = runner.run([paths[i % len(paths)] for i in range(96)], names=["S"] * 96, ref_len=L)
+    else:
+        got = runner.run_resident([dbams[i % len(paths)] for i in range(96)], names=["S"] * 96, ref_len=L)
     for i, g in enumerate(got):
         n += 1
         if g != want[i % len(paths)]:

@@ -91,6 +91,20 @@ def test_device_inflate_and_record_index_match_zlib(ctx, tmp_path):
         p = str(tmp_path / ("far%d.bam" % level))
         bamwriter.write_bam(p, far, "MN908947.3", len(ref), level=level)
         check_decode(ctx, p).close()
+    # a file that compresses like real data (6 : 1): distinct names, qualities from four bins — thousands of short matches per block,
+    # the ones bgzf_copy hands to teams of lanes, a fifth of them further back than its LDS ring
+    nh = 80_000
+    hard = sy.make_reads(ref, nh, seed=12)
+    qual = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(nh, 150), p=[0.02, 0.05, 0.13, 0.80])
+    names = rng.integers(48, 58, (nh, 27)).astype(np.uint8)
+    names[:, :10] = np.frombuffer(b"A00123:45:", np.uint8)
+    for level in (6, 1):
+        p = str(tmp_path / ("hard%d.bam" % level))
+        bamwriter.write_bam_fast(p, hard["pos"], hard["flag"], hard["seq"].reshape(nh, -1), 150, "MN908947.3", len(ref), level=level, qual=qual, names=names)
+        d = check_decode(ctx, p)
+        assert d.inflated_bytes < 12 * d.file_bytes              # (the ratio below which the host picks the team variant)
+        d.close()
+        check_counts(ctx, p, len(ref))
     # no reads at all; one read
     empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v) for k, v in reads.items()}
     empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))

@@ -379,7 +379,7 @@ def main():
     ap.add_argument("--decoders", type=int, default=0, help="BAMs being decoded at a time (0 = auto)")
     ap.add_argument("--decode-threads", type=int, default=0, help="native threads per BAM decode (0 = auto)")
     ap.add_argument("--walkers", type=int, default=2)
-    ap.add_argument("--gpu-streams", type=int, default=5, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
+    ap.add_argument("--gpu-streams", type=int, default=8, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
     ap.add_argument("--host-decode", action="store_true", help="decode the BAMs on the host (tcmi_bam_load) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")

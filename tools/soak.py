@@ -16,7 +16,7 @@ paths, _ = bench.write_inputs(tmp, ref, orfs, 8, 1_000_000, 0, False, 6)
 hard, _ = bench.write_inputs(tmp + "_i", ref, orfs, 4, 300_000, 1, True, 6) if os.makedirs(tmp + "_i", exist_ok=True) is None else (None, None)
 paths = paths + hard
 ctx = Context(0)
-runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=3, decode_threads=8, walkers=2, gpu_streams=5)
+runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=3, decode_threads=8, walkers=2, gpu_streams=8)
 want = runner.run(paths, names=["S"] * len(paths), ref_len=L)
 dbams = [DeviceBam(p).to_device(ctx) for p in paths]             # ... and the same files with their bytes resident in HBM, turn about
 t0, n, bad, turn = time.time(), 0, 0, 0

@@ -131,7 +131,7 @@ def run_batch(a):
     cores = max(1, min(int(a.threads), os.cpu_count() or 1))
     runner = FileRunner(int(os.environ.get("TCMI_DEVICE", "0")), gffrows, a.coverage_level, a.noambiguity is False,
                         decoders=min(4, max(1, cores // 4)), decode_threads=max(1, cores // 2), walkers=min(4, max(1, cores // 4)),
-                        gpu_streams=(5 if len(rows) > 8 else 3) if len(rows) > 2 else 1)
+                        gpu_streams=(8 if len(rows) > 16 else 3) if len(rows) > 2 else 1)
     runner.set_outputs(refID, refseq, vcf_header(date.today().strftime("%Y%m%d"), sys.argv[1:], a.reference, refID), IndexGff.header.raw_text,
                        [gff_row_columns(r) for r in gffrows])
     try:

@@ -614,6 +614,12 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     out.update(cold_rooflines(a, out["cold_kernels_pipelined"], cold, os.path.getsize(paths[0]), out["config"].get("bam_inflated_bytes", 0), reads0))
     if "all_kernels_of_a_bam" in out["roofline"].get("issue", {}):
         out["roofline"]["issue"]["all_kernels_of_a_bam"]["ms_per_step_pipelined"] = out["ms_per_step"] * world
+    # (`achieved` divides by the average duration of ONE launch; with several contexts the launches of different BAMs overlap and
+    #  each one is stretched by the others.  What the kernel class moves per second of the timed run:)
+    for blk in ("roofline", "roofline_hot_path"):
+        agg = out[blk]["bytes_per_launch"] / (out["ms_per_step"] * world * 1e-3) / 1e9
+        out[blk]["aggregate"] = {"achieved": agg, "frac": agg / HBM_PEAK_GBS, "unit": "GB/s",
+                                 "note": "bytes_per_launch x launches / timed seconds (launches of %d contexts overlap)" % a.gpu_streams}
     # ---- secondary: reads resident in HBM, the tally kernel's rate and its roofline ----------------------------
     if not a.no_resident:
         res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/prof_e2e.sh OUTDIR [bench args...] — rocprofv3 --kernel-trace --stats over a short file -> FASTA bench leg (every kernel
-# (three GPU contexts: with five — the bench's default — rocprofv3 7.2 segfaults in its own copy of an API record, twice out of twice)
+# (three GPU contexts: with five or more — the bench runs eight by default — rocprofv3 7.2 segfaults in its own copy of an API record, twice out of twice)
 # of the cold path: bgzf_symbols, bgzf_copy, bgzf_crc32, rec_*, pk_*, tally_planes_kernel, call_kernel); the stats CSV lands in OUTDIR.
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

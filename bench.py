@@ -379,7 +379,7 @@ def main():
     ap.add_argument("--decoders", type=int, default=0, help="BAMs being decoded at a time (0 = auto)")
     ap.add_argument("--decode-threads", type=int, default=0, help="native threads per BAM decode (0 = auto)")
     ap.add_argument("--walkers", type=int, default=2)
-    ap.add_argument("--gpu-streams", type=int, default=8, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between")
+    ap.add_argument("--gpu-streams", type=int, default=0, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between (0 = auto: 8, fewer on a host with few cores per rank — a context's thread spins while it waits for its stream)")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
     ap.add_argument("--host-decode", action="store_true", help="decode the BAMs on the host (tcmi_bam_load) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,6 +433,8 @@ def main():
     cores = min(cores, 16)                                       # the box's CPU share per GPU
     decoders = a.decoders or (3 if cores >= 12 else 2 if cores >= 8 else 1)     # (readers are near their limit at two on slower hosts)
     decode_threads = a.decode_threads or max(1, cores // decoders)
+    if a.gpu_streams <= 0:
+        a.gpu_streams = min(8, max(3, cores // 2))
 
     if a.only_resident:
         ctx = Context(local_rank)

@@ -1,5 +1,6 @@
 # kernel times of the device BGZF decoder (bgzf_symbols + bgzf_copy, or bgzf_inflate under TCMI_INFLATE_LEGACY=1), from HIP
-# events, single stream: python3 tools/inflate_time.py [headline|hard] [n_reads]
+# events, single stream: python3 tools/inflate_time.py [headline|hard|real] [n_reads]
+# (real: distinct names and qualities drawn like an Illumina run's — 3.3 : 1, what samtools writes for real data)
 import os, sys, time, tempfile, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from trueconsense_amd import synthetic as sy, engine, _ffi
@@ -16,6 +17,12 @@ if kind == "hard":
     reads["name_off"] = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.uint64)
     reads["names"] = np.frombuffer(b"".join(names), np.uint8).copy()
     bamwriter.write_bam(p, reads, "MN908947.3", L, level=6)
+elif kind == "real":
+    rng = np.random.default_rng(2)
+    q = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=(lambda w: w / w.sum())(np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004))
+    names = rng.integers(48, 58, (n, 27)).astype(np.uint8)
+    names[:, :10] = np.frombuffer(b"A00123:45:", np.uint8)
+    bamwriter.write_bam_fast(p, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=6, qual=q, names=names)
 else:
     bamwriter.write_bam_fast(p, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=6)
 ctx = engine.Context(0); db = engine.DeviceBam(p)

@@ -114,6 +114,7 @@ struct SymArgs {
     uint32_t *status;           // [n_blocks]
     int32_t n_blocks;
     uint32_t pay_dwords;        // dwords of dynamic LDS per block behind SymLds: the largest block's payload + slack
+    uint32_t win_dwords;        // bgzf_symbols<1, true>: dwords of payload staged at a time (a window that moves along the block)
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
 };
 #define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -202,7 +203,7 @@ enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
 // -> T.go = 1 and T.pos at the first symbol (a Huffman block), or the block's stream is finished / damaged (T.go = 0).  Stored
 // deflate blocks are turned into raw tokens here and the next header is taken at once.
 __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
-                                          uint64_t *stamps, int blk)
+                                          uint64_t *stamps, int blk, bool one_header = false)
 {
     const int lane = threadIdx.x & 63;
     uint32_t pos = uni(T.pos), ntok = uni(T.ntok), err = ST_OK;
@@ -232,6 +233,7 @@ __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const ui
             }
             ntok += pieces;
             pos += len * 8u;
+            if (one_header) break;                              // (the caller stages the payload behind the stored bytes first)
             continue;
         }
         if (type == 3) { err = ST_BAD_STREAM; break; }
@@ -333,9 +335,13 @@ __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const ui
     if (lane == 0) { T.pos = pos; T.ntok = ntok; T.err = err; T.go = go && err == ST_OK ? 1u : 0u; T.last = last ? 1u : 0u; }
 }
 
-template <int NB>
+// WIN (one block per workgroup): the payload is staged a window at a time.  A block of a file that compresses 2 - 4 : 1 has 16 - 26 KB of
+// payload; staged whole, four workgroups fit a CU and a BAM's blocks take four rounds and a half.  With a window of 6 KB pass A runs
+// over the symbols that START in the window, the chain's last lane says where the next window begins, and the tables stay.
+template <int NB, bool WIN>
 __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SYM_WAVES, TCMI_SYM_WAVES))) void bgzf_symbols(SymArgs a)
 {
+    static_assert(!WIN || NB == 1, "a window per wavefront");
     constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
     static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
     __shared__ SymLds<NB> L;
@@ -346,9 +352,11 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
     const int blk = blk0 + wave;                    // this wavefront's block (header, tables)
     const bool have = blk < a.n_blocks;
     BlkTabs &T = L.b[wave];
-    uint32_t *const pay = pay_all + (size_t)wave * a.pay_dwords;
+    uint32_t *const pay_lds = pay_all + (size_t)wave * (WIN ? a.win_dwords : a.pay_dwords);
+    const uint32_t *pay = pay_lds;                  // (WIN: moved so that pay[dword of the payload] hits the staged window)
     BlockDesc d = {};
     if (have) d = a.blocks[blk];
+    const uint32_t *const gsrc = a.file32 + (d.cin >> 2);
     uint32_t *const toks = a.tokens + d.tok;
     const uint32_t base_bit = (uint32_t)(d.cin & 3u) * 8u;
     const uint32_t end = base_bit + d.clen * 8u;                    // first bit behind the payload
@@ -356,30 +364,51 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
     if (have) {
         if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
         TCMI_STAMP(a.stamps, blk, 0);
-        const uint32_t *src = a.file32 + (d.cin >> 2);
-        const uint32_t n = min(a.pay_dwords, (end + 31u) / 32u + 6u);
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay[i] = src[i];
+        if constexpr (!WIN) {
+            const uint32_t n = min(a.pay_dwords, (end + 31u) / 32u + 6u);
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay_lds[i] = gsrc[i];
+        }
     }
     if (lane == 0) { T.pos = base_bit; T.end = end; T.ntok = 0; T.err = ST_OK; T.go = 0; T.last = 0; T.seg = 0; }
     wave_sync();
     if (have) TCMI_STAMP(a.stamps, blk, 1);
     bool last = !have;
+    bool hdr_due = true;                            // WIN: the next thing at T.pos is a deflate header (else: more symbols of the stream)
+    uint32_t soft_end = end;                        // WIN: first bit behind the symbols this window's pass A takes
     for (;;) {
+        if constexpr (WIN) {
+            // ---- the window: from the dword of T.pos on (a header fits in well under a window; so does a symbol behind the soft end)
+            if (have && uni(T.err) == ST_OK && (!last || !hdr_due)) {
+                const uint32_t wfirst = uni(T.pos) >> 5, total_dw = (end + 31u) / 32u + 6u;
+                const uint32_t n = min(a.win_dwords, total_dw - min(total_dw, wfirst));
+                wave_sync();
+                for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay_lds[i] = gsrc[wfirst + i];
+                wave_sync();
+                pay = pay_lds - wfirst;
+                soft_end = min(end, (wfirst + a.win_dwords - 6u) * 32u);
+            }
+        }
         // ---- every wavefront: its block's next header and tables ------------------------------------------------------------------
-        if (have && uni(T.err) == ST_OK && !last) block_header(T, L.h[wave], pay, base_bit, toks, d.tok_cap, last, a.stamps, blk);
-        else if (lane == 0) T.go = 0;
+        if (have && uni(T.err) == ST_OK && (!last || (WIN && !hdr_due))) {         // (WIN, !hdr_due: the stream's symbols go on in the new window)
+            if (!WIN || hdr_due) block_header(T, L.h[wave], pay, base_bit, toks, d.tok_cap, last, a.stamps, blk, WIN);
+        } else if (lane == 0) T.go = 0;
         __syncthreads();
         uint32_t any = 0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) any |= L.b[k].go;
-        if (uni(any) == 0) break;                   // (all streams finished or failed)
+        if (uni(any) == 0) {
+            if (WIN && have && uni(T.err) == ST_OK && !last) continue;     // (a stored block became tokens: the header behind it is next)
+            break;                                  // (all streams finished or failed)
+        }
+        if constexpr (WIN) hdr_due = false;
         if (wave == 0) {
             // ---- wavefront 0: the symbols of all four blocks, 16 lanes each ------------------------------------------------------
             const int b = lane / SYM_LANES, c = lane % SYM_LANES, lane0 = lane - c;       // block, lane in the block, the block's first lane
             BlkTabs &B = L.b[b];
-            const uint32_t *const bp = pay_all + (size_t)b * a.pay_dwords;
+            const uint32_t *const bp = WIN ? pay : pay_all + (size_t)b * a.pay_dwords;
             const bool on = B.go != 0;
             const uint32_t b_end = B.end, start = B.pos;
+            const uint32_t b_soft = WIN ? soft_end : b_end;     // where the lanes stop taking symbols (WIN: the window's end)
             const BlockDesc bd = blk0 + b < a.n_blocks ? a.blocks[blk0 + b] : BlockDesc{};
             uint32_t *const btok = a.tokens + bd.tok;
             const uint32_t bcap = bd.tok_cap;
@@ -420,15 +449,15 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             // first symbol start p in the stretch (and how many symbols it had decoded by then) in a ring of its own, and looks
             // p up in the ring of its target — the nearest lane in front that is still decoding, or the lane that one met.  Equal
             // positions are one trajectory from there on: the lane stops, its target's symbols from that one on are the true ones.
-            const uint32_t chunk = on ? (b_end - start + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
+            const uint32_t chunk = on ? (b_soft - min(b_soft, start) + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
             // stretches of >= 64 bits (a symbol takes <= 48: none is skipped), about chunk / 4: a lane trails its target by about
             // a chunk, RING stretches are kept
             const uint32_t shift = max(6u, 30u - (uint32_t)__builtin_clz(chunk | 1u));
             const uint32_t s_c = start + (uint32_t)c * chunk;
             enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
-            uint32_t state = on && s_c < b_end ? RUN : DEAD;
+            uint32_t state = on && s_c < b_soft ? RUN : DEAD;
             uint32_t tgt = (uint32_t)c + 1u, total = 0, midx = 0;
-            uint32_t p = min(s_c, b_end);
+            uint32_t p = min(s_c, b_soft);
             uint32_t kprev = 0xFFFFFFFFu;
             bool spilled = false;                   // more symbols than the scratch holds: pass B decodes this block again
             uint32_t rounds = 0;
@@ -520,7 +549,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     "s_cbranch_execz LX%=\n"
                     "LC%=:\n"
                     // ---- one symbol
-                    "v_cmp_lt_u32 vcc, %[p], %[end]\n"
+                    "v_cmp_lt_u32 vcc, %[p], %[wend]\n"
                     "s_xor_b64 s[86:87], vcc, exec\n"
                     "s_cmp_lg_u64 s[86:87], 0\n"
                     "s_cbranch_scc1 LDend%=\n"
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     "s_mov_b64 exec, s[92:93]\n"
                     : [p] "+v"(p), [total] "+v"(total), [tgt] "+v"(tgt_abs), [midx] "+v"(midx), [kprev] "+v"(kprev), [state] "+v"(state),
                       [room] "+v"(room), [crossp] "+v"(crossp), [crosst] "+v"(crosst), [sptr] "+v"(sptr), [run] "+s"(run), [rounds] "+s"(rounds)
-                    : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim),
+                    : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [wend] "v"(b_soft), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim),
                       [ringbase] "s"(ringbase), [recbase] "s"(recbase), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
                       [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)),
                       [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d))
@@ -794,6 +823,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             uint32_t before = 0;                    // symbols a lane decoded in front of its true start: they do not count
             bool alive = on && c == 0;
             uint32_t eob_pos = 0, berr = ST_OK;
+            bool more = false;                      // WIN: the stream goes on behind this window (no end-of-block code yet)
             for (int bb = 0; bb < SYM_BLOCKS; ++bb) {
                 if (uni(L.b[bb].go) == 0) continue;
                 uint32_t cc = (uint32_t)bb * SYM_LANES;
@@ -806,7 +836,11 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                         cc = t;
                     } else {
                         const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)cc);
-                        if (b == bb) { if (st == EOB) eob_pos = pp; else berr = ST_BAD_STREAM; }
+                        if (b == bb) {
+                            if (st == EOB) eob_pos = pp;
+                            else if (WIN && st == DEAD && pp >= b_soft && pp <= b_end && b_soft < b_end) { eob_pos = pp; more = true; }   // the window's end: on from there
+                            else berr = ST_BAD_STREAM;
+                        }
                         break;
                     }
                 }
@@ -827,7 +861,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             TCMI_STAMP(a.stamps, blk0, 5);
             // The block's only deflate stream (the usual BGZF block): the tokens stay where they are parked and bgzf_copy gets the
             // list of pieces.  Otherwise they are moved behind the tokens the block has already.
-            const bool pieces = on && berr == ST_OK && B.last != 0 && ntok0 == 0 && !block_redo;
+            const bool pieces = on && berr == ST_OK && B.last != 0 && ntok0 == 0 && !block_redo && !more;
             if (on && blk0 + b < a.n_blocks) {
                 uint32_t *seg = a.seg + (size_t)(blk0 + b) * 128;
                 seg[c] = pieces ? bcap + (uint32_t)c * lane_cap + before : 0u;
@@ -849,7 +883,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 } else {
                     // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------
                     // (the position of a lane's true start is not kept: decode from the lane's own start and drop `before` symbols)
-                    uint32_t pp = min(s_c, b_end);
+                    uint32_t pp = min(s_c, b_soft);
                     for (uint32_t i = 0; alive && i < before + cnt; ++i) {
                         uint32_t tok = 0;
                         (void)symbol(pp, tok);
@@ -860,6 +894,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             TCMI_STAMP(a.stamps, blk0, 6);
             if (on && c == 0) B.seg = pieces ? 1u : 0u;
             if (on && c == 0) { B.ntok = ntok0 + all; B.pos = eob_pos; B.err = berr; }
+            if constexpr (WIN) hdr_due = uni(__ballot(more) != 0 ? 1u : 0u) == 0u;       // (an end-of-block code was reached: a header comes next)
         }
         __syncthreads();
     }
@@ -1418,31 +1453,42 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.blocks = static_cast<const BlockDesc *>(g.d_desc);
     sa.tokens = g.d_tok; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)nb;
     sa.pay_dwords = g.pay_dwords;
+    sa.win_dwords = 0;
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
     // (measured on one 4 187-block file, kernel alone: 4 blocks per workgroup 372 us, 2: 285 us, 1: 325 us; on the harder file —
     //  4 611 blocks of 10.7 KB — 1 634 / 1 036 / 698 us: with larger payloads more lanes per block pay)
     const size_t pay = (size_t)g.pay_dwords * 4;
     const int per_wg = forced == 1 || forced == 2 || forced == 4 ? forced : pay <= 4096 ? 2 : 1;
-    const size_t dyn = (size_t)g.pay_dwords * 4 * per_wg;
+    // payloads of more than 16 KB (files that compress less than ~4 : 1) are staged a window of 8 KB at a time, bgzf_symbols<1, true>:
+    // 2.5 : 1 (26 KB a block): 2 766 -> 1 875 us per 1M-read file; at 6 : 1 (11 KB, eight workgroups per CU staged whole) windows cost more
+    // than they bring (413 -> 580 us): every window is a pass of its own (ring set-up, chain, tokens moved to their places)
+    static const int win_env = std::getenv("TCMI_SYM_WINDOW") ? std::atoi(std::getenv("TCMI_SYM_WINDOW")) : -1;      // (A/B: 0 = never, else the window's bytes)
+    const size_t win_bytes = per_wg == 1 ? (win_env >= 0 ? (size_t)win_env : pay > 16384 ? 8192u : 0u) : 0u;
+    const bool windowed = win_bytes >= 2048 && win_bytes + 24 < pay;
+    sa.win_dwords = windowed ? (uint32_t)(win_bytes / 4 + 6) : 0u;
+    const size_t dyn = windowed ? (size_t)sa.win_dwords * 4 : (size_t)g.pay_dwords * 4 * per_wg;
     static const bool attr_once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<2>)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<1>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<2>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<1>)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<1>)));
         return true;
     }();
     (void)attr_once;
     if (stamp_path) {                           // (diagnostic) how many workgroups of each kernel a compute unit really holds
         int occ_s = 0, occ_c = 0;
-        if (per_wg == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<2>), 128, dyn);
-        else if (per_wg == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1>), 64, dyn);
+        if (per_wg == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<2, false>), 128, dyn);
+        else if (windowed) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, true>), 64, dyn);
+        else if (per_wg == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, false>), 64, dyn);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false>), 64, 0);
-        std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
-                     nb, pay, per_wg, dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
+        std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d%s>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
+                     nb, pay, per_wg, windowed ? ", windowed" : "", dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
     }
     tcmi_prof_begin(ctx, TCMI_K_INFLATE);
-    if (per_wg == 4) hipLaunchKernelGGL(bgzf_symbols<4>, dim3((unsigned)((nb + 3) / 4)), dim3(256), dyn, ctx->stream, sa);
-    else if (per_wg == 2) hipLaunchKernelGGL(bgzf_symbols<2>, dim3((unsigned)((nb + 1) / 2)), dim3(128), dyn, ctx->stream, sa);
-    else hipLaunchKernelGGL(bgzf_symbols<1>, dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
+    if (per_wg == 4) hipLaunchKernelGGL((bgzf_symbols<4, false>), dim3((unsigned)((nb + 3) / 4)), dim3(256), dyn, ctx->stream, sa);
+    else if (per_wg == 2) hipLaunchKernelGGL((bgzf_symbols<2, false>), dim3((unsigned)((nb + 1) / 2)), dim3(128), dyn, ctx->stream, sa);
+    else if (windowed) hipLaunchKernelGGL((bgzf_symbols<1, true>), dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
+    else hipLaunchKernelGGL((bgzf_symbols<1, false>), dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
     CopyArgs ca;

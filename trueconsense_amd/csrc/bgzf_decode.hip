@@ -382,7 +382,18 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 const uint32_t wfirst = uni(T.pos) >> 5, total_dw = (end + 31u) / 32u + 6u;
                 const uint32_t n = min(a.win_dwords, total_dw - min(total_dw, wfirst));
                 wave_sync();
-                for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay_lds[i] = gsrc[wfirst + i];
+                {   // (8 bytes a lane, four loads in flight; the window starts on any dword of the file: unaligned access mode)
+                    const uint32_t n2 = (n + 1u) >> 1;
+                    uint2 *const dst2 = reinterpret_cast<uint2 *>(pay_lds);
+                    const uint32_t *const src = gsrc + wfirst;
+                    for (uint32_t i = (uint32_t)lane; i < n2; i += 256) {
+                        uint2 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (i + 64u * k < n2) __builtin_memcpy(&v[k], src + 2u * (i + 64u * k), 8);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (i + 64u * k < n2) dst2[i + 64u * k] = v[k];
+                    }
+                }
                 wave_sync();
                 pay = pay_lds - wfirst;
                 soft_end = min(end, (wfirst + a.win_dwords - 6u) * 32u);
@@ -873,12 +884,12 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 uint32_t *const dst = btok + ntok0 + (incl - cnt);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the scratch stores are this lane's own)
                 if (!block_redo) {
-                    for (uint32_t i = 0; i < cnt; i += 4) {         // (four loads in flight: the loop is all latency)
-                        uint32_t t[4];
+                    for (uint32_t i = 0; i < cnt; i += 8) {         // (eight loads in flight: the loop is all latency)
+                        uint32_t t[8];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) t[k] = i + k < cnt ? scratch[before + i + k] : 0u;
+                        for (int k = 0; k < 8; ++k) t[k] = i + k < cnt ? scratch[before + i + k] : 0u;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (i + k < cnt) dst[i + k] = t[k];
+                        for (int k = 0; k < 8; ++k) if (i + k < cnt) dst[i + k] = t[k];
                     }
                 } else {
                     // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------

@@ -15,7 +15,7 @@ Secondary blocks of the same JSON line:
   e2e_single_bam   one BAM file at a time, nothing overlapped: per-stage latency (configs[1] as written)
   cold_kernels, cold_kernels_pipelined   HIP-event times of every kernel, alone on the GPU and in the timed run
   roofline, roofline_hot_path            the dominant kernels against the 8 TB/s HBM roofline (+ `issue`: what does bound them)
-  hard_bam         a file that compresses like real data (6 : 1), one at a time, FASTA checked
+  hard_bam, real_bam   files that compress 6 : 1 and 2.5 : 1 (as real data does), one at a time and overlapped, FASTA checked
   cli_batch        the command line with --batch: all four output files per sample
   resident         reads already packed in HBM, 8 BAMs per launch: the tally kernel's rate (what round 1 called the headline)
   cpu_baseline     the same stages on this box's host cores: C restatement of decode + tally + call (oracle/),
@@ -607,6 +607,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     # ---- a file that compresses like real data (distinct names, binned random qualities): same pipeline, one BAM at a time ----
     if not a.indels and not a.host_decode and not a.no_hard_bam:
         out["hard_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx)
+        out["real_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx, kind="real")
 
     # ---- the command line itself with --batch: all four output files per sample, written by the native runner ----
     if not a.host_decode and not a.no_cli_batch:
@@ -713,10 +714,12 @@ def cli_batch_leg(a, paths, ref, orfs, L, sy, fastas):
                     "one) / (samples more): reader, GPU and walker stages overlapped, the walkers also write VCF, corrected GFF and coverage TSV"}
 
 
-def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx):
+def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx, kind="hard"):
     """tools/hard_bam.py's file shape at the bench's size: Illumina-style names (all distinct), qualities drawn from four bins —
     it compresses ~6 : 1 instead of 35 : 1, so a BGZF block holds six times the symbols and a fifth of its matches reach back
-    further than the decoder's LDS ring.  One BAM at a time through the same runner; kernel times from HIP events."""
+    further than the decoder's LDS ring.  One BAM at a time through the same runner; kernel times from HIP events.
+    kind "real": qualities drawn like an Illumina run's (a peak at Q36, a tail down to Q2) — 2.5 : 1, what real files compress like:
+    21 000 tokens and 26 KB of payload per block, two deflate streams in most blocks."""
     from trueconsense_amd.engine import DeviceBam, Walker
     from trueconsense_amd.io import bamwriter
     from oracle import c_oracle
@@ -725,13 +728,17 @@ def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx):
     n = a.reads
     rng = np.random.default_rng(1)
     reads = sy.make_reads(ref, n, seed=4242)
-    qual = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(n, 150), p=[0.02, 0.05, 0.13, 0.80])
+    if kind == "real":
+        w = np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004
+        qual = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=w / w.sum())
+    else:
+        qual = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(n, 150), p=[0.02, 0.05, 0.13, 0.80])
     def digits(v, w):
         return ((v[:, None] // 10 ** np.arange(w - 1, -1, -1)[None, :]) % 10 + 48).astype(np.uint8)
     lit = lambda t: np.tile(np.frombuffer(t, np.uint8), (n, 1))
     names = np.concatenate([lit(b"A00123:45:HXXXXX:"), digits(rng.integers(1, 5, n), 1), lit(b":"), digits(rng.integers(1101, 2679, n), 4), lit(b":"),
                             digits(rng.integers(1000, 33000, n), 5), lit(b":"), digits(rng.integers(1000, 37000, n), 5)], axis=1)
-    path = os.path.join(tmp, "hard.bam")
+    path = os.path.join(tmp, kind + ".bam")
     t0 = time.perf_counter()
     bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=a.level, qual=qual, names=names)
     t_gen = time.perf_counter() - t0
@@ -740,7 +747,7 @@ def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx):
     d.close()
     single.run([path], ref_len=L)
     lat = []
-    for _ in range(3):
+    for _ in range(3 if kind == "hard" else 2):
         t1 = time.perf_counter()
         text = single.run([path], names=["H"], ref_len=L)[0]
         lat.append(time.perf_counter() - t1)

@@ -477,3 +477,26 @@ def test_insert_tokens_resolved_on_the_device(ctx, tmp_path):
         changed |= len(want) != len(orc.region_tokens(rd, c, ignore_overlaps=False))
     assert changed
     rs.free(); d3.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("window", [2048, 4100])
+def test_windowed_symbol_decoder_at_small_windows(window, tmp_path):
+    """bgzf_symbols<1, true> stages a block's payload a window at a time (8 KB when a payload exceeds 16 KB).  Here the window is
+    forced small (the launcher reads TCMI_SYM_WINDOW once per process, hence a child process), so that every file of the
+    decoder tests above with payloads over 4 KB crosses many window ends: in the middle of a symbol, of a dynamic header,
+    of a stored block, of the last symbols before an end-of-block code.  Byte for byte against zlib, counts against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import pathlib, sys\n"
+            "from tests import test_bam_device as t\n"
+            "from trueconsense_amd import _state\n"
+            "ctx = _state.default_context()\n"
+            "for k, f in enumerate((t.test_device_inflate_and_record_index_match_zlib, t.test_device_inflate_on_other_deflate_flavours)):\n"
+            "    d = pathlib.Path(sys.argv[1]) / str(k); d.mkdir()\n"
+            "    f(ctx, d)\n"
+            "print('windowed ok')\n")
+    env = dict(os.environ, TCMI_SYM_WINDOW=str(window), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], cwd=root, env=env, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0 and "windowed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

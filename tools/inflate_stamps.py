@@ -23,3 +23,8 @@ print("  symbols kernel span (first start .. last end) %d ticks" % (s[:, 6].max(
 c = c[c[:, 7] > 0]
 print("  copy total mean %.1f max %d | tokens %.0f matches %.0f (not plain: %.0f) rounds %.0f team rounds %.0f (matches in them %.0f)" %
       ((c[:, 1] - c[:, 0]).mean(), (c[:, 1] - c[:, 0]).max(), c[:, 7].mean(), c[:, 5].mean(), c[:, 4].mean(), c[:, 6].mean(), c[:, 8].mean(), c[:, 9].mean()))
+if c[:, 10:15].any():                   # (a build with EXTRA=-DTCMI_COPY_PHASES)
+    for k, nm in enumerate(["token fetch + batch set-up", "stretch set-up, literals", "plain-match loop (TCMI_LM_ASM)", "other matches (copy_any)", "housekeeping"]):
+        print("  copy %-32s mean %9.1f" % (nm, c[:, 10 + k].mean()))
+    h = [c[:, 2] & 0xFFFFFFFF, c[:, 2] >> 32, c[:, 3] & 0xFFFFFFFF, c[:, 3] >> 32, c[:, 15] & 0xFFFFFFFF, c[:, 15] >> 32]
+    print("  copy plain matches per block by length: <8: %.0f  8-64: %.0f  65-128: %.0f  129-192: %.0f  193-256: %.0f  257+: %.0f" % tuple(x.mean() for x in h))

@@ -933,12 +933,16 @@ struct CopyArgs {
     uint32_t team_bytes;        // a batch of 64 tokens with at most this many bytes of output copies its matches in teams
 };
 
-// The copy loop of the matches of a stretch, hand-scheduled.  mm: the matches still to be copied; pm: those of them that are plain
-// (source in the ring or parked next to it, no overlap closer than 64 bytes).  Outer loop: the plain matches in front of the first
-// other one are copied without asking what they are — 16 instructions for up to 64 bytes, 7 per further 64; the lane mask of a
-// round comes from one v_cmpx on the packed operand (len << 16 | address > lane << 16 | 0xffff  <=>  len > lane) —; then the other
-// one: a far match (source flushed to HBM long ago) is copied here too, 64 bytes a load; anything else leaves with its lane in j
-// (C++ copies it: short periods, ranges across the ring's end) — or j = -1: all done.
+// The copy loop of the matches of a stretch, hand-scheduled.  mm: the matches still to be copied; pm: those of them the inner loop
+// takes unasked — plain (source in the ring or parked next to it, source and destination apart by the match's length at least) and
+// of eight bytes or more.  14 instructions a match: EIGHT bytes a lane at min(8 lane, len - 8) (the last piece overlaps the one
+// before instead of running past the end; LDS takes any byte address); the operands come packed for it (vA2 = (len - 1) << 16 |
+// (destination - 7) & 0xffff, vB2 = source - 7): one v_cmpx gives the lane mask (vA2 >= 8 lane << 16  <=>  len > 8 lane), one SDWA
+// v_min the piece's place + 7, two adds the addresses (the destination's within 16 bits); the NEXT match's operands are fetched
+// while the LDS read is under way.  (A CU of these wavefronts issues about one instruction a cycle, whatever its kind: what counts
+// is the number of instructions.)  Then the first other match: a plain one of 3 - 7 bytes goes byte-wise (LMs); a far match
+// (source flushed to HBM long ago) is copied here too, 64 bytes a load; anything else leaves with its lane in j (C++ copies it:
+// periods shorter than the match, ranges across the ring's end) — or j = -1: all done.
 #define TCMI_LM_ASM() \
                     asm volatile( \
                         "s_mov_b64 s[92:93], exec\n" \
@@ -958,20 +962,19 @@ struct CopyArgs {
                         "s_cbranch_scc1 LN%=\n" \
                         "LM%=:\n" \
                         "s_ff1_i32_b64 s84, s[82:83]\n" \
-                        "v_readlane_b32 %[sa], %[vA], s84\n" \
-                        "v_readlane_b32 %[sb], %[vB], s84\n" \
+                        "v_readlane_b32 %[sa], %[vA2], s84\n" \
+                        "v_readlane_b32 %[sb], %[vB2], s84\n" \
                         "s_bitset0_b64 s[82:83], s84\n" \
-                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
-                        "s_and_b32 %[len], %[sa], 0xffff\n" \
-                        "v_add_u32 %[t0], %[sb], %[vlane]\n" \
-                        "v_add_u32 %[t1], %[len], %[vlane]\n" \
+                        "s_cmp_lt_u32 %[sa], 0x400000\n" \
+                        "s_cbranch_scc0 LML%=\n" \
+                        "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n" \
+                        "v_add_u32 %[t0], %[sb], %[vlane7]\n" \
+                        "v_add_u32_sdwa %[t1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n" \
                         "ds_read_u8 %[t2], %[t0]\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
                         "ds_write_b8 %[t1], %[t2]\n" \
-                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
-                        "s_cbranch_scc1 LM2%=\n" \
-                        "LM1%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
+                        "LMe%=:\n" \
                         "s_cmp_lg_u64 s[82:83], 0\n" \
                         "s_cbranch_scc1 LM%=\n" \
                         "LN%=:\n" \
@@ -1005,39 +1008,40 @@ struct CopyArgs {
                         "s_cmp_lg_u64 %[mm], 0\n" \
                         "s_cbranch_scc1 LO%=\n" \
                         "s_branch LMx%=\n" \
-                        "LM2%=:\n" \
-                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
-                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
-                        "ds_read_u8 %[t2], %[t0] offset:64\n" \
+                        "LML%=:\n" \
+                        "v_readlane_b32 s85, %[vXl], s84\n" \
+                        "v_readlane_b32 s86, %[vYl], s84\n" \
+                        "v_readlane_b32 s87, %[vKl], s84\n" \
+                        "LMq%=:\n" \
+                        "s_lshr_b32 s88, s86, 16\n" \
+                        "v_add_u32 v48, s87, %[vlane32]\n" \
+                        "v_cmpx_gt_i32 vcc, 32, v48\n" \
+                        "v_add_u32_sdwa v49, s86, %[vlane4] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n" \
+                        "v_add_u32_sdwa v50, s85, %[vlane4] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n" \
+                        "ds_read2_b32 v[52:53], v49 offset1:1\n" \
+                        "ds_read_b32 v51, v50\n" \
+                        "v_max_i32 v48, 0, v48\n" \
+                        "v_lshrrev_b32_e64 v48, v48, -1\n" \
+                        "v_and_b32_sdwa v54, s85, %[vlane0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+                        "v_lshlrev_b32_e64 v54, v54, -1\n" \
+                        "v_and_b32 v48, v48, v54\n" \
                         "s_waitcnt lgkmcnt(0)\n" \
-                        "ds_write_b8 %[t1], %[t2] offset:64\n" \
-                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
-                        "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
-                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
-                        "ds_read_u8 %[t2], %[t0] offset:128\n" \
-                        "s_waitcnt lgkmcnt(0)\n" \
-                        "ds_write_b8 %[t1], %[t2] offset:128\n" \
-                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
-                        "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
-                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
-                        "ds_read_u8 %[t2], %[t0] offset:192\n" \
-                        "s_waitcnt lgkmcnt(0)\n" \
-                        "ds_write_b8 %[t1], %[t2] offset:192\n" \
-                        "s_cmp_gt_u32 %[sa], 0x40ffff\n" \
-                        "s_cbranch_scc0 LM1%=\n" \
-                        "s_sub_u32 %[sa], %[sa], 0x400000\n" \
-                        "v_cmpx_gt_u32 vcc, %[sa], %[vX]\n" \
-                        "ds_read_u8 %[t2], %[t0] offset:256\n" \
-                        "s_waitcnt lgkmcnt(0)\n" \
-                        "ds_write_b8 %[t1], %[t2] offset:256\n" \
-                        "s_branch LM1%=\n" \
+                        "v_alignbit_b32 v52, v53, v52, s88\n" \
+                        "v_bfi_b32 v51, v48, v52, v51\n" \
+                        "ds_write_b32 v50, v51\n" \
+                        "s_mov_b64 exec, s[92:93]\n" \
+                        "s_cmp_lt_i32 s87, -2016\n" \
+                        "s_cbranch_scc0 LMe%=\n" \
+                        "s_add_u32 s87, s87, 2048\n" \
+                        "s_add_u32 s85, s85, 256\n" \
+                        "s_and_b32 s85, s85, 0xffff\n" \
+                        "s_add_u32 s86, s86, 256\n" \
+                        "s_branch LMq%=\n" \
                         "LMx%=:\n" \
                         "s_mov_b64 exec, s[92:93]\n" \
                         : [mm] "+s"(mm), [j] "=&s"(j), [sa] "=&s"(sa), [sb] "=&s"(sb), [len] "=&s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) \
-                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [outp] "s"(out), [pm] "s"(plain_mask) \
-                        : "s80", "s81", "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
+                        : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [vA2] "v"(vA2), [vB2] "v"(vB2), [vXl] "v"(vXl), [vYl] "v"(vYl), [vKl] "v"(vKl), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7), [vlane4] "v"(lane_x4), [vlane32] "v"(lane_x32), [vlane0] "v"(lane0_31), [outp] "s"(out), [pm] "s"(plain_mask) \
+                        : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s92", "s93", "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 
 // TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
 // both are right for any input — the lean one is 4 % faster where no batch would use teams)
@@ -1072,6 +1076,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     uint32_t *slots = a.rec_slot + (size_t)blk * MAX_REC_PER_BLOCK;
     const uint32_t *const win32 = reinterpret_cast<const uint32_t *>(s_win);
     const uint32_t lane_hi = ((uint32_t)lane << 16) | 0xFFFFu;  // (len << 16 | anything) > lane_hi  <=>  len > lane: the copy round's lane mask from the packed operand
+    // per-lane constants of TCMI_LM_ASM's two copy rounds (bytes: lane + 7, lane << 16; dwords: 4 lane, 32 lane, lane 0's 31)
+    const uint32_t lane_p7 = (uint32_t)lane + 7u, lane_sh16 = (uint32_t)lane << 16, lane_x4 = (uint32_t)lane * 4u, lane_x32 = (uint32_t)lane * 32u;
+    const uint32_t lane0_31 = lane == 0 ? 31u : 0u;
     // (teams of eight lanes: lane l belongs to team l / 8 and takes that team's piece l % 8)
     const uint32_t team_of = (uint32_t)lane >> 3, team_sub = (uint32_t)lane & 7u, team_sub8 = team_sub * 8u;
     const uint32_t team_base = (uint32_t)(CWIN + FAR_WORDS * 4), team_slot = team_base + team_of * 8u;     // s_lds.team, as LDS addresses
@@ -1192,10 +1199,18 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     };
     if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
     TCMI_STAMP(a.stamps, blk, 0);
+#ifdef TCMI_COPY_PHASES                 // (diagnostic build: where a block's cycles go — batch set-up, match loop, other matches, housekeeping)
+    uint64_t ph_t = __builtin_amdgcn_s_memtime(), ph[5] = {0, 0, 0, 0, 0};
+    uint32_t hist[6] = {0, 0, 0, 0, 0, 0};     // plain matches of < 8, 8 - 64, 65 - 128, 129 - 192, 193 - 256, 257+ bytes
+#define PH(k_) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[k_] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define PH(k_) do { } while (0)
+#endif
     uint32_t n_match = 0, n_slow = 0, n_round = 0;
     const uint32_t n_team = 0, n_teamed = 0;
     housekeeping();
-    for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
+    // the tokens of the batch that starts at `base`, a token a lane (pieces: the lanes of bgzf_symbols parked them piece by piece)
+    auto fetch_tokens = [&](uint32_t base) __attribute__((always_inline)) {
         uint32_t t = 0;
         if (!pieces) {
             if (base + (uint32_t)lane < ntok) t = toks[base + (uint32_t)lane];
@@ -1211,6 +1226,11 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 ++p_cur;
             }
         }
+        return t;
+    };
+    uint32_t t_ahead = fetch_tokens(0);         // (a batch's tokens are asked for while the batch before is copied: HBM is a microsecond away)
+    for (uint32_t base = 0; base < ntok && err == ST_OK && !bad; base += 64) {
+        const uint32_t t = t_ahead;
         const bool is_lit = (t >> 31) != 0;
         const bool is_raw = !is_lit && (t & TOK_RAW);
         if (__builtin_expect(__ballot(is_raw) != 0, 0)) {
@@ -1241,6 +1261,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 }
                 if (op >= next_evt) housekeeping();
             }
+            t_ahead = base + 64u < ntok ? fetch_tokens(base + 64u) : 0u;
             continue;
         }
         const uint32_t mylen = is_lit ? 1u : (t & 511u);
@@ -1254,7 +1275,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
         const bool is_match = !is_lit && mylen != 0;
         const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
-        const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && (dist >= 64u || dist >= mylen) && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN;
+        const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && dist >= mylen && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN && (mylen <= 64u || sm >= 4u);
         const bool far_ok = dist > (uint32_t)CNEAR && dist + a0 <= dst && dm + mylen <= (uint32_t)CWIN;      // (its source is flushed when its turn comes: CNEAR)
         uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : far_ok ? 1u << 16 : 2u << 16);
         const uint32_t vC = dst - dist;                         // a far match's source, as a position
@@ -1294,10 +1315,27 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // matches — the same record 289 bytes back, say — only two or three matches at a time are independent.)
         const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
         const bool teamable = is_match && (vB >> 16) == 0u;
-        const unsigned long long plain_mask = __ballot(teamable);  // (plain matches, parked far ones included: what the copy loop takes unasked)
+        const unsigned long long plain_mask = __ballot(teamable);  // (plain matches, parked far ones included)
+        // TCMI_LM_ASM's operands of a plain match.  Up to 64 bytes, a byte a lane: (len - 1) << 16 | (destination - 7) & 0xffff and
+        // source - 7 (lane + 7 is added to both).  Longer ones, an ALIGNED destination dword a lane (LDS takes unaligned words at a
+        // fifth of the rate): the first dword's address | 8 (destination & 3) << 16; the aligned address of the source dword that
+        // holds the first dword's byte 0 | 8 (its place in it) << 16; and 32 - 8 (bytes from the first dword's start to the match's
+        // end): + 32 lane = how far a lane's mask of bytes is to be shifted down (< 32: the lane has bytes at all).
+        const uint32_t vA2 = ((mylen - 1u) << 16) | ((dm - 7u) & 0xFFFFu), vB2 = vB - 7u;
+        const uint32_t hoff = dm & 3u, s0 = sm - hoff;
+        const uint32_t vXl = (dm & ~3u) | (hoff * 8u) << 16, vYl = (s0 & 0xFFFCu) | ((s0 & 3u) * 8u) << 16, vKl = 32u - 8u * (hoff + mylen);
         const uint32_t srcend = teamable ? (vB >= (uint32_t)CWIN ? 0u : dst - dist + mylen) : 0xFFFFFFFFu;
         const unsigned long long team_mask = plain_mask;
         uint32_t t_cur = 0;
+        // (asked for HERE, behind the batch's set-up and its waits for earlier loads, in front of the copy loops: the load is under
+        //  way while the batch is copied)
+        t_ahead = base + 64u < ntok ? fetch_tokens(base + 64u) : 0u;
+#ifdef TCMI_COPY_PHASES
+        hist[0] += __popcll(__ballot(teamable && mylen < 8u)); hist[1] += __popcll(__ballot(teamable && mylen >= 8u && mylen <= 64u));
+        hist[2] += __popcll(__ballot(teamable && mylen > 64u && mylen <= 128u)); hist[3] += __popcll(__ballot(teamable && mylen > 128u && mylen <= 192u));
+        hist[4] += __popcll(__ballot(teamable && mylen > 192u && mylen <= 256u)); hist[5] += __popcll(__ballot(teamable && mylen > 256u));
+#endif
+        PH(0);
         while (t_cur < 64u) {
             // the tokens [t_cur, t_stop) start in front of the next housekeeping stop: their literals at once, their matches in order
             const unsigned long long from = ~0ull << t_cur;
@@ -1401,7 +1439,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                     // (with teams: this match only — the loop is handed a set of one)
                     const unsigned long long rest = use_teams ? mm & (mm - 1ull) : 0ull;
                     mm ^= rest;
+                    PH(1);
                     TCMI_LM_ASM()
+                    PH(2);
                     mm |= rest;
                 }
                 if (j < 0) { if (use_teams) continue; break; }
@@ -1409,11 +1449,14 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 copy_any((uint32_t)__builtin_amdgcn_readlane((int)dst, j), (uint32_t)__builtin_amdgcn_readlane((int)mylen, j),
                          (uint32_t)__builtin_amdgcn_readlane((int)dist, j));
                 ++n_slow;
+                PH(3);
             }
             op = t_stop < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)t_stop) : batch_end;
             t_cur = t_stop;
             ++n_round;
+            PH(1);
             if (op >= next_evt) { housekeeping(); if (err != ST_OK) break; }
+            PH(4);
             if (bad) break;
         }
     }
@@ -1446,6 +1489,10 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     }
     if (a.stamps && lane == 0) {
         uint64_t *st = a.stamps + (size_t)blk * 16;
+#ifdef TCMI_COPY_PHASES
+        for (int k = 0; k < 5; ++k) st[10 + k] = ph[k];
+        st[2] = hist[0] | (uint64_t)hist[1] << 32; st[3] = hist[2] | (uint64_t)hist[3] << 32; st[15] = hist[4] | (uint64_t)hist[5] << 32;
+#endif
         st[1] = __builtin_amdgcn_s_memtime(); st[4] = n_slow; st[5] = n_match; st[6] = n_round; st[7] = ntok; st[8] = n_team; st[9] = n_teamed;
     }
 }

@@ -5,7 +5,7 @@ import ast, json, os, re, sys
 src, committed_as = sys.argv[1], sys.argv[2]
 k = {}
 for line in open(src):
-    m = re.match(r"^([\w<>]+) (\{.*\}) n= (\d+)$", line.strip())
+    m = re.match(r"^([\w<>, ]+?) (\{.*\}) n= (\d+)$", line.strip())
     if not m:
         continue
     name = re.sub(r"<.*>", "", m.group(1))

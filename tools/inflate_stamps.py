@@ -26,5 +26,8 @@ print("  copy total mean %.1f max %d | tokens %.0f matches %.0f (not plain: %.0f
 if c[:, 10:15].any():                   # (a build with EXTRA=-DTCMI_COPY_PHASES)
     for k, nm in enumerate(["token fetch + batch set-up", "stretch set-up, literals", "plain-match loop (TCMI_LM_ASM)", "other matches (copy_any)", "housekeeping"]):
         print("  copy %-32s mean %9.1f" % (nm, c[:, 10 + k].mean()))
+    if os.environ.get("TCMI_COPY_PHASES") == "2":      # (built with EXTRA=-DTCMI_COPY_PHASES=2: the batch set-up in four parts)
+        print("  copy   of the set-up: wait for the tokens %.0f, length scan %.0f, classification + far parking %.0f, operands + prefetch %.0f" % (c[:, 2].mean(), c[:, 3].mean(), c[:, 15].mean(), c[:, 10].mean()))
+        sys.exit(0)
     h = [c[:, 2] & 0xFFFFFFFF, c[:, 2] >> 32, c[:, 3] & 0xFFFFFFFF, c[:, 3] >> 32, c[:, 15] & 0xFFFFFFFF, c[:, 15] >> 32]
     print("  copy plain matches per block by length: <8: %.0f  8-64: %.0f  65-128: %.0f  129-192: %.0f  193-256: %.0f  257+: %.0f" % tuple(x.mean() for x in h))

@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     if (a.stamps && lane < 16) a.stamps[(size_t)blk * 16 + lane] = 0;
     TCMI_STAMP(a.stamps, blk, 0);
 #ifdef TCMI_COPY_PHASES                 // (diagnostic build: where a block's cycles go — batch set-up, match loop, other matches, housekeeping)
-    uint64_t ph_t = __builtin_amdgcn_s_memtime(), ph[5] = {0, 0, 0, 0, 0};
+    uint64_t ph_t = __builtin_amdgcn_s_memtime(), ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t hist[6] = {0, 0, 0, 0, 0, 0};     // plain matches of < 8, 8 - 64, 65 - 128, 129 - 192, 193 - 256, 257+ bytes
 #define PH(k_) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[k_] += now_ - ph_t; ph_t = now_; } while (0)
 #else
@@ -1264,6 +1264,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             t_ahead = base + 64u < ntok ? fetch_tokens(base + 64u) : 0u;
             continue;
         }
+#if TCMI_COPY_PHASES == 2
+        PH(5);
+#endif
         const uint32_t mylen = is_lit ? 1u : (t & 511u);
         const uint32_t dist = ((t >> 9) & 0x7FFFu) + 1u;
         const uint32_t incl = wave_scan_add(mylen);
@@ -1273,6 +1276,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // what the copy loop needs of a match, ready in two registers: ring addresses of its destination and source, its length, and
         // whether it is one of the plain ones — source in the ring, no overlap with the destination closer than a round of 64
         // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
+#if TCMI_COPY_PHASES == 2
+        PH(6);
+#endif
         const bool is_match = !is_lit && mylen != 0;
         const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
         const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && dist >= mylen && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN && (mylen <= 64u || sm >= 4u);
@@ -1296,12 +1302,12 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                     const uint32_t sh = (src & 3u) * 8u;
                     uint32_t *park = s_lds.far + (end_w - words);
                     const uint32_t n = take ? words : 0u;
-                    for (uint32_t k = 0; __ballot(k < n); k += 4) {           // four words a turn: five loads in flight
-                        uint32_t w[5];
+                    for (uint32_t k = 0; __ballot(k < n); k += 8) {           // eight words a turn, nine loads in flight: a turn is a trip to HBM
+                        uint32_t w[9];                                      // (32 bytes and less — most far matches — in one)
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) w[i] = k + i <= n && k < n ? g[k + i] : 0u;
+                        for (int i = 0; i < 9; ++i) w[i] = k + i <= n && k < n ? g[k + i] : 0u;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 8; ++i)
                             if (k + i < n) park[k + i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
                     }
                     if (take) vB = (uint32_t)CWIN + 4u * (end_w - words);
@@ -1313,6 +1319,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // (a parked one's lies in flushed output: 0, always ready; one that is not plain never joins a team).
         // (Worth it where tokens are short: a round of teams costs about three single matches' instructions, and in a batch of long
         // matches — the same record 289 bytes back, say — only two or three matches at a time are independent.)
+#if TCMI_COPY_PHASES == 2
+        PH(7);
+#endif
         const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
         const bool teamable = is_match && (vB >> 16) == 0u;
         const unsigned long long plain_mask = __ballot(teamable);  // (plain matches, parked far ones included)
@@ -1491,7 +1500,11 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         uint64_t *st = a.stamps + (size_t)blk * 16;
 #ifdef TCMI_COPY_PHASES
         for (int k = 0; k < 5; ++k) st[10 + k] = ph[k];
+#if TCMI_COPY_PHASES == 2
+        st[2] = ph[5]; st[3] = ph[6]; st[15] = ph[7];
+#else
         st[2] = hist[0] | (uint64_t)hist[1] << 32; st[3] = hist[2] | (uint64_t)hist[3] << 32; st[15] = hist[4] | (uint64_t)hist[5] << 32;
+#endif
 #endif
         st[1] = __builtin_amdgcn_s_memtime(); st[4] = n_slow; st[5] = n_match; st[6] = n_round; st[7] = ntok; st[8] = n_team; st[9] = n_teamed;
     }

@@ -30,14 +30,14 @@
             : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t23] "=&v"(t23) \
             : [mm] "s"(mm), [vA2] "v"(vA2), [vB2] "v"(vB2), [vX8] "v"(lane8_hi), [vlane8] "v"(lane8) \
             : "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
-template <int V>
+template <int V, int FULL>
 __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps)
 {
     __shared__ unsigned char ring[8192 + 576];
     const int lane = threadIdx.x;
     for (int i = lane; i < 8192 + 576; i += 64) ring[i] = (unsigned char)i;
     __syncthreads();
-    const unsigned len = 40u + (unsigned)(lane * 37 % 200);
+    const unsigned len = FULL ? 512u : 40u + (unsigned)(lane * 37 % 200);       // FULL: every lane has a piece
     const unsigned dm = 600u + (unsigned)lane * 101u, sm = dm - 301u;
     const unsigned vA2 = ((len - 1u) << 16) | ((dm - 7u) & 0xFFFFu), vB2 = sm - 7u;
     const unsigned lane8 = (unsigned)lane * 8u + 7u, lane8_hi = (unsigned)lane << 19;
@@ -60,12 +60,12 @@ __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps)
     if (lane == 0) out[blockIdx.x] = t_b - t_a;
     if (lane == 63 && ring[17] == 255 && t0 == 12345 && t1 == 999 && (unsigned)t23 == 77 && t2 == 5) out[0] = 0;
 }
-template <int V> static void run(const char *name, int blocks, int reps)
+template <int V, int FULL = 0> static void run(const char *name, int blocks, int reps)
 {
     unsigned long long *d; hipMalloc(&d, blocks * 8);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    probe<V><<<blocks, 64>>>(d, 10); hipDeviceSynchronize();
-    hipEventRecord(a); probe<V><<<blocks, 64>>>(d, reps); hipEventRecord(b); hipDeviceSynchronize();
+    probe<V, FULL><<<blocks, 64>>>(d, 10); hipDeviceSynchronize();
+    hipEventRecord(a); probe<V, FULL><<<blocks, 64>>>(d, reps); hipEventRecord(b); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, a, b);
     std::vector<unsigned long long> h(blocks); hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
     double s = 0; for (auto x : h) s += (double)x;
@@ -86,6 +86,10 @@ int main()
         run<7>("b32: both aligned", blocks, reps);
         run<8>("bytes", blocks, reps);
         run<9>("b16 any", blocks, reps);
+        run<0, 1>("b64 any / any, all 64 lanes", blocks, reps);
+        run<3, 1>("b64 8-aligned, all 64 lanes", blocks, reps);
+        run<7, 1>("b32 aligned, all 64 lanes", blocks, reps);
+        run<8, 1>("bytes, all 64 lanes", blocks, reps);
     }
     return 0;
 }

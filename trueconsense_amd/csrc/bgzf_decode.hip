@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             t_ahead = base + 64u < ntok ? fetch_tokens(base + 64u) : 0u;
             continue;
         }
-#if TCMI_COPY_PHASES == 2
+#if TCMI_COPY_PHASES >= 2
         PH(5);
 #endif
         const uint32_t mylen = is_lit ? 1u : (t & 511u);
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // what the copy loop needs of a match, ready in two registers: ring addresses of its destination and source, its length, and
         // whether it is one of the plain ones — source in the ring, no overlap with the destination closer than a round of 64
         // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
-#if TCMI_COPY_PHASES == 2
+#if TCMI_COPY_PHASES >= 2
         PH(6);
 #endif
         const bool is_match = !is_lit && mylen != 0;
@@ -1289,6 +1289,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // away if it is fetched when the match comes up.  So the far matches of the batch whose sources are flushed already (all of
         // them, unless the batch is several KB of output long) are fetched NOW, every lane its own match's bytes, into a few
         // hundred bytes of LDS next to the ring; to the copy loop below they are plain matches whose source lies there.
+#if TCMI_COPY_PHASES == 3
+        PH(7);
+#endif
         {
             const uint32_t src = dst - dist;                    // (position of the source's first byte)
             const bool fetch = is_match && far_ok && mylen <= 64u && src + mylen <= flushed;     // (longer ones: 64 bytes an instruction in the loop)
@@ -1321,6 +1324,8 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // matches — the same record 289 bytes back, say — only two or three matches at a time are independent.)
 #if TCMI_COPY_PHASES == 2
         PH(7);
+#elif TCMI_COPY_PHASES == 3
+        PH(3);
 #endif
         const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
         const bool teamable = is_match && (vB >> 16) == 0u;
@@ -1500,7 +1505,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         uint64_t *st = a.stamps + (size_t)blk * 16;
 #ifdef TCMI_COPY_PHASES
         for (int k = 0; k < 5; ++k) st[10 + k] = ph[k];
-#if TCMI_COPY_PHASES == 2
+#if TCMI_COPY_PHASES >= 2
         st[2] = ph[5]; st[3] = ph[6]; st[15] = ph[7];
 #else
         st[2] = hist[0] | (uint64_t)hist[1] << 32; st[3] = hist[2] | (uint64_t)hist[3] << 32; st[15] = hist[4] | (uint64_t)hist[5] << 32;

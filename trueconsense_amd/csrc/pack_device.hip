@@ -335,14 +335,25 @@ __device__ inline void push_event(const PackOut &o, PackTotals *tot, uint32_t w)
     if (slot < o.event_cap) o.events[slot] = w;
 }
 
+// Any boolean function of three words in one instruction (v_bitop3_b32): TT(f) is its truth table, bit (a << 2 | b << 1 | c).  These
+// kernels are bound by vector issue, and the compiler finds only some of the three-input forms by itself.
+template <typename F> constexpr uint32_t truth_table(F f)
+{
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < 8; ++i) t |= (f((i >> 2) & 1u, (i >> 1) & 1u, i & 1u) & 1u) << i;
+    return t;
+}
+#define BITOP3(a_, b_, c_, ...) ((uint32_t)__builtin_amdgcn_bitop3_b32((a_), (b_), (c_), truth_table([](uint32_t a, uint32_t b, uint32_t c) { return (__VA_ARGS__); })))
+
 // eight 4-bit BAM codes (base k in nibble k) -> one bit per base: C|T, G|T, "is one of A C G T"
 __device__ inline void classify8(uint32_t n, uint32_t &lo, uint32_t &hi, uint32_t &ok)
 {
-    const uint32_t x0 = n & NIB, x1 = (n >> 1) & NIB, x2 = (n >> 2) & NIB, x3 = (n >> 3) & NIB;
-    const uint32_t s01 = x0 ^ x1, c01 = x0 & x1, s23 = x2 ^ x3, c23 = x2 & x3;
-    ok = (s01 ^ s23) & ~(c01 | c23);                            // exactly one bit set: A=1 C=2 G=4 T=8
-    lo = (x1 | x3) & ok;
-    hi = (x2 | x3) & ok;
+    // (bits 0, 4, .. 28 of n, n >> 1, n >> 2, n >> 3 are a base's four code bits; the other bits are masked out of `ok` and so of all three)
+    const uint32_t b = n >> 1, c = n >> 2, d = n >> 3;
+    const uint32_t one3 = BITOP3(n, b, c, (a ^ b ^ c) & ~(a & b & c)), none3 = BITOP3(n, b, c, ~(a | b | c));
+    ok = BITOP3(one3, none3, d, c ? b : a) & NIB;               // exactly one bit set: A=1 C=2 G=4 T=8
+    lo = BITOP3(b, d, ok, (a | b) & c);
+    hi = BITOP3(c, d, ok, (a | b) & c);
 }
 __device__ inline uint32_t squeeze8(uint32_t t)                 // bits 0,4,..,28 -> bits 0..7
 {
@@ -416,7 +427,7 @@ __device__ inline void pair_planes(const uint8_t *p, bool odd, int have, uint32_
     d[4] = p[16];                                               // (what lies behind a read's SEQ — its QUAL, the arrays' slack — is masked below)
     uint32_t w[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) w[k] = ((d[k] & 0x0F0F0F0Fu) << 4) | ((d[k] >> 4) & 0x0F0F0F0Fu);   // BAM keeps the first base of a byte in the high nibble
+    for (int k = 0; k < 5; ++k) w[k] = BITOP3(d[k] << 4, d[k] >> 4, 0xF0F0F0F0u, c ? a : b);        // BAM keeps the first base of a byte in the high nibble
     // The four words' planes (bits at 0, 4, .. 28: base 8 k + i of word k at bit 4 i) are squeezed TOGETHER: two bits per byte
     // within each word, the four words interleaved into one (byte b: bases 8 k + 2 b + e at bits 2 k + e), then the bytes'
     // 2-bit fields transposed with two masked swaps — 19 instructions a plane where four 3-step squeezes took 39, and this
@@ -427,11 +438,11 @@ __device__ inline void pair_planes(const uint8_t *p, bool odd, int have, uint32_
         const uint32_t n = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 4) : w[k];
         uint32_t l, h, v;
         classify8(n, l, h, v);
-        ul |= ((l | (l >> 3)) & 0x03030303u) << (2 * k);
-        uh |= ((h | (h >> 3)) & 0x03030303u) << (2 * k);
-        uv |= ((v | (v >> 3)) & 0x03030303u) << (2 * k);
+        ul |= BITOP3(l, l >> 3, 0x03030303u, (a | b) & c) << (2 * k);
+        uh |= BITOP3(h, h >> 3, 0x03030303u, (a | b) & c) << (2 * k);
+        uv |= BITOP3(v, v >> 3, 0x03030303u, (a | b) & c) << (2 * k);
     }
-    auto swap_fields = [](uint32_t x, int s, uint32_t m) { const uint32_t t = ((x >> s) ^ x) & m; return x ^ t ^ (t << s); };
+    auto swap_fields = [](uint32_t x, int s, uint32_t m) { const uint32_t t = BITOP3(x >> s, x, m, (a ^ b) & c); return BITOP3(x, t, t << s, a ^ b ^ c); };
     lo = swap_fields(swap_fields(ul, 12, 0x0000F0F0u), 6, 0x00CC00CCu);
     hi = swap_fields(swap_fields(uh, 12, 0x0000F0F0u), 6, 0x00CC00CCu);
     ok = swap_fields(swap_fields(uv, 12, 0x0000F0F0u), 6, 0x00CC00CCu);

@@ -1,30 +1,30 @@
 // bgzf_decode.hip — DEVICE: the BGZF blocks of a BAM file -> the inflated BAM byte stream + the record starts of every block
 // (pysam / htslib's role for indexing.py:19,96-100; SAM spec §4.1 BGZF, RFC 1951 DEFLATE), in two kernels:
 //
-//   bgzf_symbols   Huffman symbols -> tokens.  One wavefront per BGZF block, and ALL 64 LANES DECODE THAT ONE BLOCK, speculatively
-//                  in parallel.
+//   bgzf_symbols   Huffman symbols -> tokens.  A block's symbols are decoded by 32 lanes (two blocks per workgroup; 64 when a
+//                  payload exceeds 4 KB: one block per workgroup, staged a window at a time beyond 16 KB), speculatively in parallel.
 //   bgzf_copy      tokens -> bytes: the LZ77 copies through an LDS ring of the recent output, the chain of BAM records, the flush.
 //
 // Why two kernels.  A deflate stream is serial twice over: the position of symbol k + 1 is known only when symbol k is decoded,
-// and a match may copy what the previous match produced.  Round 2's one-kernel decoder (bam_device.hip: bgzf_inflate) walks both
-// chains in one wavefront, one symbol at a time: ~60 wave-instructions per symbol, all of them issued for a single useful lane,
-// and the kernel is bound by instruction issue (one instruction per compute unit and cycle).  Here the first chain is cut into
-// 64 pieces: lane c starts decoding at bit s_c = start + c * chunk — in the middle of nowhere, except for lane 0 — and notes, in
-// a window of WBITS bits behind s_c, every bit position on which it starts a symbol.  Huffman streams resynchronise: after a
-// few dozen bits a decoder that started on a wrong bit starts a symbol on a right one, and from there on it IS the serial
-// decoder.  A lane stops when a symbol of its own starts on a position that a lane in front of it has noted: from there the
-// two would decode the same (pass A).  Starting from lane 0 the chain of these meeting points says which lane holds the true
-// symbols of which bit range, and how many they are; an exclusive sum gives every such lane its place in the block's token
-// array, and it decodes its range once more, for real (pass B).  Nothing in this depends on luck or timing: a lane that never
-// meets anyone simply goes on to the block's end, and lane 0 alone is the serial decoder.  On the bench files
-// (tools/spec_inflate_proto.py, the same scheme in Python): 1 600 symbols in 96 + 87 lock-step rounds, 6 900 in 298 + 291.
+// and a match may copy what the previous match produced.  Round 2's one-kernel decoder walked both chains in one wavefront, one
+// symbol at a time: ~60 wave-instructions per symbol, all of them issued for a single useful lane, and the kernel was bound by
+// instruction issue.  Here the first chain is cut into pieces: lane c starts decoding at bit s_c = start + c * chunk — in the
+// middle of nowhere, except for lane 0 — and notes where its symbols cross into each new stretch of bits.  Huffman streams
+// resynchronise: after a few dozen bits a decoder that started on a wrong bit starts a symbol on a right one, and from there on it
+// IS the serial decoder.  A lane stops when a symbol of its own starts on a position that the lane in front of it has noted: from
+// there the two would decode the same (pass A).  Starting from lane 0 the chain of these meeting points says which lane holds the
+// true symbols of which bit range, and how many they are; the tokens stay where the lanes parked them and bgzf_copy gets the list
+// of pieces (a lane that overflows its scratch sends the block through pass B: the true ranges once more, tokens straight to
+// their places).  Nothing in this depends on luck or timing: a lane that never meets anyone simply goes on to the block's end, and
+// lane 0 alone is the serial decoder.  (tools/spec_inflate_proto.py: the same scheme in Python.)
 //
 // Tokens (32 bits): literal 1<<31 | byte; match len (9 bits) | (dist - 1) << 9; raw 1<<30 | len << 17 | offset of the bytes from
 // the block's payload start (a stored deflate block, in pieces of <= 8 191 bytes).  bgzf_copy takes 64 tokens at a time: an
-// inclusive scan of the lengths gives every token its output position, all literals of a round go to the ring at once, the
-// matches one after the other (each copied by all 64 lanes).
+// inclusive scan of the lengths gives every token its output position, the literals of a stretch go to the ring at once, the
+// matches one after the other (TCMI_LM_ASM: a byte a lane up to 64 bytes, an aligned dword a lane beyond — the LDS takes unaligned
+// words at about a cycle a LANE —; teams of eight lanes for up to eight independent short matches in files of short tokens).
 //
-// Bit / byte work, bound by instruction issue and LDS latency, not by HBM and not a contraction: no MFMA.
+// Bit / byte work, bound by instruction issue and the LDS pipe, not by HBM and not a contraction: no MFMA.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>

@@ -1274,8 +1274,10 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const uint32_t batch_end = op + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (batch_end > vend) { err = ST_BAD_LENGTH; break; }
         // what the copy loop needs of a match, ready in two registers: ring addresses of its destination and source, its length, and
-        // whether it is one of the plain ones — source in the ring, no overlap with the destination closer than a round of 64
-        // bytes, neither range across the ring's end.  The others (far, short period, across the end) take copy_any.
+        // whether it is one of the plain ones — source in the ring, source and destination apart by the match's length at least
+        // (a round copies the whole match at once), neither range across the ring's end, and for the dword rounds of a match beyond
+        // 64 bytes the source not within the ring's first four bytes.  The others (far, period shorter than the match, across the
+        // end) take copy_any.
 #if TCMI_COPY_PHASES >= 2
         PH(6);
 #endif

@@ -479,6 +479,38 @@ def test_insert_tokens_resolved_on_the_device(ctx, tmp_path):
     rs.free(); d3.close()
 
 
+def test_copy_loop_on_matches_of_every_length_and_alignment(ctx, tmp_path):
+    """bgzf_copy's plain-match loop copies up to 64 bytes a byte a lane and longer matches an aligned destination dword a lane
+    (the source funnel-shifted, the first and the last dword merged under a byte mask, two more dwords beyond 256 bytes).  Here
+    every read's qualities are random except for a stretch of 3 .. 300 bytes taken from an earlier read's at random offsets: matches
+    of every length at every pair of alignments, from the read before (in the LDS ring), from twelve reads back (beyond it: fetched
+    from the flushed output, parked next to the ring up to 64 bytes, 64 bytes a load beyond) and from three reads back.
+    Byte for byte against zlib; with and without teams (the variant follows the file's compression ratio: both kinds of file)."""
+    ref, _ = sy.make_reference()
+    rng = np.random.default_rng(21)
+    n, lq = 6000, 400
+    base = sy.make_reads(ref, n, read_len=lq, seed=22)
+    common = rng.integers(0, 42, lq).astype(np.uint8)
+    for k, (filler, level) in enumerate((("random", 9), ("random", 6), ("common", 9))):
+        # ("common": every read's qualities are one pattern apart from the stretch — 18 : 1, the host picks bgzf_copy<false>; random
+        #  filler: 3 : 1, bgzf_copy<true> with its teams)
+        q = np.empty((n, lq), np.uint8)
+        q[0] = common
+        for i in range(1, n):
+            row = common.copy() if filler == "common" else rng.integers(0, 42, lq).astype(np.uint8)
+            L = 3 + (i * 7) % 298
+            back = 12 if i % 5 == 0 and i >= 12 else 3 if i % 7 == 0 and i >= 3 else 1
+            a, b = int(rng.integers(0, lq - L + 1)), int(rng.integers(0, lq - L + 1))
+            row[b:b + L] = q[i - back][a:a + L]
+            q[i] = row
+        reads = dict(base)
+        reads["qual"] = q.reshape(-1)
+        p = str(tmp_path / ("lengths%d.bam" % k))
+        bamwriter.write_bam(p, reads, "MN908947.3", len(ref), level=level)
+        d = check_decode(ctx, p)
+        assert (d.inflated_bytes >= 12 * d.file_bytes) == (filler == "common")      # (the ratio at which the host changes the variant)
+        d.close()
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("window", [2048, 4100])
 def test_windowed_symbol_decoder_at_small_windows(window, tmp_path):

@@ -289,9 +289,10 @@ __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const ui
                 while (got < total && err == ST_OK) {
                     uint32_t mine = 0, j = 0, g = got, e;
                     do {
-                        e = uni(P[o]);
+                        const uint32_t ev = P[o];                   // (every lane reads the same entry: lane j keeps it — no v_writelane, whose lane select wants m0)
+                        e = uni(ev);
                         if (e == 0) break;
-                        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mine) : "s"(e), "s"(j) : "m0");
+                        mine = (uint32_t)lane == j ? ev : mine;
                         g += (e >> 4) & 255u;
                         o += e & 15u;
                         ++j;

@@ -112,6 +112,11 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    anything else takes the host packer); 0 = always pack on the host
  *   "verify_crc"     1 = the device decoder checks every BGZF block's CRC-32 (bgzf_crc32; default, as htslib does);
  *                    0 = ISIZE, stream termination and the record chain only
+ *   "one_sync"       1 = a file decoded on the device takes the one-sync path first (one kernel for record index, record chain,
+ *                    classification, prefix sums and planes; capacities instead of counts read back; default), 0 = only the
+ *                    several-kernel path with its three waits (the path that words every refusal; the tests cross-check the two)
+ *   "mid_wait"       1 = the one-sync path waits a second time, behind the decode kernels (default: two waits per file; measured
+ *                    equal or faster than 0 with eight contexts), 0 = one wait per file
  *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
  *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)
@@ -123,6 +128,9 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "profile_every"  with profiling enabled, every n-th tcmi_step_begin has its kernels bracketed by events,
  *                    the others go out unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
+/* counters of a context: "one_sync_taken" / "one_sync_declined" — files (or block ranges) the one-sync path delivered / handed to the
+ * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag) */
+int  tcmi_ctx_stat(tcmi_ctx *ctx, const char *key, int64_t *value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */
 enum { TCMI_K_TALLY = 0 /* bit-plane tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZERO = 2,
@@ -297,10 +305,10 @@ const char *tcmi_bam_text(const tcmi_bam *bam);    /* SAM header text, owned by 
 /* ---- BAM decoded ON THE DEVICE (the default file path; the host reader above stays for files it does not take) ----
  * tcmi_bamfile_read: HOST — file bytes into pinned memory, BGZF block table, BAM header (only the leading blocks the
  * header occupies are inflated on the host).  tcmi_readset_from_bamfile: the compressed bytes cross PCIe, HIP kernels
- * inflate every BGZF block (one wavefront per block), follow the record chain, and pack the reads for the tally —
- * the host never sees a decoded read.  Returns TCMI_E_UNSUPPORTED for files that need the host reader
- * (records straddling BGZF blocks — htslib never writes those —, reads spanning more than 512 positions, positions
- * beyond 2^29): fall back to tcmi_bam_load + tcmi_readset_upload.                                                  */
+ * inflate every BGZF block, follow the record chain (records may straddle blocks), and pack the reads for the tally (reads
+ * spanning more than 512 positions are tallied where they lie in the stream) — the host never sees a decoded read.
+ * Returns TCMI_E_UNSUPPORTED for files that need the host reader (a record chain that does not close, a mapped read on a
+ * second reference, a CIGAR kept in a CG:B tag, positions beyond 2^29): fall back to tcmi_bam_load + tcmi_readset_upload. */
 typedef struct tcmi_bamfile tcmi_bamfile;
 int  tcmi_bamfile_read(const char *path, tcmi_bamfile **out);
 int  tcmi_bamfile_free(tcmi_bamfile *f);
@@ -318,6 +326,17 @@ int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readse
  * count matrices of the ranges add up to the file's (what indexing.py:96-100 piles up in one pass). */
 int  tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out,
                                       int64_t *n_reads);
+/* BAM file -> call records with ONE wait of the host: what indexing.BuildIndex (indexing.py:75-154) and the position-local part of
+ * Sequences.BuildConsensus (Sequences.py:119-165 via Ambig.py / Events.py) come to for one file.  Decode, record index, record chain,
+ * classification, packing, tally and call are queued back to back on the context's stream from capacities instead of counts read
+ * back (the several calls above wait three + one times); one wait; then everything that was deferred is checked, and a file the
+ * one-pass packer cannot vouch for (a damaged block, a record chain that does not close, reads it does not take, a file beyond the
+ * capacities) is taken through tcmi_readset_from_bamfile + tcmi_step instead — same results, same errors.  The step covers
+ * L = max(ref_len, the reads' extent, 1) positions (*L_out).  Results as tcmi_step's (valid until the context's next step);
+ * *rs_out is the caller's (tcmi_readset_free), with the inflated stream resident for tcmi_readset_modal_tokens. */
+int  tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int32_t mincov, int include_ambig, tcmi_readset **rs_out,
+                       int64_t *L_out, const uint8_t **plain, const uint8_t **alt, const uint8_t **flags,
+                       const int32_t **counts_planes /* host [7][ld]; NULL: not wanted */, int64_t *ld);
 /* Events.ExtractInserts for a read set the DEVICE decoded (tcmi_readset_from_bamfile): same arguments and results as
  * tcmi_modal_tokens, but the reads of every candidate column are examined by a HIP kernel where they lie (the inflated
  * stream stays resident on the context until its next upload) and only a few thousand 48-byte entries per column reach

@@ -52,6 +52,7 @@ _SIGS = {
     "tcmi_ctx_sync": (_int, [_vp]),
     "tcmi_ctx_stream": (_vp, [_vp]),
     "tcmi_ctx_set_option": (_int, [_vp, C.c_char_p, _int]),
+    "tcmi_ctx_stat": (_int, [_vp, C.c_char_p, _P(_i64)]),
     "tcmi_profile_enable": (_int, [_vp, _int]),
     "tcmi_profile_reset": (_int, [_vp]),
     "tcmi_profile_get": (_int, [_vp, _int, _P(C.c_double), _P(_i64)]),
@@ -94,6 +95,7 @@ _SIGS = {
     "tcmi_bamfile_to_device": (_int, [_vp, _vp]),
     "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
     "tcmi_readset_from_bamfile_blocks": (_int, [_vp, _vp, _i64, _i64, _P(_vp), _P(_i64)]),
+    "tcmi_bamfile_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_i64), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
     "tcmi_bamfile_decode_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _P(_i64)]),
     "tcmi_filerunner_create": (_int, [_int, _int, _int, _int, _int, _P(_vp)]),

@@ -104,6 +104,7 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     }
     v = std::getenv("TCMI_HOST_THREADS");
     if (v && std::atoi(v) >= 1) c->host_threads = std::atoi(v);
+    if (std::getenv("TCMI_NO_FUSED")) c->one_sync = 0;          // (A/B measurements)
     v = std::getenv("TCMI_CHUNK_STAGES");
     if (v && std::atoi(v) >= 1 && std::atoi(v) <= TCMI_F_MAXSTAGE) c->chunk_stages = std::atoi(v);
 
@@ -172,9 +173,21 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "project_reads")) c->project_reads = value != 0;
     else if (!std::strcmp(key, "device_pack")) c->device_pack = value != 0;
     else if (!std::strcmp(key, "verify_crc")) c->verify_crc = value != 0;
+    else if (!std::strcmp(key, "one_sync")) c->one_sync = value != 0;
+    else if (!std::strcmp(key, "mid_wait")) c->mid_wait = value != 0;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
+    return TCMI_OK;
+}
+
+int tcmi_ctx_stat(tcmi_ctx *c, const char *key, int64_t *value)
+{
+    if (!c || !key || !value) return tcmi_fail(c, TCMI_E_ARG, "null argument");
+    if (!std::strcmp(key, "one_sync_taken")) *value = c->stat_one_sync_taken;
+    else if (!std::strcmp(key, "one_sync_declined")) *value = c->stat_one_sync_declined;
+    else if (!std::strcmp(key, "one_sync_last_decline_flags")) *value = c->stat_last_decline;
+    else return tcmi_fail(c, TCMI_E_ARG, "unknown statistic %s", key);
     return TCMI_OK;
 }
 

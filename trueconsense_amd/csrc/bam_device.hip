@@ -243,6 +243,7 @@ inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 struct tcmi_bamfile {                           // a BAM file's bytes in pinned host memory + what the host parsed of it
     uint8_t *bytes = nullptr;                   // hipHostMalloc
     uint8_t *d_bytes = nullptr;                 // the same `cap` bytes in HBM (tcmi_bamfile_to_device), or null
+    size_t desc_at = 0;                         // the block table (BlockDesc[]) lies behind the file's bytes, at this offset of `bytes` / `d_bytes` (0: it does not)
     int d_device = -1;
     size_t n_bytes = 0, cap = 0;                // cap: bytes that go to the device (file + zeroed slack)
     size_t pool_cap = 0;                        // bytes of the pinned allocation
@@ -250,6 +251,7 @@ struct tcmi_bamfile {                           // a BAM file's bytes in pinned 
     size_t inflated = 0;                        // bytes of the stream as laid out on the device (blocks padded to 16 bytes)
     size_t tok_total = 0;                       // tokens reserved for all blocks (bgzf_symbols -> bgzf_copy)
     uint32_t pay_dwords = 0;                    // the largest block's payload in dwords + slack (bgzf_symbols' dynamic LDS)
+    uint32_t rec_bytes_hint = 0;                // mean bytes of the alignment records behind the header in the blocks the host inflated (0: too few seen)
     std::string text;
     std::vector<std::string> ref_name;
     std::vector<int64_t> ref_len;
@@ -348,7 +350,9 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
     f->path = path;
     f->n_bytes = (size_t)sz;
     f->cap = ((size_t)sz + 4096 + 15) & ~(size_t)15;            // slack: the inflate kernel stages its input 1 KiB at a time
-    f->bytes = pinned_pool().take(f->cap, &f->pool_cap);
+    // (+ room for the block table behind the bytes, so that ONE copy takes both to the device: a block is at least 28 bytes, usually ~ 2 KB and more)
+    const size_t table_room = std::min<size_t>(((size_t)sz / 28 + 2) * sizeof(BlockDesc), ((size_t)sz / 512 + 64) * sizeof(BlockDesc));
+    f->bytes = pinned_pool().take(f->cap + table_room + 1024, &f->pool_cap);
     if (!f->bytes) {
         std::fclose(fp);
         delete f;
@@ -382,6 +386,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
     const auto tt2 = std::chrono::steady_clock::now();
     std::fclose(fp);
     std::memset(f->bytes + f->n_bytes, 0, f->cap - f->n_bytes);
+    const size_t table_cap = table_room;
     auto bail = [&](int code, const char *what, size_t at) {
         tcmi_bamfile_free(f);
         return tcmi_fail(nullptr, code, "%s: %s at byte %zu", path, what, at);
@@ -430,6 +435,7 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         f->blocks.push_back(b);
     }
     f->inflated = uout;
+    if (f->blocks.size() * sizeof(BlockDesc) <= table_cap) f->desc_at = (f->cap + 255) & ~(size_t)255;     // (else: blocks of < 512 bytes — the table goes by a copy of its own)
     const auto tt3 = std::chrono::steady_clock::now();
     // ---- BAM header: inflate leading blocks on this thread until it is complete ----
     std::vector<uint8_t> head;
@@ -480,6 +486,20 @@ int tcmi_bamfile_read_threads(const char *path, int read_threads, tcmi_bamfile *
         before += f->blocks[k].ulen;
     }
     if (k < f->blocks.size()) f->blocks[k].entry = (int32_t)(o - before);
+    {   // what is left of the inflated bytes behind the header are the file's first records: their mean size sizes the one-sync path's arrays
+        size_t at = o, cnt = 0;
+        while (at + 4 <= head.size()) {
+            const size_t bs = rd32(head.data() + at);
+            if (bs < 32 || bs > (1u << 24) || at + 4 + bs > head.size()) break;
+            at += 4 + bs;
+            ++cnt;
+        }
+        if (cnt >= 16) f->rec_bytes_hint = (uint32_t)((at - o) / cnt);
+    }
+    if (f->desc_at) {
+        std::memcpy(f->bytes + f->desc_at, f->blocks.data(), f->blocks.size() * sizeof(BlockDesc));
+        f->cap = f->desc_at + ((f->blocks.size() * sizeof(BlockDesc) + 255) & ~(size_t)255);      // what goes to the device: bytes, slack, table
+    }
     if (timing) {
         const auto tt4 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
@@ -506,21 +526,40 @@ const char *tcmi_bamfile_text(const tcmi_bamfile *f) { return f ? f->text.c_str(
 
 } // extern "C"
 
-// ---- device decode: H2D of the compressed file, bgzf_inflate, chain check, dense record offsets (all in the context's arena) ----
+// ---- device decode: H2D of the compressed file, bgzf_symbols + bgzf_copy + bgzf_crc32 (all in the context's arena) -----------------
 namespace {
 struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; };
 
+// a decode in flight: the range as a file of its own, and where its pieces lie in the arena
+struct Decoded {
+    tcmi_bamfile part;                  // (a block range: its blocks' places in the stream and in the token array start at 0; the bytes stay the whole file's)
+    const tcmi_bamfile *f = nullptr;
+    bool ranged = false;
+    size_t nb = 0, nb_own = 0, max_rec = 0, guess_rec = 0, b_rest = 0;
+    uint8_t *d_file = nullptr, *d_out = nullptr;
+    BlockDesc *d_desc = nullptr;
+    uint32_t *d_slot = nullptr, *d_nrec = nullptr, *d_stat = nullptr, *d_first = nullptr;
+    int32_t *d_over = nullptr;
+    uint64_t *d_base = nullptr;
+    unsigned long long *d_total = nullptr;
+};
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+// arena bytes of everything that is sized per record: the several-kernel path's arrays (rec_off + 12 words) — the one-pass packer's are fewer
+inline size_t rest_bytes(size_t n_rec, size_t nb) { return al256(n_rec * 8 + 8) + al256(n_rec * 4 + 4) * 12 + al256((n_rec / 256 + 2) * 8) * 3 + al256(nb * 33 + 64) + al256(nb * 8) + al256(nb * 4) + 8192 + 28 * 256; }
+
 // blocks [first, first + count) of the file (count < 0: to the end): the records that START in them.  A range that does not end
 // with the file takes one block more along — the last record may run into it — whose own records are left out.
-int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int64_t first_blk = 0, int64_t count = -1)
+// Queues the copies and the three kernels on the context's stream; waits for nothing.
+int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t first_blk = 0, int64_t count = -1)
 {
     if (whole->blocks.empty()) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: no BGZF blocks", whole->path.c_str());
     const int64_t all = (int64_t)whole->blocks.size();
     if (first_blk < 0 || first_blk > all) return tcmi_fail(ctx, TCMI_E_ARG, "block range starts at %lld, the file has %lld blocks", (long long)first_blk, (long long)all);
     const int64_t own = count < 0 ? all - first_blk : std::min<int64_t>(count, all - first_blk);
     const bool ranged = first_blk != 0 || own != all;
+    D.ranged = ranged;
     // the range as a file of its own: the blocks' places in the stream and in the token array start at 0
-    tcmi_bamfile part;
+    tcmi_bamfile &part = D.part;
     const tcmi_bamfile *f = whole;
     if (ranged) {
         const int64_t extra = first_blk + own < all ? 1 : 0;
@@ -541,42 +580,47 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
         part.inflated = uout;
         f = &part;
     }
-    struct Unown { tcmi_bamfile *p; ~Unown() { if (p) { p->bytes = nullptr; p->d_bytes = nullptr; } } } unown{ranged ? &part : nullptr};    // (the bytes are the whole file's)
+    D.f = f;
     const size_t nb = f->blocks.size(), nb_own = ranged ? (size_t)own : nb;
-    if (nb == 0) { D->d_out = nullptr; D->d_rec = nullptr; D->d_desc = nullptr; D->n = 0; return TCMI_OK; }
+    D.nb = nb; D.nb_own = nb_own;
+    if (nb == 0) return TCMI_OK;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // bounds on the records for the arena: a record takes at least 36 bytes of the stream; reserve for records of >= 64 bytes
     // (block_size + 32 fixed bytes + name + CIGAR + SEQ + QUAL of a 15-base read) — the arena cannot grow under live data
-    const size_t max_rec = f->inflated / 36 + 16;
-    const size_t guess_rec = std::min(max_rec, f->inflated / 64 + 1024);
+    D.max_rec = f->inflated / 36 + 16;
+    D.guess_rec = std::min(D.max_rec, f->inflated / 64 + 1024);
     const bool resident = f->d_bytes != nullptr && f->d_device == ctx->device;       // (the compressed bytes are in HBM already)
     const size_t b_file = resident ? 256 : al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
                  b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 5 + al(nb * 8) + al(nb * 512) + 256,
                  b_tok = al(f->tok_total * 4 + 256);
-    const size_t b_rest = al(guess_rec * 8 + 8) + al(guess_rec * 4 + 4) * 12 + al((guess_rec / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
-    if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
+    D.b_rest = rest_bytes(D.guess_rec, nb);
+    if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + D.b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
     uint8_t *d_file = (uint8_t *)tcmi_arena_take(ctx, b_file);
-    BlockDesc *d_desc = (BlockDesc *)tcmi_arena_take(ctx, b_desc);
-    uint8_t *d_out = (uint8_t *)tcmi_arena_take(ctx, b_out);
-    uint32_t *d_slot = (uint32_t *)tcmi_arena_take(ctx, b_slot);
-    uint32_t *d_nrec = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
-    int32_t *d_over = (int32_t *)tcmi_arena_take(ctx, al(nb * 4));
-    uint32_t *d_stat = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
-    uint32_t *d_first = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
-    uint64_t *d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
-    unsigned long long *d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
+    D.d_desc = (BlockDesc *)tcmi_arena_take(ctx, b_desc);
+    D.d_out = (uint8_t *)tcmi_arena_take(ctx, b_out);
+    D.d_slot = (uint32_t *)tcmi_arena_take(ctx, b_slot);
+    D.d_nrec = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    D.d_over = (int32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    D.d_stat = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    D.d_first = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
+    D.d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
+    D.d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
     uint32_t *d_seg = (uint32_t *)tcmi_arena_take(ctx, al(nb * 512));
     uint32_t *d_tok = (uint32_t *)tcmi_arena_take(ctx, b_tok);
 
     if (resident) d_file = f->d_bytes;
     else TCMI_HIP(ctx, hipMemcpyAsync(d_file, f->bytes, f->cap, hipMemcpyHostToDevice, ctx->stream));
-    TCMI_HIP(ctx, hipMemcpyAsync(d_desc, f->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    D.d_file = d_file;
+    // the block table: behind the file's bytes (one copy took both, or none: a resident file's table is resident too) — a range's
+    // table, re-based, goes by a copy of its own
+    if (!ranged && f->desc_at) D.d_desc = reinterpret_cast<BlockDesc *>(d_file + f->desc_at);
+    else TCMI_HIP(ctx, hipMemcpyAsync(D.d_desc, f->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
     (void)hipGetLastError();
     {
         tcmi_bgzf_decode_args g;
-        g.d_file = d_file; g.d_desc = d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = d_out; g.d_slot = d_slot; g.d_nrec = d_nrec;
-        g.d_over = d_over; g.d_first = d_first; g.d_stat = d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
+        g.d_file = d_file; g.d_desc = D.d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = D.d_out; g.d_slot = D.d_slot; g.d_nrec = D.d_nrec;
+        g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
         g.short_tokens = f->inflated < 12 * f->n_bytes ? 1 : 0;
         const int rc = tcmi_bgzf_decode_launch(ctx, g);
@@ -585,12 +629,34 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     if (ctx->verify_crc) {
         static const CrcArgs proto = [] { CrcArgs c = {}; crc_zero_operators(c.zeros, c.zeros_row); return c; }();
         CrcArgs c = proto;
-        c.file = d_file; c.out = d_out; c.blocks = d_desc; c.status = d_stat; c.n_blocks = (int32_t)nb;
+        c.file = d_file; c.out = D.d_out; c.blocks = D.d_desc; c.status = D.d_stat; c.n_blocks = (int32_t)nb;
         tcmi_prof_begin(ctx, TCMI_K_CRC);
         hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, ctx->stream, c);
         tcmi_prof_end(ctx, TCMI_K_CRC);
         TCMI_HIP(ctx, hipGetLastError());
     }
+    return TCMI_OK;
+}
+
+// The several-kernel path behind decode_enqueue: the block verdicts and the record chain come back to the host (one wait), which
+// words every refusal; then the dense record offsets.
+int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *Dout, int64_t first_blk = 0, int64_t count = -1)
+{
+    Decoded D;
+    int rc = decode_enqueue(ctx, whole, D, first_blk, count);
+    if (rc) return rc;
+    const tcmi_bamfile *f = D.f;
+    const size_t nb = D.nb, nb_own = D.nb_own;
+    const bool ranged = D.ranged;
+    if (nb == 0) { Dout->d_out = nullptr; Dout->d_rec = nullptr; Dout->d_desc = nullptr; Dout->n = 0; return TCMI_OK; }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    uint8_t *d_out = D.d_out;
+    BlockDesc *d_desc = D.d_desc;
+    uint32_t *d_slot = D.d_slot, *d_nrec = D.d_nrec, *d_stat = D.d_stat, *d_first = D.d_first;
+    int32_t *d_over = D.d_over;
+    uint64_t *d_base = D.d_base;
+    unsigned long long *d_total = D.d_total;
+    const size_t max_rec = D.max_rec, b_rest = D.b_rest;
     hipLaunchKernelGGL(rec_scan, dim3(1), dim3(1024), 0, ctx->stream, d_nrec, d_base, (int32_t)nb, (int32_t)nb_own, d_total, d_desc, d_slot, d_out, d_over);
     TCMI_HIP(ctx, hipGetLastError());
     // the verdict of every block comes back to the host: a few bytes per block
@@ -646,7 +712,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     }
     if (total > max_rec) return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: impossible record count", f->path.c_str());
     const size_t n = (size_t)total;
-    const size_t need_rest = al(n * 8 + 8) + al(n * 4 + 4) * 12 + al((n / 256 + 2) * 8) * 3 + 8192 + 20 * 256;
+    const size_t need_rest = rest_bytes(n, nb);
     if (need_rest > b_rest)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: %zu very short records need more device scratch than was reserved: host reader", f->path.c_str(), n);
     uint64_t *d_rec = (uint64_t *)tcmi_arena_take(ctx, al(n * 8 + 8));
@@ -654,7 +720,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *D, int
     if (n) hipLaunchKernelGGL(rec_compact, dim3((unsigned)nb_own), dim3(256), 0, ctx->stream, d_desc, d_slot, d_nrec, d_base, d_rec);
     tcmi_prof_end(ctx, TCMI_K_RECORDS);
     TCMI_HIP(ctx, hipGetLastError());
-    D->d_out = d_out; D->d_rec = d_rec; D->d_desc = d_desc; D->n = n;
+    Dout->d_out = d_out; Dout->d_rec = d_rec; Dout->d_desc = d_desc; Dout->n = n;
     return TCMI_OK;
 }
 } // namespace
@@ -672,13 +738,73 @@ int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset
 // ... of the records that start in BGZF blocks [first_block, first_block + n_blocks) only (n_blocks < 0: to the end of the file): ranks
 // that share ONE file each take a contiguous range of its blocks (tcmi_bamfile_info says how many there are) and decode nothing
 // else; their count matrices add up to the file's (BASELINE configs[4]; indexing.py:96).
-int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out)
+//
+// Two ways through.  The ONE-SYNC path (default): decode, record index, chain check, classification, prefix sums, planes and chunk
+// planning are all queued from capacities (decode_enqueue, tcmi_pack_fused_enqueue: pk_fused + pk_pack), the host waits once and
+// checks what was deferred.  Whatever that path cannot vouch for — a damaged block, a chain that does not close, reads it does not
+// take, a file beyond the capacities — is decoded again by the SEVERAL-KERNEL path below it (three waits), which words every refusal.
+}   // extern "C"
+
+namespace {
+std::atomic<uint64_t> g_next_uid{1ull << 40};
+
+// queue everything of the one-sync path up to the packed read set; D and J must outlive the wait
+int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, Decoded &D, tcmi_fused_job &J, tcmi_readset *rs)
+{
+    int rc = decode_enqueue(ctx, f, D, first_block, n_blocks);
+    if (rc) return rc;
+    if (D.nb == 0) return TCMI_E_UNSUPPORTED;                       // (an empty range: the other path's few lines)
+    // A wait of the host behind the decode kernels (option "mid_wait", default 1: two waits per file).  With everything queued in
+    // one go (0) eight contexts measured 60 - 64 M positions/s on boxes where this gave 64 - 66: four hardware queues that always
+    // hold a ready kernel run four kernels at once, and these kernels (each sized to fill the chip alone) get in each other's way.
+    static const int split_env = std::getenv("TCMI_ONE_SYNC_SPLIT") ? std::atoi(std::getenv("TCMI_ONE_SYNC_SPLIT")) : -1;    // (A/B: 0 none, 1 behind the decode, 2 behind the packer, 3 both)
+    const int split = split_env >= 0 ? split_env : ctx->mid_wait;
+    if (split == 1 || split == 3) TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    J.d_stream = D.d_out; J.stream_len = D.f->inflated; J.d_desc = D.d_desc; J.d_slot = D.d_slot; J.d_nrec = D.d_nrec; J.d_first = D.d_first;
+    J.d_over = D.d_over; J.d_stat = D.d_stat; J.n_blocks = (int64_t)D.nb; J.n_own = (int64_t)D.nb_own; J.ranged = D.ranged ? 1 : 0;
+    // records: from the mean size of the file's first records (+ 25 %) where the host saw enough of them, else as the arena was reserved
+    J.rec_cap = (int64_t)D.guess_rec;
+    if (f->rec_bytes_hint >= 36) J.rec_cap = std::min<int64_t>(J.rec_cap, (int64_t)(D.f->inflated / f->rec_bytes_hint) * 5 / 4 + 8192);
+    J.len_bound = (f->ref_len.empty() ? 0 : f->ref_len[0]) + 65536;
+    rs->uid = g_next_uid.fetch_add(1);
+    rs->device = ctx->device;
+    rc = tcmi_pack_fused_enqueue(ctx, &J, rs);
+    if (rc == TCMI_OK && (split == 2 || split == 3)) TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+} // namespace
+
+static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out, bool try_fused)
 {
     if (!ctx || !f || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     *out = nullptr;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     static const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
+    if (ctx->one_sync && try_fused) {
+        Decoded D;
+        tcmi_fused_job J;
+        tcmi_readset *rs = new tcmi_readset();
+        uint32_t why = 0;
+        int rc = fast_enqueue(ctx, f, first_block, n_blocks, D, J, rs);
+        if (rc == TCMI_OK) rc = tcmi_pack_fused_report(ctx, &J);
+        if (rc == TCMI_OK) {
+            TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            rc = tcmi_pack_fused_finish(ctx, &J, rs, &why);
+        }
+        if (rc == TCMI_OK) {
+            ++ctx->stat_one_sync_taken;
+            rs->packed_on_device = 2;           // decoded AND packed on the device
+            if (n_reads_out) *n_reads_out = rs->n_reads;
+            *out = rs;
+            if (timing) std::fprintf(stderr, "[tcmi bamfile] one-sync path: decode + pack %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            return TCMI_OK;
+        }
+        tcmi_readset_free(ctx, rs);
+        if (rc != TCMI_E_UNSUPPORTED) return rc;
+        ++ctx->stat_one_sync_declined; ctx->stat_last_decline = why;
+        if (timing) std::fprintf(stderr, "[tcmi bamfile] one-sync path declined (flags 0x%x): the several-kernel path\n", why);
+    }
     DeviceBam D;
     int rc = decode_on_device(ctx, f, &D, first_block, n_blocks);
     if (rc) return rc;
@@ -686,9 +812,8 @@ int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64
     if (n_reads_out) *n_reads_out = (int64_t)D.n;
     tcmi_pack_src s = {};
     s.stream = D.d_out; s.rec_off = D.d_rec; s.n = (int64_t)D.n; s.mode = 1; s.pos_shift = 0;
-    static std::atomic<uint64_t> next_uid{1ull << 40};
     tcmi_readset *rs = new tcmi_readset();
-    rs->uid = next_uid.fetch_add(1);
+    rs->uid = g_next_uid.fetch_add(1);
     rs->n_reads = (int64_t)D.n;
     rs->device = ctx->device;
     uint32_t why = 0;
@@ -708,6 +833,98 @@ int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the device packer declined (flags 0x%x: long reads, far positions, a second reference or malformed reads): host reader",
                          f->path.c_str(), why);
     return rc;
+}
+
+extern "C" {
+
+int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out)
+{
+    return readset_from_blocks(ctx, f, first_block, n_blocks, out, n_reads_out, true);
+}
+
+// BAM file -> call records with ONE wait of the host (TrueConsense.py:225-237 per file: BuildIndex + the position-local part of
+// BuildConsensus): the one-sync path's decode and pack, the tally (its grid sized from the packer's capacities, the counts taken
+// from device memory) and the call are queued back to back; then the wait; then everything that was deferred is checked.  The
+// step is queued for L = max(ref_len, 1) positions: a file whose reads reach beyond that, or with reads too long for the packed
+// set, gets its step once more (the read set is complete by then); a file the one-sync path declines goes through
+// tcmi_readset_from_bamfile + tcmi_step.  Results as tcmi_step's; *rs_out is the caller's (tcmi_readset_free), *L_out the positions.
+int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int32_t mincov, int include_ambig, tcmi_readset **rs_out, int64_t *L_out,
+                      const uint8_t **plain, const uint8_t **alt, const uint8_t **flags, const int32_t **counts_planes, int64_t *ld_out)
+{
+    if (!ctx || !f || !rs_out || !L_out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    *rs_out = nullptr;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->one_sync && ctx->step_L == 0 && !ctx->call_pending) {
+        static const bool timing = std::getenv("TCMI_STEP_TIMING") != nullptr;       // diagnostic: where the host's time goes, per 256 calls
+        static thread_local double t_acc[5] = {0, 0, 0, 0, 0};
+        static thread_local int t_n = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        const auto t0 = now();
+        Decoded D;
+        tcmi_fused_job J;
+        tcmi_readset *rs = new tcmi_readset();
+        uint32_t why = 0;
+        const int64_t L0 = std::max<int64_t>(ref_len, 1);
+        int rc = fast_enqueue(ctx, f, 0, -1, D, J, rs);
+        const auto t1 = now();
+        bool began = false;
+        if (rc == TCMI_OK) {
+            rc = tcmi_step_begin(ctx, rs, L0, mincov, include_ambig, counts_planes != nullptr);
+            began = rc == TCMI_OK;
+        }
+        const auto t2 = now();
+        if (began) {
+            rc = tcmi_pack_fused_report(ctx, &J);
+            if (rc == TCMI_OK && hipEventRecord(ctx->step_done, ctx->stream) != hipSuccess)     // (the step's end is behind the report now)
+                rc = tcmi_fail(ctx, TCMI_E_HIP, "hipEventRecord failed");
+        }
+        if (began) {
+            if (rc) ctx->step_L = 0;
+            else rc = tcmi_step_end(ctx, plain, alt, flags, counts_planes, ld_out);     // THE wait
+            const auto t3 = now();
+            if (rc == TCMI_OK) rc = tcmi_pack_fused_finish(ctx, &J, rs, &why);
+            else ctx->step_L = 0;
+            if (timing) {
+                static thread_local std::chrono::steady_clock::time_point t_last = t0;
+                t_acc[0] += us(t0, t1); t_acc[1] += us(t1, t2); t_acc[2] += us(t2, t3); t_acc[3] += us(t3, now()); t_acc[4] += us(t_last, t0);
+                t_last = now();
+                if (++t_n == 256) {
+                    std::fprintf(stderr, "[tcmi step] per file: enqueue decode + pack %.0f us, enqueue tally + call %.0f us, wait %.0f us, finish %.0f us; between calls %.0f us\n",
+                                 t_acc[0] / t_n, t_acc[1] / t_n, t_acc[2] / t_n, t_acc[3] / t_n, t_acc[4] / t_n);
+                    t_n = 0; for (double &x : t_acc) x = 0;
+                }
+            }
+        }
+        if (rc == TCMI_OK) {
+            ++ctx->stat_one_sync_taken;
+            rs->packed_on_device = 2;
+            int64_t L = L0;
+            if (rs->max_end > L0 || rs->s_reads > 0) {              // reads beyond the reference's end, or long reads that the packed set leaves out
+                L = std::max<int64_t>(L0, rs->max_end);
+                rc = tcmi_step(ctx, rs, L, mincov, include_ambig, plain, alt, flags, counts_planes, ld_out);
+                if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+            }
+            *rs_out = rs; *L_out = L;
+            return TCMI_OK;
+        }
+        if (began) {                                                // the step ran on a read set that is not to be trusted: leave the workspace as a fresh one
+            ctx->counts_clean = false;
+        }
+        tcmi_readset_free(ctx, rs);
+        if (rc != TCMI_E_UNSUPPORTED) return rc;
+        ++ctx->stat_one_sync_declined; ctx->stat_last_decline = why;
+    }
+    tcmi_readset *rs = nullptr;
+    int rc = readset_from_blocks(ctx, f, 0, -1, &rs, nullptr, false);   // (the one-sync path has had its turn)
+    if (rc) return rc;
+    int64_t max_end = 0;
+    tcmi_readset_info(rs, nullptr, nullptr, nullptr, nullptr, &max_end);
+    const int64_t L = std::max<int64_t>({ref_len, max_end, 1});
+    rc = tcmi_step(ctx, rs, L, mincov, include_ambig, plain, alt, flags, counts_planes, ld_out);
+    if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    *rs_out = rs; *L_out = L;
+    return TCMI_OK;
 }
 
 // For tests and tools: the device-inflated stream (contiguous, as the file inflates) and the record offsets, back on the host.

@@ -20,9 +20,13 @@
 //
 // HBM-streaming byte / bit work: no MFMA.  Input 91 B + 20 B of offsets per 150-bp read, output 52 B.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "tally_common.h"
+#include "bgzf_device.h"
 
 namespace {
 
@@ -48,6 +52,38 @@ __device__ inline uint32_t ld_u32(const uint8_t *p)
     return w;
 }
 
+// a record of the inflated BAM stream, `rec` at its block_size field (any byte address)
+__device__ inline ReadView view_rec(const uint8_t *rec)
+{
+    ReadView v;
+    v.bad = false;
+    v.broken = false;
+    const uint8_t *r = rec + 4;                             // behind block_size
+    // the fixed fields in two loads at the record's own (any) byte address — unaligned access mode; twelve aligned dword loads
+    // and funnel shifts kept the kernel waiting on the address unit: every lane's record lies in a cache line of its own
+    uint32_t h[6];                                         // block_size, refID, pos, l_read_name|mapq|bin, n_cigar_op|flag, l_seq
+    __builtin_memcpy(h, r - 4, 16);
+    __builtin_memcpy(h + 4, r + 12, 8);
+    v.tid = (int32_t)h[1];
+    v.pos = (int32_t)h[2];
+    const uint32_t w2 = h[3], w3 = h[4];
+    const uint32_t l_name = w2 & 0xFFu;
+    v.n_cigar = w3 & 0xFFFFu;
+    v.flag = w3 >> 16;
+    v.l_seq = (int32_t)h[5];
+    // The record walk only checked block_size itself: the variable-length fields must fit into it (what bam_reader.cpp's
+    // "alignment record fields overrun block_size" refuses) — a forged l_seq or n_cigar_op would otherwise send the kernels
+    // that follow the CIGAR and the bases far behind the record, or behind the stream.
+    const uint32_t block_size = h[0];
+    const uint64_t need = 32ull + l_name + 4ull * v.n_cigar + ((uint64_t)(uint32_t)v.l_seq + 1) / 2 + (uint64_t)(uint32_t)v.l_seq;
+    v.bad = v.l_seq < 0 || l_name == 0 || need > block_size;
+    v.broken = v.bad;
+    if (v.bad) v.n_cigar = 0;
+    v.cigar = r + 32 + l_name;
+    v.seq = v.cigar + 4 * (size_t)v.n_cigar;
+    return v;
+}
+
 __device__ inline ReadView view(const PackSrc &s, int64_t i)
 {
     ReadView v;
@@ -63,31 +99,7 @@ __device__ inline ReadView view(const PackSrc &s, int64_t i)
         v.n_cigar = v.bad ? 0u : (uint32_t)(c1 - c0);
         v.cigar = reinterpret_cast<const uint8_t *>(s.cigar + c0);
         v.seq = s.seq + q0;
-    } else {
-        const uint8_t *r = s.stream + s.rec_off[i] + 4;        // behind block_size
-        // the fixed fields in two loads at the record's own (any) byte address — unaligned access mode; twelve aligned dword loads
-        // and funnel shifts kept the kernel waiting on the address unit: every lane's record lies in a cache line of its own
-        uint32_t h[6];                                         // block_size, refID, pos, l_read_name|mapq|bin, n_cigar_op|flag, l_seq
-        __builtin_memcpy(h, r - 4, 16);
-        __builtin_memcpy(h + 4, r + 12, 8);
-        v.tid = (int32_t)h[1];
-        v.pos = (int32_t)h[2];
-        const uint32_t w2 = h[3], w3 = h[4];
-        const uint32_t l_name = w2 & 0xFFu;
-        v.n_cigar = w3 & 0xFFFFu;
-        v.flag = w3 >> 16;
-        v.l_seq = (int32_t)h[5];
-        // The record walk only checked block_size itself: the variable-length fields must fit into it (what bam_reader.cpp's
-        // "alignment record fields overrun block_size" refuses) — a forged l_seq or n_cigar_op would otherwise send the kernels
-        // that follow the CIGAR and the bases far behind the record, or behind the stream.
-        const uint32_t block_size = h[0];
-        const uint64_t need = 32ull + l_name + 4ull * v.n_cigar + ((uint64_t)(uint32_t)v.l_seq + 1) / 2 + (uint64_t)(uint32_t)v.l_seq;
-        v.bad = v.l_seq < 0 || l_name == 0 || need > block_size;
-        v.broken = v.bad;
-        if (v.bad) v.n_cigar = 0;
-        v.cigar = r + 32 + l_name;
-        v.seq = v.cigar + 4 * (size_t)v.n_cigar;
-    }
+    } else v = view_rec(s.stream + s.rec_off[i]);
     return v;
 }
 
@@ -142,6 +154,7 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t word_cursor;
     uint32_t max_len;               // longest reference span of a kept read
     uint32_t n_gen;                 // reads left to the stream-walking tally kernel (longer than TCMI_D_MAXLEN positions)
+    unsigned long long n_rec;       // pk_fused: alignment records of the decoded range
 };
 
 // words a read takes in the plane stream: its pairs, the zero pair behind them, and — for an even number of pairs — one more zero pair,
@@ -169,6 +182,57 @@ __device__ inline uint2 block_scan2(uint2 v, uint2 *wave_tot /* LDS [PB / 64] */
 }
 
 // ---- 1: classify ----------------------------------------------------------------------------------------------
+// what one read is to the packer: its per-read word (0: not kept), the words it takes in the plane stream, its SURVEY §8-d bytes,
+// its end; `longread`: left to tally_stream_kernel (a device-decoded stream only; from flat arrays PKF_LONG is raised instead)
+struct Classified { uint32_t word, nwords, len; unsigned long long alg; int32_t end; bool longread; };
+
+__device__ inline Classified classify_view(const ReadView &v, int32_t mode, int32_t pos_shift, const uint8_t *rec, bool stream_long_ok, PackTotals *tot)
+{
+    Classified c = {0u, 0u, 0u, 0ull, 0, false};
+    bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
+    if (v.broken || (v.bad && !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0)) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
+    if (!(v.flag & 0x4u) && v.tid > 0) atomicOr(&tot->flags, (uint32_t)PKF_MULTIREF);   // (the host packer words the error)
+    if (!kept) return c;
+    // one walk over the CIGAR: reference span, and is it [H]*[S]* (M|=|X)+ [S]*[H]* ?
+    int64_t span = 0, m = 0, y0 = 0;
+    int ph = 0;                     // 0 start / leading H, 1 leading S, 2 match run, 3 trailing S, 4 trailing H
+    bool simple = true;
+    for (uint32_t k = 0; k < v.n_cigar; ++k) {
+        const uint32_t cw = ld_u32(v.cigar + 4 * (size_t)k), op = cw & 0xFu, len = cw >> 4;
+        if (consumes_ref(op)) span += len;
+        if (op == 5) { if (ph >= 2) ph = 4; else if (ph == 1) simple = false; }
+        else if (op == 4) { if (ph <= 1) { ph = 1; y0 += len; } else if (ph <= 3) ph = 3; else simple = false; }
+        else if (is_match(op)) { if (ph <= 2) { ph = 2; m += len; } else simple = false; }
+        else simple = false;
+    }
+    simple = simple && ph >= 2 && m > 0 && y0 < (1 << 20);
+    if (mode == 1 && v.n_cigar == 2 && v.l_seq > 0) {   // <l_seq>S<n>N + a CG:B tag: the real CIGAR lives in the tag (SAM spec §4.2.2)
+        const uint32_t c0 = ld_u32(v.cigar), c1 = ld_u32(v.cigar + 4);
+        if ((c0 & 0xFu) == 4 && (c0 >> 4) == (uint32_t)v.l_seq && (c1 & 0xFu) == 3) {
+            if (has_cg_tag(v.seq + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq, rec + 4 + ld_u32(rec)))
+                atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);   // (the host reader words the refusal)
+        }
+    }
+    if (span <= 0) return c;
+    const int64_t end = (int64_t)v.pos + pos_shift + span;
+    const int64_t len = simple ? m : span;
+    if (end >= (int64_t)TCMI_F_EVPOS) { atomicOr(&tot->flags, (uint32_t)PKF_FARPOS); return c; }
+    c.alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
+    c.end = (int32_t)end;
+    if (len > TCMI_D_MAXLEN) {
+        // A read that spans more positions than a chunk's window (long-read platforms).  From the flat arrays: the host
+        // packer cuts it into pieces.  In a device-decoded stream: it stays out of the packed set and is walked where it
+        // lies, CIGAR op by CIGAR op, by tally_stream_kernel (one wavefront per such read).
+        if (mode == 1 && stream_long_ok) c.longread = true;
+        else { atomicOr(&tot->flags, (uint32_t)PKF_LONG); c.alg = 0; c.end = 0; }
+        return c;
+    }
+    c.word = (uint32_t)len | (simple ? 0u : INFO_PROJ) | INFO_KEPT | (simple ? (uint32_t)y0 << 12 : 0u);
+    c.nwords = words_of((uint32_t)len);
+    c.len = (uint32_t)len;
+    return c;
+}
+
 __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uint2 *rd_seq, int32_t *rd_pos, uint2 *blk_sum, unsigned long long *blk_alg,
                                                   int32_t *blk_end, PackTotals *tot, uint32_t *gen_idx)
 {
@@ -182,56 +246,9 @@ __global__ __launch_bounds__(PB) void pk_classify(PackSrc s, uint32_t *info, uin
     uint32_t my_len = 0;
     if (i < s.n) {
         const ReadView v = view(s, i);
-        bool kept = !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0 && !v.bad;
-        if (v.broken || (v.bad && !(v.flag & 0x4u) && v.tid == 0 && v.pos >= 0)) atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);
-        if (!(v.flag & 0x4u) && v.tid > 0) atomicOr(&tot->flags, (uint32_t)PKF_MULTIREF);   // (the host packer words the error)
-        if (kept) {
-            // one walk over the CIGAR: reference span, and is it [H]*[S]* (M|=|X)+ [S]*[H]* ?
-            int64_t span = 0, m = 0, y0 = 0;
-            int ph = 0;                     // 0 start / leading H, 1 leading S, 2 match run, 3 trailing S, 4 trailing H
-            bool simple = true;
-            for (uint32_t k = 0; k < v.n_cigar; ++k) {
-                const uint32_t c = ld_u32(v.cigar + 4 * (size_t)k), op = c & 0xFu, len = c >> 4;
-                if (consumes_ref(op)) span += len;
-                if (op == 5) { if (ph >= 2) ph = 4; else if (ph == 1) simple = false; }
-                else if (op == 4) { if (ph <= 1) { ph = 1; y0 += len; } else if (ph <= 3) ph = 3; else simple = false; }
-                else if (is_match(op)) { if (ph <= 2) { ph = 2; m += len; } else simple = false; }
-                else simple = false;
-            }
-            simple = simple && ph >= 2 && m > 0 && y0 < (1 << 20);
-            if (s.mode == 1 && v.n_cigar == 2 && v.l_seq > 0) {   // <l_seq>S<n>N + a CG:B tag: the real CIGAR lives in the tag (SAM spec §4.2.2)
-                const uint32_t c0 = ld_u32(v.cigar), c1 = ld_u32(v.cigar + 4);
-                if ((c0 & 0xFu) == 4 && (c0 >> 4) == (uint32_t)v.l_seq && (c1 & 0xFu) == 3) {
-                    const uint8_t *rec = s.stream + s.rec_off[i];
-                    if (has_cg_tag(v.seq + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq, rec + 4 + ld_u32(rec)))
-                        atomicOr(&tot->flags, (uint32_t)PKF_BADREAD);   // (the host reader words the refusal)
-                }
-            }
-            kept = span > 0;
-            if (kept) {
-                const int64_t end = (int64_t)v.pos + s.pos_shift + span;
-                const int64_t len = simple ? m : span;
-                if (end >= (int64_t)TCMI_F_EVPOS) { atomicOr(&tot->flags, (uint32_t)PKF_FARPOS); kept = false; }
-                else if (len > TCMI_D_MAXLEN) {
-                    // A read that spans more positions than a chunk's window (long-read platforms).  From the flat arrays: the host
-                    // packer cuts it into pieces.  In a device-decoded stream: it stays out of the packed set and is walked where it
-                    // lies, CIGAR op by CIGAR op, by tally_stream_kernel (one wavefront per such read).
-                    if (s.mode == 1 && gen_idx) {
-                        gen_idx[atomicAdd(&tot->n_gen, 1u)] = (uint32_t)i;
-                        my_alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
-                        my_end = (int32_t)end;
-                    } else atomicOr(&tot->flags, (uint32_t)PKF_LONG);
-                    kept = false;
-                }
-                else {
-                    word = (uint32_t)len | (simple ? 0u : INFO_PROJ) | INFO_KEPT | (simple ? (uint32_t)y0 << 12 : 0u);
-                    nwords = words_of((uint32_t)len);
-                    my_alg = (unsigned long long)(12 + 4 * (int64_t)v.n_cigar + ((int64_t)v.l_seq + 1) / 2);
-                    my_end = (int32_t)end;
-                    my_len = (uint32_t)len;
-                }
-            }
-        }
+        const Classified c = classify_view(v, s.mode, s.pos_shift, s.mode == 1 ? s.stream + s.rec_off[i] : nullptr, gen_idx != nullptr, tot);
+        if (c.longread) gen_idx[atomicAdd(&tot->n_gen, 1u)] = (uint32_t)i;
+        word = c.word; nwords = c.nwords; my_alg = c.alg; my_end = c.end; my_len = c.len;
         info[i] = word;
         // where the read's SEQ starts (bytes from the stream's / the SEQ array's first byte; low word | high byte) and l_seq:
         // pk_pack goes straight there instead of chasing record offset -> header -> CIGAR -> SEQ through four dependent loads
@@ -451,11 +468,10 @@ __device__ inline void pair_planes(const uint8_t *p, bool odd, int have, uint32_
 }
 
 // one PROJECTED read (anything but [H][S]M[S][H]) -> its plane pairs (out: 2 * ceil(len / 32) words, then the zero pair) and its event words
-__device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotals *tot, uint32_t i, uint32_t info, int32_t gpos, uint32_t *out)
+__device__ inline void pack_read(const ReadView &v, const PackOut &o, PackTotals *tot, uint32_t info, int32_t gpos, uint32_t *out)
 {
     const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
     {
-        const ReadView v = view(src, i);
         // Walk the CIGAR: matched bases land on their reference offset (bit-field copies into the pair being built), D / N
         // leave empty positions, and the tokens that are not plain bases become events: X for a deleted base
         // whose token is exactly "*", I on the last reference base before an insertion (also "*+..": I but not X).
@@ -505,9 +521,24 @@ __device__ inline void pack_read(const PackSrc &src, const PackOut &o, PackTotal
     *reinterpret_cast<uint2 *>(out + 2 * npair) = make_uint2(0u, 0u);
 }
 
+// dev_slots > 0 (the one-sync path: nobody has read the totals back): n_kept and n_words are taken from `tot`, and the reads per
+// workgroup are worked out here as tcmi_pack_on_device does on the host (dev_slots = the tally kernel's resident workgroups, or
+// 1 << 30: no balancing); the grid was sized from the capacity, workgroups beyond the reads leave at once.
 __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, const uint32_t *c_info, const uint32_t *c_woff,
-                                              uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages, int stage_cap, PackTotals *tot)
+                                              uint32_t n_kept, uint32_t n_words, int reads_per_wg, int n_stages, int stage_cap, PackTotals *tot,
+                                              int64_t dev_slots)
 {
+    if (dev_slots > 0) {
+        n_kept = (uint32_t)min(tot->n_kept, (unsigned long long)0xFFFFFFF0u);
+        n_words = (uint32_t)min(tot->n_words, (unsigned long long)o.word_cap - 18ull);
+        int64_t C = 2048;
+        if (dev_slots < (1ll << 30)) {
+            const int64_t longest = (int64_t)TCMI_F_MAXSTAGE * 400, nf = n_kept;
+            const int64_t k = max((int64_t)1, (nf + dev_slots * longest - 1) / (dev_slots * longest));
+            C = max((int64_t)64, (nf + k * dev_slots - 1) / (k * dev_slots));
+        }
+        reads_per_wg = (int)min(C, (int64_t)PK_CMAX);
+    }
     __shared__ int32_t s_pos[PK_CMAX];
     __shared__ uint32_t s_woff[PK_CMAX + 1];
     __shared__ uint16_t s_len[PK_CMAX];
@@ -521,6 +552,7 @@ __global__ __launch_bounds__(PB) void pk_pack(PackOut o, const int32_t *c_pos, c
         o.slack[tid] = 0u;
     }
     const uint32_t r0 = (uint32_t)blockIdx.x * (uint32_t)reads_per_wg;
+    if ((unsigned long long)blockIdx.x * (unsigned long long)reads_per_wg >= n_kept) return;     // (a grid sized from the capacity)
     const int n = (int)min((uint32_t)reads_per_wg, n_kept - r0);
     for (int t = tid; t < n; t += PB) {
         s_pos[t] = c_pos[r0 + t];
@@ -657,7 +689,7 @@ __global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const ui
         const int n_slot = (int)(words_of(info & 1023u) >> 1);
         s_info[tid] = info; s_word[tid] = word; s_pos[tid] = pos; s_seq[tid] = c_seq[g];
         for (int q = 0; q < n_slot; ++q) s_owner[slot0 + q] = own && q <= npair ? (uint16_t)0xFFFFu : (uint16_t)(tid | (q << 8));
-        if (own) pack_read(src, o, tot, c_idx[g], info, pos, o.seq + word);
+        if (own) pack_read(view(src, c_idx[g]), o, tot, info, pos, o.seq + word);
     }
     __syncthreads();
     const uint8_t *bytes = src.mode == 0 ? src.seq : src.stream;
@@ -685,6 +717,292 @@ __global__ __launch_bounds__(PB) void pk_planes(PackSrc src, PackOut o, const ui
     }
 }
 
+
+// ---- a device-decoded stream -> the packed read set, without a host round trip and without a scan kernel -------------------------
+// What rec_scan + the host's chain check + rec_compact + pk_classify + pk_scan + pk_scatter + pk_planes do in seven steps with three
+// host round trips, as TWO kernels with none, one workgroup per BGZF block each:
+//   pk_index   the records that start in the block (bgzf_copy listed them) get their place in the dense record index — the block's
+//              base is the sum of the record counts of the blocks in front of it, which every workgroup adds up for itself (a few
+//              thousand 4-byte words from L2: no scan kernel, nobody waits for anybody) —, are classified (classify_view, as
+//              pk_classify), and leave 16 bytes each for pk_place; the block leaves its aggregate: kept reads, plane words, and the
+//              record chain's transfer function across it
+//   pk_place   adds up the aggregates in front of its block the same way, checks that the chain of records arrives at its block
+//              where its first record starts (what the host checks block by block on the other path), and writes the kept reads'
+//              entries and their bit planes (pk_scatter's and pk_planes' work) at their final places
+// A first version did all of this in ONE kernel with a decoupled look-back between the workgroups (Merrill & Garland's single-pass
+// scan); alone on the GPU it took 96 us, but a workgroup that waits for its predecessors holds registers and LDS that the kernels
+// of other streams want: with eight contexts the pipeline lost 8 %, and with eight hardware queues it collapsed (16 M positions/s).
+// Nothing here waits for another workgroup.
+// The record chain across block boundaries as a function of "offset in this block at which a record must start": identity (a
+// header-only block), subtract the block's length (no record starts in it), a constant (the block's last record runs that far into
+// the next).
+enum { CH_ID = 0, CH_SUB = 1, CH_CONST = 2 };
+constexpr long long CH_BIAS = 1ll << 44;
+__device__ inline unsigned long long ch_pack(int kind, long long v) { return ((unsigned long long)kind << 56) | (unsigned long long)(v + CH_BIAS); }
+__device__ inline int ch_kind(unsigned long long p) { return (int)((p >> 56) & 3u); }
+__device__ inline long long ch_val(unsigned long long p) { return (long long)(p & ((1ull << 56) - 1ull)) - CH_BIAS; }
+constexpr uint32_t PKF_CHAIN = 256, PKF_STAT = 512, PKF_REC_OVF = 2048;
+
+struct FusedArgs {
+    const uint8_t *stream;
+    uint64_t stream_len;
+    const BlockDesc *blocks;
+    const uint32_t *rec_slot;       // [n_blocks][MAX_REC_PER_BLOCK] (bgzf_copy)
+    const uint32_t *n_rec;          // [n_blocks]
+    const uint32_t *first;          // [n_blocks] offset of the first record start the block found in itself (0xFFFFFFFF: none)
+    const int32_t *over;            // [n_blocks] bytes the block's last record runs into the next blocks (0x7FFFFFFF: read its size here)
+    const uint32_t *stat;           // [n_blocks] ST_*
+    int32_t n_blocks, n_own, ranged;
+    uint2 *agg;                     // [n_blocks] pk_index -> pk_place: {kept reads, plane words} of the block
+    unsigned long long *fn;         // [n_blocks] ... the chain's transfer function across the block (ch_pack)
+    uint32_t *rec_base;             // [n_blocks] ... index of the block's first record
+    uint4 *rrec;                    // [rec_cap] ... per record {word, where SEQ lies (2 words), pos}
+    uint64_t *rec_off;              // out [rec_cap]: dense record offsets
+    uint32_t rec_cap;
+    uint32_t *c_idx; int32_t *c_pos; uint32_t *c_info; uint32_t *c_woff; uint2 *c_seq;     // out [rec_cap]: the kept reads, compacted
+    uint32_t *gen_idx;              // out [rec_cap]: reads left to tally_stream_kernel
+    PackOut o;                      // plane stream + events (caps inside)
+    unsigned long long *blk_alg;    // out [n_blocks]: algorithmic bytes | longest span << 48
+    int32_t *blk_end;               // out [n_blocks]: max end
+    PackTotals *tot;
+};
+
+// the sum of v[0 .. n) over the workgroup (every lane gets it); s4: LDS [PB / 64]
+__device__ inline unsigned long long block_sum_u32(const uint32_t *v, int n, unsigned long long *s4)
+{
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < n; i += PB) acc += v[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < PB / 64; ++w) t += s4[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(PB) void pk_index(FusedArgs a)
+{
+    __shared__ uint2 s_w[PB / 64];
+    __shared__ unsigned long long s_alg[PB / 64];
+    __shared__ int32_t s_end[PB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const BlockDesc d = a.blocks[b];
+    const bool mine = b < a.n_own;                                  // (a block taken along for the tail of the last record: its records are not ours)
+    const uint32_t n = mine ? a.n_rec[b] : 0u;
+    const uint32_t *slots = a.rec_slot + (size_t)b * MAX_REC_PER_BLOCK;
+    const uint32_t st = a.stat[b];
+    const uint32_t first = mine ? a.first[b] : 0xFFFFFFFFu;
+    int32_t over = mine ? a.over[b] : 0;
+    if (tid == 0 && st != ST_OK) atomicOr(&a.tot->flags, PKF_STAT);
+    // the block's first record's index: the records of the blocks in front of it (all of them ours: b < n_own, or n = 0)
+    const unsigned long long base = block_sum_u32(a.n_rec, min(b, a.n_own), s_alg);
+    if (tid == 0) a.rec_base[b] = (uint32_t)min(base, (unsigned long long)0xFFFFFFFFu);
+    const bool room = base + n <= a.rec_cap;
+    if (!room && tid == 0) atomicOr(&a.tot->flags, PKF_REC_OVF);
+    unsigned long long my_alg = 0;
+    int32_t my_end = 0;
+    uint32_t my_len = 0, tot_k = 0, tot_w = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += PB) {
+        const uint32_t t = t0 + (uint32_t)tid;
+        uint32_t word = 0, nwords = 0;
+        if (t < n) {
+            const uint64_t roff = d.uout + slots[t];
+            const uint8_t *rec = a.stream + roff;
+            ReadView v = view_rec(rec);
+            // (a record that claims to end behind the stream: nothing of it is followed — the chain check will refuse the file)
+            if (roff + 4ull + ld_u32(rec) > a.stream_len) { v.bad = true; v.broken = true; v.n_cigar = 0; }
+            const Classified c = classify_view(v, 1, 0, rec, true, a.tot);
+            word = c.word; nwords = c.nwords;
+            my_alg += c.alg; my_end = max(my_end, c.end); my_len = max(my_len, c.len);
+            if (room) {
+                const uint64_t ig = base + t;
+                const unsigned long long so = (unsigned long long)(v.seq - a.stream);
+                a.rec_off[ig] = roff;
+                a.rrec[ig] = make_uint4(word, (uint32_t)so, ((uint32_t)(so >> 32) & 0xFFu) | ((uint32_t)min(v.l_seq, 0xFFFFFF) << 8), (uint32_t)v.pos);
+                if (c.longread) a.gen_idx[atomicAdd(&a.tot->n_gen, 1u)] = (uint32_t)ig;
+            }
+        }
+        const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
+        __syncthreads();
+        if (tid == PB - 1) s_w[0] = incl;
+        __syncthreads();
+        tot_k += s_w[0].x; tot_w += s_w[0].y;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        my_alg += (unsigned long long)__shfl_xor((long long)my_alg, dd, 64);
+        my_end = max(my_end, __shfl_xor(my_end, dd, 64));
+        my_len = max(my_len, (uint32_t)__shfl_xor((int)my_len, dd, 64));
+    }
+    if (lane == 0) { s_alg[wave] = my_alg | ((unsigned long long)my_len << 48); s_end[wave] = my_end; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long al = 0, ml = 0;
+        int32_t e = 0;
+        for (int w = 0; w < PB / 64; ++w) { al += s_alg[w] & 0xFFFFFFFFFFFFull; ml = max(ml, s_alg[w] >> 48); e = max(e, s_end[w]); }
+        a.blk_alg[b] = al | (ml << 48);
+        a.blk_end[b] = e;
+        a.agg[b] = make_uint2(tot_k, tot_w);
+        if (mine && over == 0x7FFFFFFF && n) {                      // the last record's size field straddles the block's end: read it from the stream
+            const uint32_t at = slots[n - 1];
+            const uint32_t bs = ld_u32(a.stream + d.uout + at);
+            over = bs - 32u > (1u << 28) - 32u ? -1 : (int32_t)(at + 4u + bs - d.ulen);
+        }
+        unsigned long long fn;
+        if (!mine || d.entry == -1) fn = ch_pack(CH_ID, 0);
+        else if (first != 0xFFFFFFFFu) fn = ch_pack(CH_CONST, over);
+        else if (d.entry >= 0) fn = ch_pack(CH_CONST, (long long)d.entry - (long long)d.ulen);
+        else fn = ch_pack(CH_SUB, d.ulen);
+        a.fn[b] = fn;
+    }
+}
+
+__global__ __launch_bounds__(PB) void pk_place(FusedArgs a)
+{
+    __shared__ uint2 s_w[PB / 64];
+    __shared__ unsigned long long s_sum[2 * (PB / 64)];
+    __shared__ uint32_t s_info[PB], s_word[PB];
+    __shared__ int32_t s_pos[PB];
+    __shared__ uint2 s_seq[PB];
+    __shared__ uint16_t s_owner[PL_SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const BlockDesc d = a.blocks[b];
+    const bool mine = b < a.n_own;
+    const uint32_t n = mine ? a.n_rec[b] : 0u;
+    const uint32_t st = a.stat[b];
+    // ---- the kept reads and words in front of this block: every workgroup adds the aggregates up for itself -------------------------
+    unsigned long long ex_k = 0, ex_w = 0;
+    {
+        for (int i = tid; i < b; i += PB) { const uint2 v = a.agg[i]; ex_k += v.x; ex_w += v.y; }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { ex_k += (unsigned long long)__shfl_xor((long long)ex_k, dd, 64); ex_w += (unsigned long long)__shfl_xor((long long)ex_w, dd, 64); }
+        if (lane == 0) { s_sum[wave] = ex_k; s_sum[PB / 64 + wave] = ex_w; }
+    }
+    // ---- the record chain (wavefront 0): the nearest block in front that fixes the state, minus the lengths of the record-less blocks behind it
+    if (wave == 0) {
+        int kind = CH_ID;
+        long long val = 0, subs = 0;
+        for (int hi = b - 1; hi >= 0 && kind != CH_CONST; hi -= 64) {
+            const int e = hi - lane;
+            const unsigned long long f = e >= 0 ? a.fn[e] : ch_pack(CH_ID, 0);
+            const int k = ch_kind(f);
+            const unsigned long long cmask = __ballot(k == CH_CONST);
+            const int fc = cmask ? (int)__builtin_ctzll(cmask) : 64;
+            long long sb = lane < fc && k == CH_SUB ? ch_val(f) : 0;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) sb += __shfl_xor(sb, dd, 64);
+            subs += sb;
+            if (fc < 64) { kind = CH_CONST; val = __shfl(ch_val(f), fc, 64); }
+        }
+        // in front of the file: expect = -1; in front of a range: OPEN (it starts wherever its first block finds a record)
+        const bool open_in = kind != CH_CONST && a.ranged != 0;
+        const long long state_in = kind == CH_CONST ? val - subs : -1 - subs;
+        if (lane == 0) {
+            const uint32_t first = mine ? a.first[b] : 0xFFFFFFFFu;
+            const bool has = first != 0xFFFFFFFFu;
+            const long long over = ch_val(a.fn[b]);                 // (pk_index resolved a size field that straddles the block's end)
+            int ok = 1;
+            long long state_out = state_in;
+            bool open_out = open_in;
+            if (mine && d.entry != -1) {
+                if (has) {
+                    const long long expect = d.entry >= 0 ? (long long)d.entry : state_in;
+                    if (st == ST_BAD_RECORD) ok = 0;
+                    if (!open_in || d.entry >= 0) { if ((long long)first != expect) ok = 0; }
+                    if (over < 0) ok = 0;
+                    state_out = over; open_out = false;
+                } else if (!open_in || d.entry >= 0) {
+                    const long long expect = d.entry >= 0 ? (long long)d.entry : state_in;
+                    if (st == ST_BAD_RECORD) ok = 0;
+                    if (expect < (long long)d.ulen) ok = 0;
+                    state_out = expect - (long long)d.ulen; open_out = false;
+                }
+            }
+            if (b == a.n_own - 1 || (a.n_own == 0 && b == 0)) {     // the end of the range: the last record must end in it — or in the block taken along
+                if (!open_out) {
+                    if (a.n_own < a.n_blocks) { if (state_out > (long long)a.blocks[a.n_own].ulen) ok = 0; }
+                    else if (state_out > 0) ok = 0;
+                }
+            }
+            if (!ok) atomicOr(&a.tot->flags, PKF_CHAIN);
+        }
+    }
+    __syncthreads();
+    ex_k = 0; ex_w = 0;
+#pragma unroll
+    for (int w = 0; w < PB / 64; ++w) { ex_k += s_sum[w]; ex_w += s_sum[PB / 64 + w]; }
+    const uint2 mine_agg = a.agg[b];
+    const uint32_t tot_w = mine_agg.y;
+    const unsigned long long ex_r = a.rec_base[b];
+    if (b == a.n_blocks - 1 && tid == 0) {
+        a.tot->n_rec = ex_r + n; a.tot->n_kept = ex_k + mine_agg.x; a.tot->n_words = ex_w + tot_w;
+        if (ex_r + n > 0x7FFFFFFFull || ex_k + mine_agg.x > 0x7FFFFFFFull) atomicOr(&a.tot->flags, PKF_REC_OVF);
+    }
+    if (n == 0) return;
+    // room for this block's records, kept reads and words?  (the arrays are sized from bounds: a file beyond them takes the other path)
+    if (ex_r + n > a.rec_cap || ex_w + tot_w + 2ull + 16ull > a.o.word_cap) {
+        if (tid == 0) atomicOr(&a.tot->flags, ex_r + n > a.rec_cap ? PKF_REC_OVF : (uint32_t)PKF_WORD_OVF);
+        return;
+    }
+    // ---- the kept reads' entries and their planes ---------------------------------------------------------------------------------------
+    uint32_t run_k = 0, run_w = 0;                                  // kept reads / words of the tiles in front of this one
+    for (uint32_t t0 = 0; t0 < n; t0 += PB) {
+        const uint32_t t = t0 + (uint32_t)tid;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (t < n) r = a.rrec[ex_r + t];
+        const uint32_t word = r.x, nwords = word ? words_of(word & 1023u) : 0u;
+        const uint2 incl = block_scan2(make_uint2(word ? 1u : 0u, nwords), s_w);
+        __syncthreads();
+        if (tid == PB - 1) s_w[0] = incl;
+        __syncthreads();
+        const uint32_t tile_k = s_w[0].x, tile_w = s_w[0].y;
+        const uint32_t w_first = (uint32_t)ex_w + run_w;            // the tile's first word offset (its reads are contiguous from there)
+        if (word) {
+            const uint32_t lk = incl.x - 1u, lwoff = incl.y - nwords;    // the read's place among the tile's kept reads; its first word, from the tile's
+            const uint32_t j = (uint32_t)ex_k + run_k + lk, woff = w_first + lwoff;
+            const int32_t pos = (int32_t)r.w;
+            const uint2 sq = make_uint2(r.y, r.z);
+            a.c_idx[j] = (uint32_t)(ex_r + t); a.c_pos[j] = pos; a.c_info[j] = word; a.c_woff[j] = woff; a.c_seq[j] = sq;
+            const int npair = (int)((word & 1023u) + 31u) >> 5;
+            const bool own = (word & INFO_PROJ) != 0;               // (its lane writes its pairs and the zero pair behind them)
+            s_info[lk] = word; s_word[lk] = 2u + woff; s_pos[lk] = pos; s_seq[lk] = sq;
+            const uint32_t slot0 = lwoff >> 1;
+            for (int q = 0; q < (int)(nwords >> 1); ++q) s_owner[slot0 + q] = own && q <= npair ? (uint16_t)0xFFFFu : (uint16_t)(lk | ((uint32_t)q << 8));
+            if (own) pack_read(view_rec(a.stream + a.rec_off[ex_r + t]), a.o, a.tot, word, pos, a.o.seq + 2u + woff);
+        }
+        __syncthreads();
+        uint2 *dst = reinterpret_cast<uint2 *>(a.o.seq + 2u + w_first);                      // (word offsets are multiples of 4: 8-byte aligned)
+        for (uint32_t k = tid; k < (tile_w >> 1); k += PB) {
+            const uint32_t ow = s_owner[k];
+            if (ow == 0xFFFFu) continue;
+            const int tt = (int)(ow & 255u), q = (int)(ow >> 8);
+            const uint32_t info = s_info[tt];
+            const int len = (int)(info & 1023u), npair = (len + 31) >> 5;
+            if (q >= npair) { dst[k] = make_uint2(0u, 0u); continue; }
+            const uint2 where = s_seq[tt];
+            const int l_seq = (int)(where.y >> 8), y = (int)(info >> 12) + 32 * q;
+            const int nb = min(32, len - 32 * q), have = min(nb, l_seq - y);
+            uint32_t lo, hi, ok;
+            pair_planes(a.stream + ((((unsigned long long)(where.y & 0xFFu) << 32) | where.x) + (uint32_t)(y >> 1)), y & 1, have, lo, hi, ok);
+            dst[k] = make_uint2(lo, hi);
+            uint32_t miss = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~ok;
+            while (miss) {
+                const int bb = __builtin_ctz(miss);
+                push_event(a.o, a.tot, (uint32_t)(s_pos[tt] + 32 * q + bb) | TCMI_F_EV_OTHER);
+                miss &= miss - 1;
+            }
+        }
+        run_k += tile_k; run_w += tile_w;
+        __syncthreads();
+    }
+}
 
 // ---- insert-candidate columns: every read of a column as an entry for the host's token vote (Events.py:47-82) -----------------
 // One lane per (candidate column, read that starts within TCMI_D_MAXLEN positions before it).  The lane applies the samtools
@@ -1031,7 +1349,7 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
         if (attempt == 0)
             hipLaunchKernelGGL(pk_scatter, dim3((unsigned)n_blk), dim3(PB), 0, ctx->stream, src, info, rd_seq, rd_pos, blk_sum, c_idx, c_pos, c_info, c_woff, c_seq);
         hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, c_pos, c_info, c_woff, (uint32_t)nf,
-                           (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot);
+                           (uint32_t)tot.n_words, (int)C, n_stages, ctx->stage_cap, d_tot, (int64_t)0);
         hipLaunchKernelGGL(pk_planes, dim3((unsigned)((nf + PB - 1) / PB)), dim3(PB), 0, ctx->stream, src, o, c_idx, c_pos, c_info, c_woff, c_seq,
                            (uint32_t)nf, (uint32_t)tot.n_words, d_tot);
         tcmi_prof_end(ctx, TCMI_K_PACK);
@@ -1059,6 +1377,163 @@ int tcmi_pack_on_device(tcmi_ctx *ctx, const void *src_, tcmi_readset *rs, uint3
                         (int64_t)tot.n_runs * 4 + (int64_t)tot.n_events * 4;
         return TCMI_OK;
     }
+}
+
+// what the host checks after its one wait, stored by the kernel itself into pinned host memory (a copy command between two kernels
+// costs the stream 40 - 100 us of hand-over between the copy engine and the compute queue; these stores cross PCIe on their own)
+__global__ __launch_bounds__(256) void pk_report(const PackTotals *tot, const unsigned long long *blk_alg, const int32_t *blk_end, const uint32_t *stat,
+                                                 int32_t nb, PackTotals *h_tot, unsigned long long *h_alg, int32_t *h_end, uint32_t *h_stat)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < nb) { h_alg[i] = blk_alg[i]; h_end[i] = blk_end[i]; h_stat[i] = stat[i]; }
+    if (i == 0) *h_tot = *tot;
+}
+
+// ---- the one-sync path: pk_fused + pk_pack queued from capacities, checked after the caller's one wait ------------------------------
+static char *take_blob(tcmi_ctx *ctx, tcmi_readset *rs, size_t want)
+{
+    for (size_t k = 0; k < ctx->blob_pool.size(); ++k)           // a freed read set of about this size?
+        if (ctx->blob_pool[k].bytes >= want && ctx->blob_pool[k].bytes <= want + want / 2 + (1 << 20)) {
+            char *blob = ctx->blob_pool[k].p;
+            rs->blob_bytes = ctx->blob_pool[k].bytes;
+            ctx->blob_pool.erase(ctx->blob_pool.begin() + (long)k);
+            return blob;
+        }
+    char *blob = nullptr;
+    rs->blob_bytes = want + want / 16;
+    if (hipMalloc((void **)&blob, rs->blob_bytes) != hipSuccess) { (void)hipGetLastError(); rs->blob_bytes = 0; return nullptr; }
+    return blob;
+}
+
+int tcmi_pack_fused_enqueue(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs)
+{
+    const int64_t nb = job->n_blocks, cap = std::max<int64_t>(job->rec_cap, 1);
+    if (cap > 0x7FFFFFF0ll) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many records for the one-pass packer");
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    uint2 *agg = (uint2 *)arena_take(ctx, al((size_t)nb * 8));
+    unsigned long long *fn = (unsigned long long *)arena_take(ctx, al((size_t)nb * 8));
+    uint32_t *rec_base = (uint32_t *)arena_take(ctx, al((size_t)nb * 4));
+    uint4 *rrec = (uint4 *)arena_take(ctx, (size_t)cap * 16);
+    unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, al((size_t)nb * 8));
+    int32_t *blk_end = (int32_t *)arena_take(ctx, al((size_t)nb * 4));
+    PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
+    job->d_rec = (uint64_t *)arena_take(ctx, (size_t)cap * 8 + 8);
+    job->c_idx = (uint32_t *)arena_take(ctx, (size_t)cap * 4);
+    job->c_pos = (int32_t *)arena_take(ctx, (size_t)cap * 4);
+    uint32_t *c_info = (uint32_t *)arena_take(ctx, (size_t)cap * 4);
+    uint32_t *c_woff = (uint32_t *)arena_take(ctx, (size_t)cap * 4);
+    uint2 *c_seq = (uint2 *)arena_take(ctx, (size_t)cap * 8);
+    job->gen_idx = (uint32_t *)arena_take(ctx, (size_t)cap * 4);
+    if (ctx->dev_arena->used > ctx->dev_arena->cap) return tcmi_fail(ctx, TCMI_E_NOMEM, "internal: one-pass packer scratch under-reserved");
+    job->d_tot = d_tot;
+    const size_t pin_bytes = al(sizeof(PackTotals)) + al((size_t)nb * 8) + al((size_t)nb * 4) + al((size_t)nb * 4);
+    job->h_pin = (char *)tcmi_ctx_pinned(ctx, pin_bytes);
+    if (!job->h_pin) return tcmi_fail(ctx, TCMI_E_NOMEM, "pinned scratch for the packer's totals");
+    // capacities: what the arrays of the packed read set are sized for (a file beyond them takes the several-kernel path)
+    const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) : TCMI_F_MAXSTAGE;
+    const bool balance = ctx->chunk_stages == 0 && ctx->balance_chunks;
+    const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu, longest = (int64_t)TCMI_F_MAXSTAGE * 400;
+    const int64_t k_cap = std::max<int64_t>(1, (cap + slots * longest - 1) / (slots * longest));
+    const int64_t n_wg = balance ? std::max<int64_t>(k_cap * slots, (cap + PK_CMAX - 1) / PK_CMAX) : (cap + PK_CMAX - 1) / PK_CMAX + (cap + 2047) / 2048;
+    // words: a read of len positions takes <= len / 16 + 7 words, and a read without long deletions / skips has len <= l_seq,
+    // each base of which takes 1.5 bytes of the stream (others overflow the capacity: PKF_WORD_OVF, the other path)
+    const uint64_t word_cap64 = job->stream_len / 24 + 8ull * (uint64_t)cap + 64;
+    if (word_cap64 > 0xF0000000ull) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "too many plane words for the one-pass packer");
+    job->word_cap = (uint32_t)word_cap64;
+    job->chunk_cap = (uint32_t)std::min<int64_t>(cap, 4 * n_wg + job->len_bound / 128 + 64);
+    job->event_cap = (uint32_t)std::min<int64_t>(0x7FFFFFF0ll, std::max<int64_t>(1 << 20, cap / 2));
+    PackOut o = {};
+    const size_t b_len = al((size_t)cap * 4), b_seq = al((size_t)job->word_cap * 4), b_chk = al((size_t)job->chunk_cap * sizeof(tcmi_fast_chunk)),
+                 b_run = b_len, b_ev = al((size_t)job->event_cap * 4);
+    char *blob = take_blob(ctx, rs, b_len + b_seq + b_chk + b_run + b_ev + 256);
+    if (!blob) return tcmi_fail(ctx, TCMI_E_NOMEM, "hipMalloc for the packed read set failed");
+    rs->d_blob = blob;
+    o.lenoff = (uint32_t *)blob;
+    o.seq = (uint32_t *)(blob + b_len);
+    o.chunks = (tcmi_fast_chunk *)(blob + b_len + b_seq);
+    o.covrun = (uint32_t *)(blob + b_len + b_seq + b_chk);
+    o.events = (uint32_t *)(blob + b_len + b_seq + b_chk + b_run);
+    o.word_cap = job->word_cap; o.chunk_cap = job->chunk_cap; o.event_cap = job->event_cap;
+    o.slack = reinterpret_cast<uint32_t *>(blob + b_len + b_seq + b_chk + b_run + b_ev);
+    TCMI_HIP(ctx, hipMemsetAsync(d_tot, 0, sizeof(PackTotals), ctx->stream));
+    FusedArgs a = {};
+    a.stream = job->d_stream; a.stream_len = job->stream_len; a.blocks = static_cast<const BlockDesc *>(job->d_desc);
+    a.rec_slot = job->d_slot; a.n_rec = job->d_nrec; a.first = job->d_first; a.over = job->d_over; a.stat = job->d_stat;
+    a.n_blocks = (int32_t)nb; a.n_own = (int32_t)job->n_own; a.ranged = job->ranged;
+    a.agg = agg; a.fn = fn; a.rec_base = rec_base; a.rrec = rrec; a.rec_off = job->d_rec; a.rec_cap = (uint32_t)cap;
+    a.c_idx = job->c_idx; a.c_pos = job->c_pos; a.c_info = c_info; a.c_woff = c_woff; a.c_seq = c_seq; a.gen_idx = job->gen_idx;
+    a.o = o; a.blk_alg = blk_alg; a.blk_end = blk_end; a.tot = d_tot;
+    (void)hipGetLastError();
+    tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
+    hipLaunchKernelGGL(pk_index, dim3((unsigned)nb), dim3(PB), 0, ctx->stream, a);
+    tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
+    TCMI_HIP(ctx, hipGetLastError());
+    tcmi_prof_begin(ctx, TCMI_K_PACK);
+    hipLaunchKernelGGL(pk_place, dim3((unsigned)nb), dim3(PB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, job->c_pos, c_info, c_woff, 0u, 0u, 0, n_stages, ctx->stage_cap, d_tot,
+                       balance ? slots : (int64_t)1 << 30);
+    tcmi_prof_end(ctx, TCMI_K_PACK);
+    TCMI_HIP(ctx, hipGetLastError());
+    // (the report of the packer's verdicts is queued by tcmi_pack_fused_report, behind whatever the caller queues behind the packer)
+    job->d_blk_alg = blk_alg; job->d_blk_end = blk_end;
+    // the read set as the tally launch needs it before anyone has read the totals: capacities + where the real counts lie
+    rs->packed_on_device = 1;
+    rs->d_flenoff = o.lenoff; rs->d_fseq = o.seq; rs->d_fchunk = o.chunks; rs->d_fcovrun = o.covrun; rs->d_fevent = o.events;
+    rs->f_chunks = job->chunk_cap; rs->f_events = job->event_cap;
+    rs->d_dev_counts = &d_tot->n_chunks;
+    static_assert(offsetof(PackTotals, n_events) == offsetof(PackTotals, n_chunks) + 4, "the tally kernel reads {n_chunks, n_events}");
+    rs->n_piled = 1;                            // (unknown yet: "there may be reads")
+    rs->max_end = 0;
+    rs->d_stream = job->d_stream; rs->d_rec_off = job->d_rec; rs->d_cidx = job->c_idx; rs->d_cpos = job->c_pos; rs->d_gen_idx = job->gen_idx;
+    rs->arena_epoch = ctx->arena_epoch;
+    return TCMI_OK;
+}
+
+// the last launch of the one-sync path's chain: totals and per-block verdicts into the job's pinned buffer
+int tcmi_pack_fused_report(tcmi_ctx *ctx, tcmi_fused_job *job)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t nb = job->n_blocks;
+    char *h = job->h_pin;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pk_report, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, static_cast<const PackTotals *>(job->d_tot),
+                       static_cast<const unsigned long long *>(job->d_blk_alg), static_cast<const int32_t *>(job->d_blk_end), job->d_stat, (int32_t)nb,
+                       reinterpret_cast<PackTotals *>(h), reinterpret_cast<unsigned long long *>(h + al(sizeof(PackTotals))),
+                       reinterpret_cast<int32_t *>(h + al(sizeof(PackTotals)) + al((size_t)nb * 8)),
+                       reinterpret_cast<uint32_t *>(h + al(sizeof(PackTotals)) + al((size_t)nb * 8) + al((size_t)nb * 4)));
+    TCMI_HIP(ctx, hipGetLastError());
+    return TCMI_OK;
+}
+
+int tcmi_pack_fused_finish(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs, uint32_t *why)
+{
+    (void)ctx;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t nb = job->n_blocks;
+    const PackTotals &tot = *reinterpret_cast<const PackTotals *>(job->h_pin);
+    const unsigned long long *blk_alg = reinterpret_cast<const unsigned long long *>(job->h_pin + al(sizeof(PackTotals)));
+    const int32_t *blk_end = reinterpret_cast<const int32_t *>(job->h_pin + al(sizeof(PackTotals)) + al((size_t)nb * 8));
+    const uint32_t *stat = reinterpret_cast<const uint32_t *>(job->h_pin + al(sizeof(PackTotals)) + al((size_t)nb * 8) + al((size_t)nb * 4));
+    uint32_t flags = tot.flags;
+    for (int64_t b = 0; b < nb; ++b) if (stat[b] != ST_OK) flags |= PKF_STAT;
+    if (tot.n_rec > (unsigned long long)job->rec_cap) flags |= PKF_REC_OVF;
+    if (tot.n_words + 18ull > job->word_cap) flags |= PKF_WORD_OVF;
+    if (tot.n_chunks > job->chunk_cap) flags |= PKF_CHUNK_OVF;
+    if (tot.n_events > job->event_cap) flags |= PKF_EVENT_OVF;
+    *why = flags;
+    rs->d_dev_counts = nullptr;
+    if (flags) return TCMI_E_UNSUPPORTED;
+    unsigned long long alg = 0, mlen = 0;
+    int32_t mend = 0;
+    for (int64_t b = 0; b < nb; ++b) { alg += blk_alg[b] & 0xFFFFFFFFFFFFull; mlen = std::max(mlen, blk_alg[b] >> 48); mend = std::max(mend, blk_end[b]); }
+    const int64_t nf = (int64_t)tot.n_kept;
+    rs->n_reads = (int64_t)tot.n_rec;
+    rs->n_piled = nf + (int64_t)tot.n_gen; rs->f_reads = nf; rs->alg_bytes = (int64_t)alg; rs->max_end = mend; rs->max_len = (int32_t)mlen;
+    rs->s_reads = (int64_t)tot.n_gen;
+    rs->f_chunks = nf ? tot.n_chunks : 0; rs->f_words = nf ? (int64_t)tot.n_words + 4 : 0; rs->f_events = tot.n_events;
+    rs->dev_bytes = nf * 4 + ((int64_t)tot.n_words + 4) * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) + (int64_t)tot.n_runs * 4 +
+                    (int64_t)tot.n_events * 4;
+    return TCMI_OK;
 }
 
 // ---- tally_stream_kernel: the reads the packer left out (spans above TCMI_D_MAXLEN), straight from the inflated BAM stream -------

@@ -568,9 +568,16 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
                 tcmi_readset *rs = nullptr;
                 tcmi_bam *hb = nullptr;
                 int rc = TCMI_E_UNSUPPORTED;
+                const bool want_cov = files && ((files->vcf && files->vcf[i]) || (files->doc && files->doc[i]));
+                const uint8_t *pl = nullptr, *al = nullptr, *fl = nullptr;
+                const int32_t *planes = nullptr;
+                int64_t ld = 0, L = 0;
+                bool stepped = false;                            // the device path queues decode, pack, tally and call back to back: ONE wait per file
                 if (it.file) {
-                    rc = tcmi_readset_from_bamfile(ctx, it.file, &rs, nullptr);
+                    rc = tcmi_bamfile_step(ctx, it.file, ref_len, mincov, include_ambig, &rs, &L, &pl, &al, &fl, want_cov ? &planes : nullptr, &ld);
                     it.on_device = rc == TCMI_OK;
+                    stepped = rc == TCMI_OK;
+                    if (rc == TCMI_E_NOMEM) rc = TCMI_E_UNSUPPORTED;     // (a file whose decode does not fit the device's memory: the host reader streams it)
                 }
                 std::string host_err;
                 if (rc == TCMI_E_UNSUPPORTED) {                  // the host reader takes it
@@ -585,14 +592,12 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
                 t_up = seconds_since(t0);
                 const auto t1 = std::chrono::steady_clock::now();
                 if (!rc) {
-                    int64_t max_end = 0;
-                    tcmi_readset_info(rs, nullptr, nullptr, nullptr, nullptr, &max_end);
-                    const int64_t L = std::max<int64_t>({ref_len, max_end, 1});
-                    const uint8_t *pl, *al, *fl;
-                    const int32_t *planes = nullptr;
-                    int64_t ld = 0;
-                    const bool want_cov = files && ((files->vcf && files->vcf[i]) || (files->doc && files->doc[i]));
-                    rc = tcmi_step(ctx, rs, L, mincov, include_ambig, &pl, &al, &fl, want_cov ? &planes : nullptr, &ld);
+                    if (!stepped) {
+                        int64_t max_end = 0;
+                        tcmi_readset_info(rs, nullptr, nullptr, nullptr, nullptr, &max_end);
+                        L = std::max<int64_t>({ref_len, max_end, 1});
+                        rc = tcmi_step(ctx, rs, L, mincov, include_ambig, &pl, &al, &fl, want_cov ? &planes : nullptr, &ld);
+                    }
                     if (!rc) {
                         it.L = L;
                         if (want_cov) it.cov.assign(planes + (size_t)TCMI_COV * ld, planes + (size_t)TCMI_COV * ld + L);

@@ -28,6 +28,11 @@ struct FastArgs {
     int64_t ld2;
     int32_t L2, n_call2;
     int32_t pair_ok;                // the matrix allows 64-bit adds over two adjacent positions (8-byte aligned, even ld)
+    // A read set whose totals are still on the device (the one-sync file path: the launch is queued behind the packer, nobody has
+    // read its counts back): {chunks, event words} as the packer left them; n_chunks / n_events above are then the CAPACITIES the
+    // grid was sized from — blocks beyond the real counts leave at once — and n_tail blocks stride over the event words.
+    const uint32_t *dev_counts;
+    int32_t n_tail;                 // tail blocks of the launch (>= 1 when there can be events)
 };
 
 constexpr int TILE = FB;            // positions per block of the ride-along call: one lane each
@@ -77,11 +82,12 @@ static __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [FB / 6
 // (position | kind).  Equal words are counted inside the wave (ballot match), one atomic per distinct word
 // and wave: at an indel site thousands of reads carry the same event.  A covered position without an
 // A/C/G/T base was counted into column A by subtraction in the chunk blocks and is taken out here.
-static __device__ inline void tally_tail_block(const FastArgs &a, int bid /* block index behind the ride-along blocks */)
+static __device__ inline void tally_tail_block(const FastArgs &a, int bid /* block index behind the ride-along blocks */, int64_t n_events)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t i = (int64_t)(bid - a.n_chunks) * FB + tid;
-    const bool valid = i < a.n_events;
+    for (int64_t i0 = (int64_t)(bid - a.n_chunks) * FB; i0 < n_events; i0 += (int64_t)a.n_tail * FB) {
+    const int64_t i = i0 + tid;
+    const bool valid = i < n_events;
     const uint32_t key = valid ? a.events[i] : 0u;
     unsigned long long todo = __ballot(valid);
     while (todo) {
@@ -98,5 +104,6 @@ static __device__ inline void tally_tail_block(const FastArgs &a, int bid /* blo
             }
         }
         todo &= ~same;
+    }
     }
 }

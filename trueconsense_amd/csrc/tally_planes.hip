@@ -136,9 +136,10 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     }
     const int bid = (int)blockIdx.x - a.n_call2;
     if (bid >= a.n_chunks) {
-        tally_tail_block(a, bid);
+        tally_tail_block(a, bid, a.dev_counts ? (int64_t)min(a.dev_counts[1], (uint32_t)a.n_events) : a.n_events);
         return;
     }
+    if (a.dev_counts && (uint32_t)bid >= a.dev_counts[0]) return;   // (the grid was sized from the packer's capacity)
     const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
@@ -405,7 +406,12 @@ int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int
     a.lenoff = rs->d_flenoff; a.seq = rs->d_fseq; a.chunks = rs->d_fchunk; a.events = rs->d_fevent; a.covrun = rs->d_fcovrun;
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
     a.pair_ok = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_counts) % 8 == 0);
-    int64_t grid = rs->f_chunks + (rs->f_events + FB - 1) / FB;
+    a.n_tail = (int32_t)((rs->f_events + FB - 1) / FB);
+    if (rs->d_dev_counts) {                                     // totals still on the device: f_chunks / f_events are the capacities
+        a.dev_counts = rs->d_dev_counts;
+        a.n_tail = (int32_t)std::min<int64_t>(a.n_tail, 256);
+    }
+    int64_t grid = rs->f_chunks + a.n_tail;
     if (ctx->ride && !ctx->ride->taken) {                     // carry another workspace's call in this launch
         tcmi_ride *r = ctx->ride;
         a.counts2 = r->counts; a.ld2 = r->ld; a.L2 = (int32_t)r->L; a.n_call2 = (int32_t)((r->L + TILE - 1) / TILE);

@@ -100,6 +100,9 @@ struct tcmi_readset {
     const uint32_t *d_gen_idx = nullptr;   // records of reads too long for the packed set (s_reads of them): tally_stream_kernel walks them in the stream
     int64_t s_reads = 0;
     uint64_t arena_epoch = 0;
+    // the one-sync file path (bam_device.hip, tcmi_bamfile_step): the packer's totals have not been read back yet — f_chunks and
+    // f_events hold the CAPACITIES, the tally kernel takes the real counts from here ({n_chunks, n_events} in the context's arena)
+    const uint32_t *d_dev_counts = nullptr;
     char *d_blob = nullptr;     // one allocation holding d_flenoff | d_fseq | d_fchunk | d_fcovrun | d_fevent
     size_t blob_bytes = 0;
     // aligned set
@@ -146,6 +149,9 @@ struct tcmi_ctx {
     char *h_pin = nullptr;
     size_t h_pin_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
+    int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
+    int mid_wait = 1;                // the one-sync path waits once more, behind the decode kernels (bam_device.hip: fast_enqueue)
+    int one_sync = 1;                // device-decoded files take the one-sync path (pk_fused) first; 0: the several-kernel path only
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)
@@ -240,6 +246,34 @@ extern "C" int tcmi_bamfile_read_threads(const char *path, int read_threads, tcm
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);
 int tcmi_pack_on_device(tcmi_ctx *ctx, const void *pack_src, tcmi_readset *rs, uint32_t *why);
+// The one-sync file path (bam_device.hip: tcmi_bamfile_step, tcmi_readset_from_bamfile): everything behind bgzf_copy / bgzf_crc32 —
+// record index, the chain of records across the blocks, classification, prefix sums, bit planes (pk_fused), chunk planning
+// (pk_pack) — queued on the context's stream from CAPACITIES instead of counts read back; _finish, once the stream has been
+// waited for, checks what was deferred (block verdicts, chain, capacities, packer flags) and fills the read set in, or says that
+// the file must take the several-kernel path (TCMI_E_UNSUPPORTED: nothing of the job may be used then).
+struct tcmi_fused_job {
+    // in: device pointers into the context's arena (bgzf_copy, bgzf_crc32)
+    const uint8_t *d_stream = nullptr;
+    uint64_t stream_len = 0;
+    const void *d_desc = nullptr;       // BlockDesc [n_blocks]
+    const uint32_t *d_slot = nullptr, *d_nrec = nullptr, *d_first = nullptr, *d_stat = nullptr;
+    const int32_t *d_over = nullptr;
+    int64_t n_blocks = 0, n_own = 0;
+    int ranged = 0;
+    int64_t rec_cap = 0;                // records the arrays are sized for
+    int64_t len_bound = 0;              // positions the reads may reach (chunk capacity)
+    // out (enqueue)
+    char *h_pin = nullptr;              // pinned: PackTotals | per-block partials (filled by the copies queued behind the kernels)
+    void *d_tot = nullptr;
+    uint64_t *d_rec = nullptr;
+    uint32_t *c_idx = nullptr, *gen_idx = nullptr;
+    int32_t *c_pos = nullptr;
+    uint32_t chunk_cap = 0, event_cap = 0, word_cap = 0;
+    const void *d_blk_alg = nullptr, *d_blk_end = nullptr;
+};
+int tcmi_pack_fused_enqueue(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs);
+int tcmi_pack_fused_report(tcmi_ctx *ctx, tcmi_fused_job *job);     // queue it LAST (behind the tally and the call, if any): then wait, then _finish
+int tcmi_pack_fused_finish(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs, uint32_t *why);
 void *tcmi_arena_reserve_take(tcmi_ctx *ctx, size_t total, size_t first);
 void *tcmi_arena_take(tcmi_ctx *ctx, size_t bytes);
 // kernels (tally.hip / call.hip)

@@ -81,6 +81,11 @@ class Context:
     def set_option(self, key, value):
         check(lib().tcmi_ctx_set_option(self.handle, key.encode(), int(value)), self.handle)
 
+    def stat(self, key):
+        v = C.c_int64(0)
+        check(lib().tcmi_ctx_stat(self.handle, key.encode(), C.byref(v)), self.handle)
+        return v.value
+
     def profile(self, on=True):
         check(lib().tcmi_profile_enable(self.handle, int(on)), self.handle)
         check(lib().tcmi_profile_reset(self.handle), self.handle)
@@ -118,6 +123,26 @@ class Context:
         check(lib().tcmi_readset_from_bamfile_blocks(self.handle, dbam.handle, int(first), int(count), C.byref(h), C.byref(n)), self.handle)
         rs = ReadSet(self, h, None)
         return rs
+
+    def bamfile_step(self, dbam, ref_len, mincov, include_ambig, want_counts=True):
+        """DeviceBam -> (ReadSet, plain, alt, flags, counts or None) with ONE wait of the host (tcmi_bamfile_step): decode, pack,
+        tally and call queued back to back; a file the one-pass packer does not take goes through upload_bamfile + step."""
+        h, L = C.c_void_p(), C.c_int64(0)
+        p, a, f, c = (C.c_void_p() for _ in range(4))
+        ld = C.c_int64(0)
+        check(lib().tcmi_bamfile_step(self.handle, dbam.handle, int(ref_len), int(mincov), int(bool(include_ambig)), C.byref(h), C.byref(L),
+                                      C.byref(p), C.byref(a), C.byref(f), C.byref(c) if want_counts else None, C.byref(ld)), self.handle)
+        n = L.value
+
+        def grab(vp, dt, k):
+            out = np.empty(k, dt)
+            C.memmove(out.ctypes.data, vp, out.nbytes)
+            return out
+        plain, alt, flags = grab(p, np.uint8, n), grab(a, np.uint8, n), grab(f, np.uint8, n)
+        counts = None
+        if want_counts:
+            counts = np.ascontiguousarray(grab(c, np.int32, 7 * ld.value).reshape(7, ld.value)[:, :n].T)
+        return ReadSet(self, h, None), plain, alt, flags, counts
 
     def readset_modal_tokens(self, readset, positions, min_base_quality=13, flag_filter=0x4 | 0x100 | 0x200 | 0x400,
                              ignore_orphans=True, max_depth=8000, ignore_overlaps=True):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TCMI_ABI_VERSION 2
+#define TCMI_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 #define TCMI_OK            0
@@ -347,6 +347,41 @@ int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_
                                int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
                                int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,
                                int32_t *status_flags);
+/* ---- ONE BAM file over several GPUs (BASELINE configs[4]; what the ranks jointly replace is the single-pass pile-up of
+ * indexing.py:96-100 and, for the insert candidates, the region pile-ups of Events.py:47-82).
+ * The library links no collective library: the one exchange of the path — a sum of the int32 count matrix to the rank that calls —
+ * is a hook of the caller's (RCCL's ncclReduce on the given stream from C: tools/tcmi_rccl_hook.cpp; torch.distributed from Python:
+ * trueconsense_amd/distributed.py).
+ *   tcmi_split_step   this rank's part of one step, in C: decode + pack + tally the alignment records that start in BGZF blocks
+ *                     [first_block, first_block + n_blocks) into d_counts (device int32 [7][ld] + ONE more int32 behind it: the
+ *                     number of ranks that failed, summed along — a rank that cannot decode its range still takes part in the
+ *                     exchange, with zeros, so nobody waits for it forever), reduce(user, d_counts, 7 * ld + 1, stream) — the
+ *                     hook must sum over the ranks, at least to the root —, and on the root (is_root != 0) the call kernel:
+ *                     results as tcmi_step's.  *rs_out (any rank; NULL on failure) keeps the rank's decoded stream resident for
+ *                     tcmi_readset_ins_entries.  Returns the rank's own error, or on the root TCMI_E_UNSUPPORTED when another
+ *                     rank failed.
+ *   tcmi_readset_ins_entries   the entries of the candidate columns (TCMI_INS_ENTRY_BYTES each, opaque; per column in file order)
+ *                     from this rank's records: what the ranks send to the root.  ent_off[n_pos + 1]; insertions of more than 12
+ *                     bases leave their bases in long_text (long_used bytes).  TCMI_E_ARG with ent_off / long_used filled in when
+ *                     a buffer is too small.
+ *   tcmi_ins_entries_rebase    before concatenating the pieces of several ranks: piece k's long-insertion texts lie `long_base`
+ *                     bytes into the concatenated text buffer
+ *   tcmi_modal_from_entries    HOST: the vote of tcmi_readset_modal_tokens over per-column concatenations (rank order = file
+ *                     order) of such pieces.  status_flags bit 1 (TCMI_TOKENS_OVERLAP_UNKNOWN): a pair of overlapping mates whose
+ *                     other mate had to be looked at on another position — not possible across pieces: use the host sweep
+ *                     (tcmi_bam_load + tcmi_modal_tokens) for that file. */
+#define TCMI_INS_ENTRY_BYTES 48
+typedef int (*tcmi_reduce_fn)(void *user, void *d_counts, int64_t n_int32, void *stream);
+int  tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, int64_t L, int64_t ld, void *d_counts,
+                     int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int is_root, tcmi_readset **rs_out,
+                     const uint8_t **plain, const uint8_t **alt, const uint8_t **flags);
+int  tcmi_readset_ins_entries(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions, uint32_t flag_filter,
+                              int ignore_orphans, void *entries, int64_t entries_cap, int64_t *ent_off, uint8_t *long_text,
+                              int64_t long_cap, int64_t *long_used);
+int  tcmi_ins_entries_rebase(void *entries, int64_t n_entries, int64_t long_base);
+int  tcmi_modal_from_entries(int32_t n_pos, void *entries, const int64_t *ent_off, int32_t min_base_quality, int64_t max_depth,
+                             int ignore_overlaps, const uint8_t *long_text, int64_t long_bytes, char *tokens, int64_t tokens_cap,
+                             int64_t *token_off, int64_t *n_tokens, int32_t *status_flags);
 /* for tests and tools: the device-inflated stream and the record offsets copied back to the host */
 int  tcmi_bamfile_decode_to_host(tcmi_ctx *ctx, const tcmi_bamfile *f, uint8_t *stream, int64_t stream_cap,
                                  uint64_t *rec_off, int64_t rec_cap, int64_t *n_rec);

@@ -36,8 +36,69 @@ def _worker(rank, world, port, use_gpu, q):
         dist.destroy_process_group()
 
 
+def _consensus_case():
+    """An indel-carrier read set whose insert-candidate columns lie around the middle of the file (where two ranks' ranges meet):
+    accepted insertions of 1, 2 and 14 bases (the last too long for an entry's key: its bases travel as text), a rejected one."""
+    from trueconsense_amd import synthetic as sy
+    ref, orfs = sy.make_reference(L=4000, cds=[(100, 1900), (2100, 3900)])
+    sites = [(1900, "I", "A", 0.9), (1990, "I", "GT", 0.7), (2005, "I", "ACGTACGTACGTAC", 0.8), (2010, "D", 3, 0.6), (2100, "I", "C", 0.4), (3000, "I", "TT", 0.95)]
+    reads = sy.make_reads(ref, 6000, seed=91, indel_sites=sites)
+    return ref, orfs, reads
+
+
+def _oracle_fasta(reads, orfs, L, mincov):
+    from oracle import c_oracle
+    from oracle import tc_oracle as orc
+    counts = c_oracle.tally(reads, L)
+    has, ins = orc.list_inserts(counts, mincov, lambda pos1: orc.region_tokens(reads, pos1))
+    cons, _ = orc.build_consensus(mincov, counts.astype(np.int64), [dict(o) for o in orfs], True, ins if has else None, True)
+    return orc.fasta_text("S", mincov, cons), ins if has else {}
+
+
+def _work_consensus(rank, world, use_gpu, td, c_oracle):
+    """configs[4] to the consensus: two ranks, candidate columns on both sides of the boundary; FASTA = the oracle chain's on the whole file."""
+    import torch.distributed as dist
+    ref, orfs, reads = _consensus_case()
+    L = len(ref)
+    rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
+    want, ins = _oracle_fasta(reads, orfs, L, 30)
+    assert len(ins) >= 4 and any(len(next(iter(v.values()))) > 12 for v in ins.values())
+    if use_gpu:
+        import tempfile
+        from trueconsense_amd.io import bamwriter
+        path = os.path.join(tempfile.gettempdir(), "tcmi_cons_%d.bam" % os.getppid())
+        ok = True
+        for split in (False, True):
+            if rank == 0:
+                bamwriter.write_bam(path, reads, "r", L, level=6, block=3000, split_records=split)
+            dist.barrier()
+            text = td.consensus_split_bamfile(path, L, rows, 30, True, "S", rank, world, device=0)
+            ok = ok and (text == want if rank == 0 else text is None)
+            dist.barrier()
+        if rank == 0:
+            os.remove(path)
+        return ok
+    from tests import entries_py
+    shard = td.shard_reads(reads, rank, world)
+    for k in ("next_tid", "next_pos", "tlen"):
+        if reads.get(k) is not None:
+            a, b = td.read_range(int(reads["n_reads"]), rank, world)
+            shard[k] = reads[k][a:b]
+
+    def step_fn(what):
+        if what == "n_blocks":
+            return world
+        if what[0] == "call":
+            return c_oracle.call(what[1], what[2], what[3])
+        return c_oracle.tally(shard, L)
+    j0 = td.read_range(int(reads["n_reads"]), rank, world)[0]
+    text = td.consensus_split_bamfile("unused", L, rows, 30, True, "S", rank, world, step_fn=step_fn,
+                                      entries_fn=lambda pos: entries_py.entries_for(shard, pos, j0=j0))
+    return text == want if rank == 0 else text is None
+
+
 def _work(rank, world, use_gpu, q, td, sy, c_oracle):
-    if True:
+    if True:                                                     # (one block: the ranks' steps below stay in lockstep)
         ref, orfs = sy.make_reference(L=4000, cds=[(100, 3000)])
         reads = sy.make_reads(ref, 9001, seed=77, indel_sites=[(800, "D", 2, 0.5), (1500, "I", "AC", 0.7)])
         L = len(ref)
@@ -69,6 +130,7 @@ def _work(rank, world, use_gpu, q, td, sy, c_oracle):
                 dist.barrier()
             if rank == 0:
                 os.remove(path)
+        ok = ok and _work_consensus(rank, world, use_gpu, td, c_oracle)
         q.put((rank, ok, int(got[:, 0].sum())))
 
 

@@ -97,6 +97,10 @@ _SIGS = {
     "tcmi_readset_from_bamfile_blocks": (_int, [_vp, _vp, _i64, _i64, _P(_vp), _P(_i64)]),
     "tcmi_bamfile_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_i64), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
+    "tcmi_split_step": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _int, _vp, _vp, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp)]),
+    "tcmi_readset_ins_entries": (_int, [_vp, _vp, _i32, _vp, _u32, _int, _vp, _i64, _vp, _vp, _i64, _P(_i64)]),
+    "tcmi_ins_entries_rebase": (_int, [_vp, _i64, _i64]),
+    "tcmi_modal_from_entries": (_int, [_i32, _vp, _vp, _i32, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _P(_i32)]),
     "tcmi_bamfile_decode_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _P(_i64)]),
     "tcmi_filerunner_create": (_int, [_int, _int, _int, _int, _int, _P(_vp)]),
     "tcmi_filerunner_destroy": (_int, [_vp]),
@@ -144,8 +148,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tcmi_abi_version() != 2:
-            raise ImportError("libtcmi ABI version %d, expected 2" % handle.tcmi_abi_version())
+        if handle.tcmi_abi_version() != 3:
+            raise ImportError("libtcmi ABI version %d, expected 3" % handle.tcmi_abi_version())
         _lib = handle
     return _lib
 

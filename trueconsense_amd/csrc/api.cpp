@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <thread>
 
 #include "tcmi_internal.h"
@@ -306,12 +307,12 @@ static int ensure_ws(tcmi_ctx *ctx, int64_t L)
     free_ws(ctx);
     ctx->counts_clean = false;
     int64_t ld = tcmi_round_up(L, 256);
-    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4));
+    TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)ld * TCMI_NCOL * 4 + 256));
     TCMI_HIP(ctx, hipMalloc((void **)&ctx->d_plain, (size_t)ld * 3));
     ctx->d_alt = ctx->d_plain + ld;
     ctx->d_flags = ctx->d_plain + 2 * ld;
     TCMI_HIP(ctx, hipHostMalloc((void **)&ctx->h_rec, (size_t)ld * 3, hipHostMallocDefault));
-    TCMI_HIP(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)ld * TCMI_NCOL * 4, hipHostMallocDefault));
+    TCMI_HIP(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)ld * TCMI_NCOL * 4 + 256, hipHostMallocDefault));
     ctx->ws_L = L;
     ctx->ws_ld = ld;
     return TCMI_OK;
@@ -553,6 +554,50 @@ int tcmi_step_end(tcmi_ctx *ctx, const uint8_t **plain, const uint8_t **alt, con
     if (counts_planes) *counts_planes = ctx->step_counts ? ctx->h_counts : nullptr;
     if (ld_out) *ld_out = ld;
     ctx->step_L = 0;
+    return TCMI_OK;
+}
+
+// One rank's part of a step of ONE BAM file shared by several GPUs (include/tcmi.h): decode + pack + tally its block range, the
+// caller's reduce hook, and on the root the call kernel.  The word behind the matrix counts the ranks that failed: every rank
+// enters the exchange exactly once, whatever happened to its range.
+int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, int64_t L, int64_t ld, void *d_counts,
+                    int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int is_root, tcmi_readset **rs_out,
+                    const uint8_t **plain, const uint8_t **alt, const uint8_t **flags)
+{
+    if (!ctx || !f || !d_counts || !reduce || !rs_out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 < L <= ld");
+    *rs_out = nullptr;
+    TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx, L);
+    if (rc) return rc;
+    const size_t n_words = (size_t)ld * TCMI_NCOL + 1;
+    TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream));
+    tcmi_readset *rs = nullptr;
+    int own = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr);
+    std::string own_err = own ? ctx->err : std::string();
+    if (!own && rs->max_end > L) { own = tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs->max_end); own_err = ctx->err; }
+    if (!own && rs->n_piled) { own = tcmi_tally_dev(ctx, rs, L, ld, d_counts, 0); if (own) own_err = ctx->err; }
+    if (own) {                                                  // this rank's share is zeros + one failure
+        static const int32_t one = 1;
+        (void)hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream);
+        (void)hipMemcpyAsync(static_cast<int32_t *>(d_counts) + (n_words - 1), &one, 4, hipMemcpyHostToDevice, ctx->stream);
+    }
+    const int rrc = reduce(user, d_counts, (int64_t)n_words, (void *)ctx->stream);
+    if (rrc) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_HIP, "the reduce hook failed (%d)", rrc); }
+    int32_t failed = 0;
+    if (is_root) {
+        rc = tcmi_launch_call(ctx, static_cast<int32_t *>(d_counts), L, ld, mincov, include_ambig, 0, ctx->h_rec, ctx->h_rec + ctx->ws_ld, ctx->h_rec + 2 * ctx->ws_ld, nullptr, nullptr);
+        if (!rc && hipMemcpyAsync(&failed, static_cast<int32_t *>(d_counts) + (n_words - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "copy failed");
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = tcmi_fail(ctx, TCMI_E_HIP, "hipStreamSynchronize failed");
+    ctx->counts_clean = false;
+    if (own) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, own, "%s", own_err.c_str()); }
+    if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    if (is_root && failed) { tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%d rank(s) could not decode their range of %s on the device", (int)failed, tcmi_bamfile_path(f)); }
+    *rs_out = rs;
+    if (plain) *plain = ctx->h_rec;
+    if (alt) *alt = ctx->h_rec + ctx->ws_ld;
+    if (flags) *flags = ctx->h_rec + 2 * ctx->ws_ld;
     return TCMI_OK;
 }
 

@@ -1646,20 +1646,21 @@ int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_read
     return tcmi_pack_on_device(ctx, &s, rs, why);
 }
 
-extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions,
-                                         int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
-                                         int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,
-                                         int32_t *status_flags)
+// the device half of Events.ExtractInserts for a device-decoded read set: every read that can reach a candidate column as a 48-byte
+// entry (ins_entries_kernel), in file order per column, in the context's pinned scratch (valid until the context's next call)
+static int collect_ins_entries(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions, uint32_t flag_filter, int ignore_orphans,
+                               std::vector<int64_t> &off, std::vector<int32_t> &cnt, const tcmi_dev_entry **ents_out, std::vector<uint8_t> &long_text)
 {
-    if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
-        return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && !positions)) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+
     if (rs->s_reads > 0)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "long reads lie outside the packed set: their tokens are not looked at here (host sweep)");
     if (!rs->d_stream || rs->arena_epoch != ctx->arena_epoch || rs->device != ctx->device)
         return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "the read set's decoded stream is no longer (or never was) resident on this context: host sweep");
     for (int32_t k = 1; k < n_pos; ++k)
         if (positions[k] <= positions[k - 1]) return tcmi_fail(ctx, TCMI_E_ARG, "positions must ascend");
-    if (n_pos == 0) { if (status_flags) *status_flags = 0; return TCMI_OK; }
+    off.assign((size_t)n_pos + 1, 0); cnt.assign((size_t)n_pos, 0); *ents_out = nullptr; long_text.clear();
+    if (n_pos == 0) return TCMI_OK;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t nf = rs->f_reads;
     // The kept reads ascend by position (the device packer takes nothing else): which of them can reach each column is a
@@ -1706,13 +1707,10 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (unsorted) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "reads are not sorted by position: host sweep");
     const std::vector<int64_t> lo_v(h_lo, h_lo + n_pos), hi_v(h_hi, h_hi + n_pos);   // (the scratch below may move)
-    std::vector<int64_t> off((size_t)n_pos + 1, 0);
     for (int32_t k = 0; k < n_pos; ++k) off[(size_t)k + 1] = off[(size_t)k] + std::max<int64_t>(0, hi_v[(size_t)k] - lo_v[(size_t)k]);
     const int64_t total = off[(size_t)n_pos];
-    std::vector<int32_t> cnt((size_t)n_pos, 0);
     for (int32_t k = 0; k < n_pos; ++k) cnt[(size_t)k] = (int32_t)(off[(size_t)k + 1] - off[(size_t)k]);
     const tcmi_dev_entry *ents = nullptr;
-    std::vector<uint8_t> long_text;
     constexpr size_t LONG_TEXT_CAP = 4u << 20;                  // bases of insertions longer than 12 on the candidate columns of one call
     if (total > 0) {
         const size_t b_head = b_cols + 2 * b_lo + b_off, b_ent = al((size_t)total * sizeof(tcmi_dev_entry));
@@ -1746,6 +1744,27 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
             TCMI_HIP(ctx, hipMemcpy(long_text.data(), a.long_text, long_text.size(), hipMemcpyDeviceToHost));
         }
     }
+    *ents_out = ents;
+    return TCMI_OK;
+}
+
+extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions,
+                                         int32_t min_base_quality, uint32_t flag_filter, int ignore_orphans, int64_t max_depth,
+                                         int ignore_overlaps, char *tokens, int64_t tokens_cap, int64_t *token_off, int64_t *n_tokens,
+                                         int32_t *status_flags)
+{
+    if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
+        return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (n_pos == 0) { if (status_flags) *status_flags = 0; return TCMI_OK; }
+    std::vector<int64_t> off;
+    std::vector<int32_t> cnt;
+    std::vector<uint8_t> long_text;
+    const tcmi_dev_entry *ents = nullptr;
+    {
+        const int rc = collect_ins_entries(ctx, rs, n_pos, positions, flag_filter, ignore_orphans, off, cnt, &ents, long_text);
+        if (rc) return rc;
+    }
+    const int64_t nf = rs->f_reads;
     // the other mate of an overlapping pair, looked at on one reference position (rare: a pair with a deletion on a candidate column)
     const tcmi_prober prober = [&](const std::vector<tcmi_probe_req> &req, std::vector<tcmi_probe_res> &res) -> int {
         const size_t n = req.size();
@@ -1780,4 +1799,60 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
     };
     return tcmi_modal_from_dev_entries(n_pos, ents, off.data(), cnt.data(), min_base_quality, max_depth, ignore_overlaps, &prober, tokens,
                                        tokens_cap, token_off, n_tokens, status_flags, long_text.data(), long_text.size());
+}
+
+// The entries themselves (48 bytes each, opaque to the caller) instead of the vote: ranks that share ONE file (BASELINE configs[4])
+// each collect the entries of the candidate columns from the records of their own block range and send them to the rank that
+// calls; concatenated in rank order (= file order) they are what tcmi_readset_modal_tokens votes on (tcmi_modal_from_entries).
+extern "C" int tcmi_readset_ins_entries(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions, uint32_t flag_filter,
+                                        int ignore_orphans, void *entries, int64_t entries_cap, int64_t *ent_off, uint8_t *long_text,
+                                        int64_t long_cap, int64_t *long_used)
+{
+    if (!ctx || !rs || n_pos < 0 || !ent_off || (n_pos > 0 && !positions)) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    static_assert(sizeof(tcmi_dev_entry) == TCMI_INS_ENTRY_BYTES, "include/tcmi.h promises 48-byte entries");
+    std::vector<int64_t> off;
+    std::vector<int32_t> cnt;
+    std::vector<uint8_t> text;
+    const tcmi_dev_entry *ents = nullptr;
+    if (rs->n_piled == 0 || rs->f_reads == 0) {                 // (no kept reads in this range: no entries)
+        for (int32_t k = 0; k <= n_pos; ++k) ent_off[k] = 0;
+        if (long_used) *long_used = 0;
+        return TCMI_OK;
+    }
+    const int rc = collect_ins_entries(ctx, rs, n_pos, positions, flag_filter, ignore_orphans, off, cnt, &ents, text);
+    if (rc) return rc;
+    for (int32_t k = 0; k <= n_pos; ++k) ent_off[k] = off[(size_t)k];
+    if (long_used) *long_used = (int64_t)text.size();
+    if (off[(size_t)n_pos] > entries_cap || (int64_t)text.size() > long_cap)
+        return tcmi_fail(ctx, TCMI_E_ARG, "entry buffer too small: %lld entries, %zu bytes of long insertions (ent_off / long_used say what is needed)",
+                         (long long)off[(size_t)n_pos], text.size());
+    if (off[(size_t)n_pos]) std::memcpy(entries, ents, (size_t)off[(size_t)n_pos] * sizeof(tcmi_dev_entry));
+    if (!text.empty()) std::memcpy(long_text, text.data(), text.size());
+    return TCMI_OK;
+}
+
+// ... and the vote over entries gathered from several read sets (HOST): per column the concatenation, in file order, of the pieces the
+// ranks sent; `long_base[k]` rebases the text offsets of piece k's long insertions (their texts concatenated in `long_text`).
+extern "C" int tcmi_modal_from_entries(int32_t n_pos, void *entries, const int64_t *ent_off, int32_t min_base_quality, int64_t max_depth,
+                                       int ignore_overlaps, const uint8_t *long_text, int64_t long_bytes, char *tokens, int64_t tokens_cap,
+                                       int64_t *token_off, int64_t *n_tokens, int32_t *status_flags)
+{
+    if (n_pos < 0 || !ent_off || (n_pos > 0 && (!tokens || !token_off || !n_tokens))) return tcmi_fail(nullptr, TCMI_E_ARG, "null argument");
+    std::vector<int32_t> cnt((size_t)std::max(n_pos, 0));
+    for (int32_t k = 0; k < n_pos; ++k) cnt[(size_t)k] = (int32_t)(ent_off[k + 1] - ent_off[k]);
+    return tcmi_modal_from_dev_entries(n_pos, static_cast<const tcmi_dev_entry *>(entries), ent_off, cnt.data(), min_base_quality, max_depth, ignore_overlaps,
+                                       nullptr, tokens, tokens_cap, token_off, n_tokens, status_flags, long_text, (size_t)std::max<int64_t>(long_bytes, 0));
+}
+
+extern "C" int tcmi_ins_entries_rebase(void *entries, int64_t n_entries, int64_t long_base)
+{
+    if (n_entries < 0 || (n_entries > 0 && !entries) || long_base < 0) return tcmi_fail(nullptr, TCMI_E_ARG, "bad argument");
+    tcmi_dev_entry *e = static_cast<tcmi_dev_entry *>(entries);
+    for (int64_t i = 0; i < n_entries; ++i)
+        if ((e[i].bits & 0x40) && !(e[i].bits & 0x80)) {        // the key says where the insertion's bases lie: bits 8-39
+            const uint64_t at = ((e[i].key >> 8) & 0xFFFFFFFFull) + (uint64_t)long_base;
+            if (at > 0xFFFFFFFFull) return tcmi_fail(nullptr, TCMI_E_UNSUPPORTED, "more than 4 GiB of long insertions on the candidate columns");
+            e[i].key = (e[i].key & ~(0xFFFFFFFFull << 8)) | (at << 8);
+        }
+    return TCMI_OK;
 }

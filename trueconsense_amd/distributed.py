@@ -17,6 +17,7 @@ import ctypes as C
 
 import numpy as np
 
+from ._ffi import E_ARG as _ffi_E_ARG
 from ._ffi import check, lib
 
 
@@ -132,8 +133,27 @@ def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to
         ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)         # tally and collective on torch's stream
     d = DeviceBam(path)
     try:
+        import torch.distributed as dist
+        from ._ffi import TcmiError
         first, count = block_range(d.n_blocks, rank, world)
-        rs = ctx.upload_bamfile(d, blocks=(first, count))
+        # A range can be refused on ONE rank only (a record chain that does not close from a false start, a record longer than a block
+        # at the range's end, a read the packer does not take): the ranks agree BEFORE anybody enters the collective — else the others
+        # wait in it forever — and then all raise.
+        rs, err = None, None
+        try:
+            rs = ctx.upload_bamfile(d, blocks=(first, count))
+            if rs.max_end > L:
+                err = (_ffi_E_ARG, "L=%d is smaller than the reads' extent %d" % (L, rs.max_end))
+        except TcmiError as e:
+            err = (e.code, str(e))
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            allv = [None] * dist.get_world_size(group)
+            dist.all_gather_object(allv, err, group=group)
+            err = next((v for v in allv if v), None)
+        if err:
+            if rs is not None:
+                rs.free()
+            raise TcmiError(err[0], "tally_split_bamfile: a rank could not decode its block range: %s" % err[1])
         t = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
         if rs.n_piled:
             check(lib().tcmi_tally_dev(ctx.handle, rs.handle, L, ld, C.c_void_p(t.data_ptr()), 0), ctx.handle)
@@ -141,7 +161,6 @@ def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to
             reduce_counts(t, 0, group)
         else:
             allreduce_counts(t, group)
-        import torch.distributed as dist
         mine = not to_root or not dist.is_initialized() or dist.get_rank(group) == 0
         counts = np.ascontiguousarray(t[:, :L].T.cpu().numpy()) if mine else None
         rs.free()
@@ -150,3 +169,184 @@ def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to
         if own:
             ctx.close()
     return counts
+
+
+# --------------------------------------------------------------------------------------------- configs[4], all the way to the consensus
+def _entries_of_readset(ctx, rs, positions):
+    """This rank's entries of the candidate columns (tcmi_readset_ins_entries) -> (bytes, ent_off list, long-insertion text bytes)."""
+    from .engine import DEFAULT_FLAG_FILTER
+    pos = np.ascontiguousarray(positions, np.int64)
+    n = len(pos)
+    off = np.zeros(n + 1, np.int64)
+    cap, lcap = 1 << 14, 1 << 16
+    while True:
+        ents = np.zeros(cap * 48, np.uint8)
+        text = np.zeros(lcap, np.uint8)
+        used = C.c_int64(0)
+        rc = lib().tcmi_readset_ins_entries(ctx.handle, rs.handle, n, pos.ctypes.data_as(C.c_void_p), DEFAULT_FLAG_FILTER, 1, ents.ctypes.data_as(C.c_void_p),
+                                            cap, off.ctypes.data_as(C.c_void_p), text.ctypes.data_as(C.c_void_p), lcap, C.byref(used))
+        if rc != 0 and (off[n] > cap or used.value > lcap):        # (the buffers were too small: the call says what is needed)
+            cap, lcap = max(cap, int(off[n]) + 16), max(lcap, used.value + 16)
+            continue
+        check(rc, ctx.handle)
+        return ents[:int(off[n]) * 48].tobytes(), off.tolist(), text[:used.value].tobytes()
+
+
+def _vote(positions, pieces):
+    """Rank 0: per column the ranks' pieces concatenated in rank order (= file order), voted on as tcmi_readset_modal_tokens votes
+    (tcmi_modal_from_entries: pysam's default filters, Events.py:66).  -> ({pos: token or None}, status flags)."""
+    from .engine import DEFAULT_MAX_DEPTH, DEFAULT_MIN_BASE_QUALITY
+    n = len(positions)
+    text = b"".join(p[2] for p in pieces)
+    base = np.cumsum([0] + [len(p[2]) for p in pieces])
+    cols, off = [], [0]
+    arrays = []
+    for r, (ents, eoff, _) in enumerate(pieces):
+        a = np.frombuffer(ents, np.uint8).copy()
+        if len(a) and base[r]:
+            check(lib().tcmi_ins_entries_rebase(a.ctypes.data_as(C.c_void_p), len(a) // 48, int(base[r])))
+        arrays.append(a)
+    for k in range(n):
+        for r, (_, eoff, _) in enumerate(pieces):
+            cols.append(arrays[r][eoff[k] * 48:eoff[k + 1] * 48])
+        off.append(off[-1] + sum(p[1][k + 1] - p[1][k] for p in pieces))
+    allents = np.ascontiguousarray(np.concatenate(cols)) if cols and sum(len(c) for c in cols) else np.zeros(48, np.uint8)
+    off = np.ascontiguousarray(off, np.int64)
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        toff, cnt, st = np.zeros(n + 1, np.int64), np.zeros(n, np.int64), C.c_int32(0)
+        tb = np.frombuffer(text, np.uint8) if text else np.zeros(1, np.uint8)
+        rc = lib().tcmi_modal_from_entries(n, allents.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), DEFAULT_MIN_BASE_QUALITY, DEFAULT_MAX_DEPTH, 1,
+                                           tb.ctypes.data_as(C.c_void_p), len(text), C.cast(buf, C.c_void_p), cap, toff.ctypes.data_as(C.c_void_p),
+                                           cnt.ctypes.data_as(C.c_void_p), C.byref(st))
+        if rc != 0 and b"token buffer too small" in (lib().tcmi_last_error(None) or b"") and cap < (1 << 30):
+            cap *= 16
+            continue
+        check(rc)
+        break
+    return {int(positions[k]): (buf.raw[toff[k]:toff[k + 1]].decode("ascii") if cnt[k] else None) for k in range(n)}, st.value
+
+
+class _Tokens:
+    """What Events.inserts_from_flags asks a `bam` for (a token per candidate column)."""
+    def __init__(self, toks):
+        self.toks = toks
+
+    def modal_token(self, pos):
+        return self.toks.get(pos)
+
+
+def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True, name="S", rank=0, world=1, device=0, group=None,
+                            step_fn=None, entries_fn=None):
+    """BASELINE configs[4] all the way: ONE BAM file over `world` ranks -> its consensus FASTA text on rank 0 (None on the others).
+    What the ranks jointly replace is the reference's single pile-up pass (indexing.py:96-100), its insert candidates' region
+    pile-ups (Events.py:47-82) and the walk (Sequences.py:168-322):
+
+      1. every rank decodes, packs and tallies the records that start in ITS contiguous range of the file's BGZF blocks and the count
+         matrices are summed to rank 0 (tcmi_split_step: the step in C, the reduce a hook — RCCL's reduce under "nccl"); a rank that
+         cannot decode its range still takes part (zeros + a failure word): nobody waits for it forever, and every rank learns the verdict;
+      2. rank 0 calls (HIP call kernel) and broadcasts the insert-candidate columns;
+      3. every rank collects the 48-byte entries of those columns from its resident stream (ins_entries_kernel) and sends them to rank 0;
+      4. rank 0 concatenates the pieces per column in rank order — file order: pysam's max_depth admission and first-seen tie-break
+         depend on it —, votes (tcmi_modal_from_entries), and walks.  Overlapping mates whose other mate would have to be looked at on
+         another rank: rank 0 decodes the file on the host for the tokens (tcmi_bam_load + tcmi_modal_tokens).
+
+    step_fn(first, count) -> (counts int [L,7] of the rank's range) and entries_fn(positions) -> (entry bytes, ent_off, long text)
+    replace the GPU on boxes without one (tests: the oracle's tally and entries; the call then comes from the oracle too)."""
+    import torch
+    import torch.distributed as dist
+    from .Events import inserts_from_flags
+    from .Sequences import consensus_from_records
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    L = int(ref_len)
+    ld = (L + 255) // 256 * 256
+    root = rank == 0
+    plain = alt = flags = None
+    ctx = d = rs = None
+    err = None
+    if step_fn is None:
+        from ._ffi import TcmiError
+        from .engine import Context, DeviceBam, ReadSet
+        torch.cuda.set_device(device)
+        ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
+        d = DeviceBam(path)
+        first, count = block_range(d.n_blocks, rank, world)
+        t = torch.zeros(7 * ld + 1, dtype=torch.int32, device="cuda")
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        def hook(user, ptr, n, stream):                             # (the tensor IS the buffer at `ptr`; torch's collective runs on the context's stream)
+            try:
+                reduce_counts(t, 0, group)
+                return 0
+            except Exception:                                       # noqa: BLE001 — a C caller gets a code, not an exception
+                return 1
+        h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = lib().tcmi_split_step(ctx.handle, d.handle, first, count, L, ld, C.c_void_p(t.data_ptr()), int(mincov), int(bool(include_ambig)), hook, None,
+                                   int(root), C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
+        if rc:
+            err = (rc, (lib().tcmi_last_error(ctx.handle) or b"").decode("utf-8", "replace"))
+        else:
+            rs = ReadSet(ctx, h, None)
+            if root:
+                def grab(vp):
+                    out = np.empty(L, np.uint8)
+                    C.memmove(out.ctypes.data, vp, L)
+                    return out
+                plain, alt, flags = grab(p_), grab(a_), grab(f_)
+    else:
+        d_blocks = step_fn("n_blocks")
+        first, count = block_range(d_blocks, rank, world)
+        part = torch.from_numpy(np.ascontiguousarray(np.asarray(step_fn((first, count))).T.astype(np.int32)))
+        if multi:
+            dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if root:
+            plain, alt, flags = step_fn(("call", np.ascontiguousarray(part.numpy().T), int(mincov), bool(include_ambig)))
+    # every rank learns whether the step held everywhere (a failed rank took part in the reduce: no deadlock, but no consensus either)
+    verdict = [err]
+    if multi:
+        allv = [None] * dist.get_world_size(group)
+        dist.all_gather_object(allv, err, group=group)
+        verdict = allv
+    bad = [v for v in verdict if v]
+    if bad:
+        if rs is not None:
+            rs.free()
+        if d is not None:
+            d.close()
+        if ctx is not None:
+            ctx.close()
+        from ._ffi import TcmiError
+        raise TcmiError(bad[0][0], "consensus_split_bamfile: %s" % bad[0][1])
+    # the insert-candidate columns, from rank 0 to everybody
+    cand = [(np.nonzero(flags & 8)[0] + 1).tolist()] if root else [None]
+    if multi:
+        dist.broadcast_object_list(cand, src=0, group=group)
+    cand = cand[0]
+    text = None
+    if cand:
+        piece = entries_fn(cand) if entries_fn is not None else _entries_of_readset(ctx, rs, cand)
+        pieces = [piece]
+        if multi:
+            pieces = [None] * dist.get_world_size(group) if root else None
+            dist.gather_object(piece, pieces, dst=0, group=group)
+    if root:
+        toks = {}
+        if cand:
+            toks, st = _vote(cand, pieces)
+            if st & 2:                                              # a pair of mates that only a sweep over the whole file resolves
+                from .engine import BamFile, modal_tokens
+                bam = BamFile(path)
+                toks = {p: t for p, (t, _) in modal_tokens(bam, cand).items()}
+                bam.close()
+        _, inserts = inserts_from_flags(flags, _Tokens(toks))
+        gff = {i: dict(r) for i, r in enumerate(gff_rows)}
+        cons, _ = consensus_from_records(plain, alt, flags, gff, inserts, True)
+        text = ">%s mincov=%d\n%s\n" % (name, int(mincov), cons)
+    if rs is not None:
+        rs.free()
+    if d is not None:
+        d.close()
+    if ctx is not None:
+        ctx.close()
+    return text

@@ -335,12 +335,19 @@ def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, or
         per_rank = g
     else:
         per_rank = [(dt_mine, int(n_mine[0]), int(count))]
+    # ... and once, outside the clock, the product's own function for this shape, all the way to the FASTA text (tcmi_split_step in C,
+    # insert candidates' entries gathered to rank 0): distributed.consensus_split_bamfile
+    rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
+    cons_product = td.consensus_split_bamfile(path, L, rows, a.mincov, True, "S", rank, world, device=local_rank)
     if rank == 0:
         from oracle import tc_oracle as orc
         got = np.ascontiguousarray(counts[:, :L].T.cpu().numpy()).astype(np.int64)
         has, ins = orc.list_inserts(want_counts, a.mincov, lambda pos1: [])
         want, _ = orc.build_consensus(a.mincov, want_counts, [dict(o) for o in orfs], True, ins if has else None, True)
+        want_text = orc.fasta_text("S", a.mincov, want)
+        product = cons_product == want_text
         print(json.dumps({
+            "consensus_split_bamfile_fasta_exact": bool(product),
             "metric": "reference positions/sec (ONE BAM FILE of %d reads, %d GPU(s) each decoding its range of the file's BGZF blocks -> consensus)" % (a.reads * world, world),
             "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_per_rank": [1e3 * x[0] / a.steps for x in per_rank],
@@ -386,6 +393,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident kernel-rate leg")
     ap.add_argument("--no-cli-batch", action="store_true", help="skip the leg through the command line (--batch, four output files per sample)")
     ap.add_argument("--no-hard-bam", action="store_true", help="skip the leg with the file that compresses like real data")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] leg (indel carriers) of the default line")
     ap.add_argument("--only-resident", action="store_true", help="only the HBM-resident leg (short runs under rocprofv3)")
     ap.add_argument("--resident-batch", type=int, default=8, help="BAMs per launch of the resident leg")
     ap.add_argument("--resident-steps", type=int, default=200)
@@ -602,8 +610,13 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     out["cold_kernels"] = cold
 
     # ---- bit-exactness of what was timed, against the oracle chain (outside the clock) -----------------
-    out.update(check_fasta(a, np, fastas[0], reads0, ref, orfs, L))
-    out["fasta_all_timed"] = check_all_fastas(a, np, paths, fastas, L, a.mincov, orfs)
+    chain_t = {}
+    out["fasta_all_timed"] = check_all_fastas(a, np, paths, fastas, L, a.mincov, orfs, workers=min(8, cores), timing=chain_t)
+    out.update({"fasta_bit_exact": out["fasta_all_timed"]["first_mismatch"] is None and len(fastas) > 0,
+                "fasta_sha256": hashlib.sha256(fastas[0].encode()).hexdigest()[:16], "consensus_len": len(fastas[0].split("\n")[1])})
+    # ---- BASELINE configs[2] in the same line: indel carriers at CDS boundaries, insert candidates resolved in the resident stream ----
+    if not a.indels and not a.host_decode and not a.no_configs2:
+        out["configs2"] = configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, os.path.dirname(paths[0]), rank, min(8, cores))
     # ---- a file that compresses like real data (distinct names, binned random qualities): same pipeline, one BAM at a time ----
     if not a.indels and not a.host_decode and not a.no_hard_bam:
         out["hard_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx)
@@ -640,29 +653,67 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
             out["cpu_baseline"] = dict(json.load(open(cache)), cached_from="the N = 1 run on this host")
         except Exception:
             pass
+    # the reference's stage B on this box's cores (19.1 s per BuildConsensus call, two calls per run, on the survey
+    # container): oracle/tc_oracle.py's build_consensus — the literal per-position walk with the O(L^2) CorrectGFF — as timed by the
+    # FASTA check above on the configs[1] matrices (several files at once, one core each)
+    if "cpu_baseline" in out and chain_t.get("build_consensus_seconds"):
+        bc = chain_t["build_consensus_seconds"]
+        one = float(np.median(bc))
+        tl = out["cpu_baseline"].get("python_loop_tally_seconds_per_bam_extrapolated")
+        out["cpu_baseline"]["python_stage_b"] = {
+            "build_consensus_seconds_per_call": one, "calls_per_run": 2, "seconds_per_bam": 2 * one, "files_timed": len(bc),
+            "what": "oracle/tc_oracle.py build_consensus (Sequences.py:168-322 + ORFs.py:111-192 restated with the reference's loop structure) on "
+                    "this run's configs[1] count matrices, %d worker processes side by side" % min(8, cores)}
+        if tl:
+            out["cpu_baseline"]["python_reference_standin_seconds_per_bam"] = tl + 2 * one
+    # ---- what matters, in short top-level keys -------------------------------------------------------------------------------------
+    if "file_to_fasta" in out:
+        out["value_file_to_fasta"] = out["file_to_fasta"]["value"]
+    for k, leg in (("value_hard_bam", "hard_bam"), ("value_real_bam", "real_bam")):
+        if leg in out and "pipelined" in out[leg]:
+            out[k] = out[leg]["pipelined"]["value"]
+    if "configs2" in out:
+        out["value_configs2"] = out["configs2"]["value"]
+        out["configs2_fasta_exact"] = out["configs2"]["fasta_all_timed"]["all_equal_the_oracle_chain"]
+    out["kernel_sum_single_stream_us"] = sum(v["us_per_bam"] for k, v in out["cold_kernels"].items() if k != "inflate")
     return out
 
 
-def check_all_fastas(a, np, paths, fastas, L, mincov, orfs):
-    """EVERY FASTA text of the timed region (K x repeats of them; the i-th is of bench file i mod F) against the oracle chain on that
-    file as oracle/bam_oracle.c reads it.  Without indel carriers: scalar C tally + call (oracle/tally_oracle.c) + the host walk (the
-    walk is pinned by the 708 golden runs; file 0 is also checked against the Python restatement of the reference's own functions:
-    check_fasta).  With --indels the inserts matter: the whole Python chain per file (oracle_fasta_text)."""
+def _oracle_chain_worker(job):
+    """(a child process: no GPU, no torch) the whole oracle chain on one bench file -> (FASTA text, seconds of the two stage-B passes)."""
+    path, orfs, L, mincov, name = job
+    import numpy as np
+    from types import SimpleNamespace
     from oracle import c_oracle
-    from trueconsense_amd.engine import Walker
-    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
-    want = []
-    for k, path in enumerate(paths):
-        reads = c_oracle.read_bam(path)
-        if a.indels:
-            want.append(oracle_fasta_text(a, np, reads, orfs, L, "S%d" % k))
-            continue
-        counts = c_oracle.tally(reads, max(L, c_oracle.extent(reads, L)))
-        plain, alt, flags = c_oracle.call(counts, mincov, True)
-        want.append(">S%d mincov=%d\n%s\n" % (k, mincov, walker(plain[:L], alt[:L], flags[:L])[0].decode("ascii")))
+    reads = c_oracle.read_bam(path)
+    t = {}
+    text = oracle_fasta_text(SimpleNamespace(mincov=mincov), np, reads, orfs, L, name, timing=t)
+    return text, t.get("build_consensus", 0.0), t.get("list_inserts", 0.0)
+
+
+def oracle_chain_many(jobs, workers):
+    """The Python oracle chain (oracle/tc_oracle.py: the reference's own loop structure, ~10 s per file) on several files at once,
+    in spawned worker processes (a fork of a process that holds a HIP runtime is not safe)."""
+    import multiprocessing as mp
+    if len(jobs) <= 1 or workers <= 1:
+        return [_oracle_chain_worker(j) for j in jobs]
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_oracle_chain_worker, jobs)
+
+
+def check_all_fastas(a, np, paths, fastas, L, mincov, orfs, workers=8, timing=None):
+    """EVERY FASTA text of the timed region (K x repeats of them; the i-th is of bench file i mod F) against the ORACLE chain on that
+    file as oracle/bam_oracle.c reads it: scalar C tally (oracle/tally_oracle.c), then oracle/tc_oracle.py's list_inserts (the
+    pile-up emulator's tokens on the candidate columns) and build_consensus — the Python restatement of the reference's own
+    functions, pinned by the golden vectors — for every distinct file (no product code in the checker)."""
+    res = oracle_chain_many([(p, [dict(o) for o in orfs], L, mincov, "S%d" % k) for k, p in enumerate(paths)], workers)
+    want = [r[0] for r in res]
+    if timing is not None:
+        timing["build_consensus_seconds"] = [r[1] for r in res]
+        timing["list_inserts_seconds"] = [r[2] for r in res]
     bad = [i for i, t in enumerate(fastas) if t != want[i % len(paths)]]
     return {"fastas": len(fastas), "files": len(paths), "all_equal_the_oracle_chain": not bad, "first_mismatch": bad[0] if bad else None,
-            "chain": "oracle/bam_oracle.c + tally_oracle.c + " + ("tc_oracle.py (list_inserts, build_consensus)" if a.indels else "the host walk"),
+            "chain": "oracle/bam_oracle.c + tally_oracle.c + tc_oracle.py (list_inserts, build_consensus) on every distinct file",
             "sha256_per_file": [hashlib.sha256(w.encode()).hexdigest()[:16] for w in want]}
 
 
@@ -712,6 +763,42 @@ def cli_batch_leg(a, paths, ref, orfs, L, sy, fastas):
             "decoded_on": s2["decoded_on"], "fasta_files_equal_the_headline_texts": same, "output_bytes_sample0": sizes,
             "note": "python -c 'TrueConsense.main(--batch ...)' in a process of its own; ms_per_bam = (runner seconds of the long manifest - of the short "
                     "one) / (samples more): reader, GPU and walker stages overlapped, the walkers also write VCF, corrected GFF and coverage TSV"}
+
+
+def configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, tmp, rank, workers):
+    """BASELINE configs[2] (1M reads, 2 % of them carrying an insertion or deletion at CDS starts / ends): two such files, their compressed
+    bytes resident in HBM, a queue of them through the headline's runner; EVERY FASTA against the whole Python oracle chain (inserts
+    included) on its file."""
+    from trueconsense_amd.engine import DeviceBam
+    from trueconsense_amd.io import bamwriter
+    sites = sy.default_indel_sites(orfs)
+    t0 = time.perf_counter()
+    paths = []
+    for k in range(2):
+        reads = sy.make_reads(ref, a.reads, seed=3000 + 1000 * rank + k, indel_sites=sites)
+        p = os.path.join(tmp, "c2_%d.bam" % k)
+        bamwriter.write_bam(p, reads, "MN908947.3", L, level=a.level)
+        paths.append(p)
+        del reads
+    t_gen = time.perf_counter() - t0
+    db = [DeviceBam(p).to_device(ctx) for p in paths]
+    runner.run_resident([db[i % 2] for i in range(8)], ref_len=L)
+    n = 64
+    ctx.sync()
+    t1 = time.perf_counter()
+    texts = runner.run_resident([db[i % 2] for i in range(n)], names=["S%d" % (i % 2) for i in range(n)], ref_len=L)
+    ctx.sync()
+    dt = time.perf_counter() - t1
+    for d in db:
+        d.close()
+    chk = check_all_fastas(a, np, paths, texts, L, a.mincov, orfs, workers=workers)
+    n_ins = texts[0].count("\n")                                   # (placeholder for the reader of the line: lengths below)
+    return {"value": L * n / dt, "unit": "positions/s", "ms_per_bam": 1e3 * dt / n, "bams": n, "files": 2,
+            "consensus_len": [len(t.split("\n")[1]) for t in texts[:2]], "fasta_all_timed": chk, "decoded_on": dict(runner.decoded_on),
+            "input_generation_seconds_outside_clock": t_gen,
+            "note": "configs[2]: 1M reads per BAM, 1 %% insertion + 1 %% deletion carriers at CDS boundaries; %d files' compressed bytes resident in HBM, "
+                    "%d of them overlapped through the headline's runner; the insert candidates' tokens are voted on from entries the device "
+                    "collects in the resident inflated stream (ins_entries_kernel)" % (2, n)}
 
 
 def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx, kind="hard"):
@@ -797,7 +884,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         except Exception:
             traffic = {}
 
-    r3 = traffic.get("round3", {})
+    r3 = traffic.get("round4") or traffic.get("round3", {})
     r3k = r3.get("kernels", {})
 
     def pmc_bytes(names):
@@ -817,15 +904,22 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         return b
 
     inflated = inflated_bytes or 273 * n
+    # SURVEY 8-a1 / a2 (BuildIndex, parse_query_sequences) are ALL the kernels behind the decode: pk_index (record index + classify),
+    # pk_place (prefix + planes), pk_pack (chunks) and the tally
+    for key in ("hot",):
+        timed[key] = {"us_per_bam": sum(timed[k]["us_per_bam"] for k in ("records", "pack_classify", "pack", "tally"))}
+        cold[key] = {"us_per_bam": sum(cold[k]["us_per_bam"] for k in ("records", "pack_classify", "pack", "tally"))}
+    hot = block("pk_index + pk_place + pk_pack + tally_planes_kernel (the several-kernel path: rec_* + pk_classify + pk_scan + pk_scatter + pk_pack + pk_planes + tally)",
+                "hot", alg_reads + 2 * 52 * n + 28 * 29903,
+                "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read written by the packer and read by "
+                "the tally + the count matrix; the bases are read out of the inflated BAM stream (289 B per record: names and qualities ride "
+                "along in the 64-byte sectors)", alg=alg_reads + 28 * 29903, pmc_of=("pk_index", "pk_place", "pk_pack", "tally_planes_kernel"))
     out = {"roofline": block("bgzf_symbols + bgzf_copy", "inflate", file_bytes + inflated,
                              "compressed bytes read + inflated bytes written per BAM (the tokens between the two kernels — 4 bytes per literal / match — "
                              "are traffic, not algorithmic bytes: the speculating lanes park theirs in scattered 4-byte stores, which is most of what the "
                              "counters see beyond the stream); Huffman symbols decoded 32 lanes per block speculatively (latency-bound), LZ77 copies through "
                              "an LDS ring (issue-bound): see `issue`; neither is an HBM kernel", pmc_of=("bgzf_symbols", "bgzf_copy")),
-           "roofline_hot_path": block("pk_scatter + pk_pack + pk_planes", "pack", alg_reads + 52 * n,
-                                      "SURVEY 8-d algorithmic bytes of the reads (12 + 4 n_cigar + l/2 each) + the 52 B per read written; the bases are "
-                                      "read out of the inflated BAM stream (289 B per record: names and qualities ride along in the sectors)",
-                                      alg=alg_reads, pmc_of=("pk_scatter", "pk_pack", "pk_planes"))}
+           "roofline_hot_path": hot}
     # what does bound the inflate kernels: wave-instructions issued per compute unit and cycle (PMC counts of the committed passes over
     # this run's single-stream kernel times; a CU of waves in mostly scalar / LDS code issues about one instruction per cycle)
     try:
@@ -849,7 +943,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
     return out
 
 
-def oracle_fasta_text(a, np, reads, orfs, L, name):
+def oracle_fasta_text(a, np, reads, orfs, L, name, timing=None):
     """The oracle chain on one file's reads -> its FASTA text: scalar C tally (oracle/tally_oracle.c), reference-pinned list_inserts
     (with the pileup emulator's tokens on the candidate columns) and build_consensus (oracle/tc_oracle.py)."""
     from oracle import c_oracle
@@ -878,8 +972,13 @@ def oracle_fasta_text(a, np, reads, orfs, L, name):
                "qual_off": (qo[i0:i1 + 1] - qo[i0]).astype(np.uint64), "qual": reads["qual"][int(qo[i0]):int(qo[i1])]}
         return orc.region_tokens(sub, pos1)
 
+    t0 = time.perf_counter()
     has, ins = orc.list_inserts(counts, a.mincov, tokens_at)
+    t1 = time.perf_counter()
     want, _ = orc.build_consensus(a.mincov, counts.astype(np.int64), [dict(o) for o in orfs], True, ins if has else None, True)
+    if timing is not None:
+        timing["list_inserts"] = t1 - t0
+        timing["build_consensus"] = time.perf_counter() - t1
     return orc.fasta_text(name, a.mincov, want)
 
 
@@ -949,8 +1048,10 @@ def resident_leg(a, ctx0, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("tally_hbm_bytes_per_launch") * B
-            traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run (per 1M-read BAM x batch), not measured in this run"
+            tj = json.load(open(tp))
+            per = (tj.get("round4") or {}).get("tally_hbm_bytes_per_bam")
+            traffic = per * B if per else None                      # (a round-1 figure stood here until round 3: dropped rather than quoted stale)
+            traffic_src = "profiles/traffic.json round4: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tally_planes_kernel per 1M-read BAM x batch" if per else None
         except Exception:
             traffic = None
     achieved = real / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0

@@ -98,40 +98,39 @@ def _work_consensus(rank, world, use_gpu, td, c_oracle):
 
 
 def _work(rank, world, use_gpu, q, td, sy, c_oracle):
-    if True:                                                     # (one block: the ranks' steps below stay in lockstep)
-        ref, orfs = sy.make_reference(L=4000, cds=[(100, 3000)])
-        reads = sy.make_reads(ref, 9001, seed=77, indel_sites=[(800, "D", 2, 0.5), (1500, "I", "AC", 0.7)])
-        L = len(ref)
-        fn = None if use_gpu else (lambda shard, L_: c_oracle.tally(shard, L_))
-        got = td.tally_split_bam(reads, L, rank, world, device=0, tally_fn=fn)
-        want = c_oracle.tally(reads, L)
-        ok = bool(np.array_equal(got, want))
-        # the reduce-to-root form of the same exchange (what bench.py --split-bam does per step): only rank 0 gets the sum
-        import torch
-        part = torch.from_numpy(np.ascontiguousarray(c_oracle.tally(td.shard_reads(reads, rank, world), L).T.astype(np.int32)))
-        mine = part.clone()
-        td.reduce_counts(part, dst=0)
-        if rank == 0:
-            ok = ok and bool(np.array_equal(part.numpy().T, want))
-        else:
-            del mine                                             # (gloo leaves the non-root buffers unspecified)
-        if use_gpu:
-            # ... and from ONE FILE: every rank decodes only the records that start in its range of the file's BGZF blocks
-            import tempfile
-            from trueconsense_amd.io import bamwriter
-            path = os.path.join(tempfile.gettempdir(), "tcmi_split_%d.bam" % os.getppid())
-            for split in (False, True):                          # blocks cut on record boundaries / filled to the brim
-                if rank == 0:
-                    bamwriter.write_bam(path, reads, "r", L, level=6, block=4000, split_records=split)
-                import torch.distributed as dist
-                dist.barrier()
-                both = td.tally_split_bamfile(path, L, rank, world, device=0)
-                ok = ok and bool(np.array_equal(both, want))
-                dist.barrier()
+    ref, orfs = sy.make_reference(L=4000, cds=[(100, 3000)])
+    reads = sy.make_reads(ref, 9001, seed=77, indel_sites=[(800, "D", 2, 0.5), (1500, "I", "AC", 0.7)])
+    L = len(ref)
+    fn = None if use_gpu else (lambda shard, L_: c_oracle.tally(shard, L_))
+    got = td.tally_split_bam(reads, L, rank, world, device=0, tally_fn=fn)
+    want = c_oracle.tally(reads, L)
+    ok = bool(np.array_equal(got, want))
+    # the reduce-to-root form of the same exchange (what bench.py --split-bam does per step): only rank 0 gets the sum
+    import torch
+    part = torch.from_numpy(np.ascontiguousarray(c_oracle.tally(td.shard_reads(reads, rank, world), L).T.astype(np.int32)))
+    mine = part.clone()
+    td.reduce_counts(part, dst=0)
+    if rank == 0:
+        ok = ok and bool(np.array_equal(part.numpy().T, want))
+    else:
+        del mine                                             # (gloo leaves the non-root buffers unspecified)
+    if use_gpu:
+        # ... and from ONE FILE: every rank decodes only the records that start in its range of the file's BGZF blocks
+        import tempfile
+        from trueconsense_amd.io import bamwriter
+        path = os.path.join(tempfile.gettempdir(), "tcmi_split_%d.bam" % os.getppid())
+        for split in (False, True):                          # blocks cut on record boundaries / filled to the brim
             if rank == 0:
-                os.remove(path)
-        ok = ok and _work_consensus(rank, world, use_gpu, td, c_oracle)
-        q.put((rank, ok, int(got[:, 0].sum())))
+                bamwriter.write_bam(path, reads, "r", L, level=6, block=4000, split_records=split)
+            import torch.distributed as dist
+            dist.barrier()
+            both = td.tally_split_bamfile(path, L, rank, world, device=0)
+            ok = ok and bool(np.array_equal(both, want))
+            dist.barrier()
+        if rank == 0:
+            os.remove(path)
+    ok = ok and _work_consensus(rank, world, use_gpu, td, c_oracle)
+    q.put((rank, ok, int(got[:, 0].sum())))
 
 
 def _run(world, use_gpu):
@@ -189,14 +188,14 @@ def test_split_bam_allreduce_gpu_tally_gloo_world2():
     _run(2, use_gpu=True)
 
 
-def _bench_ranks(extra, env_extra=None):
+def _bench_ranks(extra, env_extra=None, nproc=2):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed with two ranks on
     ONE GPU over gloo (TCMI_BENCH_REHEARSE=1: RCCL wants a GPU per rank); returns rank 0's JSON line."""
     import json
     import subprocess
     env = dict(os.environ, TCMI_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
@@ -223,3 +222,14 @@ def test_bench_split_bam_two_ranks_rehearsal():
     d = _bench_ranks(["--split-bam", "--steps", "3", "--warmup", "1", "--reads", "40000"])
     assert d["n_gpus"] == 2 and d["coverage_sum"] == d["coverage_sum_expected"] == 150 * 40000 * 2
     assert d["consensus_len"] == 29903 and "gloo" in d["config"]["collective"]
+
+
+@pytest.mark.gpu
+def test_bench_many_bam_shard_four_ranks_rehearsal():
+    """The driver's N = 8 launch shape at tiny sizes, to shake out collisions of temporary files, ports and thread counts between
+    the ranks of one host — with FOUR ranks: the GPU boxes allow at most six processes on a card at once, and the test runner
+    itself holds one (six ranks were killed by the box's process guard)."""
+    d = _bench_ranks(["--steps", "2", "--warmup", "1", "--reads", "20000", "--files", "2", "--no-cpu-baseline", "--no-resident", "--no-hard-bam",
+                      "--no-cli-batch", "--no-configs2", "--min-seconds", "0"], nproc=4)
+    assert d["n_gpus"] == 4 and d["steps"] == 2 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
+    assert d["fasta_all_timed"]["all_equal_the_oracle_chain"] is True

@@ -477,6 +477,86 @@ def test_cli_batch_writes_the_same_four_files(ctx, tmp_path, monkeypatch):
     assert n_done >= 20
 
 
+def test_cli_gpus_n_batch_shards_and_one_bam_split(ctx, tmp_path, monkeypatch):
+    """--gpus N (additive flag; the reference's flag surface is TrueConsense.py:75-209): N child processes started before any GPU
+    call.  --batch: the manifest dealt round-robin to N runners (configs[3]); -i: ONE BAM file shared by N ranks, a reduce of the count
+    matrix, entries of the insert candidates gathered to rank 0 (configs[4]).  Rehearsed with N = 2 on this one GPU (gloo for the
+    exchange): every output file byte-identical to the golden text / to the single-GPU command line."""
+    import subprocess
+    env = dict(os.environ, TCMI_SPLIT_ONE_GPU="1", TCMI_SPLIT_BACKEND="gloo", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    monkeypatch.chdir(tmp_path)
+    case = next(c for c in load("outputs") if "raises" not in c["runs"]["amb1"] and c["runs"]["amb1"]["fa"].count("\n") == 2)
+    spec, run = case["spec"], case["runs"]["amb1"]
+    bamwriter.write_bam("in.bam", ss.reads_from_spec(spec), "refid", len(spec["ref"]))
+    with open("ref.fa", "w") as fh:
+        fh.write(">refid some description\n" + spec["ref"] + "\n")
+    with open("f.gff", "w") as fh:
+        fh.write("##gff-version 3\n")
+        for k, o in enumerate(spec["orfs"]):
+            fh.write("S\tx\tCDS\t%d\t%d\t.\t%s\t0\tID=o%d;Name=orf%d\n" % (o["start"], o["end"], o["strand"], k, k))
+    with open("m.tsv", "w") as fh:
+        for k in range(5):
+            fh.write("in.bam\tSAMPLE\ts%d.fa\ts%d.vcf\ts%d.gff\ts%d.tsv\n" % (k, k, k, k))
+    base = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "-ref", "ref.fa", "-gff", "f.gff", "-cov", str(spec["mincov"])]
+    r = subprocess.run(base + ["--batch=m.tsv", "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for k in range(5):
+        assert open("s%d.fa" % k).read() == run["fa"] and open("s%d.tsv" % k).read() == run["tsv"]
+        assert open("s%d.gff" % k).read() == run["gff_cli"]
+        lines, want = open("s%d.vcf" % k).read().split("\n"), run["vcf"].split("\n")
+        assert lines[:1] + lines[3:] == want[:1] + want[3:]         # (all but the date and the ##source line, which carries each child's own argv)
+    # ONE file over two ranks, indel carriers with candidate columns in the middle of the file: the four outputs = the single-GPU command line's
+    ref, orfs = sy.make_reference(L=4000, cds=[(100, 1900), (2100, 3900)])
+    sites = [(1900, "I", "A", 0.9), (1990, "I", "GT", 0.7), (2005, "I", "ACGTACGTACGTAC", 0.8), (2010, "D", 3, 0.6), (3000, "I", "TT", 0.95)]
+    reads = sy.make_reads(ref, 6000, seed=91, indel_sites=sites)
+    bamwriter.write_bam("one.bam", reads, "MN", len(ref), block=3000, split_records=True)
+    with open("r2.fa", "w") as fh:
+        fh.write(">MN x\n" + ref + "\n")
+    head, body = sy.gff_text(orfs, seqid="MN")
+    with open("g2.gff", "w") as fh:
+        fh.write(head + body)
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2"])):
+        argv = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "-i", "one.bam", "-ref", "r2.fa", "-gff", "g2.gff", "-cov", "30", "-name", "S",
+                "-o", tag + ".fa", "-vcf", tag + ".vcf", "-ogff", tag + ".gff", "-doc", tag + ".tsv"] + extra
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        vcf = open(tag + ".vcf").read().split("\n")
+        outs[tag] = (open(tag + ".fa").read(), open(tag + ".gff").read(), open(tag + ".tsv").read(), vcf[:1] + vcf[3:])
+    assert outs["one"] == outs["two"]
+    assert "ACGTACGTACGTAC" in outs["two"][0]                        # (the 14-base insertion, whose bases travelled as text, is in the consensus)
+
+
+def test_configs1_full_size_from_bam_files_through_eight_contexts(ctx, tmp_path):
+    """BASELINE configs[1] at full size FROM BAM FILES through the runner the bench's headline uses (FileRunner.run_resident, eight
+    GPU contexts, the files' compressed bytes resident in HBM): every FASTA text against the Python oracle chain on its file
+    (oracle/bam_oracle.c + tally_oracle.c + tc_oracle.py list_inserts / build_consensus — no product code in the checker)."""
+    import bench
+    ref, orfs = sy.make_reference()
+    L = len(ref)
+    paths = []
+    for k in range(2):
+        n = 1_000_000
+        reads = sy.make_reads(ref, n, seed=8100 + k)
+        p = str(tmp_path / ("full%d.bam" % k))
+        bamwriter.write_bam_fast(p, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=6)
+        paths.append(p)
+        del reads
+    rows = [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs]
+    runner = engine.FileRunner(ctx, rows, 30, True, decoders=2, decode_threads=4, walkers=2, gpu_streams=8)
+    dbams = [engine.DeviceBam(p).to_device(ctx) for p in paths]
+    n_items = 24
+    texts = runner.run_resident([dbams[i % 2] for i in range(n_items)], names=["S%d" % (i % 2) for i in range(n_items)], ref_len=L)
+    assert runner.decoded_on == {"device": n_items, "host": 0}
+    want = [r[0] for r in bench.oracle_chain_many([(p, [dict(o) for o in orfs], L, 30, "S%d" % k) for k, p in enumerate(paths)], 2)]
+    for i, t in enumerate(texts):
+        assert t == want[i % 2], i
+    assert len(texts[0].split("\n")[1]) == L
+    for d in dbams:
+        d.close()
+    runner.close()
+
+
 def test_self_cleaning_steps_and_pipeline(ctx):
     """Steps that do not fetch the counts leave the matrix zeroed by the call kernel (no memset
     between them); the native pipeline must give what the step-by-step path gives, inserts included."""

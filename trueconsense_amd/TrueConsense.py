@@ -87,7 +87,14 @@ def GetArgs(givenargs):
     additive.append((("--batch",), dict(type=str, default=None, metavar="File",
                                         help="many samples: a tab-separated manifest (BAM, name, FASTA[, VCF, GFF, TSV] per line)\n"
                                              "instead of -i / -name / -o / -vcf / -ogff / -doc")))
-    batch = "--batch" in givenargs
+    additive.append((("--gpus",), dict(type=int, default=1, metavar="N",
+                                       help="GPUs of this node to use: with --batch the manifest's samples are dealt to N processes,\n"
+                                            "one per GPU (independent files, no exchange); with -i ONE BAM file is shared — every GPU\n"
+                                            "takes a range of its BGZF blocks, one reduce of the count matrix")))
+    # (is this the --batch form?  asked of a small parser of its own: "--batch=FILE" and argparse's abbreviations count too)
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--batch", default=None)
+    batch = pre.parse_known_args(givenargs)[0].batch is not None
     for title, rows, req in (("Required arguments", required, True), ("Optional arguments", optional, False),
                              ("MI355X arguments (additive)", additive, False)):
         group = parser.add_argument_group(title)
@@ -96,6 +103,66 @@ def GetArgs(givenargs):
                 kw["required"] = not (batch and flags[0] in ("--input", "--output", "--samplename"))
             group.add_argument(*flags, **kw)
     return parser.parse_args(givenargs)
+
+
+def _spawn(cmds, envs):
+    """Start the children BEFORE this process touches a GPU (never re-exec a process that did), wait for all, -> worst exit code."""
+    import subprocess
+    procs = [subprocess.Popen(c, env=e) for c, e in zip(cmds, envs)]
+    rcs = [p.wait() for p in procs]
+    return max((abs(r) for r in rcs), default=0)
+
+
+def run_gpus(a, args):
+    """--gpus N: N processes, one per GPU.  --batch: the manifest's samples dealt round-robin (BASELINE configs[3]: independent files,
+    no collective); -i: ONE BAM file shared by the GPUs (configs[4]: trueconsense_amd.split_main)."""
+    import socket
+    import tempfile
+    n = int(a.gpus)
+    rest, skip = [], False
+    for x in args:                                                  # the children get the same command line without --gpus / --batch / --device
+        if skip:
+            skip = False
+            continue
+        if x in ("--gpus", "--batch", "--device", "--stats"):
+            skip = True
+            continue
+        if x.startswith(("--gpus=", "--batch=", "--device=", "--stats=")):
+            continue
+        rest.append(x)
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                    PYTHONPATH=os.pathsep.join([pkg_parent] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
+    one_gpu = os.environ.get("TCMI_SPLIT_ONE_GPU") == "1"              # (rehearsal on a one-GPU box: every child on GPU 0)
+    if a.batch:
+        rows = [ln for ln in open(a.batch).read().split("\n") if ln.strip() and not ln.startswith("#")]
+        with tempfile.TemporaryDirectory(prefix="tcmi_gpus_") as tmp:
+            cmds, envs = [], []
+            for k in range(n):
+                mine = rows[k::n]
+                if not mine:
+                    continue
+                shard = os.path.join(tmp, "shard%d.tsv" % k)
+                with open(shard, "w") as fh:
+                    fh.write("\n".join(mine) + "\n")
+                cmd = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "--batch", shard, "--device", str(0 if one_gpu else k)] + rest
+                if a.stats:
+                    cmd += ["--stats", "%s.gpu%d" % (a.stats, k)]
+                cmds.append(cmd)
+                envs.append(base_env)
+            return _spawn(cmds, envs)
+    if a.index_override:
+        print("--index-override goes with one GPU. Exiting...")
+        return 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmds, envs = [], []
+    for k in range(n):
+        cmds.append([sys.executable, "-m", "trueconsense_amd.split_main"] + rest)
+        envs.append(dict(base_env, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    return _spawn(cmds, envs)
 
 
 def run_batch(a):
@@ -137,6 +204,13 @@ def run_batch(a):
     try:
         runner.run_files([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
                          [r[5] for r in rows], ref_len=len(refseq))
+    except Exception:                                                # every failed sample is named; the first one's error (what the reference would raise) goes on up: non-zero exit
+        failed = [(rows[i][1], int(c)) for i, c in enumerate(getattr(runner, "last_status", [])) if int(c) != 0]
+        for nm, code in failed:
+            print(f'sample "{nm}" failed (libtcmi error {code})', file=sys.stderr)
+        if failed:
+            print(f"{len(failed)} of {len(rows)} samples failed", file=sys.stderr)
+        raise
     finally:
         if a.stats:
             with open(a.stats, "w") as fh:
@@ -154,6 +228,11 @@ def main(args=None):
               "Use 'TrueConsense -h' to see the help document")
         sys.exit(1)
     a = GetArgs(args)
+    if a.gpus and a.gpus > 1:
+        rc = run_gpus(a, list(args))
+        if rc:
+            sys.exit(rc)
+        return
     if a.device is not None:
         os.environ["TCMI_DEVICE"] = str(a.device)
     if a.batch:

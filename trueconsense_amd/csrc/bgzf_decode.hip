@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
     constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
     static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
     __shared__ SymLds<NB> L;
-    extern __shared__ uint32_t pay_all[];           // per block: its compressed payload, from the dword that holds its first byte on
+    extern __shared__ __attribute__((aligned(8))) uint32_t pay_all[];   // per block: its compressed payload, from the dword that holds its first byte on
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int blk0 = blockIdx.x * SYM_BLOCKS;
@@ -1544,7 +1544,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     static const int win_env = std::getenv("TCMI_SYM_WINDOW") ? std::atoi(std::getenv("TCMI_SYM_WINDOW")) : -1;      // (A/B: 0 = never, else the window's bytes)
     const size_t win_bytes = per_wg == 1 ? (win_env >= 0 ? (size_t)win_env : pay > 16384 ? 8192u : 0u) : 0u;
     const bool windowed = win_bytes >= 2048 && win_bytes + 24 < pay;
-    sa.win_dwords = windowed ? (uint32_t)(win_bytes / 4 + 6) : 0u;
+    sa.win_dwords = windowed ? (uint32_t)((win_bytes / 4 + 6 + 1) & ~(size_t)1) : 0u;    // (even: the window loader stores 8 bytes a lane)
     const size_t dyn = windowed ? (size_t)sa.win_dwords * 4 : (size_t)g.pay_dwords * 4 * per_wg;
     static const bool attr_once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));

@@ -238,7 +238,7 @@ class _Tokens:
 
 
 def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True, name="S", rank=0, world=1, device=0, group=None,
-                            step_fn=None, entries_fn=None):
+                            step_fn=None, entries_fn=None, return_parts=False):
     """BASELINE configs[4] all the way: ONE BAM file over `world` ranks -> its consensus FASTA text on rank 0 (None on the others).
     What the ranks jointly replace is the reference's single pile-up pass (indexing.py:96-100), its insert candidates' region
     pile-ups (Events.py:47-82) and the walk (Sequences.py:168-322):
@@ -253,7 +253,9 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
          another rank: rank 0 decodes the file on the host for the tokens (tcmi_bam_load + tcmi_modal_tokens).
 
     step_fn(first, count) -> (counts int [L,7] of the rank's range) and entries_fn(positions) -> (entry bytes, ent_off, long text)
-    replace the GPU on boxes without one (tests: the oracle's tally and entries; the call then comes from the oracle too)."""
+    replace the GPU on boxes without one (tests: the oracle's tally and entries; the call then comes from the oracle too).
+    return_parts: rank 0 gets (FASTA text, counts int32 [L,7], {candidate column: modal token}) — what the command line's other
+    writers need (Outputs.WriteOutputs, Coverage.BuildCoverage)."""
     import torch
     import torch.distributed as dist
     from .Events import inserts_from_flags
@@ -262,7 +264,7 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
     L = int(ref_len)
     ld = (L + 255) // 256 * 256
     root = rank == 0
-    plain = alt = flags = None
+    plain = alt = flags = counts_root = None
     ctx = d = rs = None
     err = None
     if step_fn is None:
@@ -294,6 +296,8 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
                     C.memmove(out.ctypes.data, vp, L)
                     return out
                 plain, alt, flags = grab(p_), grab(a_), grab(f_)
+                if return_parts:
+                    counts_root = np.ascontiguousarray(t[:7 * ld].view(7, ld)[:, :L].T.cpu().numpy())
     else:
         d_blocks = step_fn("n_blocks")
         first, count = block_range(d_blocks, rank, world)
@@ -301,7 +305,8 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
         if multi:
             dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, group=group)
         if root:
-            plain, alt, flags = step_fn(("call", np.ascontiguousarray(part.numpy().T), int(mincov), bool(include_ambig)))
+            counts_root = np.ascontiguousarray(part.numpy().T)
+            plain, alt, flags = step_fn(("call", counts_root, int(mincov), bool(include_ambig)))
     # every rank learns whether the step held everywhere (a failed rank took part in the reduce: no deadlock, but no consensus either)
     verdict = [err]
     if multi:
@@ -330,8 +335,8 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
         if multi:
             pieces = [None] * dist.get_world_size(group) if root else None
             dist.gather_object(piece, pieces, dst=0, group=group)
+    toks = {}
     if root:
-        toks = {}
         if cand:
             toks, st = _vote(cand, pieces)
             if st & 2:                                              # a pair of mates that only a sweep over the whole file resolves
@@ -349,4 +354,6 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
         d.close()
     if ctx is not None:
         ctx.close()
+    if return_parts:
+        return (text, counts_root, toks) if root else None
     return text

@@ -18,7 +18,7 @@ from .io import fasta, gff
 def Readbam(f):
     """indexing.py:6-19 — the BAM as the later stages see it (plays pysam.AlignmentFile's role downstream): decoded on the
     host only when somebody asks for reads (insert tokens)."""
-    return f if isinstance(f, (BamFile, LazyBam)) else LazyBam(f)
+    return f if isinstance(f, (BamFile, LazyBam)) or hasattr(f, "modal_token") else LazyBam(f)    # (modal_token: tokens resolved beforehand, e.g. gathered from several GPUs)
 
 
 def Gffindex(file):

@@ -285,22 +285,56 @@ __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const ui
                     P[o] = nb && o < CL_SLAB ? (nb + eb) | (rep << 4) | (val << 12) : 0u;      // (0 behind the slab: the chain stops there)
                 }
                 wave_sync();
+                // The chain of symbols through the table — a symbol's place is known when its predecessor is decoded — was followed one
+                // LDS round trip per symbol (~300 of them per header: a fifth of this kernel's time).  Pointer doubling instead: J holds,
+                // for every bit position, where the chain stands 2^k symbols later (a position without a code stays where it is);
+                // six squarings of the table — every lane takes eight positions — and lane j, applying the squarings its bits ask for,
+                // knows where symbol j starts; symbols j + 64, j + 128, .. lie J_6 further each.
+                uint16_t *const J = reinterpret_cast<uint16_t *>(T.long_ll);       // 512 entries (the long-code tables are built later)
+                static_assert(sizeof(T.long_ll) >= 512 * sizeof(uint16_t) && CL_SLAB + 16 <= 512, "the doubling table borrows the long-code table's LDS");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t at0 = (uint32_t)lane + 64u * i;
+                    const uint32_t e0 = at0 < (uint32_t)CL_SLAB + 16u ? P[at0] : 0u;
+                    J[at0] = (uint16_t)(e0 ? at0 + (e0 & 15u) : at0);
+                }
+                wave_sync();
+                uint32_t pm[5];
+                pm[0] = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (((uint32_t)lane >> k) & 1u) pm[0] = J[pm[0]];
+                    uint32_t t8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t8[i] = J[lane + 64 * i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t8[i] = J[t8[i]];
+                    wave_sync();                                            // (every lane has read before any lane writes)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) J[lane + 64 * i] = (uint16_t)t8[i];
+                    wave_sync();
+                }
+#pragma unroll
+                for (int m = 1; m < 5; ++m) pm[m] = J[pm[m - 1]];
                 uint32_t o = 0;
-                while (got < total && err == ST_OK) {
-                    uint32_t mine = 0, j = 0, g = got, e;
-                    do {
-                        const uint32_t ev = P[o];                   // (every lane reads the same entry: lane j keeps it — no v_writelane, whose lane select wants m0)
-                        e = uni(ev);
-                        if (e == 0) break;
-                        mine = (uint32_t)lane == j ? ev : mine;
-                        g += (e >> 4) & 255u;
-                        o += e & 15u;
-                        ++j;
-                    } while (g < total && j < 64u);
+                bool stopped = false;
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    if (!(got < total && err == ST_OK && !stopped)) break;
+                    uint32_t mine = P[pm[m]];
+                    // the symbols of this batch that lie on the chain (a prefix of the lanes), and of them those that are still wanted:
+                    // up to and including the one that completes the `total` lengths
+                    const unsigned long long zmask = __ballot(mine == 0);
+                    const uint32_t nv = zmask ? (uint32_t)__builtin_ctzll(zmask) : 64u;
+                    if ((uint32_t)lane >= nv) mine = 0;
+                    uint32_t rep = (mine >> 4) & 255u;
+                    const uint32_t incl0 = wave_scan_add(rep);
+                    const unsigned long long reach = __ballot(mine != 0 && got + incl0 >= total);
+                    const uint32_t n_take = reach ? min(nv, (uint32_t)__builtin_ctzll(reach) + 1u) : nv;
+                    if ((uint32_t)lane >= n_take) { mine = 0; rep = 0; }
                     // lane j: its symbol's place and value
-                    const uint32_t rep = (mine >> 4) & 255u, v = mine >> 12;
-                    const uint32_t incl = wave_scan_add(rep);
-                    const uint32_t at = got + incl - rep;
+                    const uint32_t v = mine >> 12;
+                    const uint32_t at = got + incl0 - ((mine >> 4) & 255u);
                     const uint32_t named = wave_scan_max(mine != 0 && v != 16u ? (uint32_t)lane + 1u : 0u);     // 1 + the lane whose value a "16" here repeats
                     const uint32_t theirs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((named - 1u) << 2), (int)v);
                     const uint32_t val = named ? theirs : prev;
@@ -310,11 +344,20 @@ __device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const ui
                         for (uint32_t i = 0; i < 6; ++i)            // (zeros are not stored, so rep <= 6)
                             if (i < rep) H.lens[at + i] = (uint8_t)val;
                     }
-                    if (j) prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(j - 1u));
-                    got = g;
-                    first = false;
-                    if (e == 0) { if (o < (uint32_t)CL_SLAB) err = ST_BAD_STREAM; break; }      // no such code / the slab's end
+                    if (n_take) {
+                        prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(n_take - 1u));
+                        got += (uint32_t)__builtin_amdgcn_readlane((int)incl0, (int)(n_take - 1u));
+                        // behind the last symbol taken
+                        o = (uint32_t)__builtin_amdgcn_readlane((int)(pm[m] + (mine & 15u)), (int)(n_take - 1u));
+                        first = false;
+                    }
+                    if (n_take < 64u && got < total) {                     // the chain ends here: no such code, or the slab's end
+                        stopped = true;
+                        o = (uint32_t)__builtin_amdgcn_readlane((int)pm[m], (int)n_take);
+                        if (o < (uint32_t)CL_SLAB) err = ST_BAD_STREAM;
+                    }
                 }
+                if (err == ST_OK && got < total && !stopped) err = ST_BAD_STREAM;      // (320 symbols give at least 320 lengths: not reached)
                 pos += o;
                 if (pos > end) err = ST_BAD_STREAM;
             }

@@ -468,7 +468,10 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             uint32_t *const btok = a.tokens + bd.tok;
             const uint32_t bcap = bd.tok_cap;
             const uint32_t lane_cap = bcap / (uint32_t)SYM_LANES;                    // tokens a lane may park in the scratch half
-            uint32_t *const scratch = btok + bcap + (uint32_t)c * lane_cap;
+            // A lane's k-th parked token lies at scratch[k * SYM_LANES]: the lanes of a block decode one symbol a round each, so the
+            // stores of a round fall into consecutive words (4-byte stores into a region of its own per lane cost a memory transaction
+            // each: 115 MB of writes per BAM for 4.4 MB of tokens).
+            uint32_t *const scratch = btok + bcap + (uint32_t)c;
 
             // One literal / length / end-of-block code at bit p; a length is followed by its distance.
             auto symbol = [&](uint32_t &p, uint32_t &tok) __attribute__((always_inline)) -> int {
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             {
                 uint32_t tgt_abs = (uint32_t)lane0 + tgt, room = lane_cap, crossp = 0xFFFFFFFFu, crosst = 0;
                 uint64_t sptr = reinterpret_cast<uint64_t>(scratch);
+                const uint64_t sstride = (uint64_t)SYM_LANES * 4u;
                 const uint32_t tabs = (uint32_t)reinterpret_cast<uintptr_t>(&B), payb = (uint32_t)reinterpret_cast<uintptr_t>(bp);
                 const uint32_t ringbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.a.ring[0][0]), recbase = (uint32_t)reinterpret_cast<uintptr_t>(&L.a.rec[0]);
                 const uint32_t ringb = ringbase + (uint32_t)lane * (RING * 8), recb = recbase + (uint32_t)lane * 8u;
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     "s_and_b64 exec, exec, vcc\n"
                     "global_store_dword %[sptr], v51, off\n"
                     "v_add_u32 %[room], -1, %[room]\n"
-                    "v_lshl_add_u64 %[sptr], %[sptr], 0, 4\n"
+                    "v_lshl_add_u64 %[sptr], %[sptr], 0, %[sstride]\n"
                     "s_mov_b64 exec, s[80:81]\n"
                     "v_add_u32 %[total], 1, %[total]\n"
                     "s_add_u32 %[rounds], %[rounds], 1\n"
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     : [p] "+v"(p), [total] "+v"(total), [tgt] "+v"(tgt_abs), [midx] "+v"(midx), [kprev] "+v"(kprev), [state] "+v"(state),
                       [room] "+v"(room), [crossp] "+v"(crossp), [crosst] "+v"(crosst), [sptr] "+v"(sptr), [run] "+s"(run), [rounds] "+s"(rounds)
                     : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [wend] "v"(b_soft), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim),
-                      [ringbase] "s"(ringbase), [recbase] "s"(recbase), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
+                      [ringbase] "s"(ringbase), [recbase] "s"(recbase), [sstride] "s"(sstride), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
                       [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)),
                       [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d))
                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     if (k == SY_BAD || p > b_end) state = DEAD;
                     else {
                         if (k == SY_EOB) state = EOB;
-                        else if (total < lane_cap) scratch[total] = tok;
+                        else if (total < lane_cap) scratch[(size_t)total * SYM_LANES] = tok;
                         else spilled = true;
                         ++total;
                     }
@@ -919,7 +923,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             const bool pieces = on && berr == ST_OK && B.last != 0 && ntok0 == 0 && !block_redo && !more;
             if (on && blk0 + b < a.n_blocks) {
                 uint32_t *seg = a.seg + (size_t)(blk0 + b) * 128;
-                seg[c] = pieces ? bcap + (uint32_t)c * lane_cap + before : 0u;
+                seg[c] = pieces ? bcap + before * (uint32_t)SYM_LANES + (uint32_t)c : 0u;      // (its tokens: every SYM_LANES-th word from there)
                 seg[64 + c] = pieces ? cnt : 0u;
 #pragma unroll
                 for (int k = 1; k < NB; ++k) { seg[c + SYM_LANES * k] = 0; seg[64 + c + SYM_LANES * k] = 0; }
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     for (uint32_t i = 0; i < cnt; i += 8) {         // (eight loads in flight: the loop is all latency)
                         uint32_t t[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) t[k] = i + k < cnt ? scratch[before + i + k] : 0u;
+                        for (int k = 0; k < 8; ++k) t[k] = i + k < cnt ? scratch[(size_t)(before + i + k) * SYM_LANES] : 0u;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) if (i + k < cnt) dst[i + k] = t[k];
                     }
@@ -965,6 +969,7 @@ struct CopyArgs {
     const uint32_t *tokens;
     const uint32_t *n_tok;
     const uint32_t *seg;        // pieces of blocks whose n_tok has bit 31 set
+    uint32_t piece_stride;      // a piece's tokens lie this many words apart (the lanes per block of the bgzf_symbols variant that parked them)
     uint8_t *out;
     uint32_t *rec_slot;
     uint32_t *n_rec;
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                 const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)p_cnt, (int)p_cur);
                 const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)p_off, (int)p_cur);
                 if (ps >= base + 64u) break;
-                if (g >= ps && g < ps + pc) t = toks[po + (g - ps)];
+                if (g >= ps && g < ps + pc) t = toks[po + (g - ps) * a.piece_stride];
                 if (ps + pc > base + 64u) break;
                 ++p_cur;
             }
@@ -1619,6 +1624,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     static const int team_env = std::getenv("TCMI_TEAM_BYTES") ? std::atoi(std::getenv("TCMI_TEAM_BYTES")) : -1;      // (A/B measurements)
     ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;
+    ca.piece_stride = 64u / (uint32_t)per_wg;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
     if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL(bgzf_copy<true>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
     else hipLaunchKernelGGL(bgzf_copy<false>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);

@@ -1,8 +1,9 @@
-"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round3" block of profiles/traffic.json that
+"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round4" block (or the key given as third argument) of profiles/traffic.json that
 bench.py's roofline blocks quote.   python3 tools/pmc_to_traffic.py gpurun_out/TAG/pmc_e2e_summary.txt profiles/TAG_pmc_e2e.txt"""
 import ast, json, os, re, sys
 
 src, committed_as = sys.argv[1], sys.argv[2]
+key = sys.argv[3] if len(sys.argv) > 3 else "round4"
 k = {}
 for line in open(src):
     m = re.match(r"^([\w<>, ]+?) (\{.*\}) n= (\d+)$", line.strip())
@@ -26,8 +27,10 @@ for name, c in k.items():
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tp = os.path.join(root, "profiles", "traffic.json")
 t = json.load(open(tp))
-t["round3"] = {"source": committed_as + " (tools/pmc_e2e.sh: one --pmc set per pass, kernel trace only; one 1M-read BAM per launch, single stream)",
+t[key] = {"source": committed_as + " (tools/pmc_e2e.sh: one --pmc set per pass, kernel trace only; one 1M-read BAM per launch, single stream)",
                "kernels": out, "wave_insts_per_bam": sum(v["wave_insts_total"] for v in out.values()),
                "hbm_bytes_per_bam": sum(v["hbm_bytes"] for v in out.values())}
 json.dump(t, open(tp, "w"), indent=1)
-print(json.dumps(t["round3"], indent=1)[:1500])
+if "tally_planes_kernel" in out:
+    t[key]["tally_hbm_bytes_per_bam"] = out["tally_planes_kernel"]["hbm_bytes"]
+print(json.dumps(t[key], indent=1)[:1500])

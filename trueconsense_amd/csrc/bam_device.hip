@@ -749,7 +749,8 @@ namespace {
 std::atomic<uint64_t> g_next_uid{1ull << 40};
 
 // queue everything of the one-sync path up to the packed read set; D and J must outlive the wait
-int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, Decoded &D, tcmi_fused_job &J, tcmi_readset *rs)
+// (safe_caps: the arrays sized from the worst case the arena was reserved for, not from a hint of the records' mean size)
+int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, Decoded &D, tcmi_fused_job &J, tcmi_readset *rs, bool safe_caps = false)
 {
     int rc = decode_enqueue(ctx, f, D, first_block, n_blocks);
     if (rc) return rc;
@@ -764,7 +765,10 @@ int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int6
     J.d_over = D.d_over; J.d_stat = D.d_stat; J.n_blocks = (int64_t)D.nb; J.n_own = (int64_t)D.nb_own; J.ranged = D.ranged ? 1 : 0;
     // records: from the mean size of the file's first records (+ 25 %) where the host saw enough of them, else as the arena was reserved
     J.rec_cap = (int64_t)D.guess_rec;
-    if (f->rec_bytes_hint >= 36) J.rec_cap = std::min<int64_t>(J.rec_cap, (int64_t)(D.f->inflated / f->rec_bytes_hint) * 5 / 4 + 8192);
+    // (a file whose header fills its first block shows the host no record: the last file of this context stands in — files of a
+    //  batch are alike, and a file beyond the capacity takes the several-kernel path)
+    const uint32_t hint = f->rec_bytes_hint >= 36 ? f->rec_bytes_hint : ctx->rec_bytes_seen;
+    if (hint >= 36 && !safe_caps) J.rec_cap = std::min<int64_t>(J.rec_cap, (int64_t)(D.f->inflated / hint) * 5 / 4 + 8192);
     J.len_bound = (f->ref_len.empty() ? 0 : f->ref_len[0]) + 65536;
     rs->uid = g_next_uid.fetch_add(1);
     rs->device = ctx->device;
@@ -781,12 +785,12 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     static const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    if (ctx->one_sync && try_fused) {
+    for (int attempt = 0; ctx->one_sync && try_fused && attempt < 2; ++attempt) {
         Decoded D;
         tcmi_fused_job J;
         tcmi_readset *rs = new tcmi_readset();
         uint32_t why = 0;
-        int rc = fast_enqueue(ctx, f, first_block, n_blocks, D, J, rs);
+        int rc = fast_enqueue(ctx, f, first_block, n_blocks, D, J, rs, attempt > 0);
         if (rc == TCMI_OK) rc = tcmi_pack_fused_report(ctx, &J);
         if (rc == TCMI_OK) {
             TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -794,6 +798,7 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
         }
         if (rc == TCMI_OK) {
             ++ctx->stat_one_sync_taken;
+            if (rs->n_reads > 64) ctx->rec_bytes_seen = (uint32_t)std::min<uint64_t>(J.stream_len / (uint64_t)rs->n_reads, 1u << 24);
             rs->packed_on_device = 2;           // decoded AND packed on the device
             if (n_reads_out) *n_reads_out = rs->n_reads;
             *out = rs;
@@ -802,8 +807,10 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
         }
         tcmi_readset_free(ctx, rs);
         if (rc != TCMI_E_UNSUPPORTED) return rc;
+        if (attempt == 0 && (why & 0x800u)) { ctx->rec_bytes_seen = 0; continue; }     // (PKF_REC_OVF: records shorter than the hint said — once more, sized for the worst case)
         ++ctx->stat_one_sync_declined; ctx->stat_last_decline = why;
         if (timing) std::fprintf(stderr, "[tcmi bamfile] one-sync path declined (flags 0x%x): the several-kernel path\n", why);
+        break;
     }
     DeviceBam D;
     int rc = decode_on_device(ctx, f, &D, first_block, n_blocks);
@@ -854,7 +861,7 @@ int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int
     if (!ctx || !f || !rs_out || !L_out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     *rs_out = nullptr;
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->one_sync && ctx->step_L == 0 && !ctx->call_pending) {
+    for (int attempt = 0; ctx->one_sync && ctx->step_L == 0 && !ctx->call_pending && attempt < 2; ++attempt) {
         static const bool timing = std::getenv("TCMI_STEP_TIMING") != nullptr;       // diagnostic: where the host's time goes, per 256 calls
         static thread_local double t_acc[5] = {0, 0, 0, 0, 0};
         static thread_local int t_n = 0;
@@ -866,7 +873,7 @@ int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int
         tcmi_readset *rs = new tcmi_readset();
         uint32_t why = 0;
         const int64_t L0 = std::max<int64_t>(ref_len, 1);
-        int rc = fast_enqueue(ctx, f, 0, -1, D, J, rs);
+        int rc = fast_enqueue(ctx, f, 0, -1, D, J, rs, attempt > 0);
         const auto t1 = now();
         bool began = false;
         if (rc == TCMI_OK) {
@@ -898,6 +905,7 @@ int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int
         }
         if (rc == TCMI_OK) {
             ++ctx->stat_one_sync_taken;
+            if (rs->n_reads > 64) ctx->rec_bytes_seen = (uint32_t)std::min<uint64_t>(J.stream_len / (uint64_t)rs->n_reads, 1u << 24);
             rs->packed_on_device = 2;
             int64_t L = L0;
             if (rs->max_end > L0 || rs->s_reads > 0) {              // reads beyond the reference's end, or long reads that the packed set leaves out
@@ -913,7 +921,9 @@ int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int
         }
         tcmi_readset_free(ctx, rs);
         if (rc != TCMI_E_UNSUPPORTED) return rc;
+        if (attempt == 0 && (why & 0x800u)) { ctx->rec_bytes_seen = 0; continue; }     // (PKF_REC_OVF: once more, sized for the worst case)
         ++ctx->stat_one_sync_declined; ctx->stat_last_decline = why;
+        break;
     }
     tcmi_readset *rs = nullptr;
     int rc = readset_from_blocks(ctx, f, 0, -1, &rs, nullptr, false);   // (the one-sync path has had its turn)

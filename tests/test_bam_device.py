@@ -105,6 +105,16 @@ def test_device_inflate_and_record_index_match_zlib(ctx, tmp_path):
         assert d.inflated_bytes < 12 * d.file_bytes              # (the ratio below which the host picks the team variant)
         d.close()
         check_counts(ctx, p, len(ref))
+    # ... and one that compresses like real data with unbinned qualities (2.5 : 1): most matches are 3 - 8 bytes long and come from
+    # anywhere in the 32 KB window — the far ones among them are finished in the batch's set-up (bgzf_copy<true, true>)
+    q = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(nh, 150), p=(lambda w: w / w.sum())(np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004))
+    for level in (6, 1, 9):
+        p = str(tmp_path / ("real%d.bam" % level))
+        bamwriter.write_bam_fast(p, hard["pos"], hard["flag"], hard["seq"].reshape(nh, -1), 150, "MN908947.3", len(ref), level=level, qual=q, names=names)
+        d = check_decode(ctx, p)
+        assert d.inflated_bytes < 4 * d.file_bytes
+        d.close()
+        check_counts(ctx, p, len(ref))
     # no reads at all; one read
     empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("cigar_off", "seq_off", "qual_off") else v) for k, v in reads.items()}
     empty.update(n_reads=0, cigar_off=np.zeros(1, np.uint64), seq_off=np.zeros(1, np.uint64), qual_off=np.zeros(1, np.uint64))

@@ -1,6 +1,6 @@
-"""GPU: the one-sync file path (pk_fused: record index + record chain + classification + prefix sums + planes in one kernel, a
-decoupled look-back between the workgroups; tcmi_bamfile_step: decode, pack, tally and call queued back to back, one wait)
-against the several-kernel path (three + one waits) and against the oracle.  Integer / byte work: bit-exact.  What the reference
+"""GPU: the one-sync file path (pk_index + pk_place + pk_pack: record index, record chain, classification and the places of
+records and kept reads from per-block aggregates every workgroup adds up for itself, no host round trip; tcmi_bamfile_step:
+decode, pack, tally and call queued back to back) against the several-kernel path (three + one waits) and against the oracle.  Integer / byte work: bit-exact.  What the reference
 computes here is indexing.BuildIndex (indexing.py:75-154) and the position-local part of BuildConsensus (Sequences.py:119-165)."""
 import os
 
@@ -82,8 +82,8 @@ def test_one_sync_path_equals_the_several_kernel_path_and_the_oracle(ctx, tmp_pa
 
 def test_one_sync_path_on_block_ranges_and_straddling_records(ctx, tmp_path):
     """Block ranges (the record chain starts OPEN: wherever the range's first block finds a record) add up to the file; records
-    that straddle BGZF blocks (every block filled to the brim; tiny blocks: a record over several) go through the look-back's
-    chain function."""
+    that straddle BGZF blocks (every block filled to the brim; tiny blocks: a record over several) go through the blocks'
+    chain functions."""
     ref, orfs = sy.make_reference(L=6000, cds=[(100, 2500), (3000, 5800)])
     L = len(ref)
     reads = sy.make_reads(ref, 30_000, seed=41, indel_sites=sy.default_indel_sites(orfs))

@@ -622,7 +622,7 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
         g.d_file = d_file; g.d_desc = D.d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = D.d_out; g.d_slot = D.d_slot; g.d_nrec = D.d_nrec;
         g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
-        g.short_tokens = f->inflated < 12 * f->n_bytes ? 1 : 0;
+        g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;
         const int rc = tcmi_bgzf_decode_launch(ctx, g);
         if (rc) return rc;
     }
@@ -740,7 +740,7 @@ int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset
 // else; their count matrices add up to the file's (BASELINE configs[4]; indexing.py:96).
 //
 // Two ways through.  The ONE-SYNC path (default): decode, record index, chain check, classification, prefix sums, planes and chunk
-// planning are all queued from capacities (decode_enqueue, tcmi_pack_fused_enqueue: pk_fused + pk_pack), the host waits once and
+// planning are all queued from capacities (decode_enqueue, tcmi_pack_fused_enqueue: pk_index + pk_place + pk_pack), the host waits once and
 // checks what was deferred.  Whatever that path cannot vouch for — a damaged block, a chain that does not close, reads it does not
 // take, a file beyond the capacities — is decoded again by the SEVERAL-KERNEL path below it (three waits), which words every refusal.
 }   // extern "C"

@@ -1094,7 +1094,9 @@ struct CopyArgs {
 
 // TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
 // both are right for any input — the lean one is 4 % faster where no batch would use teams)
-template <bool TEAMS>
+// DIRECT: with the short far matches of a teams' batch finished in the batch's set-up (files that compress less than ~4 : 1: most of
+// their matches are 3 - 8 bytes long and come from anywhere in the 32 KB window; at 6 : 1 few do and the lean set-up is 3 % faster)
+template <bool TEAMS, bool DIRECT>
 __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 {
     __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; } s_lds;     // (the ring first: ring index = LDS address)
@@ -1343,10 +1345,58 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 #if TCMI_COPY_PHASES == 3
         PH(7);
 #endif
+        // Teams' batches (short tokens: data that compresses like real data, whose matches are mostly 3 - 8 bytes from anywhere in
+        // the 32 KB behind): a far match of up to 8 bytes is FINISHED here — three words from the flushed stream, its bytes straight
+        // to their place in the ring (exactly `len` of them: lanes write next to each other) — instead of being parked and copied by
+        // a team later: 17 + 12 instructions for all of them, and the teams' rounds are left with the near matches.  (The batch is at
+        // most team_bytes long: what these writes replace in the ring was flushed long ago and is further back than CNEAR.)
+        const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
+        bool done = false;
+        const bool far_now = is_match && far_ok && mylen <= 64u && dst - dist + mylen <= flushed;     // far, flushed, and short enough to be fetched here
+        const unsigned long long far_mask = __ballot(far_now);
+        if (DIRECT && use_teams && far_mask) {
+            const uint32_t src = dst - dist;
+            done = far_now && mylen <= 8u;
+            const unsigned long long dmask = __ballot(done);
+            if (dmask) {
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wavefront's own flush stores)
+                if (done) {
+                    const uint32_t *g = reinterpret_cast<const uint32_t *>(out + (src & ~3u));
+                    w0 = g[0]; w1 = g[1];
+                    if ((src & 3u) + mylen > 8u) w2 = g[2];
+                }
+                const uint32_t sh = (src & 3u) * 8u;
+                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                uint32_t lo8, hi8;
+                asm volatile(
+                    "s_mov_b64 s[92:93], exec\n"
+                    "s_mov_b64 exec, %[dmask]\n"
+                    "v_lshrrev_b32 %[lo8], 8, %[lo]\n"
+                    "v_lshrrev_b32 %[hi8], 8, %[hi]\n"
+                    "ds_write_b8 %[at], %[lo]\n"
+                    "ds_write_b8 %[at], %[lo8] offset:1\n"
+                    "ds_write_b8_d16_hi %[at], %[lo] offset:2\n"
+                    "v_cmpx_lt_u32 vcc, 3, %[len]\n"
+                    "ds_write_b8_d16_hi %[at], %[lo8] offset:3\n"
+                    "v_cmpx_lt_u32 vcc, 4, %[len]\n"
+                    "ds_write_b8 %[at], %[hi] offset:4\n"
+                    "v_cmpx_lt_u32 vcc, 5, %[len]\n"
+                    "ds_write_b8 %[at], %[hi8] offset:5\n"
+                    "v_cmpx_lt_u32 vcc, 6, %[len]\n"
+                    "ds_write_b8_d16_hi %[at], %[hi] offset:6\n"
+                    "v_cmpx_lt_u32 vcc, 7, %[len]\n"
+                    "ds_write_b8_d16_hi %[at], %[hi8] offset:7\n"
+                    "s_mov_b64 exec, s[92:93]\n"
+                    : [lo8] "=&v"(lo8), [hi8] "=&v"(hi8)
+                    : [dmask] "s"(dmask), [lo] "v"(lo), [hi] "v"(hi), [at] "v"(dm), [len] "v"(mylen)
+                    : "s92", "s93", "vcc", "memory");
+            }
+        }
         {
             const uint32_t src = dst - dist;                    // (position of the source's first byte)
-            const bool fetch = is_match && far_ok && mylen <= 64u && src + mylen <= flushed;     // (longer ones: 64 bytes an instruction in the loop)
-            if (__ballot(fetch)) {
+            const bool fetch = far_now && !done;                // (longer ones: 64 bytes an instruction in the loop)
+            if (far_mask && __ballot(fetch)) {
                 const uint32_t words = fetch ? (mylen + 3u) >> 2 : 0u;
                 const uint32_t end_w = wave_scan_add(words);
                 const bool take = fetch && end_w <= (uint32_t)FAR_WORDS;
@@ -1378,8 +1428,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 #elif TCMI_COPY_PHASES == 3
         PH(3);
 #endif
-        const bool use_teams = TEAMS && uni(batch_end - op <= a.team_bytes ? 1u : 0u) != 0u;
-        const bool teamable = is_match && (vB >> 16) == 0u;
+        const bool teamable = is_match && !done && (vB >> 16) == 0u;
         const unsigned long long plain_mask = __ballot(teamable);  // (plain matches, parked far ones included)
         // TCMI_LM_ASM's operands of a plain match.  Up to 64 bytes, a byte a lane: (len - 1) << 16 | (destination - 7) & 0xffff and
         // source - 7 (lane + 7 is added to both).  Longer ones, an ALIGNED destination dword a lane (LDS takes unaligned words at a
@@ -1409,7 +1458,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             const unsigned long long rng = t_stop < 64u ? from & ~(~0ull << t_stop) : from;
             const bool mine = (rng >> lane) & 1ull;
             if (mine && is_lit) s_win[dm] = (uint8_t)t;
-            unsigned long long mm = __ballot(mine && is_match);
+            unsigned long long mm = __ballot(mine && is_match && !done);
             n_match += (uint32_t)__popcll(mm);
             while (mm) {
                 if (use_teams) {
@@ -1607,7 +1656,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
         if (per_wg == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<2, false>), 128, dyn);
         else if (windowed) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, true>), 64, dyn);
         else if (per_wg == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, false>), 64, dyn);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false>), 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false, false>), 64, 0);
         std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d%s>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
                      nb, pay, per_wg, windowed ? ", windowed" : "", dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
     }
@@ -1626,8 +1675,9 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;
     ca.piece_stride = 64u / (uint32_t)per_wg;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
-    if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL(bgzf_copy<true>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
-    else hipLaunchKernelGGL(bgzf_copy<false>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    if (TCMI_COPY_TEAMS && g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    else if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    else hipLaunchKernelGGL((bgzf_copy<false, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
     tcmi_prof_end(ctx, TCMI_K_INFLATE_COPY);
     TCMI_HIP(ctx, hipGetLastError());
     if (d_stamps) {

@@ -197,6 +197,6 @@ struct tcmi_bgzf_decode_args {
     size_t n_blocks;
     uint32_t pay_dwords;            // the largest block's payload in dwords + slack
     uint32_t n_ref;                 // reference sequences of the BAM header (a record's refID must be one of them)
-    int short_tokens;               // the file compresses less than ~12 : 1 (many short matches): bgzf_copy's variant with teams
+    int short_tokens;               // the file compresses less than ~12 : 1 (many short matches): bgzf_copy's variant with teams; 2: less than ~4 : 1: ... and short far matches finished in the set-up
 };
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &a);

@@ -154,7 +154,7 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t word_cursor;
     uint32_t max_len;               // longest reference span of a kept read
     uint32_t n_gen;                 // reads left to the stream-walking tally kernel (longer than TCMI_D_MAXLEN positions)
-    unsigned long long n_rec;       // pk_fused: alignment records of the decoded range
+    unsigned long long n_rec;       // pk_place: alignment records of the decoded range
 };
 
 // words a read takes in the plane stream: its pairs, the zero pair behind them, and — for an even number of pairs — one more zero pair,
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256) void pk_report(const PackTotals *tot, const un
     if (i == 0) *h_tot = *tot;
 }
 
-// ---- the one-sync path: pk_fused + pk_pack queued from capacities, checked after the caller's one wait ------------------------------
+// ---- the one-sync path: pk_index + pk_place + pk_pack queued from capacities, checked after the caller's one wait ------------------------------
 static char *take_blob(tcmi_ctx *ctx, tcmi_readset *rs, size_t want)
 {
     for (size_t k = 0; k < ctx->blob_pool.size(); ++k)           // a freed read set of about this size?

@@ -152,7 +152,7 @@ struct tcmi_ctx {
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
     uint32_t rec_bytes_seen = 0;     // mean record size of the last file this context decoded (sizes the next file's arrays when the file's own first blocks say nothing)
     int mid_wait = 1;                // the one-sync path waits once more, behind the decode kernels (bam_device.hip: fast_enqueue)
-    int one_sync = 1;                // device-decoded files take the one-sync path (pk_fused) first; 0: the several-kernel path only
+    int one_sync = 1;                // device-decoded files take the one-sync path (pk_index + pk_place + pk_pack) first; 0: the several-kernel path only
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)
@@ -248,7 +248,7 @@ extern "C" int tcmi_bamfile_read_threads(const char *path, int read_threads, tcm
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);
 int tcmi_pack_on_device(tcmi_ctx *ctx, const void *pack_src, tcmi_readset *rs, uint32_t *why);
 // The one-sync file path (bam_device.hip: tcmi_bamfile_step, tcmi_readset_from_bamfile): everything behind bgzf_copy / bgzf_crc32 —
-// record index, the chain of records across the blocks, classification, prefix sums, bit planes (pk_fused), chunk planning
+// record index, the chain of records across the blocks, classification, prefix sums, bit planes (pk_index, pk_place), chunk planning
 // (pk_pack) — queued on the context's stream from CAPACITIES instead of counts read back; _finish, once the stream has been
 // waited for, checks what was deferred (block verdicts, chain, capacities, packer flags) and fills the read set in, or says that
 // the file must take the several-kernel path (TCMI_E_UNSUPPORTED: nothing of the job may be used then).

@@ -1635,11 +1635,13 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     //  4 611 blocks of 10.7 KB — 1 634 / 1 036 / 698 us: with larger payloads more lanes per block pay)
     const size_t pay = (size_t)g.pay_dwords * 4;
     const int per_wg = forced == 1 || forced == 2 || forced == 4 ? forced : pay <= 4096 ? 2 : 1;
-    // payloads of more than 16 KB (files that compress less than ~4 : 1) are staged a window of 8 KB at a time, bgzf_symbols<1, true>:
-    // 2.5 : 1 (26 KB a block): 2 766 -> 1 875 us per 1M-read file; at 6 : 1 (11 KB, eight workgroups per CU staged whole) windows cost more
-    // than they bring (413 -> 580 us): every window is a pass of its own (ring set-up, chain, tokens moved to their places)
+    // payloads of more than 16 KB (files that compress less than ~4 : 1) are staged a window of 5 KB at a time, bgzf_symbols<1, true>:
+    // 2.5 : 1 (26 KB a block): 2 766 -> 1 875 us per 1M-read file in round 3 (8 KB windows); at 6 : 1 (11 KB, eight workgroups per CU
+    // staged whole) windows cost more than they bring (413 -> 580 us): every window is a pass of its own (ring set-up, chain, tokens
+    // moved to their places).  Round 4, same file: windows of 16 / 12 / 8 / 6 / 5 / 4 / 3 KB 1 959 / 1 826 / 1 436 / 1 395 / 1 348 /
+    // 1 381 / 1 448 us — the smaller the window the more workgroups a CU holds (12 at 5 KB), the more passes a block takes.
     static const int win_env = std::getenv("TCMI_SYM_WINDOW") ? std::atoi(std::getenv("TCMI_SYM_WINDOW")) : -1;      // (A/B: 0 = never, else the window's bytes)
-    const size_t win_bytes = per_wg == 1 ? (win_env >= 0 ? (size_t)win_env : pay > 16384 ? 8192u : 0u) : 0u;
+    const size_t win_bytes = per_wg == 1 ? (win_env >= 0 ? (size_t)win_env : pay > 16384 ? 5120u : 0u) : 0u;
     const bool windowed = win_bytes >= 2048 && win_bytes + 24 < pay;
     sa.win_dwords = windowed ? (uint32_t)((win_bytes / 4 + 6 + 1) & ~(size_t)1) : 0u;    // (even: the window loader stores 8 bytes a lane)
     const size_t dyn = windowed ? (size_t)sa.win_dwords * 4 : (size_t)g.pay_dwords * 4 * per_wg;

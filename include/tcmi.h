@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TCMI_ABI_VERSION 3
+#define TCMI_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 #define TCMI_OK            0
@@ -326,6 +326,13 @@ int  tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readse
  * count matrices of the ranges add up to the file's (what indexing.py:96-100 piles up in one pass). */
 int  tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out,
                                       int64_t *n_reads);
+/* A range that starts in the middle of the file starts at the first PLAUSIBLE record its first block finds — nothing in front of
+ * it vouches for that offset.  *first: where that record starts, *next: where the first record behind the range starts, both as
+ * offsets into the whole file's inflated stream (-1: the range starts with the file or holds no record start / its chain was never
+ * fixed).  Ranges that tile a file are all true record chains iff every range's *next equals the *first of the next range that has
+ * one (by induction from the header: what any reader of a BAM file relies on, htslib's bam_read1 included); tcmi_split_step checks
+ * exactly that along with its reduce, trueconsense_amd/distributed.py before its collective. */
+int  tcmi_readset_range_anchors(const tcmi_readset *rs, int64_t *first, int64_t *next);
 /* BAM file -> call records with ONE wait of the host: what indexing.BuildIndex (indexing.py:75-154) and the position-local part of
  * Sequences.BuildConsensus (Sequences.py:119-165 via Ambig.py / Events.py) come to for one file.  Decode, record index, record chain,
  * classification, packing, tally and call are queued back to back on the context's stream from capacities instead of counts read
@@ -353,13 +360,17 @@ int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_
  * is a hook of the caller's (RCCL's ncclReduce on the given stream from C: tools/tcmi_rccl_hook.cpp; torch.distributed from Python:
  * trueconsense_amd/distributed.py).
  *   tcmi_split_step   this rank's part of one step, in C: decode + pack + tally the alignment records that start in BGZF blocks
- *                     [first_block, first_block + n_blocks) into d_counts (device int32 [7][ld] + ONE more int32 behind it: the
- *                     number of ranks that failed, summed along — a rank that cannot decode its range still takes part in the
- *                     exchange, with zeros, so nobody waits for it forever), reduce(user, d_counts, 7 * ld + 1, stream) — the
+ *                     [first_block, first_block + n_blocks) into d_counts (device int32 [7][ld] + TWO more int32 behind it: the
+ *                     ranges' anchors — every rank adds (where the first record behind its range starts) - (where its own first
+ *                     record starts; 0 for the range that starts with the file), modulo 2^32: the sum over ranges that tile the
+ *                     file telescopes to the inflated length iff every range starts where the one in front ends
+ *                     (tcmi_readset_range_anchors) —, and the number of ranks that failed — a rank that cannot decode its range
+ *                     still takes part in the exchange, with zeros, so nobody waits for it forever),
+ *                     reduce(user, d_counts, 7 * ld + 2, stream) — the
  *                     hook must sum over the ranks, at least to the root —, and on the root (is_root != 0) the call kernel:
  *                     results as tcmi_step's.  *rs_out (any rank; NULL on failure) keeps the rank's decoded stream resident for
  *                     tcmi_readset_ins_entries.  Returns the rank's own error, or on the root TCMI_E_UNSUPPORTED when another
- *                     rank failed.
+ *                     rank failed or the ranges' record chains do not join.
  *   tcmi_readset_ins_entries   the entries of the candidate columns (TCMI_INS_ENTRY_BYTES each, opaque; per column in file order)
  *                     from this rank's records: what the ranks send to the root.  ent_off[n_pos + 1]; insertions of more than 12
  *                     bases leave their bases in long_text (long_used bytes).  TCMI_E_ARG with ent_off / long_used filled in when

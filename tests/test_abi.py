@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _ffi._SIGS, "no ctypes signature for " + n
-    assert lib.tcmi_abi_version() == 3
+    assert lib.tcmi_abi_version() == 4
 
 
 def test_no_device_is_reported_not_hidden():

@@ -233,3 +233,21 @@ def test_bench_many_bam_shard_four_ranks_rehearsal():
                       "--no-cli-batch", "--no-configs2", "--min-seconds", "0"], nproc=4)
     assert d["n_gpus"] == 4 and d["steps"] == 2 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
     assert d["fasta_all_timed"]["all_equal_the_oracle_chain"] is True
+
+
+def test_check_range_anchors_joins_the_ranks_ranges_into_one_chain():
+    """distributed.check_range_anchors (what tally_split_bamfile's ranks agree on before their collective; tcmi_split_step carries the
+    same condition as a telescoping sum): every range's first record must start where the range in front says its last one ends."""
+    from trueconsense_amd.distributed import check_range_anchors as chk
+    total = 10_000
+    assert chk([(0, 4, -1, 2500), (4, 4, 2500, 5200), (8, 4, 5200, total)], total) is None
+    assert chk([(0, 12, -1, -1)], total) is None                               # one range: the whole file, nothing to join
+    assert chk([(0, 4, -1, 2500), (4, 0, -1, -1), (4, 8, 2500, total)], total) is None        # a rank without blocks
+    assert chk([(0, 4, -1, 2500), (4, 4, -1, -1), (8, 4, 2500, total)], total) is None        # a range inside one long record: no start of its own
+    assert chk([(0, 1, -1, 300), (1, 11, 300, total)], total) is None                         # rank 0: header blocks only, the header says where records begin
+    why = chk([(0, 4, -1, 2500), (4, 4, 2466, 5200), (8, 4, 5200, total)], total)
+    assert why and "rank 1" in why and "2466" in why and "2500" in why
+    why = chk([(0, 4, -1, 2500), (4, 4, 2500, 5200), (8, 4, 5200, total - 7)], total)
+    assert why and "last alignment record" in why
+    why = chk([(0, 4, -1, -1), (4, 8, 2500, total)], total)                                   # nobody vouches for rank 1's start
+    assert why and "no range in front" in why

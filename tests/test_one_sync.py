@@ -188,3 +188,137 @@ def test_damaged_files_are_refused_as_before(ctx, tmp_path):
     ctx.set_option("one_sync", 1)
     assert msgs[0] == msgs[1]
     assert ctx.stat("one_sync_declined") >= 1 or msgs[0][0] in ("read", "ok")
+
+
+def _stream_and_records(path):
+    """The file's inflated stream and, per alignment record, (start, end, start of its QUAL) — by zlib."""
+    import gzip
+    import struct
+    s = gzip.open(path).read()
+    l_text, = struct.unpack_from("<i", s, 4)
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", s, at)
+    at += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", s, at)
+        at += 4 + l_name + 4
+    recs = []
+    while at < len(s):
+        bs, = struct.unpack_from("<i", s, at)
+        l_name = s[at + 12]
+        n_cig, = struct.unpack_from("<H", s, at + 16)
+        l_seq, = struct.unpack_from("<i", s, at + 20)
+        recs.append((at, at + 4 + bs, at + 36 + l_name + 4 * n_cig + (l_seq + 1) // 2))
+        at += 4 + bs
+    return s, recs
+
+
+def test_block_ranges_must_join_into_one_chain_of_records(ctx, tmp_path):
+    """A block range in the middle of a file starts at the first offset that LOOKS like an alignment record.  Here one read's
+    qualities spell a complete record header (every field plausible, its block_size ending where the real record ends) right where
+    a BGZF block begins: a range that starts with that block takes it for a read and carries on in step with the true chain —
+    nothing inside the range can tell.  The range in front knows better (its last record ends further on): the ranges' anchors
+    (tcmi_readset_range_anchors) do not join, distributed.check_range_anchors and tcmi_split_step's anchor word refuse the file."""
+    import ctypes as C
+    import struct
+
+    import torch
+
+    from trueconsense_amd import distributed as td
+    ref, _ = sy.make_reference(L=4000, cds=[(100, 2000)])
+    L = len(ref)
+    n = 3000
+    reads = sy.make_reads(ref, n, seed=81)
+    assert int(reads["l_qseq"].min()) == 150 == int(reads["l_qseq"].max())
+    reads["qual"] = np.full(n * 150, 30, np.uint8)
+    B = 4093
+    p0 = write(tmp_path, "plain.bam", reads, "ref", L, split_records=True, block=B)
+    s0, recs = _stream_and_records(p0)
+    # a block boundary X inside a record's QUAL with 56 bytes of it to spare
+    pick = next((i, x) for i, (a, e, q) in enumerate(recs) for x in [(q + B - 1) // B * B] if i > 200 and q <= x and x + 56 <= e)
+    i, X = pick
+    E = recs[i][1]
+    fake = struct.pack("<iiiBBHHHiiii", E - X - 4, 0, 100, 1, 0, 0, 1, 0, 10, -1, -1, 0) + b"\0" + struct.pack("<I", 10 << 4) + b"\x11" * 5 + b"\x1e" * 10
+    assert len(fake) == 56
+    at = i * 150 + (X - recs[i][2])
+    reads["qual"][at:at + 56] = np.frombuffer(fake, np.uint8)
+    p = write(tmp_path, "trap.bam", reads, "ref", L, split_records=True, block=B)
+    s1, recs1 = _stream_and_records(p)
+    assert recs1 == recs and s1[X:X + 56] == fake and len(s1) == len(s0)
+    want = c_oracle.tally(reads, L)
+    d0, d = engine.DeviceBam(p0), engine.DeviceBam(p)
+    nb, k = d.n_blocks, X // B
+    assert nb > k + 2 and d0.n_blocks == nb
+
+    def ranges(dbam, cut):
+        out, acc = [], np.zeros_like(want)
+        for a, c in ((0, cut), (cut, nb - cut)):
+            rs = ctx.upload_bamfile(dbam, blocks=(a, c))
+            out.append((a, c) + rs.range_anchors)
+            acc += ctx.step(rs, L, 30, True)[3]
+            rs.free()
+        return out, acc
+
+    for one_sync in (1, 0):
+        ctx.set_option("one_sync", one_sync)
+        # wherever block k has a block in front of it in the same decode, the chain does not close there: the file as a whole and a
+        # range that holds block k but does not start with it are refused (the host reader's)
+        for blocks in (None, (0, k + 1), (k - 1, 3)):
+            with pytest.raises(_ffi.TcmiError) as e:
+                ctx.upload_bamfile(d, blocks=blocks)
+            assert e.value.code == _ffi.E_UNSUPPORTED and "does not close at BGZF block" in str(e.value)
+        # ... but a range that STARTS with block k cannot know: both ranges decode, and only their anchors tell
+        r, acc = ranges(d, k)
+        assert r[0][3] == E and r[1][2] == X, r
+        assert not np.array_equal(acc, want)                         # (what the fake read would have cost: counts that are not the file's)
+        why = td.check_range_anchors(r, d.inflated_bytes)
+        assert why and "starts a record at stream offset %d" % X in why
+        for cut in (k - 1, k, k + 1, 1, nb - 1):                     # the same file without the trap: every cut joins
+            r, acc = ranges(d0, cut)
+            assert td.check_range_anchors(r, d0.inflated_bytes) is None, (cut, r)
+            assert np.array_equal(acc, want)
+    ctx.set_option("one_sync", 1)
+
+    # tcmi_split_step: the anchors ride in the reduce (two "ranks" one after the other on this GPU; the hook adds the first one's share)
+    ld = (L + 255) // 256 * 256
+    lib = _ffi.lib()
+
+    def split(dbam, cut):
+        share = {}
+        bufs = [torch.zeros(7 * ld + 2, dtype=torch.int32, device="cuda") for _ in range(2)]
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        def keep(user, ptr, nw, stream):
+            assert nw == 7 * ld + 2
+            torch.cuda.synchronize()
+            share["t"] = bufs[1].clone()
+            return 0
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        def add(user, ptr, nw, stream):
+            torch.cuda.synchronize()
+            bufs[0] += share["t"]
+            torch.cuda.synchronize()
+            return 0
+        out = []
+        for rank, (a, c, hook) in ((1, (cut, nb - cut, keep)), (0, (0, cut, add))):
+            h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            rc = lib.tcmi_split_step(ctx.handle, dbam.handle, a, c, L, ld, C.c_void_p(bufs[rank].data_ptr()), 30, 1, hook, None, int(rank == 0),
+                                     C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
+            msg = (lib.tcmi_last_error(ctx.handle) or b"").decode()
+            fl = None
+            if rc == 0:
+                if rank == 0:
+                    fl = np.empty(L, np.uint8)
+                    C.memmove(fl.ctypes.data, f_, L)
+                lib.tcmi_readset_free(ctx.handle, h)
+            out.append((rc, msg, fl))
+        return out
+
+    wf = c_oracle.call(want, 30, True)[2]
+    (rc1, _, _), (rc0, msg0, fl0) = split(d0, k)
+    assert rc1 == 0 and rc0 == 0 and np.array_equal(fl0, wf), (rc1, rc0, msg0)
+    (rc1, _, _), (rc0, msg0, fl0) = split(d, k)
+    assert rc1 == 0 and rc0 == _ffi.E_UNSUPPORTED and "do not join" in msg0, (rc0, msg0)
+    d.close()
+    d0.close()

@@ -95,6 +95,7 @@ _SIGS = {
     "tcmi_bamfile_to_device": (_int, [_vp, _vp]),
     "tcmi_readset_from_bamfile": (_int, [_vp, _vp, _P(_vp), _P(_i64)]),
     "tcmi_readset_from_bamfile_blocks": (_int, [_vp, _vp, _i64, _i64, _P(_vp), _P(_i64)]),
+    "tcmi_readset_range_anchors": (_int, [_vp, _P(_i64), _P(_i64)]),
     "tcmi_bamfile_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_i64), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
     "tcmi_split_step": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _int, _vp, _vp, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp)]),
@@ -148,8 +149,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tcmi_abi_version() != 3:
-            raise ImportError("libtcmi ABI version %d, expected 3" % handle.tcmi_abi_version())
+        if handle.tcmi_abi_version() != 4:
+            raise ImportError("libtcmi ABI version %d, expected 4" % handle.tcmi_abi_version())
         _lib = handle
     return _lib
 

@@ -570,7 +570,7 @@ int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, i
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_ws(ctx, L);
     if (rc) return rc;
-    const size_t n_words = (size_t)ld * TCMI_NCOL + 1;
+    const size_t n_words = (size_t)ld * TCMI_NCOL + 2;         // the matrix, the ranges' anchors, the ranks that failed
     TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream));
     tcmi_readset *rs = nullptr;
     int own = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr);
@@ -581,19 +581,39 @@ int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, i
         static const int32_t one = 1;
         (void)hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream);
         (void)hipMemcpyAsync(static_cast<int32_t *>(d_counts) + (n_words - 1), &one, 4, hipMemcpyHostToDevice, ctx->stream);
+    } else {
+        // the anchors: (where the first record behind the range starts) - (where the range's own first record starts), modulo 2^32.
+        // The range that starts with the file is vouched for by the header (first = 0); a range without a record start of its
+        // own adds nothing; the last range's chain ends with the stream (checked when it was decoded).
+        int64_t all = 0, inflated = 0;
+        (void)tcmi_bamfile_info(f, nullptr, &inflated, &all, nullptr, nullptr, nullptr);
+        const int64_t cnt = n_blocks < 0 ? all - first_block : std::min<int64_t>(n_blocks, all - first_block);
+        uint32_t word = 0;
+        if (cnt > 0 && rs->range_next >= 0 && (first_block == 0 || rs->range_first >= 0))
+            word = (uint32_t)((uint64_t)rs->range_next - (uint64_t)(first_block == 0 ? 0 : rs->range_first));
+        else if (cnt == all) word = (uint32_t)(uint64_t)inflated;     // (one range: the whole file, no anchors to join)
+        ctx->split_anchor = word;
+        (void)hipMemcpyAsync(static_cast<int32_t *>(d_counts) + (n_words - 2), &ctx->split_anchor, 4, hipMemcpyHostToDevice, ctx->stream);
     }
     const int rrc = reduce(user, d_counts, (int64_t)n_words, (void *)ctx->stream);
     if (rrc) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_HIP, "the reduce hook failed (%d)", rrc); }
-    int32_t failed = 0;
+    int32_t tail[2] = {0, 0};                                   // {anchors, failed}
     if (is_root) {
         rc = tcmi_launch_call(ctx, static_cast<int32_t *>(d_counts), L, ld, mincov, include_ambig, 0, ctx->h_rec, ctx->h_rec + ctx->ws_ld, ctx->h_rec + 2 * ctx->ws_ld, nullptr, nullptr);
-        if (!rc && hipMemcpyAsync(&failed, static_cast<int32_t *>(d_counts) + (n_words - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "copy failed");
+        if (!rc && hipMemcpyAsync(tail, static_cast<int32_t *>(d_counts) + (n_words - 2), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "copy failed");
     }
+    const int32_t &failed = tail[1];
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = tcmi_fail(ctx, TCMI_E_HIP, "hipStreamSynchronize failed");
     ctx->counts_clean = false;
     if (own) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, own, "%s", own_err.c_str()); }
     if (rc) { tcmi_readset_free(ctx, rs); return rc; }
     if (is_root && failed) { tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%d rank(s) could not decode their range of %s on the device", (int)failed, tcmi_bamfile_path(f)); }
+    int64_t inflated_all = 0;
+    (void)tcmi_bamfile_info(f, nullptr, &inflated_all, nullptr, nullptr, nullptr, nullptr);
+    if (is_root && (uint32_t)tail[0] != (uint32_t)(uint64_t)inflated_all) {
+        tcmi_readset_free(ctx, rs);
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the ranks' block ranges do not join into one chain of alignment records (a range started at an offset that only looked like a record): host reader", tcmi_bamfile_path(f));
+    }
     *rs_out = rs;
     if (plain) *plain = ctx->h_rec;
     if (alt) *alt = ctx->h_rec + ctx->ws_ld;

@@ -528,7 +528,7 @@ const char *tcmi_bamfile_text(const tcmi_bamfile *f) { return f ? f->text.c_str(
 
 // ---- device decode: H2D of the compressed file, bgzf_symbols + bgzf_copy + bgzf_crc32 (all in the context's arena) -----------------
 namespace {
-struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; };
+struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; int64_t range_first = -1, range_next = -1; };
 
 // a decode in flight: the range as a file of its own, and where its pieces lie in the arena
 struct Decoded {
@@ -686,7 +686,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *Dout, 
         for (size_t b = 0; b < nb_own; ++b) {
             const BlockDesc &d = f->blocks[b];
             if (d.entry == -1) continue;                        // header only
-            if (open && first[b] != 0xFFFFFFFFu) { expect = first[b]; open = false; }
+            if (open && first[b] != 0xFFFFFFFFu) { expect = first[b]; open = false; if (d.entry < 0) Dout->range_first = (int64_t)d.uout + first[b]; }
             if (open) continue;
             if (stat[b] == ST_BAD_RECORD)
                 return tcmi_fail(ctx, TCMI_E_FORMAT, "%s: alignment record with an impossible block_size in BGZF block %zu", f->path.c_str(), b);
@@ -702,6 +702,7 @@ int decode_on_device(tcmi_ctx *ctx, const tcmi_bamfile *whole, DeviceBam *Dout, 
                                  f->path.c_str(), b, first[b], (long long)expect);
             expect = over[b];
         }
+        if (!open && nb_own > 0) Dout->range_next = (int64_t)(f->blocks[nb_own - 1].uout + f->blocks[nb_own - 1].ulen) + expect;
         if (nb_own < nb) {                                      // the range's last record must end in the block taken along
             if (expect > (int64_t)f->blocks[nb_own].ulen)
                 return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: a record longer than a BGZF block at the end of a block range: host reader", f->path.c_str());
@@ -778,6 +779,19 @@ int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int6
 }
 } // namespace
 
+// a range of nothing but header blocks at the start of the file: the first record starts where the header ends (the host parsed it)
+static int64_t header_only_next(const tcmi_bamfile *f, int64_t first_block, int64_t own)
+{
+    if (first_block != 0) return -1;
+    const int64_t all = (int64_t)f->blocks.size();
+    for (int64_t b = 0; b < all; ++b) {
+        if (f->blocks[(size_t)b].entry == -1) continue;            // header only
+        if (f->blocks[(size_t)b].entry >= 0 && b >= std::min(own, all)) return (int64_t)f->blocks[(size_t)b].uout + f->blocks[(size_t)b].entry;
+        return -1;
+    }
+    return -1;
+}
+
 static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out, bool try_fused)
 {
     if (!ctx || !f || !out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
@@ -800,6 +814,12 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
             ++ctx->stat_one_sync_taken;
             if (rs->n_reads > 64) ctx->rec_bytes_seen = (uint32_t)std::min<uint64_t>(J.stream_len / (uint64_t)rs->n_reads, 1u << 24);
             rs->packed_on_device = 2;           // decoded AND packed on the device
+            if (D.ranged && first_block < (int64_t)f->blocks.size()) {      // (the anchors: from the range's stream to the file's)
+                const int64_t at = (int64_t)f->blocks[(size_t)first_block].uout;
+                if (rs->range_first >= 0) rs->range_first += at;
+                if (rs->range_next >= 0) rs->range_next += at;
+                else rs->range_next = header_only_next(f, first_block, (int64_t)D.nb_own);
+            } else rs->range_first = rs->range_next = -1;
             if (n_reads_out) *n_reads_out = rs->n_reads;
             *out = rs;
             if (timing) std::fprintf(stderr, "[tcmi bamfile] one-sync path: decode + pack %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -827,6 +847,11 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
     rc = D.n ? tcmi_pack_on_device(ctx, &s, rs, &why) : TCMI_OK;
     if (rc == TCMI_OK) {
         rs->packed_on_device = 2;               // decoded AND packed on the device
+        if ((first_block != 0 || (n_blocks >= 0 && first_block + n_blocks < (int64_t)f->blocks.size())) && first_block >= 0 && first_block < (int64_t)f->blocks.size()) {
+            const int64_t at = (int64_t)f->blocks[(size_t)first_block].uout;
+            rs->range_first = D.range_first >= 0 ? D.range_first + at : -1;
+            rs->range_next = D.range_next >= 0 ? D.range_next + at : header_only_next(f, first_block, n_blocks < 0 ? (int64_t)f->blocks.size() - first_block : n_blocks);
+        }
         *out = rs;
         if (timing) {
             const auto t2 = std::chrono::steady_clock::now();
@@ -847,6 +872,14 @@ extern "C" {
 int tcmi_readset_from_bamfile_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, tcmi_readset **out, int64_t *n_reads_out)
 {
     return readset_from_blocks(ctx, f, first_block, n_blocks, out, n_reads_out, true);
+}
+
+int tcmi_readset_range_anchors(const tcmi_readset *rs, int64_t *first, int64_t *next)
+{
+    if (!rs) return TCMI_E_ARG;
+    if (first) *first = rs->range_first;
+    if (next) *next = rs->range_next;
+    return TCMI_OK;
 }
 
 // BAM file -> call records with ONE wait of the host (TrueConsense.py:225-237 per file: BuildIndex + the position-local part of

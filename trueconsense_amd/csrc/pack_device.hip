@@ -155,6 +155,9 @@ struct PackTotals {                 // device scalars, copied back to the host
     uint32_t max_len;               // longest reference span of a kept read
     uint32_t n_gen;                 // reads left to the stream-walking tally kernel (longer than TCMI_D_MAXLEN positions)
     unsigned long long n_rec;       // pk_place: alignment records of the decoded range
+    // pk_place, a block range: where its first record starts / where the first record behind it starts, as offsets into the range's
+    // stream + 1 (0: no record starts in the range / the chain was never fixed) — tcmi_readset_range_anchors
+    unsigned long long range_first, range_next;
 };
 
 // words a read takes in the plane stream: its pairs, the zero pair behind them, and — for an even number of pairs — one more zero pair,
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(PB) void pk_place(FusedArgs a)
                     const long long expect = d.entry >= 0 ? (long long)d.entry : state_in;
                     if (st == ST_BAD_RECORD) ok = 0;
                     if (!open_in || d.entry >= 0) { if ((long long)first != expect) ok = 0; }
+                    else a.tot->range_first = d.uout + first + 1ull;      // (the range starts here, unvouched for: the range in front must end here)
                     if (over < 0) ok = 0;
                     state_out = over; open_out = false;
                 } else if (!open_in || d.entry >= 0) {
@@ -929,6 +933,7 @@ __global__ __launch_bounds__(PB) void pk_place(FusedArgs a)
                 if (!open_out) {
                     if (a.n_own < a.n_blocks) { if (state_out > (long long)a.blocks[a.n_own].ulen) ok = 0; }
                     else if (state_out > 0) ok = 0;
+                    if (mine) a.tot->range_next = (unsigned long long)((long long)(d.uout + d.ulen) + state_out) + 1ull;
                 }
             }
             if (!ok) atomicOr(&a.tot->flags, PKF_CHAIN);
@@ -1530,6 +1535,8 @@ int tcmi_pack_fused_finish(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs,
     rs->n_reads = (int64_t)tot.n_rec;
     rs->n_piled = nf + (int64_t)tot.n_gen; rs->f_reads = nf; rs->alg_bytes = (int64_t)alg; rs->max_end = mend; rs->max_len = (int32_t)mlen;
     rs->s_reads = (int64_t)tot.n_gen;
+    rs->range_first = tot.range_first ? (int64_t)(tot.range_first - 1ull) : -1;
+    rs->range_next = tot.range_next ? (int64_t)(tot.range_next - 1ull) : -1;
     rs->f_chunks = nf ? tot.n_chunks : 0; rs->f_words = nf ? (int64_t)tot.n_words + 4 : 0; rs->f_events = tot.n_events;
     rs->dev_bytes = nf * 4 + ((int64_t)tot.n_words + 4) * 4 + (int64_t)tot.n_chunks * (int64_t)sizeof(tcmi_fast_chunk) + (int64_t)tot.n_runs * 4 +
                     (int64_t)tot.n_events * 4;

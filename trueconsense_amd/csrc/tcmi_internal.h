@@ -99,6 +99,11 @@ struct tcmi_readset {
     const int32_t *d_cpos = nullptr;
     const uint32_t *d_gen_idx = nullptr;   // records of reads too long for the packed set (s_reads of them): tally_stream_kernel walks them in the stream
     int64_t s_reads = 0;
+    // a read set of a block RANGE of a file (tcmi_readset_from_bamfile_blocks): where its first record starts when the range began
+    // in the middle of the file (nothing in front of it vouches for that start), and where the first record behind the range starts —
+    // offsets into the WHOLE file's inflated stream, -1: none.  The range in front must end where this one starts
+    // (tcmi_readset_range_anchors; tcmi_split_step sums the differences along with the counts).
+    int64_t range_first = -1, range_next = -1;
     uint64_t arena_epoch = 0;
     // the one-sync file path (bam_device.hip, tcmi_bamfile_step): the packer's totals have not been read back yet — f_chunks and
     // f_events hold the CAPACITIES, the tally kernel takes the real counts from here ({n_chunks, n_events} in the context's arena)
@@ -150,6 +155,7 @@ struct tcmi_ctx {
     size_t h_pin_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
+    uint32_t split_anchor = 0;       // tcmi_split_step: this rank's anchor word on its way to the device (the copy is asynchronous)
     uint32_t rec_bytes_seen = 0;     // mean record size of the last file this context decoded (sizes the next file's arrays when the file's own first blocks say nothing)
     int mid_wait = 1;                // the one-sync path waits once more, behind the decode kernels (bam_device.hip: fast_enqueue)
     int one_sync = 1;                // device-decoded files take the one-sync path (pk_index + pk_place + pk_pack) first; 0: the several-kernel path only

@@ -118,6 +118,28 @@ def tally_split_bam(reads, L, rank, world, device=0, group=None, tally_fn=None):
     return counts
 
 
+def check_range_anchors(ranges, inflated_bytes):
+    """ranges: per rank, in rank order, (first_block, n_blocks, first, next) — engine.ReadSet.range_anchors of its block range
+    (tcmi_readset_range_anchors).  A range in the middle of the file starts at the first offset its first block finds PLAUSIBLE for an
+    alignment record; that offset is a record start for sure only if the range in front ends there (by induction from the header,
+    whose end the first range starts at).  -> None, or what does not join (a message): then no rank's result is to be trusted and
+    the file takes the host reader."""
+    expect = None                                                   # where the next record must start, once a range has fixed it
+    for r, (first_block, n_blocks, first, nxt) in enumerate(ranges):
+        if n_blocks <= 0:
+            continue
+        if first_block != 0 and first >= 0:
+            if expect is not None and first != expect:
+                return "rank %d's block range starts a record at stream offset %d, the range in front ends its last record at %d" % (r, first, expect)
+            if expect is None and r > 0 and any(n > 0 for _, n, _, _ in ranges[:r]):
+                return "rank %d's block range starts a record at stream offset %d, but no range in front says where its last record ends" % (r, first)
+        if nxt >= 0:
+            expect = nxt
+    if expect is not None and expect != inflated_bytes:
+        return "the last alignment record ends at stream offset %d, the file's stream at %d" % (expect, inflated_bytes)
+    return None
+
+
 def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to_root=False):
     """BASELINE configs[4] from ONE FILE: every rank opens the same BAM, decodes on its GPU only the alignment records that start
     in its contiguous range of BGZF blocks (engine.Context.upload_bamfile(blocks=...): inflate, record index, pack), tallies
@@ -148,8 +170,12 @@ def tally_split_bamfile(path, L, rank, world, device=0, group=None, ctx=None, to
             err = (e.code, str(e))
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             allv = [None] * dist.get_world_size(group)
-            dist.all_gather_object(allv, err, group=group)
-            err = next((v for v in allv if v), None)
+            dist.all_gather_object(allv, (err, (first, count) + (rs.range_anchors if rs is not None else (-1, -1))), group=group)
+            err = next((v[0] for v in allv if v[0]), None)
+            if not err:                                             # ... and the ranges must join into ONE chain of records
+                why = check_range_anchors([v[1] for v in allv], d.inflated_bytes)
+                if why:
+                    err = (_ffi_E_UNSUPPORTED, "%s: %s: host reader" % (path, why))
         if err:
             if rs is not None:
                 rs.free()
@@ -274,7 +300,7 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
         ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
         d = DeviceBam(path)
         first, count = block_range(d.n_blocks, rank, world)
-        t = torch.zeros(7 * ld + 1, dtype=torch.int32, device="cuda")
+        t = torch.zeros(7 * ld + 2, dtype=torch.int32, device="cuda")
 
         @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
         def hook(user, ptr, n, stream):                             # (the tensor IS the buffer at `ptr`; torch's collective runs on the context's stream)

@@ -26,6 +26,11 @@ class ReadSet:
         o = C.c_int32(0)
         check(lib().tcmi_readset_origin(handle, C.byref(o)))
         self.packed_on_device = bool(o.value)       # pack_device.hip built it (else the host packer)
+        a, b = C.c_int64(-1), C.c_int64(-1)
+        check(lib().tcmi_readset_range_anchors(handle, C.byref(a), C.byref(b)))
+        # a block range of a file: where its first record starts (a range in the middle of the file; nothing in front vouches for it)
+        # and where the first record behind it starts, offsets into the file's inflated stream (-1: none) — distributed.check_range_anchors
+        self.range_anchors = (a.value, b.value)
 
     def free(self):
         if self.handle:

@@ -112,11 +112,14 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    anything else takes the host packer); 0 = always pack on the host
  *   "verify_crc"     1 = the device decoder checks every BGZF block's CRC-32 (bgzf_crc32; default, as htslib does);
  *                    0 = ISIZE, stream termination and the record chain only
- *   "one_sync"       1 = a file decoded on the device takes the one-sync path first (one kernel for record index, record chain,
- *                    classification, prefix sums and planes; capacities instead of counts read back; default), 0 = only the
+ *   "one_sync"       1 = a file decoded on the device takes the one-sync path first (pk_index + pk_place + pk_pack: record index,
+ *                    record chain, classification, places and planes without a host round trip; capacities instead of counts read back; default), 0 = only the
  *                    several-kernel path with its three waits (the path that words every refusal; the tests cross-check the two)
  *   "mid_wait"       1 = the one-sync path waits a second time, behind the decode kernels (default: two waits per file; measured
  *                    equal or faster than 0 with eight contexts), 0 = one wait per file
+ *   "decode_token_mb" the device decoder's token scratch, MiB (default 4096): a file whose BGZF blocks need more (tokens take 3 - 10
+ *                    times the inflated bytes while a block is decoded) is decoded in batches of blocks that share the scratch —
+ *                    the inflated stream stays whole
  *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
  *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)
@@ -129,7 +132,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    the others go out unmeasured (default 1) */
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 /* counters of a context: "one_sync_taken" / "one_sync_declined" — files (or block ranges) the one-sync path delivered / handed to the
- * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag) */
+ * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag);
+ * "decode_batched" — files (or ranges) whose blocks the device decoder took in batches ("decode_token_mb") */
 int  tcmi_ctx_stat(tcmi_ctx *ctx, const char *key, int64_t *value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

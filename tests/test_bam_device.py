@@ -542,3 +542,51 @@ def test_windowed_symbol_decoder_at_small_windows(window, tmp_path):
     env = dict(os.environ, TCMI_SYM_WINDOW=str(window), PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], cwd=root, env=env, capture_output=True, text=True, timeout=550)
     assert r.returncode == 0 and "windowed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_files_beyond_the_token_scratch_are_decoded_in_batches_of_blocks(tmp_path):
+    """"decode_token_mb": the decoder's token scratch.  A block in flight needs 3 - 10 times its inflated bytes of it; a file that
+    needs more than the scratch holds goes through bgzf_symbols + bgzf_copy a batch of blocks at a time (a large real file: tens of
+    GB otherwise) — same stream, same records, same counts, in both packer paths, whole and as block ranges."""
+    c = engine.Context(0)
+    ref, orfs = sy.make_reference()
+    L = len(ref)
+    rng = np.random.default_rng(41)
+    files = []
+    n = 60_000
+    r = sy.make_reads(ref, n, seed=42)
+    p = str(tmp_path / "plain.bam")
+    bamwriter.write_bam_fast(p, r["pos"], r["flag"], r["seq"].reshape(n, -1), 150, "MN908947.3", L, level=6)            # pairs of blocks per workgroup
+    files.append(p)
+    q = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=(lambda w: w / w.sum())(np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004))
+    names = rng.integers(48, 58, (n, 27)).astype(np.uint8)
+    p = str(tmp_path / "real.bam")
+    bamwriter.write_bam_fast(p, r["pos"], r["flag"], r["seq"].reshape(n, -1), 150, "MN908947.3", L, level=6, qual=q, names=names)   # windowed decoder, tokens moved
+    files.append(p)
+    indel = sy.make_reads(ref, 20_000, seed=43, indel_sites=sy.default_indel_sites(orfs))
+    p = str(tmp_path / "brim.bam")
+    bamwriter.write_bam(p, indel, "MN908947.3", L, level=6, split_records=True)                                          # records across blocks — and across batches
+    files.append(p)
+    try:
+        for path in files:
+            for mb in (1, 3):
+                c.set_option("decode_token_mb", mb)
+                before = c.stat("decode_batched")
+                check_decode(c, path).close()
+                assert c.stat("decode_batched") > before, "the file fits %d MiB of tokens: no batches" % mb
+                for one_sync in (1, 0):
+                    c.set_option("one_sync", one_sync)
+                    check_counts(c, path, L)
+                    d = engine.DeviceBam(path)
+                    nb = d.n_blocks
+                    acc = None
+                    for a, k in ((0, nb // 2), (nb // 2, nb - nb // 2)):
+                        rs = c.upload_bamfile(d, blocks=(a, k))
+                        got = c.step(rs, L, 30, True)[3].astype(np.int64)
+                        acc = got if acc is None else acc + got
+                        rs.free()
+                    d.close()
+                    assert np.array_equal(acc, c_oracle.tally(c_oracle.read_bam(path), L))
+                c.set_option("one_sync", 1)
+    finally:
+        c.close()

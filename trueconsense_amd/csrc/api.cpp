@@ -176,6 +176,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "verify_crc")) c->verify_crc = value != 0;
     else if (!std::strcmp(key, "one_sync")) c->one_sync = value != 0;
     else if (!std::strcmp(key, "mid_wait")) c->mid_wait = value != 0;
+    else if (!std::strcmp(key, "decode_token_mb")) c->decode_token_mb = value > 0 ? value : 4096;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
@@ -187,6 +188,7 @@ int tcmi_ctx_stat(tcmi_ctx *c, const char *key, int64_t *value)
     if (!c || !key || !value) return tcmi_fail(c, TCMI_E_ARG, "null argument");
     if (!std::strcmp(key, "one_sync_taken")) *value = c->stat_one_sync_taken;
     else if (!std::strcmp(key, "one_sync_declined")) *value = c->stat_one_sync_declined;
+    else if (!std::strcmp(key, "decode_batched")) *value = c->stat_decode_batched;
     else if (!std::strcmp(key, "one_sync_last_decline_flags")) *value = c->stat_last_decline;
     else return tcmi_fail(c, TCMI_E_ARG, "unknown statistic %s", key);
     return TCMI_OK;

@@ -590,9 +590,26 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
     D.max_rec = f->inflated / 36 + 16;
     D.guess_rec = std::min(D.max_rec, f->inflated / 64 + 1024);
     const bool resident = f->d_bytes != nullptr && f->d_device == ctx->device;       // (the compressed bytes are in HBM already)
+    // The tokens of a block in flight take 3 - 10 times its inflated bytes (a token per literal, as many again of scratch for the
+    // speculating lanes): a file whose blocks need more than the context's token scratch ("decode_token_mb") is decoded in batches
+    // of blocks that share it, one pair of launches per batch — the inflated stream, the record slots and the verdicts stay whole.
+    const uint64_t tok_cap_words = (uint64_t)std::max<int64_t>(ctx->decode_token_mb, 1) << 18;
+    std::vector<size_t> batch_at;                               // first block of every batch (+ the end)
+    uint64_t tok_words = f->tok_total;
+    if (f->tok_total > tok_cap_words) {
+        tok_words = 0;
+        uint64_t at = f->blocks[0].tok;
+        batch_at.push_back(0);
+        for (size_t b = 0; b < nb; ++b) {
+            const uint64_t e = b + 1 < nb ? f->blocks[b + 1].tok : f->tok_total;
+            if (e - at > tok_cap_words && b > batch_at.back()) { tok_words = std::max(tok_words, f->blocks[b].tok - at); batch_at.push_back(b); at = f->blocks[b].tok; }
+        }
+        tok_words = std::max(tok_words, f->tok_total - at);
+        batch_at.push_back(nb);
+    }
     const size_t b_file = resident ? 256 : al(f->cap), b_desc = al(nb * sizeof(BlockDesc)), b_out = al(f->inflated + 128),
                  b_slot = al(nb * (size_t)MAX_REC_PER_BLOCK * 4), b_small = al(nb * 4) * 5 + al(nb * 8) + al(nb * 512) + 256,
-                 b_tok = al(f->tok_total * 4 + 256);
+                 b_tok = al(tok_words * 4 + 256);
     D.b_rest = rest_bytes(D.guess_rec, nb);
     if (!tcmi_arena_reserve_take(ctx, b_file + b_desc + b_out + b_slot + b_small + b_tok + D.b_rest + 16 * 256, 0)) return TCMI_E_NOMEM;
     uint8_t *d_file = (uint8_t *)tcmi_arena_take(ctx, b_file);
@@ -623,8 +640,17 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
         g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
         g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;
-        const int rc = tcmi_bgzf_decode_launch(ctx, g);
-        if (rc) return rc;
+        if (batch_at.empty()) {
+            const int rc = tcmi_bgzf_decode_launch(ctx, g);
+            if (rc) return rc;
+        } else {
+            for (size_t k = 0; k + 1 < batch_at.size(); ++k) {  // (one after the other on the stream: the next batch's tokens overwrite this one's)
+                g.first_block = batch_at[k]; g.count = batch_at[k + 1] - batch_at[k]; g.tok_base = f->blocks[batch_at[k]].tok;
+                const int rc = tcmi_bgzf_decode_launch(ctx, g);
+                if (rc) return rc;
+            }
+            ++ctx->stat_decode_batched;
+        }
     }
     if (ctx->verify_crc) {
         static const CrcArgs proto = [] { CrcArgs c = {}; crc_zero_operators(c.zeros, c.zeros_row); return c; }();

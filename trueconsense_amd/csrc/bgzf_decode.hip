@@ -112,7 +112,8 @@ struct SymArgs {
     uint32_t *n_tok;            // [n_blocks]: tokens | 1 << 31 when they are in pieces
     uint32_t *seg;              // [n_blocks][128]: per piece its first token (offset from the block's tokens), per piece its tokens
     uint32_t *status;           // [n_blocks]
-    int32_t n_blocks;
+    int32_t n_blocks;           // (the launch's blocks end here)
+    int32_t first_block;        // ... and start here: workgroup 0's first block
     uint32_t pay_dwords;        // dwords of dynamic LDS per block behind SymLds: the largest block's payload + slack
     uint32_t win_dwords;        // bgzf_symbols<1, true>: dwords of payload staged at a time (a window that moves along the block)
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
     extern __shared__ __attribute__((aligned(8))) uint32_t pay_all[];   // per block: its compressed payload, from the dword that holds its first byte on
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int blk0 = blockIdx.x * SYM_BLOCKS;
+    const int blk0 = a.first_block + (int)blockIdx.x * SYM_BLOCKS;
     const int blk = blk0 + wave;                    // this wavefront's block (header, tables)
     const bool have = blk < a.n_blocks;
     BlkTabs &T = L.b[wave];
@@ -976,7 +977,8 @@ struct CopyArgs {
     int32_t *overshoot;         // bytes by which the block's last record runs into the next blocks (0x7FFFFFFF: its size field does)
     uint32_t *first_rec;        // offset of the first record start found in the block (0xFFFFFFFF: none)
     uint32_t *status;           // in: bgzf_symbols' verdict; out: the block's
-    int32_t n_blocks;
+    int32_t n_blocks;           // (the launch's blocks end here)
+    int32_t first_block;        // ... and start here
     uint32_t n_ref;             // reference sequences of the BAM header
     uint64_t *stamps;           // diagnostic, as SymArgs::stamps
     uint32_t team_bytes;        // a batch of 64 tokens with at most this many bytes of output copies its matches in teams
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; } s_lds;     // (the ring first: ring index = LDS address)
     uint8_t *const s_win = s_lds.win;
     const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
+    const int blk = a.first_block + (int)blockIdx.x;
     if (blk >= a.n_blocks) return;
     const BlockDesc d = a.blocks[blk];
     const uint32_t ulen = d.ulen;
@@ -1619,15 +1621,17 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
 
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
 {
-    const size_t nb = g.n_blocks;
+    const size_t nb_all = g.n_blocks;
+    const size_t b_first = std::min(g.first_block, nb_all), nb = std::min(g.count, nb_all - b_first), b_end = b_first + nb;       // this launch's blocks
+    if (nb == 0) return TCMI_OK;
     static const char *stamp_path = std::getenv("TCMI_INFLATE_STAMPS");      // diagnostic: phase clocks of both kernels, per block
     uint64_t *d_stamps = nullptr;
-    if (stamp_path) TCMI_HIP(ctx, hipMalloc((void **)&d_stamps, nb * 16 * 8 * 2));
+    if (stamp_path && nb == nb_all) TCMI_HIP(ctx, hipMalloc((void **)&d_stamps, nb * 16 * 8 * 2));       // (whole-file launches only)
     SymArgs sa;
     sa.stamps = d_stamps;
     sa.file32 = reinterpret_cast<const uint32_t *>(g.d_file);
     sa.blocks = static_cast<const BlockDesc *>(g.d_desc);
-    sa.tokens = g.d_tok; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)nb;
+    sa.tokens = g.d_tok - g.tok_base; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)b_end; sa.first_block = (int32_t)b_first;
     sa.pay_dwords = g.pay_dwords;
     sa.win_dwords = 0;
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
@@ -1670,8 +1674,8 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
     CopyArgs ca;
-    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = g.d_tok; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
-    ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)nb; ca.n_ref = g.n_ref;
+    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = sa.tokens; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
+    ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)b_end; ca.first_block = (int32_t)b_first; ca.n_ref = g.n_ref;
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     static const int team_env = std::getenv("TCMI_TEAM_BYTES") ? std::atoi(std::getenv("TCMI_TEAM_BYTES")) : -1;      // (A/B measurements)
     ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;

@@ -194,7 +194,9 @@ struct tcmi_bgzf_decode_args {
     int32_t *d_over;                // [n_blocks] bytes by which a block's last record runs into the next blocks
     uint32_t *d_first;              // [n_blocks] offset of the first record start the block found in itself (0xFFFFFFFF: none)
     uint32_t *d_stat;               // [n_blocks] ST_*
-    size_t n_blocks;
+    size_t n_blocks;                // of the file (or range): the arrays' length
+    size_t first_block = 0, count = ~(size_t)0;    // the blocks this launch decodes ([first_block, first_block + count), clipped): a batch
+    uint64_t tok_base = 0;          // d_tok holds the tokens from BlockDesc::tok = tok_base on (the batch's first block's)
     uint32_t pay_dwords;            // the largest block's payload in dwords + slack
     uint32_t n_ref;                 // reference sequences of the BAM header (a record's refID must be one of them)
     int short_tokens;               // the file compresses less than ~12 : 1 (many short matches): bgzf_copy's variant with teams; 2: less than ~4 : 1: ... and short far matches finished in the set-up

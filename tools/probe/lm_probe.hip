@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
 template <int V>
 __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps)
 {
@@ -116,6 +117,124 @@ __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps)
             : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t23] "=&v"(t23)
             : [mm] "s"(mm), [vA2] "v"(vA2), [vB2] "v"(vB2), [vX8] "v"(lane8_hi), [vlane8] "v"(lane8)
             : "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
+        // ---- round 4's byte rounds (a byte a lane, matches of up to 64 bytes): as shipped (4), two matches in flight (5), without LDS (6)
+        const unsigned len1 = 8u + (unsigned)(lane * 37 % 56);          // 8 .. 63
+        const unsigned vA1 = ((len1 - 1u) << 16) | ((dm - 7u) & 0xFFFFu);
+        const unsigned lane_sh16 = (unsigned)lane << 16, lane_p7 = (unsigned)lane + 7u;
+        unsigned u0, u1, u2;
+        if (V == 4)
+        asm volatile(
+            "s_mov_b64 s[92:93], exec\n"
+            "s_mov_b64 s[82:83], %[mm]\n"
+            "LMb%=:\n"
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "s_cmp_lt_u32 %[sa], 0x400000\n"
+            "s_cbranch_scc0 LXb%=\n"
+            "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n"
+            "v_add_u32 %[t0], %[sb], %[vlane7]\n"
+            "v_add_u32_sdwa %[t1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "ds_read_u8 %[t2], %[t0]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[t1], %[t2]\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            "s_cmp_lg_u64 s[82:83], 0\n"
+            "s_cbranch_scc1 LMb%=\n"
+            "LXb%=:\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            : [mm] "s"(mm), [vA2] "v"(vA1), [vB2] "v"(vB2), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7)
+            : "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
+        if (V == 6)
+        asm volatile(
+            "s_mov_b64 s[92:93], exec\n"
+            "s_mov_b64 s[82:83], %[mm]\n"
+            "LMb%=:\n"
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "s_cmp_lt_u32 %[sa], 0x400000\n"
+            "s_cbranch_scc0 LXb%=\n"
+            "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n"
+            "v_add_u32 %[t0], %[sb], %[vlane7]\n"
+            "v_add_u32_sdwa %[t1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            "s_cmp_lg_u64 s[82:83], 0\n"
+            "s_cbranch_scc1 LMb%=\n"
+            "LXb%=:\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            : [mm] "s"(mm), [vA2] "v"(vA1), [vB2] "v"(vB2), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7)
+            : "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
+        if (V == 5)                                             // two matches in flight: the next one's read goes out before this one's write
+        asm volatile(
+            "s_mov_b64 s[92:93], exec\n"
+            "s_mov_b64 s[82:83], %[mm]\n"
+            // prologue: the first match -> set A, its read under way
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n"
+            "s_mov_b64 s[96:97], exec\n"
+            "v_add_u32 %[t0], %[sb], %[vlane7]\n"
+            "v_add_u32_sdwa %[t1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "ds_read_u8 %[t2], %[t0]\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            "LPa%=:\n"                                           // A in flight: fetch B
+            "s_cmp_eq_u64 s[82:83], 0\n"
+            "s_cbranch_scc1 LDa%=\n"
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "s_cmp_lt_u32 %[sa], 0x400000\n"
+            "s_cbranch_scc0 LDa%=\n"
+            "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n"
+            "s_mov_b64 s[94:95], exec\n"
+            "v_add_u32 %[u0], %[sb], %[vlane7]\n"
+            "v_add_u32_sdwa %[u1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "ds_read_u8 %[u2], %[u0]\n"
+            "s_mov_b64 exec, s[96:97]\n"
+            "s_waitcnt lgkmcnt(1)\n"
+            "ds_write_b8 %[t1], %[t2]\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            // B in flight: fetch A
+            "s_cmp_eq_u64 s[82:83], 0\n"
+            "s_cbranch_scc1 LDb%=\n"
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "s_cmp_lt_u32 %[sa], 0x400000\n"
+            "s_cbranch_scc0 LDb%=\n"
+            "v_cmpx_ge_u32 vcc, %[sa], %[vX1]\n"
+            "s_mov_b64 s[96:97], exec\n"
+            "v_add_u32 %[t0], %[sb], %[vlane7]\n"
+            "v_add_u32_sdwa %[t1], %[sa], %[vlane7] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "ds_read_u8 %[t2], %[t0]\n"
+            "s_mov_b64 exec, s[94:95]\n"
+            "s_waitcnt lgkmcnt(1)\n"
+            "ds_write_b8 %[u1], %[u2]\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            "s_branch LPa%=\n"
+            "LDa%=:\n"                                           // drain A
+            "s_mov_b64 exec, s[96:97]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[t1], %[t2]\n"
+            "s_branch LXc%=\n"
+            "LDb%=:\n"                                           // drain B
+            "s_mov_b64 exec, s[94:95]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[u1], %[u2]\n"
+            "LXc%=:\n"
+            "s_mov_b64 exec, s[92:93]\n"
+            : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2)
+            : [mm] "s"(mm), [vA2] "v"(vA1), [vB2] "v"(vB2), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7)
+            : "s82", "s83", "s84", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc", "memory");
     }
     const unsigned long long t_b = __builtin_amdgcn_s_memtime();
     if (lane == 0) out[blockIdx.x] = t_b - t_a;
@@ -141,6 +260,9 @@ int main()
         run<1>("without the LDS read / write", blocks, reps);
         run<2>("LDS only (operands fixed)", blocks, reps);
         run<3>("aligned 4-byte LDS ops", blocks, reps);
+        run<4>("round 4: byte rounds as shipped", blocks, reps);
+        run<5>("round 4: two matches in flight", blocks, reps);
+        run<6>("round 4: byte rounds without LDS", blocks, reps);
     }
     return 0;
 }

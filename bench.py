@@ -697,8 +697,13 @@ def oracle_chain_many(jobs, workers):
     import multiprocessing as mp
     if len(jobs) <= 1 or workers <= 1:
         return [_oracle_chain_worker(j) for j in jobs]
-    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-        return pool.map(_oracle_chain_worker, jobs)
+    # (the workers are CPU only: under rocprofv3 they must not inherit the profiler's preloaded library — a counter pass has hung on their exit)
+    hidden = {k: os.environ.pop(k) for k in list(os.environ) if k == "LD_PRELOAD" or k.startswith(("ROCP_", "ROCPROF", "HSA_TOOLS_"))}
+    try:
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            return pool.map(_oracle_chain_worker, jobs)
+    finally:
+        os.environ.update(hidden)
 
 
 def check_all_fastas(a, np, paths, fastas, L, mincov, orfs, workers=8, timing=None):

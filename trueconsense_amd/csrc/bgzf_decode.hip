@@ -84,6 +84,9 @@ struct HdrScratch {                                 // per block, while its head
 #ifndef TCMI_SYM_ASM
 #define TCMI_SYM_ASM 1
 #endif
+#ifndef TCMI_SYM_MOVE
+#define TCMI_SYM_MOVE 16                            // bgzf_symbols: tokens a lane has in flight when a window's tokens are moved to their places
+#endif
 #ifndef TCMI_SYM_WAVES
 #define TCMI_SYM_WAVES 5                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (5: 96 VGPRs; with 4 — 128 —
                                                     // a BAM's 2 094 workgroups fill every CU's register file: 182 us instead of 173)
@@ -933,12 +936,13 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 uint32_t *const dst = btok + ntok0 + (incl - cnt);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the scratch stores are this lane's own)
                 if (!block_redo) {
-                    for (uint32_t i = 0; i < cnt; i += 8) {         // (eight loads in flight: the loop is all latency)
-                        uint32_t t[8];
+                    constexpr int MV = TCMI_SYM_MOVE;
+                    for (uint32_t i = 0; i < cnt; i += MV) {        // (MV loads in flight: the loop is all latency)
+                        uint32_t t[MV];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) t[k] = i + k < cnt ? scratch[(size_t)(before + i + k) * SYM_LANES] : 0u;
+                        for (int k = 0; k < MV; ++k) t[k] = i + k < cnt ? scratch[(size_t)(before + i + k) * SYM_LANES] : 0u;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) if (i + k < cnt) dst[i + k] = t[k];
+                        for (int k = 0; k < MV; ++k) if (i + k < cnt) dst[i + k] = t[k];
                     }
                 } else {
                     // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------

@@ -22,7 +22,10 @@
 // the block's payload start (a stored deflate block, in pieces of <= 8 191 bytes).  bgzf_copy takes 64 tokens at a time: an
 // inclusive scan of the lengths gives every token its output position, the literals of a stretch go to the ring at once, the
 // matches one after the other (TCMI_LM_ASM: a byte a lane up to 64 bytes, an aligned dword a lane beyond — the LDS takes unaligned
-// words at about a cycle a LANE —; teams of eight lanes for up to eight independent short matches in files of short tokens).
+// words at about a cycle a LANE —; teams of eight lanes for up to eight independent short matches in files of short tokens; in
+// files under 4 : 1 the far matches of up to 8 bytes are finished in the batch's set-up, straight from the flushed stream).
+// A launch takes a range of the file's blocks and the token array's base: a file whose tokens do not fit the context's scratch is
+// decoded a batch of blocks at a time (bam_device.hip: decode_enqueue).
 //
 // Bit / byte work, bound by instruction issue and the LDS pipe, not by HBM and not a contraction: no MFMA.
 #include <atomic>

@@ -26,6 +26,7 @@ rs = ctx.upload_bamfile(d)
 got = ctx.step(rs, L, 30, True)[3]
 print("reads %d piled %d decode + pack + tally %.1f ms (first call: allocations included)" % (rs.n_reads, rs.n_piled, 1e3 * (time.time() - t1)))
 print("counts equal the oracle's:", bool(np.array_equal(got, want)), "coverage sum", int(got[:, 0].sum()), "expected", 150 * n * m)
+print("decoded in batches of blocks (token scratch %d MiB):" % 4096, ctx.stat("decode_batched") > 0, "| one-sync path taken:", ctx.stat("one_sync_taken"))
 rs.free()
 ctx.profile(True)
 t1 = time.time()
@@ -43,5 +44,12 @@ for first, count in ((0, half), (half, d.n_blocks - half)):
     rs = ctx.upload_bamfile(d, blocks=(first, count))
     acc += ctx.step(rs, L, 30, True)[3]
     rs.free()
+anchors = []
+for first, count in ((0, half), (half, d.n_blocks - half)):
+    rs = ctx.upload_bamfile(d, blocks=(first, count))
+    anchors.append((first, count) + rs.range_anchors)
+    rs.free()
+from trueconsense_amd.distributed import check_range_anchors
 print("two block ranges add up to the same:", bool(np.array_equal(acc, want)))
+print("the ranges' anchors join:", check_range_anchors(anchors, d.inflated_bytes) is None, anchors)
 os.remove(path)

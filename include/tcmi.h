@@ -117,6 +117,9 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *                    several-kernel path with its three waits (the path that words every refusal; the tests cross-check the two)
  *   "mid_wait"       1 = the one-sync path waits a second time, behind the decode kernels (default: two waits per file; measured
  *                    equal or faster than 0 with eight contexts), 0 = one wait per file
+ *   "prefix_kernels" the one-sync path's kernels need, per BGZF block, the records / kept reads / plane words in front of it: 0 = every
+ *                    workgroup adds them up for itself below 16 384 blocks and three one-workgroup scan launches do it from there on
+ *                    (the sums are quadratic in the blocks; default), 1 = always the scan launches, -1 = never
  *   "decode_token_mb" the device decoder's token scratch, MiB (default 4096): a file whose BGZF blocks need more (tokens take 3 - 10
  *                    times the inflated bytes while a block is decoded) is decoded in batches of blocks that share the scratch —
  *                    the inflated stream stays whole

@@ -322,3 +322,29 @@ def test_block_ranges_must_join_into_one_chain_of_records(ctx, tmp_path):
     assert rc1 == 0 and rc0 == _ffi.E_UNSUPPORTED and "do not join" in msg0, (rc0, msg0)
     d.close()
     d0.close()
+
+
+def test_prefix_kernels_for_files_of_very_many_blocks(ctx, tmp_path):
+    """From 16 384 blocks on the sums in front of a block (records, kept reads, plane words) come from three scan launches instead of
+    every workgroup adding them up for itself ("prefix_kernels"): forced on here for small files — whole, as ranges, with records
+    across blocks — against the several-kernel path and the oracle."""
+    ref, orfs = sy.make_reference(L=6000, cds=[(100, 2500), (3000, 5800)])
+    L = len(ref)
+    reads = sy.make_reads(ref, 40_000, seed=91, indel_sites=sy.default_indel_sites(orfs))
+    want = c_oracle.tally(reads, L)
+    try:
+        ctx.set_option("prefix_kernels", 1)
+        for name, kw in (("brim.bam", dict(split_records=True, block=3001)), ("htslib.bam", dict(block=2500))):       # ~ 3 000 - 4 000 blocks: several tiles of the scan
+            p = write(tmp_path, name, reads, "ref", L, **kw)
+            whole = both_paths(ctx, p, L)
+            assert np.array_equal(whole[8], want)
+            d = engine.DeviceBam(p)
+            nb = d.n_blocks
+            d.close()
+            assert nb > 2048
+            acc = np.zeros_like(want)
+            for a, b in ((0, nb // 3), (nb // 3, nb - nb // 3)):
+                acc += both_paths(ctx, p, L, blocks=(a, b))[8]
+            assert np.array_equal(acc, want)
+    finally:
+        ctx.set_option("prefix_kernels", 0)

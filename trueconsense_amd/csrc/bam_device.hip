@@ -545,7 +545,7 @@ struct Decoded {
 };
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 // arena bytes of everything that is sized per record: the several-kernel path's arrays (rec_off + 12 words) — the one-pass packer's are fewer
-inline size_t rest_bytes(size_t n_rec, size_t nb) { return al256(n_rec * 8 + 8) + al256(n_rec * 4 + 4) * 12 + al256((n_rec / 256 + 2) * 8) * 3 + al256(nb * 33 + 64) + al256(nb * 8) + al256(nb * 4) + 8192 + 28 * 256; }
+inline size_t rest_bytes(size_t n_rec, size_t nb) { return al256(n_rec * 8 + 8) + al256(n_rec * 4 + 4) * 12 + al256((n_rec / 256 + 2) * 8) * 3 + al256(nb * 33 + 64) + al256(nb * 8) * 4 + al256(nb * 4) + 8192 + 32 * 256; }
 
 // blocks [first, first + count) of the file (count < 0: to the end): the records that START in them.  A range that does not end
 // with the file takes one block more along — the last record may run into it — whose own records are left out.

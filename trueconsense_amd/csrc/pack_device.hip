@@ -759,6 +759,9 @@ struct FusedArgs {
     uint2 *agg;                     // [n_blocks] pk_index -> pk_place: {kept reads, plane words} of the block
     unsigned long long *fn;         // [n_blocks] ... the chain's transfer function across the block (ch_pack)
     uint32_t *rec_base;             // [n_blocks] ... index of the block's first record
+    // files of very many blocks (every workgroup adding up everything in front of it is quadratic): exclusive prefix sums made by
+    // pk_prefix between the kernels — records in front of a block (for pk_index), kept reads and plane words (for pk_place); else null
+    const unsigned long long *pre_rec, *pre_k, *pre_w;
     uint4 *rrec;                    // [rec_cap] ... per record {word, where SEQ lies (2 words), pos}
     uint64_t *rec_off;              // out [rec_cap]: dense record offsets
     uint32_t rec_cap;
@@ -787,6 +790,35 @@ __device__ inline unsigned long long block_sum_u32(const uint32_t *v, int n, uns
     return t;
 }
 
+// exclusive prefix sums of v[i * stride] over i < n (entries from n_lim on count as nothing), one workgroup: out[i], out[n] = the total
+__global__ __launch_bounds__(1024) void pk_prefix(const uint32_t *v, int stride, int n, int n_lim, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const unsigned long long x = i < n && i < n_lim ? v[(size_t)i * (size_t)stride] : 0ull;
+        unsigned long long incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long y = (unsigned long long)__shfl_up((long long)incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        unsigned long long before = s_run;
+        for (int w = 0; w < wave; ++w) before += s_w[w];
+        if (i < n) out[i] = before + incl - x;
+        __syncthreads();
+        if (tid == 1023) s_run = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = s_run;
+}
+
 __global__ __launch_bounds__(PB) void pk_index(FusedArgs a)
 {
     __shared__ uint2 s_w[PB / 64];
@@ -803,7 +835,7 @@ __global__ __launch_bounds__(PB) void pk_index(FusedArgs a)
     int32_t over = mine ? a.over[b] : 0;
     if (tid == 0 && st != ST_OK) atomicOr(&a.tot->flags, PKF_STAT);
     // the block's first record's index: the records of the blocks in front of it (all of them ours: b < n_own, or n = 0)
-    const unsigned long long base = block_sum_u32(a.n_rec, min(b, a.n_own), s_alg);
+    const unsigned long long base = a.pre_rec ? a.pre_rec[b] : block_sum_u32(a.n_rec, min(b, a.n_own), s_alg);
     if (tid == 0) a.rec_base[b] = (uint32_t)min(base, (unsigned long long)0xFFFFFFFFu);
     const bool room = base + n <= a.rec_cap;
     if (!room && tid == 0) atomicOr(&a.tot->flags, PKF_REC_OVF);
@@ -883,7 +915,8 @@ __global__ __launch_bounds__(PB) void pk_place(FusedArgs a)
     // ---- the kept reads and words in front of this block: every workgroup adds the aggregates up for itself -------------------------
     unsigned long long ex_k = 0, ex_w = 0;
     {
-        for (int i = tid; i < b; i += PB) { const uint2 v = a.agg[i]; ex_k += v.x; ex_w += v.y; }
+        if (a.pre_k) { if (tid == 0) { ex_k = a.pre_k[b]; ex_w = a.pre_w[b]; } }
+        else for (int i = tid; i < b; i += PB) { const uint2 v = a.agg[i]; ex_k += v.x; ex_w += v.y; }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) { ex_k += (unsigned long long)__shfl_xor((long long)ex_k, dd, 64); ex_w += (unsigned long long)__shfl_xor((long long)ex_w, dd, 64); }
         if (lane == 0) { s_sum[wave] = ex_k; s_sum[PB / 64 + wave] = ex_w; }
@@ -1422,6 +1455,10 @@ int tcmi_pack_fused_enqueue(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs
     unsigned long long *blk_alg = (unsigned long long *)arena_take(ctx, al((size_t)nb * 8));
     int32_t *blk_end = (int32_t *)arena_take(ctx, al((size_t)nb * 4));
     PackTotals *d_tot = (PackTotals *)arena_take(ctx, sizeof(PackTotals));
+    // (every workgroup adds up what lies in front of its block: a few thousand words for a 1M-read file, but quadratic in the blocks —
+    //  at 67 000 blocks, a 4 GiB stream, it was 40 % of these kernels' time: from 16 384 blocks on three small scan launches do it)
+    const bool prefix = ctx->prefix_kernels > 0 || (ctx->prefix_kernels == 0 && nb >= 16384);
+    unsigned long long *pre = prefix ? (unsigned long long *)arena_take(ctx, al(((size_t)nb + 1) * 8) * 3) : nullptr;
     job->d_rec = (uint64_t *)arena_take(ctx, (size_t)cap * 8 + 8);
     job->c_idx = (uint32_t *)arena_take(ctx, (size_t)cap * 4);
     job->c_pos = (int32_t *)arena_take(ctx, (size_t)cap * 4);
@@ -1468,12 +1505,19 @@ int tcmi_pack_fused_enqueue(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs
     a.agg = agg; a.fn = fn; a.rec_base = rec_base; a.rrec = rrec; a.rec_off = job->d_rec; a.rec_cap = (uint32_t)cap;
     a.c_idx = job->c_idx; a.c_pos = job->c_pos; a.c_info = c_info; a.c_woff = c_woff; a.c_seq = c_seq; a.gen_idx = job->gen_idx;
     a.o = o; a.blk_alg = blk_alg; a.blk_end = blk_end; a.tot = d_tot;
+    const size_t pre_n = al(((size_t)nb + 1) * 8) / 8;
+    if (prefix) { a.pre_rec = pre; a.pre_k = pre + pre_n; a.pre_w = pre + 2 * pre_n; }
     (void)hipGetLastError();
     tcmi_prof_begin(ctx, TCMI_K_PACK_CLASSIFY);
+    if (prefix) hipLaunchKernelGGL(pk_prefix, dim3(1), dim3(1024), 0, ctx->stream, job->d_nrec, 1, (int)nb, (int)job->n_own, pre);
     hipLaunchKernelGGL(pk_index, dim3((unsigned)nb), dim3(PB), 0, ctx->stream, a);
     tcmi_prof_end(ctx, TCMI_K_PACK_CLASSIFY);
     TCMI_HIP(ctx, hipGetLastError());
     tcmi_prof_begin(ctx, TCMI_K_PACK);
+    if (prefix) {
+        hipLaunchKernelGGL(pk_prefix, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const uint32_t *>(agg), 2, (int)nb, (int)nb, pre + pre_n);
+        hipLaunchKernelGGL(pk_prefix, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const uint32_t *>(agg) + 1, 2, (int)nb, (int)nb, pre + 2 * pre_n);
+    }
     hipLaunchKernelGGL(pk_place, dim3((unsigned)nb), dim3(PB), 0, ctx->stream, a);
     hipLaunchKernelGGL(pk_pack, dim3((unsigned)n_wg), dim3(PB), 0, ctx->stream, o, job->c_pos, c_info, c_woff, 0u, 0u, 0, n_stages, ctx->stage_cap, d_tot,
                        balance ? slots : (int64_t)1 << 30);

@@ -169,6 +169,31 @@ __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps)
             : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
             : [mm] "s"(mm), [vA2] "v"(vA1), [vB2] "v"(vB2), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7)
             : "s82", "s83", "s84", "s92", "s93", "vcc", "scc", "memory");
+        if (V == 7)                                             // no exec mask: lanes beyond the match copy its last byte once more
+        {
+        const unsigned vA7 = ((len1 - 1u) << 16) | (dm & 0xFFFFu);
+        asm volatile(
+            "s_mov_b64 s[82:83], %[mm]\n"
+            "LMb%=:\n"
+            "s_ff1_i32_b64 s84, s[82:83]\n"
+            "v_readlane_b32 %[sa], %[vA2], s84\n"
+            "v_readlane_b32 %[sb], %[vB2], s84\n"
+            "s_bitset0_b64 s[82:83], s84\n"
+            "s_cmp_lt_u32 %[sa], 0x400000\n"
+            "s_cbranch_scc0 LXb%=\n"
+            "v_min_u32_sdwa %[t2], %[sa], %[vlane] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+            "v_add_u32 %[t0], %[sb], %[t2]\n"
+            "v_add_u32_sdwa %[t1], %[sa], %[t2] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+            "ds_read_u8 %[t2], %[t0]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[t1], %[t2]\n"
+            "s_cmp_lg_u64 s[82:83], 0\n"
+            "s_cbranch_scc1 LMb%=\n"
+            "LXb%=:\n"
+            : [sa] "=&s"(sa), [sb] "=&s"(sb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            : [mm] "s"(mm), [vA2] "v"(vA7), [vB2] "v"(sm), [vlane] "v"((unsigned)lane)
+            : "s82", "s83", "s84", "vcc", "scc", "memory");
+        }
         if (V == 5)                                             // two matches in flight: the next one's read goes out before this one's write
         asm volatile(
             "s_mov_b64 s[92:93], exec\n"
@@ -263,6 +288,7 @@ int main()
         run<4>("round 4: byte rounds as shipped", blocks, reps);
         run<5>("round 4: two matches in flight", blocks, reps);
         run<6>("round 4: byte rounds without LDS", blocks, reps);
+        run<7>("byte rounds, no exec mask (min)", blocks, reps);
     }
     return 0;
 }

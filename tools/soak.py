@@ -15,6 +15,19 @@ tmp = tempfile.mkdtemp(prefix="tcmi_soak_", dir="/dev/shm" if os.path.isdir("/de
 paths, _ = bench.write_inputs(tmp, ref, orfs, 8, 1_000_000, 0, False, 6)
 hard, _ = bench.write_inputs(tmp + "_i", ref, orfs, 4, 300_000, 1, True, 6) if os.makedirs(tmp + "_i", exist_ok=True) is None else (None, None)
 paths = paths + hard
+# ... and two files that compress like real data (2.5 : 1 and 6 : 1: bgzf_symbols<1, windowed> / bgzf_copy<true, true> and <true, false>)
+import numpy as np                                               # noqa: E402
+from trueconsense_amd.io import bamwriter                        # noqa: E402
+rng = np.random.default_rng(7)
+nr = 200_000
+rr = sy.make_reads(ref, nr, seed=77)
+names = rng.integers(48, 58, (nr, 27)).astype(np.uint8)
+names[:, :10] = np.frombuffer(b"A00123:45:", np.uint8)
+for tag, q in (("real", rng.choice(np.arange(2, 42, dtype=np.uint8), size=(nr, 150), p=(lambda w: w / w.sum())(np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004))),
+               ("hard", rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(nr, 150), p=[0.02, 0.05, 0.13, 0.80]))):
+    p = os.path.join(tmp, "soak_%s.bam" % tag)
+    bamwriter.write_bam_fast(p, rr["pos"], rr["flag"], rr["seq"].reshape(nr, -1), 150, "MN908947.3", L, level=6, qual=q, names=names)
+    paths.append(p)
 ctx = Context(0)
 runner = FileRunner(ctx, [{"start": o["start"], "end": o["end"], "strand": o["strand"]} for o in orfs], 30, True, decoders=3, decode_threads=8, walkers=2, gpu_streams=8)
 want = runner.run(paths, names=["S"] * len(paths), ref_len=L)

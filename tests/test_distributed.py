@@ -251,3 +251,45 @@ def test_check_range_anchors_joins_the_ranks_ranges_into_one_chain():
     assert why and "last alignment record" in why
     why = chk([(0, 4, -1, -1), (4, 8, 2500, total)], total)                                   # nobody vouches for rank 1's start
     assert why and "no range in front" in why
+
+
+def test_check_range_anchors_on_random_chains_and_cuts():
+    """The joining rule on random record chains cut into random BGZF blocks and random block ranges: the true anchors always join,
+    and a range whose first record start is off by any amount is always caught (as is a last record that does not end with the stream)."""
+    from trueconsense_amd.distributed import check_range_anchors as chk
+    rng = np.random.default_rng(123)
+    for _ in range(300):
+        header = int(rng.integers(20, 3000))
+        sizes = rng.integers(40, 900, int(rng.integers(1, 400)))
+        starts = header + np.concatenate(([0], np.cumsum(sizes)[:-1]))          # record starts in the stream
+        total = int(header + sizes.sum())
+        cuts = [0]
+        while cuts[-1] < total:
+            cuts.append(min(total, cuts[-1] + int(rng.integers(200, 2500))))   # block boundaries (records straddle them)
+        nb = len(cuts) - 1
+        world = int(rng.integers(1, 9))
+        edges = sorted(set([0, nb] + [int(x) for x in rng.integers(0, nb + 1, world - 1)]))
+        ranges = []
+        for b0, b1 in zip(edges[:-1], edges[1:]):
+            lo, hi = cuts[b0], cuts[b1]
+            inside = starts[(starts >= lo) & (starts < hi)]
+            first = int(inside[0]) if len(inside) and b0 != 0 else -1           # (the range that starts with the file is vouched for by the header)
+            if len(inside):
+                after = starts[starts >= hi]
+                nxt = int(after[0]) if len(after) else total
+            else:
+                nxt = header if b0 == 0 and hi <= header else -1                # header blocks only: the header says where the records begin
+            ranges.append((b0, b1 - b0, first, nxt))
+        assert chk(ranges, total) is None, ranges
+        cand = [i for i, r in enumerate(ranges) if r[2] >= 0]
+        if cand:
+            i = int(rng.choice(cand))
+            b0, n, first, nxt = ranges[i]
+            bad = list(ranges)
+            bad[i] = (b0, n, first + int(rng.choice([-7, -1, 1, 33])), nxt)
+            assert chk(bad, total) is not None, (ranges, i)
+        last = max(i for i, r in enumerate(ranges) if r[3] >= 0)
+        bad = list(ranges)
+        bad[last] = ranges[last][:3] + (ranges[last][3] + 5,) if ranges[last][3] == total else bad[last]
+        if bad[last] != ranges[last]:
+            assert chk(bad, total) is not None

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TCMI_ABI_VERSION 4
+#define TCMI_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 #define TCMI_OK            0
@@ -366,18 +366,20 @@ int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_
  * The library links no collective library: the one exchange of the path — a sum of the int32 count matrix to the rank that calls —
  * is a hook of the caller's (RCCL's ncclReduce on the given stream from C: tools/tcmi_rccl_hook.cpp; torch.distributed from Python:
  * trueconsense_amd/distributed.py).
- *   tcmi_split_step   this rank's part of one step, in C: decode + pack + tally the alignment records that start in BGZF blocks
- *                     [first_block, first_block + n_blocks) into d_counts (device int32 [7][ld] + TWO more int32 behind it: the
- *                     ranges' anchors — every rank adds (where the first record behind its range starts) - (where its own first
- *                     record starts; 0 for the range that starts with the file), modulo 2^32: the sum over ranges that tile the
- *                     file telescopes to the inflated length iff every range starts where the one in front ends
- *                     (tcmi_readset_range_anchors) —, and the number of ranks that failed — a rank that cannot decode its range
- *                     still takes part in the exchange, with zeros, so nobody waits for it forever),
- *                     reduce(user, d_counts, 7 * ld + 2, stream) — the
- *                     hook must sum over the ranks, at least to the root —, and on the root (is_root != 0) the call kernel:
- *                     results as tcmi_step's.  *rs_out (any rank; NULL on failure) keeps the rank's decoded stream resident for
- *                     tcmi_readset_ins_entries.  Returns the rank's own error, or on the root TCMI_E_UNSUPPORTED when another
- *                     rank failed or the ranges' record chains do not join.
+ *   tcmi_split_step   this rank's part of one step, in C (rank 0 is the root): decode + pack + tally the alignment records that
+ *                     start in BGZF blocks [first_block, first_block + n_blocks) into d_counts — device int32 [7][ld] +
+ *                     TCMI_SPLIT_TAIL_WORDS(world) more int32 behind it: six words per rank, written by that rank into its own
+ *                     slot and zero in everybody else's, so that the sum hands the root the table {first_block, n_blocks, first,
+ *                     next (two words each)} of all ranges — a range in the middle of the file starts at the first offset its
+ *                     first block finds plausible for a record, and only the range in front can vouch for it: the root checks
+ *                     PAIRWISE that every range starts where the one in front ends and that the last one ends with the stream
+ *                     (tcmi_readset_range_anchors; the same rule as distributed.check_range_anchors) —, and one word that counts
+ *                     the ranks that failed: a rank that cannot do its share (a range that is refused, a workspace that cannot
+ *                     be allocated) still takes part in the exchange, with zeros, so nobody waits for it forever;
+ *                     reduce(user, d_counts, 7 * ld + TCMI_SPLIT_TAIL_WORDS(world), stream) — the hook must sum over the ranks,
+ *                     at least to rank 0 —, and on rank 0 the call kernel: results as tcmi_step's.  *rs_out (any rank; NULL on
+ *                     failure) keeps the rank's decoded stream resident for tcmi_readset_ins_entries.  Returns the rank's own
+ *                     error, or on rank 0 TCMI_E_UNSUPPORTED when another rank failed or the ranges' record chains do not join.
  *   tcmi_readset_ins_entries   the entries of the candidate columns (TCMI_INS_ENTRY_BYTES each, opaque; per column in file order)
  *                     from this rank's records: what the ranks send to the root.  ent_off[n_pos + 1]; insertions of more than 12
  *                     bases leave their bases in long_text (long_used bytes).  TCMI_E_ARG with ent_off / long_used filled in when
@@ -390,8 +392,9 @@ int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_
  *                     (tcmi_bam_load + tcmi_modal_tokens) for that file. */
 #define TCMI_INS_ENTRY_BYTES 48
 typedef int (*tcmi_reduce_fn)(void *user, void *d_counts, int64_t n_int32, void *stream);
+#define TCMI_SPLIT_TAIL_WORDS(world) (6 * (world) + 1)
 int  tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, int64_t L, int64_t ld, void *d_counts,
-                     int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int is_root, tcmi_readset **rs_out,
+                     int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int rank, int world, tcmi_readset **rs_out,
                      const uint8_t **plain, const uint8_t **alt, const uint8_t **flags);
 int  tcmi_readset_ins_entries(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_pos, const int64_t *positions, uint32_t flag_filter,
                               int ignore_orphans, void *entries, int64_t entries_cap, int64_t *ent_off, uint8_t *long_text,

@@ -10,8 +10,8 @@ from trueconsense_amd import _ffi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "tcmi.h")).read()
+def declared_symbols(header="tcmi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tcmi_[a-z_0-9]+)\s*\(", text)))
 
@@ -23,7 +23,25 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _ffi._SIGS, "no ctypes signature for " + n
-    assert lib.tcmi_abi_version() == 4
+    assert lib.tcmi_abi_version() == 5
+
+
+def test_every_header_under_include_is_covered():
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["tcmi.h", "tcmi_rccl.h"]
+
+
+def test_rccl_hook_library_exports_what_its_header_declares():
+    """include/tcmi_rccl.h -> trueconsense_amd/lib/libtcmi_rccl.so, built by build(): tcmi_split_step's reduce hook over RCCL
+    (no collective is called here: that needs a GPU, tests/test_rccl.py)."""
+    lib = _ffi.rccl_lib()
+    names = declared_symbols("tcmi_rccl.h")
+    assert len(names) == 6 and "tcmi_rccl_reduce" in names, names
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _ffi._RCCL_SIGS, "no ctypes signature for " + n
+    assert lib.tcmi_rccl_reduce(None, None, 0, None) != 0 and b"tcmi_rccl_reduce" in lib.tcmi_rccl_last_error()
+    src = open(os.path.join(ROOT, "trueconsense_amd", "csrc", "rccl_hook.cpp")).read()
+    assert "TCMI_RCCL_ID_BYTES" in src and _ffi.RCCL_ID_BYTES == 128
 
 
 def test_no_device_is_reported_not_hidden():

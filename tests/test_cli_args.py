@@ -47,3 +47,47 @@ def test_exit_codes_match_the_reference(tmp_path, capsys, monkeypatch):
     with pytest.raises(SystemExit) as e:                      # no arguments at all: message + exit 1 (:216-220)
         cli.main([])
     assert e.value.code == 1
+
+
+def test_gpus_children_get_the_parsed_arguments_not_the_typed_ones(tmp_path, monkeypatch):
+    """--gpus N deals the work to N child processes.  argparse takes abbreviations (`--gpu`, `--bat`, `--dev`: the reference's parser
+    does too, TrueConsense.py:25-30), so a child's command line is built from the parsed namespace: it never carries the parent's
+    --gpus / --batch / --device again, and always an explicit `--gpus 1` — a child can never deal itself out once more."""
+    f = _files(tmp_path)
+    man = tmp_path / "m.tsv"
+    man.write_text("\n".join("%s\tS%d\t%s" % (f["x.bam"], k, tmp_path / ("o%d.fa" % k)) for k in range(5)) + "\n")
+    seen = {}
+
+    def fake_spawn(cmds, envs):
+        seen["cmds"], seen["envs"] = cmds, envs
+        seen["rows"] = [open(c[4]).read().count("\n") for c in cmds if c[3] == "--batch"]   # (the shards live as long as the children)
+        return 0
+    monkeypatch.setattr(cli, "_spawn", fake_spawn)
+    cli.main(["--gpu", "2", "--bat", str(man), "--dev", "5", "-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "12", "-noambig", "-t", "3"])
+    assert len(seen["cmds"]) == 2
+    for k, cmd in enumerate(seen["cmds"]):
+        tail = cmd[3:]
+        assert tail[0] == "--batch" and tail[2:4] == ["--device", str(k)]
+        rest = tail[4:]
+        assert rest == ["-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "12", "-t", "3", "-noambig", "--gpus", "1"], rest
+        child = cli.GetArgs(tail)                                # what the child itself will understand
+        assert child.gpus == 1 and child.batch == tail[1] and child.device == k and child.coverage_level == 12 and child.noambiguity
+        assert seen["rows"] == [3, 2]
+    # ONE file over N GPUs: the split workers get the single-sample flags, again with --gpus 1
+    cli.main(["--gpu=3", "--inp", f["x.bam"], "-ref", f["r.fa"], "-gff", f["f.gff"], "-cov", "30", "--samplen", "S", "-o", "o.fa", "-vcf", "v.vcf"])
+    assert len(seen["cmds"]) == 3 and [e["RANK"] for e in seen["envs"]] == ["0", "1", "2"]
+    for cmd in seen["cmds"]:
+        assert cmd[1:3] == ["-m", "trueconsense_amd.split_main"]
+        child = cli.GetArgs(cmd[3:])
+        assert child.gpus == 1 and child.input == f["x.bam"] and child.samplename == "S" and child.variants == "v.vcf" and child.batch is None
+
+
+def test_spawn_ends_the_others_when_one_child_fails(monkeypatch):
+    """A child that dies early would leave the others waiting in a collective: the rest are terminated after a short grace."""
+    import sys
+    import time
+    monkeypatch.setenv("TCMI_SPAWN_GRACE", "0.5")
+    t0 = time.monotonic()
+    rc = cli._spawn([[sys.executable, "-c", "import sys; sys.exit(3)"], [sys.executable, "-c", "import time; time.sleep(120)"]], [None, None])
+    assert rc >= 3 and time.monotonic() - t0 < 30
+    assert cli._spawn([[sys.executable, "-c", "pass"]] * 2, [None, None]) == 0

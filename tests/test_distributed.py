@@ -94,7 +94,34 @@ def _work_consensus(rank, world, use_gpu, td, c_oracle):
     j0 = td.read_range(int(reads["n_reads"]), rank, world)[0]
     text = td.consensus_split_bamfile("unused", L, rows, 30, True, "S", rank, world, step_fn=step_fn,
                                       entries_fn=lambda pos: entries_py.entries_for(shard, pos, j0=j0))
-    return text == want if rank == 0 else text is None
+    ok = text == want if rank == 0 else text is None
+    # ONE rank cannot collect its entries (TCMI_E_UNSUPPORTED: a read of more than 512 positions in its range, ONT data): the ranks
+    # agree before the gather — nobody is left waiting in it — and rank 0 sweeps the file on the host for the tokens: the same FASTA
+    import tempfile
+    from trueconsense_amd import _ffi
+    from trueconsense_amd.io import bamwriter
+    path = os.path.join(tempfile.gettempdir(), "tcmi_cons_cpu_%d.bam" % os.getppid())
+    if rank == 0:
+        bamwriter.write_bam(path, reads, "r", L, level=1)
+    dist.barrier()
+
+    def refusing(code):
+        def fn(pos):
+            if rank == 1:
+                raise _ffi.TcmiError(code, "rank 1 cannot collect its entries")
+            return entries_py.entries_for(shard, pos, j0=j0)
+        return fn
+    text = td.consensus_split_bamfile(path, L, rows, 30, True, "S", rank, world, step_fn=step_fn, entries_fn=refusing(_ffi.E_UNSUPPORTED))
+    ok = ok and (text == want if rank == 0 else text is None)
+    try:                                                             # any other failure: every rank raises, none hangs
+        td.consensus_split_bamfile(path, L, rows, 30, True, "S", rank, world, step_fn=step_fn, entries_fn=refusing(_ffi.E_NOMEM))
+        ok = False
+    except _ffi.TcmiError as e:
+        ok = ok and e.code == _ffi.E_NOMEM
+    dist.barrier()
+    if rank == 0:
+        os.remove(path)
+    return ok
 
 
 def _work(rank, world, use_gpu, q, td, sy, c_oracle):
@@ -127,6 +154,19 @@ def _work(rank, world, use_gpu, q, td, sy, c_oracle):
             both = td.tally_split_bamfile(path, L, rank, world, device=0)
             ok = ok and bool(np.array_equal(both, want))
             dist.barrier()
+        # ranges that do not join (here: the rule is made to say so) are TCMI_E_UNSUPPORTED on every rank — what a caller catches to
+        # fall back to the host reader —, before anybody enters the collective
+        from trueconsense_amd import _ffi
+        real = td.check_range_anchors
+        td.check_range_anchors = lambda ranges, n: "rank 1's block range starts a record at stream offset 7, the range in front ends its last record at 9"
+        try:
+            td.tally_split_bamfile(path, L, rank, world, device=0)
+            ok = False
+        except _ffi.TcmiError as e:
+            ok = ok and e.code == _ffi.E_UNSUPPORTED and "host reader" in str(e)
+        finally:
+            td.check_range_anchors = real
+        dist.barrier()
         if rank == 0:
             os.remove(path)
     ok = ok and _work_consensus(rank, world, use_gpu, td, c_oracle)

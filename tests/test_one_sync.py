@@ -279,17 +279,17 @@ def test_block_ranges_must_join_into_one_chain_of_records(ctx, tmp_path):
             assert np.array_equal(acc, want)
     ctx.set_option("one_sync", 1)
 
-    # tcmi_split_step: the anchors ride in the reduce (two "ranks" one after the other on this GPU; the hook adds the first one's share)
+    # tcmi_split_step: the ranges' table rides in the reduce (two "ranks" one after the other on this GPU; the hook adds the first one's share)
     ld = (L + 255) // 256 * 256
     lib = _ffi.lib()
 
     def split(dbam, cut):
         share = {}
-        bufs = [torch.zeros(7 * ld + 2, dtype=torch.int32, device="cuda") for _ in range(2)]
+        bufs = [torch.zeros(7 * ld + 13, dtype=torch.int32, device="cuda") for _ in range(2)]   # TCMI_SPLIT_TAIL_WORDS(2)
 
         @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
         def keep(user, ptr, nw, stream):
-            assert nw == 7 * ld + 2
+            assert nw == 7 * ld + 13
             torch.cuda.synchronize()
             share["t"] = bufs[1].clone()
             return 0
@@ -303,7 +303,7 @@ def test_block_ranges_must_join_into_one_chain_of_records(ctx, tmp_path):
         out = []
         for rank, (a, c, hook) in ((1, (cut, nb - cut, keep)), (0, (0, cut, add))):
             h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-            rc = lib.tcmi_split_step(ctx.handle, dbam.handle, a, c, L, ld, C.c_void_p(bufs[rank].data_ptr()), 30, 1, hook, None, int(rank == 0),
+            rc = lib.tcmi_split_step(ctx.handle, dbam.handle, a, c, L, ld, C.c_void_p(bufs[rank].data_ptr()), 30, 1, hook, None, rank, 2,
                                      C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
             msg = (lib.tcmi_last_error(ctx.handle) or b"").decode()
             fl = None

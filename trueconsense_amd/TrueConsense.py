@@ -106,30 +106,56 @@ def GetArgs(givenargs):
 
 
 def _spawn(cmds, envs):
-    """Start the children BEFORE this process touches a GPU (never re-exec a process that did), wait for all, -> worst exit code."""
+    """Start the children BEFORE this process touches a GPU (never re-exec a process that did), wait for all, -> worst exit code.
+    The children are polled together: once one of them has failed the others get a short grace (they may be waiting for it in a
+    collective) and are then terminated, so nobody sits out a collective's time-out."""
     import subprocess
     procs = [subprocess.Popen(c, env=e) for c, e in zip(cmds, envs)]
-    rcs = [p.wait() for p in procs]
+    rcs = [None] * len(procs)
+    failed_at = None
+    while any(r is None for r in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and failed_at is None:
+                    failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > float(os.environ.get("TCMI_SPAWN_GRACE", "20")):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.02)
     return max((abs(r) for r in rcs), default=0)
 
 
-def run_gpus(a, args):
+def _child_argv(a, single):
+    """The command line of a --gpus child, built from the PARSED namespace (argparse takes abbreviations, so the spelling the user typed
+    cannot be filtered by name): the reference's flags as they were understood, never --gpus / --batch / --device / --stats — the
+    caller adds its own — plus an explicit `--gpus 1`, so that a child can never deal itself out again."""
+    out = ["-ref", a.reference, "-gff", a.features, "-cov", str(a.coverage_level), "-t", str(a.threads)]
+    if a.noambiguity:
+        out.append("-noambig")
+    if single:
+        out += ["-i", a.input, "-o", a.output, "-name", a.samplename]
+        for flag, v in (("-vcf", a.variants), ("-doc", a.depth_of_coverage), ("-ogff", a.output_gff)):
+            if v is not None:
+                out += [flag, v]
+    return out + ["--gpus", "1"]
+
+
+def run_gpus(a):
     """--gpus N: N processes, one per GPU.  --batch: the manifest's samples dealt round-robin (BASELINE configs[3]: independent files,
     no collective); -i: ONE BAM file shared by the GPUs (configs[4]: trueconsense_amd.split_main)."""
     import socket
     import tempfile
     n = int(a.gpus)
-    rest, skip = [], False
-    for x in args:                                                  # the children get the same command line without --gpus / --batch / --device
-        if skip:
-            skip = False
-            continue
-        if x in ("--gpus", "--batch", "--device", "--stats"):
-            skip = True
-            continue
-        if x.startswith(("--gpus=", "--batch=", "--device=", "--stats=")):
-            continue
-        rest.append(x)
     pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                     PYTHONPATH=os.pathsep.join([pkg_parent] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
@@ -145,7 +171,7 @@ def run_gpus(a, args):
                 shard = os.path.join(tmp, "shard%d.tsv" % k)
                 with open(shard, "w") as fh:
                     fh.write("\n".join(mine) + "\n")
-                cmd = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "--batch", shard, "--device", str(0 if one_gpu else k)] + rest
+                cmd = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "--batch", shard, "--device", str(0 if one_gpu else k)] + _child_argv(a, False)
                 if a.stats:
                     cmd += ["--stats", "%s.gpu%d" % (a.stats, k)]
                 cmds.append(cmd)
@@ -160,7 +186,7 @@ def run_gpus(a, args):
     s.close()
     cmds, envs = [], []
     for k in range(n):
-        cmds.append([sys.executable, "-m", "trueconsense_amd.split_main"] + rest)
+        cmds.append([sys.executable, "-m", "trueconsense_amd.split_main"] + _child_argv(a, True))
         envs.append(dict(base_env, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     return _spawn(cmds, envs)
 
@@ -229,7 +255,7 @@ def main(args=None):
         sys.exit(1)
     a = GetArgs(args)
     if a.gpus and a.gpus > 1:
-        rc = run_gpus(a, list(args))
+        rc = run_gpus(a)
         if rc:
             sys.exit(rc)
         return

@@ -98,7 +98,7 @@ _SIGS = {
     "tcmi_readset_range_anchors": (_int, [_vp, _P(_i64), _P(_i64)]),
     "tcmi_bamfile_step": (_int, [_vp, _vp, _i64, _i32, _int, _P(_vp), _P(_i64), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _P(_i64)]),
     "tcmi_readset_modal_tokens": (_int, [_vp, _vp, _i32, _vp, _i32, _u32, _int, _i64, _int, _vp, _i64, _vp, _vp, _P(_i32)]),
-    "tcmi_split_step": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _int, _vp, _vp, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp)]),
+    "tcmi_split_step": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _int, _vp, _vp, _int, _int, _P(_vp), _P(_vp), _P(_vp), _P(_vp)]),
     "tcmi_readset_ins_entries": (_int, [_vp, _vp, _i32, _vp, _u32, _int, _vp, _i64, _vp, _vp, _i64, _P(_i64)]),
     "tcmi_ins_entries_rebase": (_int, [_vp, _i64, _i64]),
     "tcmi_modal_from_entries": (_int, [_i32, _vp, _vp, _i32, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _P(_i32)]),
@@ -149,10 +149,54 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tcmi_abi_version() != 4:
-            raise ImportError("libtcmi ABI version %d, expected 4" % handle.tcmi_abi_version())
+        if handle.tcmi_abi_version() != 5:
+            raise ImportError("libtcmi ABI version %d, expected 5" % handle.tcmi_abi_version())
         _lib = handle
     return _lib
+
+
+RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtcmi_rccl.so")
+RCCL_ID_BYTES = 128
+_RCCL_SIGS = {
+    "tcmi_rccl_unique_id": (_int, [_vp]),
+    "tcmi_rccl_comm_init": (_int, [_int, _int, _vp, _P(_vp)]),
+    "tcmi_rccl_comm_destroy": (_int, [_vp]),
+    "tcmi_rccl_comm_info": (_int, [_vp, _P(_int), _P(_int), _P(_int)]),
+    "tcmi_rccl_reduce": (_int, [_vp, _vp, _i64, _vp]),
+    "tcmi_rccl_last_error": (C.c_char_p, []),
+}
+_rccl = None
+
+
+class RcclUser(C.Structure):
+    """struct tcmi_rccl_user (include/tcmi_rccl.h): the `user` of tcmi_rccl_reduce."""
+    _fields_ = [("comm", _vp), ("root", _int)]
+
+
+def rccl_lib():
+    """libtcmi_rccl.so (include/tcmi_rccl.h): tcmi_split_step's reduce hook over RCCL and the calls that make a communicator for it.
+    One process must hold ONE librccl too: torch's wheel bundles its own (soname librccl.so.1, as /opt/rocm's), so torch's copy is
+    loaded first when torch is installed and the hook library's NEEDED entry binds to it."""
+    global _rccl
+    if _rccl is None:
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C trueconsense_amd/csrc` (needs hipcc and librccl)" % RCCL_LIB_PATH)
+        lib()                                                        # (the HIP runtime first)
+        if os.environ.get("TCMI_HIP_RUNTIME") != "system":
+            try:
+                import importlib.util
+                spec = importlib.util.find_spec("torch")
+            except (ImportError, ValueError):
+                spec = None
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so") if spec is not None and spec.origin else ""
+            if cand and os.path.exists(cand):
+                C.CDLL(cand)                                         # (RTLD_LOCAL: its symbols in the global scope upset torch's own libraries at exit; the soname is what the hook binds by)
+        handle = C.CDLL(RCCL_LIB_PATH)
+        for name, (res, args) in _RCCL_SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _rccl = handle
+    return _rccl
 
 
 def check(rc, ctx=None):

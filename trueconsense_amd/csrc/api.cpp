@@ -560,62 +560,98 @@ int tcmi_step_end(tcmi_ctx *ctx, const uint8_t **plain, const uint8_t **alt, con
     return TCMI_OK;
 }
 
+// The joining rule of block ranges (include/tcmi.h, tcmi_split_step; distributed.check_range_anchors is the same rule in Python):
+// ranges in rank order, each {first_block, n_blocks, first, next}; a range in the middle of the file starts at the first offset its
+// first block finds plausible for a record, and only the range in front can vouch for it: its last record ends there.
+static const char *ranges_join(const int64_t (*rg)[4], int world, int64_t inflated, int *who, int64_t *at, int64_t *want)
+{
+    bool have = false, any_before = false;
+    int64_t expect = -1;
+    for (int r = 0; r < world; ++r) {
+        const int64_t fb = rg[r][0], nb = rg[r][1], first = rg[r][2], nxt = rg[r][3];
+        if (nb <= 0) continue;
+        if (fb != 0 && first >= 0) {
+            *who = r; *at = first; *want = expect;
+            if (have && first != expect) return "starts a record where the range in front does not end its last one";
+            if (!have && any_before) return "starts a record, but no range in front says where its last record ends";
+        }
+        any_before = true;
+        if (nxt >= 0) { expect = nxt; have = true; }
+    }
+    if (have && expect != inflated) { *who = world - 1; *at = expect; *want = inflated; return "the last alignment record does not end with the file's stream"; }
+    return nullptr;
+}
+
 // One rank's part of a step of ONE BAM file shared by several GPUs (include/tcmi.h): decode + pack + tally its block range, the
-// caller's reduce hook, and on the root the call kernel.  The word behind the matrix counts the ranks that failed: every rank
-// enters the exchange exactly once, whatever happened to its range.
+// caller's reduce hook, and on rank 0 the call kernel.  Behind the matrix: six words per rank (its range and anchors, in its own
+// slot, zeros in the others' — the sum hands rank 0 the table) and one word that counts the ranks that failed.  Every rank enters
+// the exchange exactly once, whatever happened to it before — a device that cannot be set, a workspace that cannot be allocated,
+// a range that is refused: its share is then zeros + one failure.
 int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, int64_t L, int64_t ld, void *d_counts,
-                    int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int is_root, tcmi_readset **rs_out,
+                    int32_t mincov, int include_ambig, tcmi_reduce_fn reduce, void *user, int rank, int world, tcmi_readset **rs_out,
                     const uint8_t **plain, const uint8_t **alt, const uint8_t **flags)
 {
     if (!ctx || !f || !d_counts || !reduce || !rs_out) return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
     if (L <= 0 || ld < L) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 < L <= ld");
+    if (world < 1 || rank < 0 || rank >= world) return tcmi_fail(ctx, TCMI_E_ARG, "need 0 <= rank < world");
     *rs_out = nullptr;
-    TCMI_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_ws(ctx, L);
-    if (rc) return rc;
-    const size_t n_words = (size_t)ld * TCMI_NCOL + 2;         // the matrix, the ranges' anchors, the ranks that failed
-    TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream));
+    const bool is_root = rank == 0;
+    const size_t n_mat = (size_t)ld * TCMI_NCOL, n_words = n_mat + (size_t)TCMI_SPLIT_TAIL_WORDS(world);
+    int32_t *const d_all = static_cast<int32_t *>(d_counts);
     tcmi_readset *rs = nullptr;
-    int own = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr);
-    std::string own_err = own ? ctx->err : std::string();
-    if (!own && rs->max_end > L) { own = tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs->max_end); own_err = ctx->err; }
-    if (!own && rs->n_piled) { own = tcmi_tally_dev(ctx, rs, L, ld, d_counts, 0); if (own) own_err = ctx->err; }
+    int own = TCMI_OK;
+    std::string own_err;
+    auto note = [&](int code) { own = code; own_err = ctx->err; };
+    // (all of these are argument checks of the caller's on every rank alike — the collective has not been entered — or failures of THIS
+    // rank, which must not keep it from the exchange)
+    if (hipSetDevice(ctx->device) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipSetDevice(%d) failed", ctx->device));
+    if (!own) { const int rc0 = ensure_ws(ctx, L); if (rc0) note(rc0); }
+    if (!own && hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipMemsetAsync of the count matrix failed"));
+    if (!own) { const int rc0 = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr); if (rc0) note(rc0); }
+    if (!own && rs->max_end > L) note(tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs->max_end));
+    if (!own && rs->n_piled) { const int rc0 = tcmi_tally_dev(ctx, rs, L, ld, d_counts, 0); if (rc0) note(rc0); }
+    int64_t all = 0, inflated = 0;
+    (void)tcmi_bamfile_info(f, nullptr, &inflated, &all, nullptr, nullptr, nullptr);
     if (own) {                                                  // this rank's share is zeros + one failure
         static const int32_t one = 1;
         (void)hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream);
-        (void)hipMemcpyAsync(static_cast<int32_t *>(d_counts) + (n_words - 1), &one, 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(d_all + (n_words - 1), &one, 4, hipMemcpyHostToDevice, ctx->stream);
     } else {
-        // the anchors: (where the first record behind the range starts) - (where the range's own first record starts), modulo 2^32.
-        // The range that starts with the file is vouched for by the header (first = 0); a range without a record start of its
-        // own adds nothing; the last range's chain ends with the stream (checked when it was decoded).
-        int64_t all = 0, inflated = 0;
-        (void)tcmi_bamfile_info(f, nullptr, &inflated, &all, nullptr, nullptr, nullptr);
-        const int64_t cnt = n_blocks < 0 ? all - first_block : std::min<int64_t>(n_blocks, all - first_block);
-        uint32_t word = 0;
-        if (cnt > 0 && rs->range_next >= 0 && (first_block == 0 || rs->range_first >= 0))
-            word = (uint32_t)((uint64_t)rs->range_next - (uint64_t)(first_block == 0 ? 0 : rs->range_first));
-        else if (cnt == all) word = (uint32_t)(uint64_t)inflated;     // (one range: the whole file, no anchors to join)
-        ctx->split_anchor = word;
-        (void)hipMemcpyAsync(static_cast<int32_t *>(d_counts) + (n_words - 2), &ctx->split_anchor, 4, hipMemcpyHostToDevice, ctx->stream);
+        const int64_t cnt = std::max<int64_t>(0, n_blocks < 0 ? all - first_block : std::min<int64_t>(n_blocks, all - first_block));
+        const int64_t v[3] = {rs->range_first, rs->range_next, 0};
+        int32_t *t = ctx->split_tail;
+        t[0] = (int32_t)first_block; t[1] = (int32_t)cnt;
+        std::memcpy(t + 2, &v[0], 8); std::memcpy(t + 4, &v[1], 8);
+        (void)hipMemcpyAsync(d_all + n_mat + (size_t)6 * rank, t, 24, hipMemcpyHostToDevice, ctx->stream);
     }
     const int rrc = reduce(user, d_counts, (int64_t)n_words, (void *)ctx->stream);
     if (rrc) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_HIP, "the reduce hook failed (%d)", rrc); }
-    int32_t tail[2] = {0, 0};                                   // {anchors, failed}
-    if (is_root) {
-        rc = tcmi_launch_call(ctx, static_cast<int32_t *>(d_counts), L, ld, mincov, include_ambig, 0, ctx->h_rec, ctx->h_rec + ctx->ws_ld, ctx->h_rec + 2 * ctx->ws_ld, nullptr, nullptr);
-        if (!rc && hipMemcpyAsync(tail, static_cast<int32_t *>(d_counts) + (n_words - 2), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "copy failed");
+    int rc = TCMI_OK;
+    std::vector<int32_t> tail((size_t)TCMI_SPLIT_TAIL_WORDS(world), 0);
+    if (is_root && !own) {
+        rc = tcmi_launch_call(ctx, d_all, L, ld, mincov, include_ambig, 0, ctx->h_rec, ctx->h_rec + ctx->ws_ld, ctx->h_rec + 2 * ctx->ws_ld, nullptr, nullptr);
+        if (!rc && hipMemcpyAsync(tail.data(), d_all + n_mat, tail.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = tcmi_fail(ctx, TCMI_E_HIP, "copy failed");
     }
-    const int32_t &failed = tail[1];
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = tcmi_fail(ctx, TCMI_E_HIP, "hipStreamSynchronize failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc && !own) rc = tcmi_fail(ctx, TCMI_E_HIP, "hipStreamSynchronize failed");
     ctx->counts_clean = false;
     if (own) { if (rs) tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, own, "%s", own_err.c_str()); }
     if (rc) { tcmi_readset_free(ctx, rs); return rc; }
+    const int32_t failed = tail.back();
     if (is_root && failed) { tcmi_readset_free(ctx, rs); return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%d rank(s) could not decode their range of %s on the device", (int)failed, tcmi_bamfile_path(f)); }
-    int64_t inflated_all = 0;
-    (void)tcmi_bamfile_info(f, nullptr, &inflated_all, nullptr, nullptr, nullptr, nullptr);
-    if (is_root && (uint32_t)tail[0] != (uint32_t)(uint64_t)inflated_all) {
-        tcmi_readset_free(ctx, rs);
-        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the ranks' block ranges do not join into one chain of alignment records (a range started at an offset that only looked like a record): host reader", tcmi_bamfile_path(f));
+    if (is_root) {
+        std::vector<int64_t> rg((size_t)world * 4);
+        for (int r = 0; r < world; ++r) {
+            const int32_t *t = tail.data() + (size_t)6 * r;
+            rg[4 * r] = t[0]; rg[4 * r + 1] = t[1];
+            std::memcpy(&rg[4 * r + 2], t + 2, 8); std::memcpy(&rg[4 * r + 3], t + 4, 8);
+        }
+        int who = 0; int64_t at = 0, want = 0;
+        const char *why = ranges_join(reinterpret_cast<const int64_t (*)[4]>(rg.data()), world, inflated, &who, &at, &want);
+        if (why) {
+            tcmi_readset_free(ctx, rs);
+            return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "%s: the ranks' block ranges do not join into one chain of alignment records (rank %d %s: offset %lld, expected %lld): host reader",
+                             tcmi_bamfile_path(f), who, why, (long long)at, (long long)want);
+        }
     }
     *rs_out = rs;
     if (plain) *plain = ctx->h_rec;

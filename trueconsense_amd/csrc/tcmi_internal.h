@@ -156,7 +156,7 @@ struct tcmi_ctx {
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
     int64_t stat_decode_batched = 0; // files the device decoder took in batches of blocks (tcmi_ctx_stat "decode_batched")
-    uint32_t split_anchor = 0;       // tcmi_split_step: this rank's anchor word on its way to the device (the copy is asynchronous)
+    int32_t split_tail[6] = {0, 0, 0, 0, 0, 0};   // tcmi_split_step: this rank's slot of the range table on its way to the device (the copy is asynchronous)
     uint32_t rec_bytes_seen = 0;     // mean record size of the last file this context decoded (sizes the next file's arrays when the file's own first blocks say nothing)
     int64_t decode_token_mb = 4096;  // bam_device.hip decode_enqueue: the token scratch's size; files that need more are decoded in batches of blocks
     int prefix_kernels = 0;          // pk_index / pk_place take the sums in front of a block from scan launches: 0 = from 16 384 blocks on, 1 = always, -1 = never

@@ -18,6 +18,7 @@ import ctypes as C
 import numpy as np
 
 from ._ffi import E_ARG as _ffi_E_ARG
+from ._ffi import E_UNSUPPORTED as _ffi_E_UNSUPPORTED
 from ._ffi import check, lib
 
 
@@ -263,27 +264,55 @@ class _Tokens:
         return self.toks.get(pos)
 
 
+def rccl_communicator(rank, world, group=None):
+    """An RCCL communicator of this process's own (include/tcmi_rccl.h) for tcmi_split_step's C hook: rank 0 draws the id, the bytes
+    travel through the process group that is already up (any backend) — or nowhere at world 1.  -> (comm handle, _ffi.RcclUser);
+    destroy with _ffi.rccl_lib().tcmi_rccl_comm_destroy(comm).  The current HIP device must be the rank's."""
+    from . import _ffi
+    r = _ffi.rccl_lib()
+    ident = C.create_string_buffer(_ffi.RCCL_ID_BYTES)
+    if rank == 0 and r.tcmi_rccl_unique_id(ident):
+        raise RuntimeError((r.tcmi_rccl_last_error() or b"").decode())
+    if world > 1:
+        import torch.distributed as dist
+        box = [ident.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = C.create_string_buffer(box[0], _ffi.RCCL_ID_BYTES)
+    comm = C.c_void_p()
+    if r.tcmi_rccl_comm_init(int(world), int(rank), ident, C.byref(comm)):
+        raise RuntimeError((r.tcmi_rccl_last_error() or b"").decode())
+    return comm, _ffi.RcclUser(comm, 0)
+
+
 def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True, name="S", rank=0, world=1, device=0, group=None,
-                            step_fn=None, entries_fn=None, return_parts=False):
+                            step_fn=None, entries_fn=None, return_parts=False, rccl_user=None, ctx=None, dbam=None, timings=None):
     """BASELINE configs[4] all the way: ONE BAM file over `world` ranks -> its consensus FASTA text on rank 0 (None on the others).
     What the ranks jointly replace is the reference's single pile-up pass (indexing.py:96-100), its insert candidates' region
     pile-ups (Events.py:47-82) and the walk (Sequences.py:168-322):
 
       1. every rank decodes, packs and tallies the records that start in ITS contiguous range of the file's BGZF blocks and the count
-         matrices are summed to rank 0 (tcmi_split_step: the step in C, the reduce a hook — RCCL's reduce under "nccl"); a rank that
-         cannot decode its range still takes part (zeros + a failure word): nobody waits for it forever, and every rank learns the verdict;
+         matrices are summed to rank 0 (tcmi_split_step: the step in C, the reduce a hook — with `rccl_user` (rccl_communicator) the C
+         hook tcmi_rccl_reduce: ncclReduce queued on the context's stream; else torch.distributed's reduce, RCCL under "nccl"); a rank
+         that cannot decode its range still takes part (zeros + a failure word): nobody waits for it forever, and every rank learns
+         the verdict;
       2. rank 0 calls (HIP call kernel) and broadcasts the insert-candidate columns;
-      3. every rank collects the 48-byte entries of those columns from its resident stream (ins_entries_kernel) and sends them to rank 0;
+      3. every rank collects the 48-byte entries of those columns from its resident stream (ins_entries_kernel); the ranks agree that
+         all of them could (a rank whose range holds reads the entry kernel does not take — longer than 512 positions — says so
+         instead of leaving the others in the gather), then send them to rank 0;
       4. rank 0 concatenates the pieces per column in rank order — file order: pysam's max_depth admission and first-seen tie-break
          depend on it —, votes (tcmi_modal_from_entries), and walks.  Overlapping mates whose other mate would have to be looked at on
-         another rank: rank 0 decodes the file on the host for the tokens (tcmi_bam_load + tcmi_modal_tokens).
+         another rank, or a rank that could not collect its entries: rank 0 decodes the file on the host for the tokens
+         (tcmi_bam_load + tcmi_modal_tokens).
 
     step_fn(first, count) -> (counts int [L,7] of the rank's range) and entries_fn(positions) -> (entry bytes, ent_off, long text)
     replace the GPU on boxes without one (tests: the oracle's tally and entries; the call then comes from the oracle too).
     return_parts: rank 0 gets (FASTA text, counts int32 [L,7], {candidate column: modal token}) — what the command line's other
-    writers need (Outputs.WriteOutputs, Coverage.BuildCoverage)."""
+    writers need (Outputs.WriteOutputs, Coverage.BuildCoverage).  ctx / dbam: the caller's (kept open: a bench loop); timings: a dict
+    that receives the seconds of "step" (tcmi_split_step, reduce included) and "entries" (steps 2-4 up to the vote)."""
+    import time
     import torch
     import torch.distributed as dist
+    from ._ffi import TcmiError
     from .Events import inserts_from_flags
     from .Sequences import consensus_from_records
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
@@ -291,95 +320,134 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
     ld = (L + 255) // 256 * 256
     root = rank == 0
     plain = alt = flags = counts_root = None
-    ctx = d = rs = None
+    own_ctx, own_d = ctx is None, dbam is None
+    d, rs = dbam, None
     err = None
-    if step_fn is None:
-        from ._ffi import TcmiError
-        from .engine import Context, DeviceBam, ReadSet
-        torch.cuda.set_device(device)
-        ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
-        d = DeviceBam(path)
-        first, count = block_range(d.n_blocks, rank, world)
-        t = torch.zeros(7 * ld + 2, dtype=torch.int32, device="cuda")
-
-        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
-        def hook(user, ptr, n, stream):                             # (the tensor IS the buffer at `ptr`; torch's collective runs on the context's stream)
+    t0 = time.perf_counter()
+    try:
+        if step_fn is None:
+            from .engine import Context, DeviceBam, ReadSet
+            torch.cuda.set_device(device)
             try:
-                reduce_counts(t, 0, group)
-                return 0
-            except Exception:                                       # noqa: BLE001 — a C caller gets a code, not an exception
-                return 1
-        h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        rc = lib().tcmi_split_step(ctx.handle, d.handle, first, count, L, ld, C.c_void_p(t.data_ptr()), int(mincov), int(bool(include_ambig)), hook, None,
-                                   int(root), C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
-        if rc:
-            err = (rc, (lib().tcmi_last_error(ctx.handle) or b"").decode("utf-8", "replace"))
+                if ctx is None:
+                    ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
+                if d is None:
+                    d = DeviceBam(path)
+            except (TcmiError, OSError) as e:                        # this rank cannot even start: it must still meet the others in the reduce
+                err = (getattr(e, "code", _ffi_E_ARG), str(e))
+            n_tail = 6 * int(world) + 1                              # TCMI_SPLIT_TAIL_WORDS(world)
+            t = torch.zeros(7 * ld + n_tail, dtype=torch.int32, device="cuda")
+            if err is not None:
+                t[-1] = 1
+                if rccl_user is not None:                            # (the others are in ncclReduce on that communicator)
+                    from . import _ffi
+                    _ffi.rccl_lib().tcmi_rccl_reduce(C.cast(C.pointer(rccl_user), C.c_void_p), C.c_void_p(t.data_ptr()), t.numel(),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                    torch.cuda.synchronize()
+                else:
+                    reduce_counts(t, 0, group)
+            else:
+                first, count = block_range(d.n_blocks, rank, world)
+
+                @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+                def hook(user, ptr, n, stream):                      # (the tensor IS the buffer at `ptr`; torch's collective runs on the context's stream)
+                    try:
+                        reduce_counts(t, 0, group)
+                        return 0
+                    except Exception:                                # noqa: BLE001 — a C caller gets a code, not an exception
+                        return 1
+                if rccl_user is not None:
+                    from . import _ffi
+                    fn, user = C.cast(_ffi.rccl_lib().tcmi_rccl_reduce, C.c_void_p), C.cast(C.pointer(rccl_user), C.c_void_p)
+                else:
+                    fn, user = hook, None
+                h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+                rc = lib().tcmi_split_step(ctx.handle, d.handle, first, count, L, ld, C.c_void_p(t.data_ptr()), int(mincov), int(bool(include_ambig)), fn, user,
+                                           int(rank), int(world), C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
+                if rc:
+                    err = (rc, (lib().tcmi_last_error(ctx.handle) or b"").decode("utf-8", "replace"))
+                else:
+                    rs = ReadSet(ctx, h, None)
+                    if root:
+                        def grab(vp):
+                            out = np.empty(L, np.uint8)
+                            C.memmove(out.ctypes.data, vp, L)
+                            return out
+                        plain, alt, flags = grab(p_), grab(a_), grab(f_)
+                        if return_parts:
+                            counts_root = np.ascontiguousarray(t[:7 * ld].view(7, ld)[:, :L].T.cpu().numpy())
         else:
-            rs = ReadSet(ctx, h, None)
+            d_blocks = step_fn("n_blocks")
+            first, count = block_range(d_blocks, rank, world)
+            part = torch.from_numpy(np.ascontiguousarray(np.asarray(step_fn((first, count))).T.astype(np.int32)))
+            if multi:
+                dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, group=group)
             if root:
-                def grab(vp):
-                    out = np.empty(L, np.uint8)
-                    C.memmove(out.ctypes.data, vp, L)
-                    return out
-                plain, alt, flags = grab(p_), grab(a_), grab(f_)
-                if return_parts:
-                    counts_root = np.ascontiguousarray(t[:7 * ld].view(7, ld)[:, :L].T.cpu().numpy())
-    else:
-        d_blocks = step_fn("n_blocks")
-        first, count = block_range(d_blocks, rank, world)
-        part = torch.from_numpy(np.ascontiguousarray(np.asarray(step_fn((first, count))).T.astype(np.int32)))
+                counts_root = np.ascontiguousarray(part.numpy().T)
+                plain, alt, flags = step_fn(("call", counts_root, int(mincov), bool(include_ambig)))
+        if timings is not None:
+            timings["step"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        # every rank learns whether the step held everywhere (a failed rank took part in the reduce: no deadlock, but no consensus either)
+        verdict = [err]
         if multi:
-            dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, group=group)
+            allv = [None] * dist.get_world_size(group)
+            dist.all_gather_object(allv, err, group=group)
+            verdict = allv
+        bad = [v for v in verdict if v]
+        if bad:
+            raise TcmiError(bad[0][0], "consensus_split_bamfile: %s" % bad[0][1])
+        # the insert-candidate columns, from rank 0 to everybody
+        cand = [(np.nonzero(flags & 8)[0] + 1).tolist()] if root else [None]
+        if multi:
+            dist.broadcast_object_list(cand, src=0, group=group)
+        cand = cand[0]
+        text = None
+        host_sweep = False
+        if cand:
+            piece, perr = None, None
+            try:
+                piece = entries_fn(cand) if entries_fn is not None else _entries_of_readset(ctx, rs, cand)
+            except TcmiError as e:                                   # e.g. TCMI_E_UNSUPPORTED: a read of more than 512 positions in this rank's range
+                perr = (e.code, str(e))
+            pieces = [piece]
+            if multi:                                                # nobody enters the gather unless everybody has a piece
+                allp = [None] * dist.get_world_size(group)
+                dist.all_gather_object(allp, perr, group=group)
+                perr = next((v for v in allp if v), None)
+            if perr is not None:
+                if perr[0] != _ffi_E_UNSUPPORTED:
+                    raise TcmiError(perr[0], "consensus_split_bamfile: insert entries: %s" % perr[1])
+                host_sweep = True                                    # rank 0 sweeps the file on the host, as it does for st & 2 below
+            elif multi:
+                pieces = [None] * dist.get_world_size(group) if root else None
+                dist.gather_object(piece, pieces, dst=0, group=group)
+        toks = {}
         if root:
-            counts_root = np.ascontiguousarray(part.numpy().T)
-            plain, alt, flags = step_fn(("call", counts_root, int(mincov), bool(include_ambig)))
-    # every rank learns whether the step held everywhere (a failed rank took part in the reduce: no deadlock, but no consensus either)
-    verdict = [err]
-    if multi:
-        allv = [None] * dist.get_world_size(group)
-        dist.all_gather_object(allv, err, group=group)
-        verdict = allv
-    bad = [v for v in verdict if v]
-    if bad:
+            if cand:
+                st = 2
+                if not host_sweep:
+                    toks, st = _vote(cand, pieces)
+                if st & 2:                                          # a pair of mates that only a sweep over the whole file resolves
+                    from .engine import BamFile, modal_tokens
+                    bam = BamFile(path)
+                    try:
+                        toks = {p: tk for p, (tk, _) in modal_tokens(bam, cand).items()}
+                    finally:
+                        bam.close()
+            if timings is not None:
+                timings["entries"] = time.perf_counter() - t1
+            _, inserts = inserts_from_flags(flags, _Tokens(toks))
+            gff = {i: dict(r) for i, r in enumerate(gff_rows)}
+            cons, _ = consensus_from_records(plain, alt, flags, gff, inserts, True)
+            text = ">%s mincov=%d\n%s\n" % (name, int(mincov), cons)
+    finally:
         if rs is not None:
             rs.free()
-        if d is not None:
+        if d is not None and own_d:
             d.close()
-        if ctx is not None:
+        if ctx is not None and own_ctx and step_fn is None:
             ctx.close()
-        from ._ffi import TcmiError
-        raise TcmiError(bad[0][0], "consensus_split_bamfile: %s" % bad[0][1])
-    # the insert-candidate columns, from rank 0 to everybody
-    cand = [(np.nonzero(flags & 8)[0] + 1).tolist()] if root else [None]
-    if multi:
-        dist.broadcast_object_list(cand, src=0, group=group)
-    cand = cand[0]
-    text = None
-    if cand:
-        piece = entries_fn(cand) if entries_fn is not None else _entries_of_readset(ctx, rs, cand)
-        pieces = [piece]
-        if multi:
-            pieces = [None] * dist.get_world_size(group) if root else None
-            dist.gather_object(piece, pieces, dst=0, group=group)
-    toks = {}
-    if root:
-        if cand:
-            toks, st = _vote(cand, pieces)
-            if st & 2:                                              # a pair of mates that only a sweep over the whole file resolves
-                from .engine import BamFile, modal_tokens
-                bam = BamFile(path)
-                toks = {p: t for p, (t, _) in modal_tokens(bam, cand).items()}
-                bam.close()
-        _, inserts = inserts_from_flags(flags, _Tokens(toks))
-        gff = {i: dict(r) for i, r in enumerate(gff_rows)}
-        cons, _ = consensus_from_records(plain, alt, flags, gff, inserts, True)
-        text = ">%s mincov=%d\n%s\n" % (name, int(mincov), cons)
-    if rs is not None:
-        rs.free()
-    if d is not None:
-        d.close()
-    if ctx is not None:
-        ctx.close()
     if return_parts:
         return (text, counts_root, toks) if root else None
     return text

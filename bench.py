@@ -257,14 +257,15 @@ def run_split_bam(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs):
 
 def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, orfs, ctx, tile):
     """configs[4] from ONE FILE: rank 0 writes one BAM of world x --reads reads (outside the clock); every rank maps it and, per
-    step, sends the compressed bytes of ITS contiguous range of BGZF blocks to its GPU, inflates them, indexes and packs the records
-    that start there, tallies; ONE reduce (sum) of the int32 [7][ld] matrix to rank 0, which calls and walks.  Nothing of the
-    file is decoded on the host, and no rank decodes another rank's blocks (one block at a range's end excepted: the last
-    record may run into it)."""
+    step, runs the product's function for this shape (distributed.consensus_split_bamfile): tcmi_split_step in C — the compressed bytes
+    of ITS contiguous range of BGZF blocks to its GPU, inflate, index and pack the records that start there, tally, ONE reduce (sum) of
+    the int32 [7][ld] matrix to rank 0 through the RCCL hook, call kernel on rank 0 —, then the insert candidates' entries to rank 0,
+    vote, walk, FASTA text.  Nothing of the file is decoded on the host, and no rank decodes another rank's blocks (one block at a
+    range's end excepted: the last record may run into it)."""
     from trueconsense_amd import _ffi
     from trueconsense_amd import distributed as td
     from trueconsense_amd import synthetic as sy
-    from trueconsense_amd.engine import DeviceBam, Walker
+    from trueconsense_amd.engine import DeviceBam
     from trueconsense_amd.io import bamwriter
     import numpy as np
     L = len(ref)
@@ -287,28 +288,37 @@ def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, or
         dist.barrier()
     d = DeviceBam(path)
     first, count = td.block_range(d.n_blocks, rank, world)
-    counts = torch.zeros((7, ld), dtype=torch.int32, device="cuda")
-    rec = torch.zeros((3, ld), dtype=torch.uint8).pin_memory()
-    walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
-    rec_np = rec.numpy()
-    n_mine = [0]
+    rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
+    # The exchange: tcmi_split_step's C hook over an RCCL communicator of this job's own (include/tcmi_rccl.h: ncclReduce queued on the
+    # context's stream behind the tally) — at ONE rank too, so that the collective itself runs wherever this leg runs; a rehearsal of
+    # several ranks on one GPU (gloo) keeps torch.distributed's reduce.
+    user, comm, hook_kind = None, None, "torch.distributed reduce (gloo, rehearsal on one GPU)"
+    if not rehearse and os.environ.get("TCMI_SPLIT_HOOK", "rccl") == "rccl":
+        try:
+            comm, user = td.rccl_communicator(rank, world)
+            hook_kind = "tcmi_rccl_reduce: ncclReduce on the context's stream, %d-rank communicator" % world
+        except Exception as e:                                       # noqa: BLE001 — the line says which exchange ran
+            hook_kind = "torch.distributed reduce (RCCL communicator of its own failed: %s)" % e
+        if dist is not None:                                         # all ranks the same hook, or the collectives would not meet
+            flags = [None] * world
+            dist.all_gather_object(flags, user is not None)
+            if not all(flags):
+                user = None
+                hook_kind = "torch.distributed reduce (a rank could not make its RCCL communicator)"
+    elif not rehearse:
+        hook_kind = "torch.distributed reduce (RCCL)" if world > 1 else "torch.distributed reduce (no-op at one rank)"
+    rs0 = ctx.upload_bamfile(d, blocks=(first, count))               # (outside the clock: how many records start in this rank's range)
+    n_mine = int(rs0.n_reads)
+    rs0.free()
+    tms = []
 
     def step():
-        rs = ctx.upload_bamfile(d, blocks=(first, count))            # H2D of the range's compressed bytes, inflate, index, pack
-        n_mine[0] = rs.n_reads
-        counts.zero_()
-        if rs.n_piled:
-            ctx.tally_dev(rs, L, ld, counts.data_ptr(), zero=False)
-        td.reduce_counts(counts, dst=0)                              # ONE exchange: int32 sum of 7 x ld, to rank 0 only
-        out = None
-        if rank == 0:
-            ctx.call_dev(counts.data_ptr(), L, ld, a.mincov, True, rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr())
-            torch.cuda.current_stream().synchronize()
-            out = walker(rec_np[0, :L], rec_np[1, :L], rec_np[2, :L])[0]
-        else:
-            torch.cuda.current_stream().synchronize()                # (the read set's memory goes back to the pool below)
-        rs.free()
-        return out
+        # the product's function for this shape, all the way to the FASTA text: tcmi_split_step (H2D of the range's compressed bytes,
+        # inflate, index, pack, tally, the reduce, call on rank 0 — in C), the insert candidates' entries gathered to rank 0, vote, walk
+        tm = {}
+        text = td.consensus_split_bamfile(path, L, rows, a.mincov, True, "S", rank, world, device=local_rank, rccl_user=user, ctx=ctx, dbam=d, timings=tm)
+        tms.append(tm)
+        return text
 
     def fence():
         torch.cuda.synchronize()
@@ -318,6 +328,7 @@ def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, or
 
     for _ in range(a.warmup):
         step()
+    del tms[:]
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -325,42 +336,42 @@ def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, or
     fence()
     dt_mine = time.perf_counter() - t0
     dt = dt_mine
-    per_rank = [dt_mine]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        g = [None] * world
-        dist.all_gather_object(g, (dt_mine, int(n_mine[0]), int(count)))
-        per_rank = g
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, (dt_mine, n_mine, int(count)))
     else:
-        per_rank = [(dt_mine, int(n_mine[0]), int(count))]
-    # ... and once, outside the clock, the product's own function for this shape, all the way to the FASTA text (tcmi_split_step in C,
-    # insert candidates' entries gathered to rank 0): distributed.consensus_split_bamfile
-    rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
-    cons_product = td.consensus_split_bamfile(path, L, rows, a.mincov, True, "S", rank, world, device=local_rank)
+        per_rank = [(dt_mine, n_mine, int(count))]
+    # ... and once more outside the clock, with the count matrix handed back, for the checks
+    parts = td.consensus_split_bamfile(path, L, rows, a.mincov, True, "S", rank, world, device=local_rank, rccl_user=user, ctx=ctx, dbam=d, return_parts=True)
     if rank == 0:
         from oracle import tc_oracle as orc
-        got = np.ascontiguousarray(counts[:, :L].T.cpu().numpy()).astype(np.int64)
+        got = parts[1].astype(np.int64)
         has, ins = orc.list_inserts(want_counts, a.mincov, lambda pos1: [])
         want, _ = orc.build_consensus(a.mincov, want_counts, [dict(o) for o in orfs], True, ins if has else None, True)
         want_text = orc.fasta_text("S", a.mincov, want)
-        product = cons_product == want_text
+        step_ms = 1e3 * float(np.mean([t_["step"] for t_ in tms]))
         print(json.dumps({
-            "consensus_split_bamfile_fasta_exact": bool(product),
-            "metric": "reference positions/sec (ONE BAM FILE of %d reads, %d GPU(s) each decoding its range of the file's BGZF blocks -> consensus)" % (a.reads * world, world),
+            "consensus_split_bamfile_fasta_exact": bool(parts[0] == want_text),
+            "metric": "reference positions/sec (ONE BAM FILE of %d reads, %d GPU(s) each decoding its range of the file's BGZF blocks -> consensus FASTA)" % (a.reads * world, world),
             "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_per_rank": [1e3 * x[0] / a.steps for x in per_rank],
+            "ms_per_step_in_tcmi_split_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, ONE BAM file of %d x %d synthetic 150-bp reads (%d bytes, %d BGZF blocks, "
-                                   "zlib level %d); per step every rank sends the compressed bytes of its contiguous block range to its GPU, "
-                                   "inflates / indexes / packs / tallies there, ONE reduce (sum) of the int32 [7][%d] matrix (%d bytes) to rank 0, "
-                                   "call kernel + walk on rank 0" % (world, a.reads, d.file_bytes, d.n_blocks, a.level, ld, 28 * ld),
-                       "collective": "gloo (rehearsal on one GPU)" if rehearse else ("RCCL reduce" if world > 1 else "none"),
+                                   "zlib level %d); a step is distributed.consensus_split_bamfile — the product's function: tcmi_split_step in C (every rank "
+                                   "sends the compressed bytes of its contiguous block range to its GPU, inflates / indexes / packs / tallies there, ONE reduce (sum) "
+                                   "of the int32 [7][%d] matrix + range table (%d bytes) to rank 0 through the hook, call kernel on rank 0), the ranks' verdicts, "
+                                   "the insert candidates' entries to rank 0, vote, walk, FASTA text" % (world, a.reads, d.file_bytes, d.n_blocks, a.level, ld, 4 * (7 * ld + 6 * world + 1)),
+                       "collective": hook_kind,
                        "blocks_per_rank": [x[2] for x in per_rank], "reads_per_rank": [x[1] for x in per_rank],
                        "input_generation_seconds_outside_clock": t_gen},
-            "counts_bit_exact": bool(np.array_equal(got, want_counts)), "fasta_bit_exact": bool(cons.decode("ascii") == want),
-            "consensus_len": len(cons), "coverage_sum": int(got[:, 0].sum()), "coverage_sum_expected": 150 * a.reads * world}))
+            "counts_bit_exact": bool(np.array_equal(got, want_counts)), "fasta_bit_exact": bool(cons == want_text),
+            "consensus_len": len(want), "coverage_sum": int(got[:, 0].sum()), "coverage_sum_expected": 150 * a.reads * world}))
+    if comm is not None:
+        _ffi.rccl_lib().tcmi_rccl_comm_destroy(comm)
     d.close()
     if dist is not None:
         dist.barrier()

@@ -405,6 +405,7 @@ def main():
     ap.add_argument("--no-cli-batch", action="store_true", help="skip the leg through the command line (--batch, four output files per sample)")
     ap.add_argument("--no-hard-bam", action="store_true", help="skip the leg with the file that compresses like real data")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] leg (indel carriers) of the default line")
+    ap.add_argument("--no-configs0", action="store_true", help="skip the configs[0] leg (10k reads: the Python stand-in for the reference's run beside the command line)")
     ap.add_argument("--only-resident", action="store_true", help="only the HBM-resident leg (short runs under rocprofv3)")
     ap.add_argument("--resident-batch", type=int, default=8, help="BAMs per launch of the resident leg")
     ap.add_argument("--resident-steps", type=int, default=200)
@@ -481,6 +482,7 @@ def main():
 
 def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, Context, FileRunner, Pipeline, ref, orfs, L,
               paths, reads0, decoders, decode_threads, cores, t_gen):
+    t_bench0 = time.perf_counter()
     ctx = Context(local_rank)
     for kv in a.ctx_option:
         k, v = kv.split("=")
@@ -620,38 +622,52 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     sctx.profile(False)
     out["cold_kernels"] = cold
 
+    # ---- the GPU legs first, back to back; the host-side checks of what they produced (a minute of oracle work) come behind them ----
+    deferred = []
+    # BASELINE configs[2] in the same line: indel carriers at CDS boundaries, insert candidates resolved in the resident stream
+    if not a.indels and not a.host_decode and not a.no_configs2:
+        out["configs2"] = configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, os.path.dirname(paths[0]), rank, min(8, cores), deferred)
+    # a file that compresses like real data (distinct names, binned random qualities): same pipeline, one BAM at a time
+    if not a.indels and not a.host_decode and not a.no_hard_bam:
+        out["hard_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx)
+        out["real_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx, kind="real")
+    # the command line itself with --batch: all four output files per sample, written by the native runner
+    if not a.host_decode and not a.no_cli_batch:
+        out["cli_batch"] = cli_batch_leg(a, paths, ref, orfs, L, sy, fastas)
+    # secondary: reads resident in HBM, the tally kernel's rate and its roofline
+    if not a.no_resident:
+        res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
+        out["resident"] = res["resident"]
+        out["resident"]["roofline"] = res["roofline"]
+    out["gpu_legs_done_after_seconds"] = time.perf_counter() - t_bench0
+
     # ---- bit-exactness of what was timed, against the oracle chain (outside the clock) -----------------
     chain_t = {}
     out["fasta_all_timed"] = check_all_fastas(a, np, paths, fastas, L, a.mincov, orfs, workers=min(8, cores), timing=chain_t)
     out.update({"fasta_bit_exact": out["fasta_all_timed"]["first_mismatch"] is None and len(fastas) > 0,
                 "fasta_sha256": hashlib.sha256(fastas[0].encode()).hexdigest()[:16], "consensus_len": len(fastas[0].split("\n")[1])})
-    # ---- BASELINE configs[2] in the same line: indel carriers at CDS boundaries, insert candidates resolved in the resident stream ----
-    if not a.indels and not a.host_decode and not a.no_configs2:
-        out["configs2"] = configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, os.path.dirname(paths[0]), rank, min(8, cores))
-    # ---- a file that compresses like real data (distinct names, binned random qualities): same pipeline, one BAM at a time ----
-    if not a.indels and not a.host_decode and not a.no_hard_bam:
-        out["hard_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx)
-        out["real_bam"] = hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, os.path.dirname(paths[0]), runner, ctx, kind="real")
-
-    # ---- the command line itself with --batch: all four output files per sample, written by the native runner ----
-    if not a.host_decode and not a.no_cli_batch:
-        out["cli_batch"] = cli_batch_leg(a, paths, ref, orfs, L, sy, fastas)
+    for fn in deferred:
+        fn()
+    # ---- BASELINE configs[0]: the Python stand-in for the reference's whole run beside the product's command line, one 10k-read file ----
+    if not a.indels and not a.host_decode and not a.no_configs0:
+        out["configs0"] = configs0_leg(np, sy, ref, orfs, L, os.path.dirname(paths[0]), a.mincov)
 
     # ---- rooflines of the cold path's kernels (HIP events of the timed run above; traffic from the committed PMC passes) ----
     out.update(cold_rooflines(a, out["cold_kernels_pipelined"], cold, os.path.getsize(paths[0]), out["config"].get("bam_inflated_bytes", 0), reads0))
     if "all_kernels_of_a_bam" in out["roofline"].get("issue", {}):
-        out["roofline"]["issue"]["all_kernels_of_a_bam"]["ms_per_step_pipelined"] = out["ms_per_step"] * world
+        ak = out["roofline"]["issue"]["all_kernels_of_a_bam"]
+        ak["ms_per_step_pipelined"] = out["ms_per_step"] * world
+        ak["issue_floor_over_pipelined_time"] = ak["issue_floor_ms"] / ak["ms_per_step_pipelined"]
+        if ak.get("hbm_bytes_per_bam"):                                # what the pipeline pulls through the L2s' far side, all kernels together
+            agg = ak["hbm_bytes_per_bam"] / (ak["ms_per_step_pipelined"] * 1e-3) / 1e9
+            ak["aggregate_traffic"] = {"achieved": agg, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS}
+        out["parked"] = {k: v.get("parked") for k, v in out["roofline"]["issue"]["kernels"].items() if v.get("parked") is not None}
     # (`achieved` divides by the average duration of ONE launch; with several contexts the launches of different BAMs overlap and
     #  each one is stretched by the others.  What the kernel class moves per second of the timed run:)
     for blk in ("roofline", "roofline_hot_path"):
         agg = out[blk]["bytes_per_launch"] / (out["ms_per_step"] * world * 1e-3) / 1e9
         out[blk]["aggregate"] = {"achieved": agg, "frac": agg / HBM_PEAK_GBS, "unit": "GB/s",
                                  "note": "bytes_per_launch x launches / timed seconds (launches of %d contexts overlap)" % a.gpu_streams}
-    # ---- secondary: reads resident in HBM, the tally kernel's rate and its roofline ----------------------------
-    if not a.no_resident:
-        res = resident_leg(a, ctx, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank, fence)
-        out["resident"] = res["resident"]
-        out["resident"]["roofline"] = res["roofline"]
     cache = os.path.join(tempfile.gettempdir(), "tcmi_cpu_baseline_%d_%d.json" % (a.reads, a.level))
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(paths, L, a.mincov, orfs, n_threads=cores)
@@ -683,6 +699,8 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
     for k, leg in (("value_hard_bam", "hard_bam"), ("value_real_bam", "real_bam")):
         if leg in out and "pipelined" in out[leg]:
             out[k] = out[leg]["pipelined"]["value"]
+    if "configs0" in out and "error" not in out["configs0"]:
+        out["configs0_outputs_equal"] = out["configs0"]["all_four_outputs_equal"]
     if "configs2" in out:
         out["value_configs2"] = out["configs2"]["value"]
         out["configs2_fasta_exact"] = out["configs2"]["fasta_all_timed"]["all_equal_the_oracle_chain"]
@@ -781,7 +799,75 @@ def cli_batch_leg(a, paths, ref, orfs, L, sy, fastas):
                     "one) / (samples more): reader, GPU and walker stages overlapped, the walkers also write VCF, corrected GFF and coverage TSV"}
 
 
-def configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, tmp, rank, workers):
+def configs0_leg(np, sy, ref, orfs, L, tmp, mincov=30, n_reads=10_000, seed=77):
+    """BASELINE configs[0] ("10k synthetic 150 bp reads, reference CPU path only (plumbing)"): ONE 10 k-read BAM file through the Python
+    stand-in for the reference's whole run (TrueConsense.py:212-264) — oracle/tc_oracle.py end to end with the reference's own loop
+    structure: the per-token tally loop (indexing.py:102-132), ListInserts with the region pile-ups (Events.py:5-82), both BuildConsensus
+    walks (Sequences.py:168-322, ORFs.py), the writers (Outputs.py, Coverage.py) — timed, beside the product's command line on the same
+    file in a process of its own, timed, and the four outputs compared: FASTA text, VCF record lines, the corrected ORF coordinates of
+    the GFF, the coverage TSV.  The only leg where a whole stand-in run is timed rather than extrapolated."""
+    import subprocess
+    from oracle import c_oracle
+    from oracle import tc_oracle as orc
+    from trueconsense_amd.io import bamwriter
+    d = os.path.join(tmp, "configs0")
+    os.makedirs(d, exist_ok=True)
+    reads = sy.make_reads(ref, n_reads, seed=seed, indel_sites=sy.default_indel_sites(orfs))
+    bam = os.path.join(d, "in.bam")
+    bamwriter.write_bam(bam, reads, "MN908947.3", L, level=6)
+    with open(os.path.join(d, "ref.fa"), "w") as fh:
+        fh.write(">MN908947.3 synthetic\n" + "\n".join(ref[i:i + 70] for i in range(0, len(ref), 70)) + "\n")
+    head, body = sy.gff_text(orfs)
+    with open(os.path.join(d, "f.gff"), "w") as fh:
+        fh.write(head + body)
+    # ---- the stand-in, one core: file -> reads (oracle/bam_oracle.c: what pysam's C code does for the reference) -> everything else in Python
+    t = {}
+    t0 = time.perf_counter()
+    rd = c_oracle.read_bam(bam)
+    t["read_bam_c"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    counts = np.asarray(orc.tally_matrix(rd, L), np.int64)
+    t["tally_python"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    has, ins = orc.list_inserts(counts, mincov, lambda pos1: orc.region_tokens(rd, pos1))
+    t["list_inserts"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    rows = [dict(o) for o in orfs]
+    cons, cur = orc.build_consensus(mincov, counts, rows, True, ins if has else None, True)
+    cons_noins, _ = orc.build_consensus(mincov, counts, [dict(o) for o in orfs], True, ins if has else None, False)
+    t["build_consensus_x2"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    want = {"fa": orc.fasta_text("S", mincov, cons), "tsv": orc.coverage_tsv(counts),
+            "vcf": orc.vcf_records("MN908947.3", ref, cons_noins, counts, mincov, ins if has else None),
+            "gff": [[int(o["start"]), int(o["end"])] for o in (cur.values() if isinstance(cur, dict) else cur)]}
+    t["writers"] = time.perf_counter() - t1
+    standin = time.perf_counter() - t0
+    # ---- the product's command line on the same file (a process of its own, as from a shell: interpreter start and HIP set-up included)
+    outs = {e: os.path.join(d, "out." + e) for e in ("fa", "vcf", "gff", "tsv")}
+    code = "import sys; sys.path.insert(0, %r); from trueconsense_amd import TrueConsense as c; c.main(sys.argv[1:])" % ROOT
+    argv = ["-i", bam, "-ref", os.path.join(d, "ref.fa"), "-gff", os.path.join(d, "f.gff"), "-cov", str(mincov), "-name", "S", "-o", outs["fa"],
+            "-vcf", outs["vcf"], "-ogff", outs["gff"], "-doc", outs["tsv"], "--stats", os.path.join(d, "stats.json")]
+    walls = []
+    for _ in range(2):                                               # (the second call: code objects and page cache warm)
+        t1 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-c", code] + argv, capture_output=True, text=True)
+        walls.append(time.perf_counter() - t1)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+    stats = json.load(open(os.path.join(d, "stats.json")))
+    got = {"fa": open(outs["fa"]).read(), "tsv": open(outs["tsv"]).read(),
+           "vcf": "".join(ln + "\n" for ln in open(outs["vcf"]).read().split("\n") if ln and not ln.startswith("#")),
+           "gff": [[int(f[3]), int(f[4])] for f in (ln.split("\t") for ln in open(outs["gff"]).read().split("\n") if ln and not ln.startswith("#"))]}
+    same = {k: bool(got[k] == want[k]) for k in want}
+    return {"reads": n_reads, "positions": L, "indel_sites": len(sy.default_indel_sites(orfs)), "accepted_inserts": len(ins) if has else 0,
+            "python_standin_seconds": standin, "python_standin_stage_seconds": t, "cores": 1,
+            "product_cli_process_seconds": min(walls), "product_cli_process_seconds_runs": walls, "product_cli_in_process_seconds": stats.get("seconds"),
+            "outputs_equal": same, "all_four_outputs_equal": all(same.values()), "vcf_records": want["vcf"].count("\n"),
+            "note": "configs[0]: one 10k-read BAM (indel carriers at CDS boundaries included); oracle/tc_oracle.py end to end (the reference's loop structure, "
+                    "single core; reading the BAM is C on both sides) beside `TrueConsense -i .. -o .. -vcf .. -ogff .. -doc ..` in a process of its own"}
+
+
+def configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, tmp, rank, workers, deferred=None):
     """BASELINE configs[2] (1M reads, 2 % of them carrying an insertion or deletion at CDS starts / ends): two such files, their compressed
     bytes resident in HBM, a queue of them through the headline's runner; EVERY FASTA against the whole Python oracle chain (inserts
     included) on its file."""
@@ -807,14 +893,21 @@ def configs2_leg(a, np, sy, runner, ctx, ref, orfs, L, tmp, rank, workers):
     dt = time.perf_counter() - t1
     for d in db:
         d.close()
-    chk = check_all_fastas(a, np, paths, texts, L, a.mincov, orfs, workers=workers)
-    n_ins = texts[0].count("\n")                                   # (placeholder for the reader of the line: lengths below)
-    return {"value": L * n / dt, "unit": "positions/s", "ms_per_bam": 1e3 * dt / n, "bams": n, "files": 2,
-            "consensus_len": [len(t.split("\n")[1]) for t in texts[:2]], "fasta_all_timed": chk, "decoded_on": dict(runner.decoded_on),
+    res = {}
+
+    def check():                                                     # (the Python oracle chain on both files: after the GPU legs)
+        res["fasta_all_timed"] = check_all_fastas(a, np, paths, texts, L, a.mincov, orfs, workers=workers)
+    if deferred is None:
+        check()
+    else:
+        deferred.append(check)
+    res.update({"value": L * n / dt, "unit": "positions/s", "ms_per_bam": 1e3 * dt / n, "bams": n, "files": 2,
+            "consensus_len": [len(t.split("\n")[1]) for t in texts[:2]], "decoded_on": dict(runner.decoded_on),
             "input_generation_seconds_outside_clock": t_gen,
             "note": "configs[2]: 1M reads per BAM, 1 %% insertion + 1 %% deletion carriers at CDS boundaries; %d files' compressed bytes resident in HBM, "
                     "%d of them overlapped through the headline's runner; the insert candidates' tokens are voted on from entries the device "
-                    "collects in the resident inflated stream (ins_entries_kernel)" % (2, n)}
+                    "collects in the resident inflated stream (ins_entries_kernel)" % (2, n)})
+    return res
 
 
 def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx, kind="hard"):
@@ -900,7 +993,8 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         except Exception:
             traffic = {}
 
-    r3 = traffic.get("round4") or traffic.get("round3", {})
+    r3_key = next((k for k in ("round5", "round4", "round3") if k in traffic), None)
+    r3 = traffic.get(r3_key, {})
     r3k = r3.get("kernels", {})
 
     def pmc_bytes(names):
@@ -912,7 +1006,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         tr = pmc_bytes(pmc_of)
         b = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "single_stream_us": us1, "single_stream_frac": (bytes_moved / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS) if us1 > 0 else None,
-             "traffic": tr, "traffic_source": ("profiles/traffic.json round3: FETCH_SIZE + WRITE_SIZE of " + " + ".join(pmc_of) + ", " + r3.get("source", "")) if tr else None,
+             "traffic": tr, "traffic_source": ("profiles/traffic.json %s: FETCH_SIZE + WRITE_SIZE of " % r3_key + " + ".join(pmc_of) + ", " + r3.get("source", "")) if tr else None,
              "bytes_per_launch": bytes_moved, "avg_launch_us": us, "note": note}
         if alg is not None:
             b["algorithmic"] = {"bytes_per_launch": alg, "achieved": alg / (us * 1e-6) / 1e9 if us > 0 else 0.0,
@@ -936,24 +1030,41 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
                              "counters see beyond the stream); Huffman symbols decoded 32 lanes per block speculatively (latency-bound), LZ77 copies through "
                              "an LDS ring (issue-bound): see `issue`; neither is an HBM kernel", pmc_of=("bgzf_symbols", "bgzf_copy")),
            "roofline_hot_path": hot}
-    # what does bound the inflate kernels: wave-instructions issued per compute unit and cycle (PMC counts of the committed passes over
-    # this run's single-stream kernel times; a CU of waves in mostly scalar / LDS code issues about one instruction per cycle)
+    # What does bound these kernels.  The chip's issue rate (MI355X_MICROARCH.md: four SIMD-32 per CU, a wave64 VALU instruction takes
+    # a SIMD two cycles -> TWO vector wave-instructions per CU and cycle; one scalar unit per CU -> ONE scalar wave-instruction per CU
+    # and cycle) gives every kernel an issue floor: max(VALU / 2, SALU) / (CUs x clock).  Where the wave-cycles go instead, from the
+    # committed counter passes: `parked` = 1 - (SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY) / SQ_WAVE_CYCLES — waves that neither issue nor
+    # wait for their instruction's unit: at an s_waitcnt or a barrier, i.e. on memory.
     try:
         import torch
         pr = torch.cuda.get_device_properties(0)
         n_cu, ghz = int(pr.multi_processor_count), float(getattr(pr, "clock_rate", 2400000)) / 1e6
     except Exception:
         n_cu, ghz = 256, 2.4
-    issue = {"compute_units": n_cu, "clock_ghz": ghz, "source": r3.get("source"), "kernels": {}}
-    for name, key in (("bgzf_symbols", "inflate_symbols"), ("bgzf_copy", "inflate_copy")):
-        if name in r3k and cold.get(key, {}).get("us_per_bam", 0) > 0:
-            us1 = cold[key]["us_per_bam"]
-            issue["kernels"][name] = {"wave_insts_per_launch": r3k[name]["wave_insts_total"], "mix": r3k[name]["wave_insts"], "kernel_us": us1,
-                                      "insts_per_cu_cycle": r3k[name]["wave_insts_total"] / (n_cu * ghz * 1e3 * us1)}
+    issue = {"compute_units": n_cu, "clock_ghz": ghz, "source": r3.get("source"),
+             "rates": "2 VALU + 1 SALU wave-instructions per CU and cycle (4 SIMD-32, a wave64 VALU instruction = 2 cycles of one SIMD)", "kernels": {}}
+    cold_key = {"bgzf_symbols": "inflate_symbols", "bgzf_copy": "inflate_copy", "bgzf_crc32": "crc32", "pk_index": "records", "tally_planes_kernel": "tally", "call_kernel": "call"}
+    floor_sum = 0.0
+    for name, c in r3k.items():
+        wi = c.get("wave_insts")
+        if not wi:
+            continue
+        valu_us = wi.get("valu", 0) / (2.0 * n_cu * ghz * 1e3)
+        salu_us = (wi.get("salu", 0) + wi.get("smem", 0)) / (n_cu * ghz * 1e3)
+        e = {"wave_insts_per_launch": c.get("wave_insts_total"), "mix": wi, "valu_floor_us": valu_us, "salu_floor_us": salu_us,
+             "issue_floor_us": max(valu_us, salu_us), "parked": c.get("parked")}
+        floor_sum += e["issue_floor_us"]
+        us1 = cold.get(cold_key.get(name, ""), {}).get("us_per_bam", 0)
+        if us1 > 0:
+            e.update(kernel_us=us1, floor_over_kernel_time=e["issue_floor_us"] / us1)
+        issue["kernels"][name] = e
     if r3.get("wave_insts_per_bam"):
-        issue["all_kernels_of_a_bam"] = {"wave_insts": r3["wave_insts_per_bam"],
-                                         "ms_if_every_issue_slot_were_used": r3["wave_insts_per_bam"] / (n_cu * ghz * 1e6),
-                                         "ms_per_step_pipelined": None}
+        tv = sum(c.get("wave_insts", {}).get("valu", 0) for c in r3k.values())
+        ts = sum(c.get("wave_insts", {}).get("salu", 0) + c.get("wave_insts", {}).get("smem", 0) for c in r3k.values())
+        issue["all_kernels_of_a_bam"] = {"wave_insts": r3["wave_insts_per_bam"], "valu": tv, "salu": ts,
+                                         "valu_floor_ms": tv / (2.0 * n_cu * ghz * 1e6), "salu_floor_ms": ts / (n_cu * ghz * 1e6),
+                                         "issue_floor_ms": floor_sum / 1e3, "ms_per_step_pipelined": None,
+                                         "hbm_bytes_per_bam": r3.get("hbm_bytes_per_bam")}
     if issue["kernels"]:
         out["roofline"]["issue"] = issue
     return out
@@ -1065,9 +1176,10 @@ def resident_leg(a, ctx0, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            per = (tj.get("round4") or {}).get("tally_hbm_bytes_per_bam")
+            rk = next((k for k in ("round5", "round4") if k in tj), None)
+            per = ((tj.get(rk) or {}).get("kernels", {}).get("tally_planes_kernel") or {}).get("hbm_bytes")
             traffic = per * B if per else None                      # (a round-1 figure stood here until round 3: dropped rather than quoted stale)
-            traffic_src = "profiles/traffic.json round4: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tally_planes_kernel per 1M-read BAM x batch" if per else None
+            traffic_src = ("profiles/traffic.json %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tally_planes_kernel per 1M-read BAM (one BAM per launch) x batch" % rk) if per else None
         except Exception:
             traffic = None
     achieved = real / (tally_us * 1e-6) / 1e9 if tally_us > 0 else 0.0

@@ -853,3 +853,18 @@ def test_pipeline_long_queue_every_item_right(ctx):
         for r in rss + single:
             r.free()
         pipe.close()
+
+
+@pytest.mark.gpu
+def test_configs0_python_standin_beside_the_command_line(tmp_path):
+    """BASELINE configs[0] (10k synthetic 150-bp reads over the 29 903-bp reference): the Python stand-in for the reference's whole run
+    (TrueConsense.py:212-264 — oracle/tc_oracle.py end to end: per-token tally loop, ListInserts with region pile-ups, both BuildConsensus
+    walks, the writers) beside the product's command line on the same BAM file: FASTA text, VCF records, corrected ORF coordinates and
+    coverage TSV must be the same.  (bench.py's `configs0` leg, at its own size.)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ref, orfs = sy.make_reference()
+    r = bench.configs0_leg(np, sy, ref, orfs, len(ref), str(tmp_path), 30)
+    assert "error" not in r, r
+    assert r["outputs_equal"] == {"fa": True, "tsv": True, "vcf": True, "gff": True}, r
+    assert r["accepted_inserts"] >= 1 and r["vcf_records"] > 10 and r["python_standin_seconds"] > r["product_cli_in_process_seconds"]["tally"]

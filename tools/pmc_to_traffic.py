@@ -1,9 +1,9 @@
-"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round4" block (or the key given as third argument) of profiles/traffic.json that
+"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round5" block (or the key given as third argument: round5_hard, round5_real) of profiles/traffic.json that
 bench.py's roofline blocks quote.   python3 tools/pmc_to_traffic.py gpurun_out/TAG/pmc_e2e_summary.txt profiles/TAG_pmc_e2e.txt"""
 import ast, json, os, re, sys
 
 src, committed_as = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else "round4"
+key = sys.argv[3] if len(sys.argv) > 3 else "round5"
 k = {}
 for line in open(src):
     m = re.match(r"^([\w<>, ]+?) (\{.*\}) n= (\d+)$", line.strip())
@@ -24,6 +24,11 @@ for name, c in k.items():
                  "hbm_bytes": round((c["FETCH_SIZE"] * (2 if name in wide else 1) + c.get("WRITE_SIZE", 0.0)) * 1024),
                  "wave_insts": insts, "wave_insts_total": sum(insts.values()), "waves": round(c.get("SQ_WAVES", 0)),
                  "lds_bank_conflict_cycles": round(c.get("SQ_LDS_BANK_CONFLICT", 0))}
+    # where the wave-cycles go: a wave that neither issues (ACTIVE_INST_ANY) nor waits in the issue stage for its instruction's unit
+    # (WAIT_INST_ANY) is parked at an s_waitcnt or a barrier — on memory, mostly
+    wc, act, wait = c.get("SQ_WAVE_CYCLES", 0.0), c.get("SQ_ACTIVE_INST_ANY", 0.0), c.get("SQ_WAIT_INST_ANY", 0.0)
+    if wc > 0:
+        out[name].update(wave_cycles=round(wc), active_inst_any=round(act), wait_inst_any=round(wait), parked=round(1.0 - (act + wait) / wc, 4))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tp = os.path.join(root, "profiles", "traffic.json")
 t = json.load(open(tp))

@@ -155,7 +155,7 @@ def lib():
     return _lib
 
 
-RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtcmi_rccl.so")
+RCCL_LIB_PATH = os.path.join(_HERE, "lib", "libtcmi_rccl.so")
 RCCL_ID_BYTES = 128
 _RCCL_SIGS = {
     "tcmi_rccl_unique_id": (_int, [_vp]),

@@ -623,7 +623,6 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
     D.d_base = (uint64_t *)tcmi_arena_take(ctx, al(nb * 8));
     D.d_total = (unsigned long long *)tcmi_arena_take(ctx, 256);
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
-    uint32_t *d_seg = (uint32_t *)tcmi_arena_take(ctx, al(nb * 512));
     uint32_t *d_tok = (uint32_t *)tcmi_arena_take(ctx, b_tok);
 
     if (resident) d_file = f->d_bytes;
@@ -636,7 +635,7 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
     (void)hipGetLastError();
     {
         tcmi_bgzf_decode_args g;
-        g.d_file = d_file; g.d_desc = D.d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_seg = d_seg; g.d_out = D.d_out; g.d_slot = D.d_slot; g.d_nrec = D.d_nrec;
+        g.d_file = d_file; g.d_desc = D.d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_out = D.d_out; g.d_slot = D.d_slot; g.d_nrec = D.d_nrec;
         g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
         g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;

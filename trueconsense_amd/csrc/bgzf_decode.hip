@@ -75,7 +75,6 @@ struct BlkTabs {                                    // per block
     uint32_t err;               // ST_*
     uint32_t go;                // 1: symbols to decode at pos
     uint32_t last;              // 1: the stream's last deflate block
-    uint32_t seg;               // 1: the tokens are left in the lanes' scratch, in pieces (SymArgs::seg)
 };
 struct HdrScratch {                                 // per block, while its header is decoded and its tables are built
     uint8_t lens[320];
@@ -88,7 +87,7 @@ struct HdrScratch {                                 // per block, while its head
 #define TCMI_SYM_ASM 1
 #endif
 #ifndef TCMI_SYM_MOVE
-#define TCMI_SYM_MOVE 16                            // bgzf_symbols: tokens a lane has in flight when a window's tokens are moved to their places
+#define TCMI_SYM_MOVE 8                             // bgzf_symbols: tokens a lane has in flight when the tokens are gathered to their places
 #endif
 #ifndef TCMI_SYM_WAVES
 #define TCMI_SYM_WAVES 5                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (5: 96 VGPRs; with 4 — 128 —
@@ -115,8 +114,7 @@ struct SymArgs {
     const uint32_t *__restrict__ file32;
     const BlockDesc *blocks;
     uint32_t *tokens;           // block b's tokens at tokens + blocks[b].tok: tok_cap final ones, then tok_cap of scratch
-    uint32_t *n_tok;            // [n_blocks]: tokens | 1 << 31 when they are in pieces
-    uint32_t *seg;              // [n_blocks][128]: per piece its first token (offset from the block's tokens), per piece its tokens
+    uint32_t *n_tok;            // [n_blocks]
     uint32_t *status;           // [n_blocks]
     int32_t n_blocks;           // (the launch's blocks end here)
     int32_t first_block;        // ... and start here: workgroup 0's first block
@@ -205,11 +203,16 @@ __device__ __forceinline__ uint32_t group_scan_add(uint32_t v)
 }
 
 enum { SY_LIT = 0, SY_MATCH = 1, SY_EOB = 2, SY_BAD = 3 };
+#ifdef TCMI_HDR_CALL                                  // (A/B: -DTCMI_HDR_CALL gives the header step a register budget of its own: a real call)
+#define TCMI_HDR_INLINE __attribute__((noinline))
+#else
+#define TCMI_HDR_INLINE __forceinline__
+#endif
 
 // ---- header of one deflate block and its tables: one wavefront, the block's own (T, pay) ------------------------------------------
 // -> T.go = 1 and T.pos at the first symbol (a Huffman block), or the block's stream is finished / damaged (T.go = 0).  Stored
 // deflate blocks are turned into raw tokens here and the next header is taken at once.
-__device__ __forceinline__ void block_header(BlkTabs &T, HdrScratch &H, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
+__device__ TCMI_HDR_INLINE void block_header(BlkTabs &T, HdrScratch &H, const uint32_t *pay, uint32_t base_bit, uint32_t *toks, uint32_t cap, bool &last,
                                           uint64_t *stamps, int blk, bool one_header = false)
 {
     const int lane = threadIdx.x & 63;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             for (uint32_t i = (uint32_t)lane; i < n; i += 64) pay_lds[i] = gsrc[i];
         }
     }
-    if (lane == 0) { T.pos = base_bit; T.end = end; T.ntok = 0; T.err = ST_OK; T.go = 0; T.last = 0; T.seg = 0; }
+    if (lane == 0) { T.pos = base_bit; T.end = end; T.ntok = 0; T.err = ST_OK; T.go = 0; T.last = 0; }
     wave_sync();
     if (have) TCMI_STAMP(a.stamps, blk, 1);
     bool last = !have;
@@ -925,31 +928,41 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             const unsigned long long spill_mask = __ballot(alive && spilled);
             const bool block_redo = ((spill_mask >> lane0) & (NB == 1 ? ~0ull : (1ull << (SYM_LANES & 63)) - 1ull)) != 0;
             TCMI_STAMP(a.stamps, blk0, 5);
-            // The block's only deflate stream (the usual BGZF block): the tokens stay where they are parked and bgzf_copy gets the
-            // list of pieces.  Otherwise they are moved behind the tokens the block has already.
-            const bool pieces = on && berr == ST_OK && B.last != 0 && ntok0 == 0 && !block_redo && !more;
-            if (on && blk0 + b < a.n_blocks) {
-                uint32_t *seg = a.seg + (size_t)(blk0 + b) * 128;
-                seg[c] = pieces ? bcap + before * (uint32_t)SYM_LANES + (uint32_t)c : 0u;      // (its tokens: every SYM_LANES-th word from there)
-                seg[64 + c] = pieces ? cnt : 0u;
-#pragma unroll
-                for (int k = 1; k < NB; ++k) { seg[c + SYM_LANES * k] = 0; seg[64 + c + SYM_LANES * k] = 0; }
-            }
-            if (on && berr == ST_OK && !pieces) {
-                uint32_t *const dst = btok + ntok0 + (incl - cnt);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the scratch stores are this lane's own)
+            // The true tokens to their places, in order, behind those the block has already.  They lie where the lanes parked them: lane
+            // j's k-th at scratch[k][j], of which [before_j, before_j + cnt_j) are true and belong at excl_j onwards.  The lanes of the
+            // block take the OUTPUT tokens in turn (lane c: c, c + SYM_LANES, ..): every lane follows the table {where lane j's tokens
+            // end, before_j - excl_j} through LDS — the owner of a lane's next token is the same lane or a later one —, reads the token
+            // from the parked rows (this workgroup wrote them a moment ago: L2) and the stores of a turn are consecutive words.
+            // (Round 4 left the tokens parked and gave bgzf_copy a list of 32 pieces: its lanes then fetched a batch of 64 tokens from
+            // 64 rows — 170 MB of 64-byte sectors per BAM for 4.4 MB of tokens, from HBM: the rows of the 4 000 blocks in flight do
+            // not fit the L2s.  Before that every lane moved its own tokens: a store per token and lane into 32 places.)
+            L.a.ring[lane][0] = make_uint2(incl, before - (incl - cnt));
+            wave_sync();
+            if (on && berr == ST_OK) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the parked tokens are this wavefront's own stores)
                 if (!block_redo) {
-                    constexpr int MV = TCMI_SYM_MOVE;
-                    for (uint32_t i = 0; i < cnt; i += MV) {        // (MV loads in flight: the loop is all latency)
-                        uint32_t t[MV];
+                    constexpr int GV = TCMI_SYM_MOVE;
+                    const uint32_t *const rows = btok + bcap;
+                    uint32_t *const dst = btok + ntok0;
+                    uint32_t owner = 0;
+                    uint2 e = L.a.ring[lane0][0];
+                    for (uint32_t i0 = (uint32_t)c; i0 < all; i0 += GV * SYM_LANES) {      // (GV loads in flight: the loop is all latency)
+                        uint32_t at[GV], t[GV];
 #pragma unroll
-                        for (int k = 0; k < MV; ++k) t[k] = i + k < cnt ? scratch[(size_t)(before + i + k) * SYM_LANES] : 0u;
+                        for (int k = 0; k < GV; ++k) {
+                            const uint32_t i = min(i0 + (uint32_t)(k * SYM_LANES), all - 1u);
+                            while (e.x <= i && owner + 1u < (uint32_t)SYM_LANES) { ++owner; e = L.a.ring[lane0 + (int)owner][0]; }
+                            at[k] = (i + e.y) * (uint32_t)SYM_LANES + owner;
+                        }
 #pragma unroll
-                        for (int k = 0; k < MV; ++k) if (i + k < cnt) dst[i + k] = t[k];
+                        for (int k = 0; k < GV; ++k) t[k] = rows[at[k]];
+#pragma unroll
+                        for (int k = 0; k < GV; ++k) if (i0 + (uint32_t)(k * SYM_LANES) < all) dst[i0 + (uint32_t)(k * SYM_LANES)] = t[k];
                     }
                 } else {
                     // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------
                     // (the position of a lane's true start is not kept: decode from the lane's own start and drop `before` symbols)
+                    uint32_t *const dst = btok + ntok0 + (incl - cnt);
                     uint32_t pp = min(s_c, b_soft);
                     for (uint32_t i = 0; alive && i < before + cnt; ++i) {
                         uint32_t tok = 0;
@@ -959,14 +972,13 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 }
             }
             TCMI_STAMP(a.stamps, blk0, 6);
-            if (on && c == 0) B.seg = pieces ? 1u : 0u;
             if (on && c == 0) { B.ntok = ntok0 + all; B.pos = eob_pos; B.err = berr; }
             if constexpr (WIN) hdr_due = uni(__ballot(more) != 0 ? 1u : 0u) == 0u;       // (an end-of-block code was reached: a header comes next)
         }
         __syncthreads();
     }
     if (have && lane == 0) {
-        a.n_tok[blk] = T.ntok | (T.seg << 31);
+        a.n_tok[blk] = T.ntok;
         a.status[blk] = T.err;
     }
 }
@@ -976,8 +988,6 @@ struct CopyArgs {
     const BlockDesc *blocks;
     const uint32_t *tokens;
     const uint32_t *n_tok;
-    const uint32_t *seg;        // pieces of blocks whose n_tok has bit 31 set
-    uint32_t piece_stride;      // a piece's tokens lie this many words apart (the lanes per block of the bgzf_symbols variant that parked them)
     uint8_t *out;
     uint32_t *rec_slot;
     uint32_t *n_rec;
@@ -1116,16 +1126,8 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     const BlockDesc d = a.blocks[blk];
     const uint32_t ulen = d.ulen;
     uint32_t err = uni(a.status[blk]);
-    const uint32_t ntok_raw = err == ST_OK ? uni(a.n_tok[blk]) : 0u;
-    const uint32_t ntok = ntok_raw & 0x7FFFFFFFu;
-    const bool pieces = (ntok_raw >> 31) != 0;      // the tokens lie where bgzf_symbols' lanes parked them: piece `lane` is mine to describe
+    const uint32_t ntok = err == ST_OK ? uni(a.n_tok[blk]) : 0u;
     const uint32_t *toks = a.tokens + d.tok;
-    uint32_t p_off = 0, p_cnt = 0, p_pre = 0, p_cur = 0;
-    if (pieces) {
-        p_off = a.seg[(size_t)blk * 128 + lane];
-        p_cnt = a.seg[(size_t)blk * 128 + 64 + lane];
-        p_pre = wave_scan_add(p_cnt) - p_cnt;
-    }
     // The blocks' outputs follow each other in the stream without gaps, so this block's starts at any byte.  Positions in this
     // kernel count from the 16-byte boundary in front of it (`a0` bytes of the previous block come first and are never touched):
     // ring index and stream address of a byte are then equal modulo 16 and the flush can use 16-byte rows.
@@ -1269,28 +1271,14 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     uint32_t n_match = 0, n_slow = 0, n_round = 0;
     const uint32_t n_team = 0, n_teamed = 0;
     housekeeping();
-    // the tokens of the batch that starts at `base`, a token a lane (pieces: the lanes of bgzf_symbols parked them piece by piece)
-    // ONE load, of every lane, outside any branch, masked where it is used: a load under a condition (or in the loop over the pieces)
-    // makes the compiler wait for it on the spot, and the batch's copy loops would start a trip to memory later (2.5 : 1: 1 035 -> 977 us).
-    // (The pieces cover the block's tokens without gaps: a lane has a token iff its index is below ntok.)
+    // the tokens of the batch that starts at `base`, a token a lane: consecutive words (bgzf_symbols left them in order).
+    // ONE load, of every lane, outside any branch, masked where it is used: a load under a condition makes the compiler wait for it on
+    // the spot, and the batch's copy loops would start a trip to memory later (2.5 : 1: 1 035 -> 977 us).
     bool t_has = false;
     auto fetch_tokens = [&](uint32_t base) __attribute__((always_inline)) {
         const uint32_t g = base + (uint32_t)lane;
         t_has = g < ntok;
-        uint32_t at = g;
-        if (pieces) {
-            at = 0;
-            while (p_cur < 64u) {
-                const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)p_pre, (int)p_cur);
-                const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)p_cnt, (int)p_cur);
-                const uint32_t po = (uint32_t)__builtin_amdgcn_readlane((int)p_off, (int)p_cur);
-                if (ps >= base + 64u) break;
-                at = g >= ps && g < ps + pc ? po + (g - ps) * a.piece_stride : at;
-                if (ps + pc > base + 64u) break;
-                ++p_cur;
-            }
-        }
-        return toks[t_has ? at : 0u];                       // (a lane without a token reads word 0 and drops it)
+        return toks[t_has ? g : 0u];                        // (a lane without a token reads word 0 and drops it)
     };
     uint32_t t_ahead = fetch_tokens(0);         // (a batch's tokens are asked for while the batch before is copied: HBM is a microsecond away)
     bool t_ahead_has = t_has;
@@ -1643,7 +1631,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.stamps = d_stamps;
     sa.file32 = reinterpret_cast<const uint32_t *>(g.d_file);
     sa.blocks = static_cast<const BlockDesc *>(g.d_desc);
-    sa.tokens = g.d_tok - g.tok_base; sa.n_tok = g.d_ntok; sa.seg = g.d_seg; sa.status = g.d_stat; sa.n_blocks = (int32_t)b_end; sa.first_block = (int32_t)b_first;
+    sa.tokens = g.d_tok - g.tok_base; sa.n_tok = g.d_ntok; sa.status = g.d_stat; sa.n_blocks = (int32_t)b_end; sa.first_block = (int32_t)b_first;
     sa.pay_dwords = g.pay_dwords;
     sa.win_dwords = 0;
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
@@ -1686,12 +1674,11 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
     CopyArgs ca;
-    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = sa.tokens; ca.n_tok = g.d_ntok; ca.seg = g.d_seg; ca.out = g.d_out; ca.rec_slot = g.d_slot;
+    ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = sa.tokens; ca.n_tok = g.d_ntok; ca.out = g.d_out; ca.rec_slot = g.d_slot;
     ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)b_end; ca.first_block = (int32_t)b_first; ca.n_ref = g.n_ref;
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     static const int team_env = std::getenv("TCMI_TEAM_BYTES") ? std::atoi(std::getenv("TCMI_TEAM_BYTES")) : -1;      // (A/B measurements)
     ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;
-    ca.piece_stride = 64u / (uint32_t)per_wg;
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
     if (TCMI_COPY_TEAMS && g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
     else if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);

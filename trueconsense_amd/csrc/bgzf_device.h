@@ -187,7 +187,6 @@ struct tcmi_bgzf_decode_args {
     const void *d_desc;             // BlockDesc [n_blocks]
     uint32_t *d_tok;                // token array (BlockDesc::tok / tok_cap)
     uint32_t *d_ntok;               // [n_blocks]
-    uint32_t *d_seg;                // [n_blocks][128]: where the pieces of a block's tokens lie
     uint8_t *d_out;                 // inflated stream (BlockDesc::uout)
     uint32_t *d_slot;               // [n_blocks][MAX_REC_PER_BLOCK] record starts
     uint32_t *d_nrec;               // [n_blocks]

@@ -33,6 +33,7 @@ struct FastArgs {
     // grid was sized from — blocks beyond the real counts leave at once — and n_tail blocks stride over the event words.
     const uint32_t *dev_counts;
     int32_t n_tail;                 // tail blocks of the launch (>= 1 when there can be events)
+    int32_t n_chunk_blocks;         // blocks that take chunks: block b the chunks b, b + n_chunk_blocks, ..
 };
 
 constexpr int TILE = FB;            // positions per block of the ride-along call: one lane each
@@ -78,14 +79,14 @@ static __device__ inline int block_scan_incl(int v, int *wave_tot /* LDS [FB / 6
     return v + base;
 }
 
-// Tail blocks (block index >= n_chunks): the tokens that are no plain A/C/G/T bases, as event words
+// Tail blocks (behind the ride-along blocks, in front of the chunk blocks): the tokens that are no plain A/C/G/T bases, as event words
 // (position | kind).  Equal words are counted inside the wave (ballot match), one atomic per distinct word
 // and wave: at an indel site thousands of reads carry the same event.  A covered position without an
 // A/C/G/T base was counted into column A by subtraction in the chunk blocks and is taken out here.
-static __device__ inline void tally_tail_block(const FastArgs &a, int bid /* block index behind the ride-along blocks */, int64_t n_events)
+static __device__ inline void tally_tail_block(const FastArgs &a, int tail /* which of the n_tail tail blocks */, int64_t n_events)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int64_t i0 = (int64_t)(bid - a.n_chunks) * FB; i0 < n_events; i0 += (int64_t)a.n_tail * FB) {
+    for (int64_t i0 = (int64_t)tail * FB; i0 < n_events; i0 += (int64_t)a.n_tail * FB) {
     const int64_t i = i0 + tid;
     const bool valid = i < n_events;
     const uint32_t key = valid ? a.events[i] : 0u;

@@ -134,12 +134,18 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         call_other_tile(a, (int)blockIdx.x);
         return;
     }
-    const int bid = (int)blockIdx.x - a.n_call2;
-    if (bid >= a.n_chunks) {
-        tally_tail_block(a, bid, a.dev_counts ? (int64_t)min(a.dev_counts[1], (uint32_t)a.n_events) : a.n_events);
+    // then the tail blocks (event words) — in FRONT of the chunk blocks: behind them they started only when chunk blocks had left
+    // (the chunk blocks of a 1M-read BAM fill every slot of the chip) and ran on their own at the launch's end
+    const int b1 = (int)blockIdx.x - a.n_call2;
+    if (b1 < a.n_tail) {
+        tally_tail_block(a, b1, a.dev_counts ? (int64_t)min(a.dev_counts[1], (uint32_t)a.n_events) : a.n_events);
         return;
     }
-    if (a.dev_counts && (uint32_t)bid >= a.dev_counts[0]) return;   // (the grid was sized from the packer's capacity)
+    // A chunk block takes the chunks b, b + n_chunk_blocks, ..: when the counts are still on the device (the one-sync file path) the
+    // grid is sized from the resident slots, not from the packer's CAPACITY — 5 700 blocks for the ~1 100 chunks of a 1M-read BAM, each
+    // of the idle ones a trip to memory for the count while it held a slot (LDS and registers) that a chunk block was waiting for.
+    const int n_real = a.dev_counts ? (int)min(a.dev_counts[0], (uint32_t)a.n_chunks) : a.n_chunks;
+    for (int bid = b1 - a.n_tail; bid < n_real; bid += a.n_chunk_blocks) {
     const tcmi_fast_chunk *chp = a.chunks + bid;
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
@@ -389,6 +395,8 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             if (nT) atomicAdd(&a.counts[(int64_t)TCMI_T * a.ld + gp], nT);
         }
     }
+    __syncthreads();                            // (the next chunk's set-up writes what the adds above read)
+    }
 }
 
 #undef TCMI_ISSUE_STAGE
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 
 
 
-// Launch over the aligned set of a read set: [ride-along call blocks][one block per chunk][tail blocks: event words].
+// Launch over the aligned set of a read set: [ride-along call blocks][tail blocks: event words][chunk blocks].
 int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld, int32_t *d_counts)
 {
     FastArgs a = {};
@@ -407,11 +415,15 @@ int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int
     a.counts = d_counts; a.ld = ld; a.n_events = rs->f_events; a.L = (int32_t)L;
     a.pair_ok = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_counts) % 8 == 0);
     a.n_tail = (int32_t)((rs->f_events + FB - 1) / FB);
+    int64_t n_chunk_blocks = rs->f_chunks;
     if (rs->d_dev_counts) {                                     // totals still on the device: f_chunks / f_events are the capacities
         a.dev_counts = rs->d_dev_counts;
-        a.n_tail = (int32_t)std::min<int64_t>(a.n_tail, 256);
+        a.n_tail = (int32_t)std::min<int64_t>(a.n_tail, 128);
+        // (one round of the chip's slots and a half: pk_pack cuts a file into about one chunk per slot; a file with more takes turns)
+        n_chunk_blocks = std::min<int64_t>(n_chunk_blocks, (int64_t)ctx->n_cu * ctx->wg_per_cu * 3 / 2);
     }
-    int64_t grid = rs->f_chunks + a.n_tail;
+    a.n_chunk_blocks = (int32_t)std::max<int64_t>(1, n_chunk_blocks);
+    int64_t grid = (rs->f_chunks ? n_chunk_blocks : 0) + a.n_tail;
     if (ctx->ride && !ctx->ride->taken) {                     // carry another workspace's call in this launch
         tcmi_ride *r = ctx->ride;
         a.counts2 = r->counts; a.ld2 = r->ld; a.L2 = (int32_t)r->L; a.n_call2 = (int32_t)((r->L + TILE - 1) / TILE);

@@ -67,9 +67,29 @@ def kernel_times(contexts, _ffi, n):
 
 
 # ----------------------------------------------------------------------------------------------- inputs
-def write_inputs(tmp, ref, orfs, n_files, n_reads, rank, indels, level):
-    """Seeded synthetic BAM files of configs[1] (or [2] with --indels).  -> (paths, reads of file 0)."""
+def like_real_data(np, kind, n, seed=1):
+    """Qualities and names that make a synthetic BAM compress like real data.  "hard": Illumina-style names (all distinct), qualities drawn
+    from four bins — 6 : 1 instead of 35 : 1; "real": qualities drawn like an Illumina run's (a peak at Q36, a tail down to Q2) — 2.5 : 1."""
+    rng = np.random.default_rng(seed)
+    if kind == "real":
+        w = np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004
+        qual = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=w / w.sum())
+    else:
+        qual = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(n, 150), p=[0.02, 0.05, 0.13, 0.80])
+
+    def digits(v, w):
+        return ((v[:, None] // 10 ** np.arange(w - 1, -1, -1)[None, :]) % 10 + 48).astype(np.uint8)
+    lit = lambda t: np.tile(np.frombuffer(t, np.uint8), (n, 1))
+    names = np.concatenate([lit(b"A00123:45:HXXXXX:"), digits(rng.integers(1, 5, n), 1), lit(b":"), digits(rng.integers(1101, 2679, n), 4), lit(b":"),
+                            digits(rng.integers(1000, 33000, n), 5), lit(b":"), digits(rng.integers(1000, 37000, n), 5)], axis=1)
+    return qual, names
+
+
+def write_inputs(tmp, ref, orfs, n_files, n_reads, rank, indels, level, kind="headline"):
+    """Seeded synthetic BAM files of configs[1] (or [2] with --indels; kind "hard" / "real": files that compress like real data, for
+    counter passes over them).  -> (paths, reads of file 0)."""
     from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
     from trueconsense_amd import synthetic as sy
     from trueconsense_amd.io import bamwriter
     sites = sy.default_indel_sites(orfs) if indels else None
@@ -80,6 +100,11 @@ def write_inputs(tmp, ref, orfs, n_files, n_reads, rank, indels, level):
         path = os.path.join(tmp, "r%d_%d.bam" % (rank, k))
         if indels:
             bamwriter.write_bam(path, reads, "MN908947.3", len(ref), level=level)
+        elif kind != "headline":
+            qual, names = like_real_data(np, kind, n_reads, seed=k + 1)
+            bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n_reads, -1), 150, "MN908947.3", len(ref), level=level,
+                                     qual=qual, names=names)
+            reads["qual"] = qual.reshape(-1)                      # (the oracle chain's region pile-ups read the qualities)
         else:
             bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n_reads, -1), 150,
                                      "MN908947.3", len(ref), level=level)
@@ -399,6 +424,8 @@ def main():
     ap.add_argument("--walkers", type=int, default=2)
     ap.add_argument("--gpu-streams", type=int, default=0, help="contexts (stream + device arena) the GPU stage of consecutive BAMs alternates between (0 = auto: 8, fewer on a host with few cores per rank — a context's thread spins while it waits for its stream)")
     ap.add_argument("--indels", action="store_true", help="BASELINE configs[2]: indel carriers at CDS boundaries")
+    ap.add_argument("--file-kind", choices=("headline", "hard", "real"), default="headline",
+                    help="the bench files themselves written to compress like real data (6 : 1 / 2.5 : 1): counter passes over those decoders (tools/pmc_e2e.sh)")
     ap.add_argument("--host-decode", action="store_true", help="decode the BAMs on the host (tcmi_bam_load) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident kernel-rate leg")
@@ -467,7 +494,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tcmi_bench_", dir=base)
     try:
         t_gen = time.perf_counter()
-        paths, reads0 = write_inputs(tmp, ref, orfs, a.files, a.reads, rank, a.indels, a.level)
+        paths, reads0 = write_inputs(tmp, ref, orfs, a.files, a.reads, rank, a.indels, a.level, a.file_kind)
         t_gen = time.perf_counter() - t_gen
         out = run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, Context, FileRunner, Pipeline,
                         ref, orfs, L, paths, reads0, decoders, decode_threads, cores, t_gen)
@@ -577,7 +604,7 @@ def run_bench(a, rank, local_rank, world, rehearse, dist, torch, np, _ffi, sy, C
                                % (2 if a.indels else 1, a.reads, a.reads * 150 // L,
                                   ", indel carriers at CDS boundaries" if a.indels else "", len(paths), a.level,
                                   "; many-BAM shard over %d GPUs, no data-path collective" % world if world > 1 else ""),
-                   "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov,
+                   "positions": L, "reads_per_bam": a.reads, "mincov": a.mincov, "file_kind": a.file_kind,
                    "stages": "[file_to_fasta only: read (file bytes into pinned memory, BGZF block table, BAM header; host, %d files in flight) -> "
                              "H2D of the COMPRESSED file ->] HIP: BGZF inflate + record chain + CIGAR projection / "
                              "classification / bit-plane pack -> HIP tally + call (records to pinned host memory) -> host walk + "
@@ -922,18 +949,8 @@ def hard_bam_leg(a, single, sctx, _ffi, np, sy, ref, L, tmp, runner, ctx, kind="
     orfs = sy.make_reference()[1]
     single_walker = Walker([o["start"] for o in orfs], [o["end"] for o in orfs], [1] * len(orfs))
     n = a.reads
-    rng = np.random.default_rng(1)
     reads = sy.make_reads(ref, n, seed=4242)
-    if kind == "real":
-        w = np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004
-        qual = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=w / w.sum())
-    else:
-        qual = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(n, 150), p=[0.02, 0.05, 0.13, 0.80])
-    def digits(v, w):
-        return ((v[:, None] // 10 ** np.arange(w - 1, -1, -1)[None, :]) % 10 + 48).astype(np.uint8)
-    lit = lambda t: np.tile(np.frombuffer(t, np.uint8), (n, 1))
-    names = np.concatenate([lit(b"A00123:45:HXXXXX:"), digits(rng.integers(1, 5, n), 1), lit(b":"), digits(rng.integers(1101, 2679, n), 4), lit(b":"),
-                            digits(rng.integers(1000, 33000, n), 5), lit(b":"), digits(rng.integers(1000, 37000, n), 5)], axis=1)
+    qual, names = like_real_data(np, kind, n, seed=1)
     path = os.path.join(tmp, kind + ".bam")
     t0 = time.perf_counter()
     bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=a.level, qual=qual, names=names)

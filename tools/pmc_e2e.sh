@@ -8,7 +8,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_W
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   d=$out/pmc_$(echo $set | cut -c1-16 | tr ' ' '_')
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 bench.py --no-resident --no-cpu-baseline --no-hard-bam --no-cli-batch --steps 8 --warmup 2 --min-seconds 0 --gpu-streams 1 "$@" > $d.json 2> $d.err || { echo "pass failed: $set"; tail -5 $d.err; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 bench.py --no-resident --no-cpu-baseline --no-hard-bam --no-cli-batch --no-configs0 --steps 8 --warmup 2 --min-seconds 0 --gpu-streams 1 "$@" > $d.json 2> $d.err || { echo "pass failed: $set"; tail -5 $d.err; exit 1; }
 done
 python3 - $out/pmc_* <<'PY'
 import csv, sys, glob, collections, re

@@ -29,167 +29,6 @@
 
 namespace {
 
-// ---- bgzf_crc32: the CRC-32 of every block's inflated bytes against the value in the block's trailer (SAM spec §4.1; htslib
-// checks it on every block it reads).  One wavefront per block, four blocks per workgroup.  The block is read in rows of
-// 2 KiB, coalesced: lane l takes the 32 bytes at l * 32 of every row (the rows are cut from the block's END, so the short row
-// comes first).  A lane's 16 bytes go through sixteen byte-indexed tables at once ("slicing by 16": table k holds the register
-// after one byte and k zero bytes; one shift-and-select, one LDS read and half an XOR per byte — the byte-at-a-time loop this
-// replaces needed five instructions a byte, and the kernel is bound by instruction issue).  CRCs are joined zlib's
-// crc32_combine way: "append n zero bytes" is a linear operator on the CRC register (a 32 x 32 matrix over GF(2)).  Down its
-// column a lane needs the operator for 2 KiB once per row (four byte-indexed tables in LDS, built from the 32 columns of the
-// matrix the host passes); across the lanes the 64 column CRCs are joined pairwise with the operators for 32, 64, .. 1024 bytes.
-struct CrcArgs {
-    const uint8_t *file;        // compressed file (for the trailers)
-    const uint8_t *out;         // inflated stream
-    const BlockDesc *blocks;
-    uint32_t *status;           // [n_blocks]: ST_OK -> ST_BAD_CRC on a mismatch (blocks that already failed are skipped)
-    int32_t n_blocks;
-    uint32_t zeros[6][32];      // zeros[k][i]: the CRC register with only bit i set, after 32 << k zero bytes
-    uint32_t zeros_row[32];     // ... after 2048 zero bytes
-};
-
-__global__ __launch_bounds__(256) void bgzf_crc32(CrcArgs a)
-{
-    __shared__ uint32_t s_t[16][256];                       // s_t[k][v]: the register after byte v and k zero bytes
-    __shared__ uint32_t s_row[4][256];                      // s_row[b][v]: the register (v << 8 b), 2 KiB of zeros later
-    __shared__ uint32_t s_op[6][32];
-    {
-        uint32_t c = threadIdx.x;                           // the reflected CRC-32 table (polynomial 0xEDB88320)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        s_t[0][threadIdx.x] = c;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) m ^= a.zeros_row[8 * b + i] & (0u - ((threadIdx.x >> i) & 1u));
-            s_row[b][threadIdx.x] = m;
-        }
-        if (threadIdx.x < 192) s_op[threadIdx.x >> 5][threadIdx.x & 31] = a.zeros[threadIdx.x >> 5][threadIdx.x & 31];
-        __syncthreads();
-        for (int k = 1; k < 16; ++k) {                      // one more zero byte behind it
-            c = s_t[0][c & 0xFFu] ^ (c >> 8);
-            s_t[k][threadIdx.x] = c;
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= a.n_blocks) return;
-    if (a.status[blk] != ST_OK) return;
-    const BlockDesc d = a.blocks[blk];
-    // The blocks' outputs follow each other without gaps (a record may run from one into the next), so a block starts at any byte:
-    // the rows are cut on 32-byte boundaries of the STREAM.  In the linear form below zero bytes in front of a message leave the
-    // register at zero: the head of the first piece (the previous block's last bytes) is simply masked out.
-    const uint32_t head = (uint32_t)(d.uout & 31u);
-    const uint8_t *p = a.out + (d.uout - head);             // 32-byte aligned; the block's bytes are p[head .. head + ulen)
-    const uint8_t *e = a.file + d.cin + d.clen;             // the block's trailer: CRC32, ISIZE (little endian)
-    const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
-    if (d.ulen < 128u) {                                    // (short blocks — the end-of-file marker's is empty — byte by byte)
-        if (lane == 0) {
-            uint32_t t = 0xFFFFFFFFu;
-            for (uint32_t i = 0; i < d.ulen; ++i) t = s_t[0][(t ^ p[head + i]) & 0xFFu] ^ (t >> 8);
-            if (~t != want) a.status[blk] = ST_BAD_CRC;
-        }
-        return;
-    }
-    const uint32_t vlen = head + d.ulen;
-    const int32_t body = (int32_t)(vlen & ~31u);            // whole 32-byte pieces; the last vlen % 32 bytes follow at the end
-    const int32_t rows = (body + 2047) >> 11;
-    // All of it in the CRC's LINEAR form (register starts at 0, no final inversion: then crc(A || B) = later(crc(A), |B|) ^ crc(B)
-    // and pieces may be taken in any order); the standard's all-ones start is the same as inverting the block's first four bytes.
-    auto x3 = [](uint32_t x, uint32_t y, uint32_t z) { return (uint32_t)__builtin_amdgcn_bitop3_b32(x, y, z, 0x96); };     // x ^ y ^ z, one instruction
-    auto step16 = [&](uint32_t c, uint4 v) {                // the register after sixteen more bytes
-        const uint32_t w0 = v.x ^ c;
-        const uint32_t t0 = x3(s_t[15][w0 & 0xFFu], s_t[14][(w0 >> 8) & 0xFFu], s_t[13][(w0 >> 16) & 0xFFu]);
-        const uint32_t t1 = x3(s_t[12][w0 >> 24], s_t[11][v.y & 0xFFu], s_t[10][(v.y >> 8) & 0xFFu]);
-        const uint32_t t2 = x3(s_t[9][(v.y >> 16) & 0xFFu], s_t[8][v.y >> 24], s_t[7][v.z & 0xFFu]);
-        const uint32_t t3 = x3(s_t[6][(v.z >> 8) & 0xFFu], s_t[5][(v.z >> 16) & 0xFFu], s_t[4][v.z >> 24]);
-        const uint32_t t4 = x3(s_t[3][v.w & 0xFFu], s_t[2][(v.w >> 8) & 0xFFu], s_t[1][(v.w >> 16) & 0xFFu]);
-        return x3(x3(t0, t1, t2), x3(t3, t4, s_t[0][v.w >> 24]), 0u);
-    };
-    auto later_row = [&](uint32_t c, uint32_t x) {          // (the register, 2 KiB of zeros later) ^ x
-        return x3(x3(s_row[0][c & 0xFFu], s_row[1][(c >> 8) & 0xFFu], s_row[2][(c >> 16) & 0xFFu]), s_row[3][c >> 24], x);
-    };
-    // the pieces with the block's first bytes (all in the first row): bytes in front of them are not the block's, its first four
-    // are inverted (the all-ones start)
-    auto masked = [&](uint4 v, int32_t at) {
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t keep = 0, inv = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t vi = (uint32_t)at + 4u * k + b;
-                if (vi >= head) keep |= 0xFFu << (8 * b);
-                if (vi >= head && vi < head + 4u) inv |= 0xFFu << (8 * b);
-            }
-            w[k] = (w[k] & keep) ^ inv;
-        }
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    };
-    int32_t off = body - rows * 2048 + lane * 32;           // this lane's piece of the first row; negative: the row is short and starts later
-    uint32_t acc = 0;
-    int32_t r = 0;
-    for (; r < min(rows, 2); ++r, off += 2048)              // (the first 36 bytes lie in the first row, or — if that one is short — in the first two)
-        if (off >= 0) {
-            const uint4 v0 = masked(*reinterpret_cast<const uint4 *>(p + off), off), v1 = masked(*reinterpret_cast<const uint4 *>(p + off + 16), off + 16);
-            acc = later_row(acc, step16(step16(0u, v0), v1));
-        }
-    // two rows at a time (two independent look-up chains), the next two rows' loads in flight while these are looked up: a
-    // wavefront walks its block alone, and without the prefetch it spends half its time waiting for HBM
-    if (r + 2 <= rows) {
-        uint4 a0 = *reinterpret_cast<const uint4 *>(p + off), a1 = *reinterpret_cast<const uint4 *>(p + off + 16);
-        uint4 b0 = *reinterpret_cast<const uint4 *>(p + off + 2048), b1 = *reinterpret_cast<const uint4 *>(p + off + 2064);
-        for (; r + 2 <= rows; r += 2, off += 4096) {
-            uint4 n0 = a0, n1 = a1, m0 = b0, m1 = b1;
-            if (r + 4 <= rows) {
-                n0 = *reinterpret_cast<const uint4 *>(p + off + 4096); n1 = *reinterpret_cast<const uint4 *>(p + off + 4112);
-                m0 = *reinterpret_cast<const uint4 *>(p + off + 6144); m1 = *reinterpret_cast<const uint4 *>(p + off + 6160);
-            }
-            const uint32_t ca = step16(step16(0u, a0), a1), cb = step16(step16(0u, b0), b1);
-            acc = later_row(later_row(acc, ca), cb);
-            a0 = n0; a1 = n1; b0 = m0; b1 = m1;
-        }
-    }
-    if (r < rows) {
-        const uint4 a0 = *reinterpret_cast<const uint4 *>(p + off), a1 = *reinterpret_cast<const uint4 *>(p + off + 16);
-        acc = later_row(acc, step16(step16(0u, a0), a1));
-    }
-    // pairwise across the lanes: a lane that starts a span of 2s columns takes its right neighbour's span (32 s bytes) behind its own
-    uint32_t c = acc;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << k, 64);
-        uint32_t m = 0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) m ^= s_op[k][i] & (0u - ((c >> i) & 1u));
-        c = m ^ right;
-    }
-    if (lane == 0) {
-        uint32_t t = c;                                     // the register after the body; the last vlen % 32 bytes one by one
-        for (uint32_t i = (uint32_t)body; i < vlen; ++i) t = s_t[0][(t ^ p[i]) & 0xFFu] ^ (t >> 8);
-        if (~t != want) a.status[blk] = ST_BAD_CRC;
-    }
-}
-
-// the operators bgzf_crc32 takes: zlib's crc32_combine construction (one zero bit, squared up)
-static void crc_zero_operators(uint32_t zeros[6][32], uint32_t zeros_row[32])
-{
-    auto times = [](const uint32_t *mat, uint32_t vec) { uint32_t s = 0; for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1u) s ^= mat[i]; return s; };
-    uint32_t a[32], b[32];
-    a[0] = 0xEDB88320u;                                     // one zero BIT
-    for (int i = 1; i < 32; ++i) a[i] = 1u << (i - 1);
-    uint32_t *cur = a, *nxt = b;
-    for (int bits = 1; bits <= 8 * 2048; bits <<= 1) {      // `cur` appends `bits` zero bits
-        for (int k = 0; k < 6; ++k)
-            if (bits == 8 * (32 << k)) std::memcpy(zeros[k], cur, 32 * sizeof(uint32_t));
-        if (bits == 8 * 2048) std::memcpy(zeros_row, cur, 32 * sizeof(uint32_t));
-        for (int i = 0; i < 32; ++i) nxt[i] = times(cur, cur[i]);
-        std::swap(cur, nxt);
-    }
-}
-
 // per-block record lists -> dense offsets into the stream; base[b] = exclusive scan of n_rec (done by one workgroup first)
 // A block whose last record starts within its last three bytes could not read that record's size: it is read here, from the stream
 // (`overshoot` = TAIL_UNKNOWN on entry: the record's start is the block's last listed one).
@@ -638,6 +477,7 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
         g.d_file = d_file; g.d_desc = D.d_desc; g.d_tok = d_tok; g.d_ntok = d_ntok; g.d_out = D.d_out; g.d_slot = D.d_slot; g.d_nrec = D.d_nrec;
         g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
+        g.verify_crc = ctx->verify_crc;
         g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;
         if (batch_at.empty()) {
             const int rc = tcmi_bgzf_decode_launch(ctx, g);
@@ -650,15 +490,6 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
             }
             ++ctx->stat_decode_batched;
         }
-    }
-    if (ctx->verify_crc) {
-        static const CrcArgs proto = [] { CrcArgs c = {}; crc_zero_operators(c.zeros, c.zeros_row); return c; }();
-        CrcArgs c = proto;
-        c.file = d_file; c.out = D.d_out; c.blocks = D.d_desc; c.status = D.d_stat; c.n_blocks = (int32_t)nb;
-        tcmi_prof_begin(ctx, TCMI_K_CRC);
-        hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, ctx->stream, c);
-        tcmi_prof_end(ctx, TCMI_K_CRC);
-        TCMI_HIP(ctx, hipGetLastError());
     }
     return TCMI_OK;
 }

@@ -31,6 +31,9 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "bgzf_device.h"
@@ -89,6 +92,9 @@ struct HdrScratch {                                 // per block, while its head
 #ifndef TCMI_SYM_MOVE
 #define TCMI_SYM_MOVE 8                             // bgzf_symbols: tokens a lane has in flight when the tokens are gathered to their places
 #endif
+#ifndef TCMI_SYM_ROWS
+#define TCMI_SYM_ROWS 32                            // bgzf_symbols: parked rows a turn of the row-by-row mover takes (a load each, all in flight)
+#endif
 #ifndef TCMI_SYM_WAVES
 #define TCMI_SYM_WAVES 5                            // bgzf_symbols: wavefronts per SIMD the register budget is cut for (5: 96 VGPRs; with 4 — 128 —
                                                     // a BAM's 2 094 workgroups fill every CU's register file: 182 us instead of 173)
@@ -120,6 +126,7 @@ struct SymArgs {
     int32_t first_block;        // ... and start here: workgroup 0's first block
     uint32_t pay_dwords;        // dwords of dynamic LDS per block behind SymLds: the largest block's payload + slack
     uint32_t win_dwords;        // bgzf_symbols<1, true>: dwords of payload staged at a time (a window that moves along the block)
+    uint32_t gather_max;        // a pass with more true tokens than this moves them row by row (else: gathered in output order)
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
 };
 #define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -937,10 +944,13 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             // 64 rows — 170 MB of 64-byte sectors per BAM for 4.4 MB of tokens, from HBM: the rows of the 4 000 blocks in flight do
             // not fit the L2s.  Before that every lane moved its own tokens: a store per token and lane into 32 places.)
             L.a.ring[lane][0] = make_uint2(incl, before - (incl - cnt));
+            uint32_t rows_max = alive && on && berr == ST_OK ? before + cnt : 0u;      // the parked rows that hold true tokens (the wavefront's: uniform turns below)
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) rows_max = max(rows_max, (uint32_t)__shfl_xor((int)rows_max, dd, 64));
             wave_sync();
             if (on && berr == ST_OK) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the parked tokens are this wavefront's own stores)
-                if (!block_redo) {
+                if (!block_redo && all <= a.gather_max) {
                     constexpr int GV = TCMI_SYM_MOVE;
                     const uint32_t *const rows = btok + bcap;
                     uint32_t *const dst = btok + ntok0;
@@ -958,6 +968,32 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                         for (int k = 0; k < GV; ++k) t[k] = rows[at[k]];
 #pragma unroll
                         for (int k = 0; k < GV; ++k) if (i0 + (uint32_t)(k * SYM_LANES) < all) dst[i0 + (uint32_t)(k * SYM_LANES)] = t[k];
+                    }
+                } else if (!block_redo) {
+                    // A block of many tokens (a file that compresses like real data: thousands per block, its parked rows 50 KB and
+                    // more — with every block of the chip's round in flight they are in no L2 any more, and a lane that follows ONE
+                    // owner reads one word of every row: sixteen times the bytes).  Here the rows are read as they were written — row
+                    // k + r, every lane its own word: whole sectors, each once — R rows at a time, all their loads in flight; a lane's R tokens are
+                    // consecutive in the output, so it stores them as four 16-byte words (word-aligned; the ends of its true range word
+                    // by word).
+                    constexpr int R = TCMI_SYM_ROWS;
+                    const uint32_t *const mine = btok + bcap + (uint32_t)c;
+                    uint32_t *const dst = btok + ntok0 + (incl - cnt);              // this lane's first true token goes here
+                    const uint32_t lo = before, hi = before + cnt;
+                    const uint32_t kmax = rows_max;
+                    const uint32_t last_row = lane_cap ? lane_cap - 1u : 0u;
+                    for (uint32_t k0 = 0; k0 < kmax; k0 += R) {
+                        uint32_t t[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) t[r] = mine[(size_t)min(k0 + (uint32_t)r, last_row) * SYM_LANES];
+                        if (k0 >= lo && k0 + R <= hi) {
+                            uint4 *q = reinterpret_cast<uint4 *>(dst + (k0 - lo));
+#pragma unroll
+                            for (int r = 0; r < R; r += 4) __builtin_memcpy(q + r / 4, &t[r], 16);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) if (k0 + r >= lo && k0 + r < hi) dst[k0 + r - lo] = t[r];
+                        }
                     }
                 } else {
                     // ---- pass B: the true ranges once more, tokens straight to their places -----------------------------------
@@ -999,6 +1035,11 @@ struct CopyArgs {
     uint32_t n_ref;             // reference sequences of the BAM header
     uint64_t *stamps;           // diagnostic, as SymArgs::stamps
     uint32_t team_bytes;        // a batch of 64 tokens with at most this many bytes of output copies its matches in teams
+    // the CRC-32 of every block's output against the value in its trailer (SAM spec 4.1; htslib checks it on every block it reads), taken
+    // while the bytes are flushed from the ring (crc != 0):
+    uint32_t crc;
+    uint32_t zeros_seg[32];     // zeros_seg[i]: the CRC register with only bit i set, CSEG zero bytes later
+    const uint32_t *crc_ops;    // [CRC_NOPS][8][16]: the register after 2^k more zero bytes, by nibble (crc_later)
 };
 
 // The copy loop of the matches of a stretch, hand-scheduled.  mm: the matches still to be copied; pm: those of them the inner loop
@@ -1111,17 +1152,100 @@ struct CopyArgs {
                         : [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [vlane] "v"(lane), [vX] "v"(lane_hi), [vA2] "v"(vA2), [vB2] "v"(vB2), [vXl] "v"(vXl), [vYl] "v"(vYl), [vKl] "v"(vKl), [vX1] "v"(lane_sh16), [vlane7] "v"(lane_p7), [vlane4] "v"(lane_x4), [vlane32] "v"(lane_x32), [vlane0] "v"(lane0_31), [outp] "s"(out), [pm] "s"(plain_mask) \
                         : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s92", "s93", "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 
+// bgzf_copy: CW blocks per workgroup, a wavefront each (they share nothing but the CRC tables); every wavefront has its ring, the 512
+// bytes next to it where far matches are parked, and the teams' slots.  LDS addresses stay below 64 K: the copy loops do their
+// address arithmetic in 16 bits.
+constexpr int CW = 4;
+constexpr int CRC_NOPS = 12;                        // crc_ops: 1, 2, 4, .. 2048 zero bytes
+struct CopyLds { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; };
+struct CopyShared {
+    CopyLds w[CW];
+    uint32_t t[4][256];         // t[k][v]: the CRC register after byte v and k zero bytes ("slicing by 4")
+    uint32_t seg[8][16];        // seg[j][n]: the register n << 4 j, CSEG zero bytes later
+};
+static_assert(sizeof(CopyLds) % 16 == 0 && CW * sizeof(CopyLds) + CWIN < 65536, "16-bit LDS addresses in the copy loops");
+static_assert(4 * sizeof(CopyShared) <= 160 * 1024, "four workgroups (sixteen blocks) per compute unit");
+
+// the CRC register (linear form: starts at 0, no final inversion) after the 16 bytes of v, from state c
+__device__ __forceinline__ uint32_t crc16(const uint32_t (*t)[256], uint32_t c, uint4 v)
+{
+    auto x3 = [](uint32_t x, uint32_t y, uint32_t z) { return (uint32_t)__builtin_amdgcn_bitop3_b32(x, y, z, 0x96); };
+    auto step = [&](uint32_t x) { return x3(t[3][x & 0xFFu], t[2][(x >> 8) & 0xFFu], t[1][(x >> 16) & 0xFFu]) ^ t[0][x >> 24]; };
+    c = step(c ^ v.x);
+    c = step(c ^ v.y);
+    c = step(c ^ v.z);
+    return step(c ^ v.w);
+}
+// a linear operator on the register given by nibble tables (tab[j][n] = op(n << 4 j)): LDS or global memory
+__device__ __forceinline__ uint32_t crc_apply(const uint32_t (*tab)[16], uint32_t c)
+{
+    auto x3 = [](uint32_t x, uint32_t y, uint32_t z) { return (uint32_t)__builtin_amdgcn_bitop3_b32(x, y, z, 0x96); };
+    return x3(x3(tab[0][c & 15u], tab[1][(c >> 4) & 15u], tab[2][(c >> 8) & 15u]), x3(tab[3][(c >> 12) & 15u], tab[4][(c >> 16) & 15u], tab[5][(c >> 20) & 15u]),
+              tab[6][(c >> 24) & 15u] ^ tab[7][c >> 28]);
+}
+// XOR over the lanes of (x of lane l, 32 (63 - l) zero bytes later): a lane that starts a span of 2 s columns takes its right
+// neighbour's span (32 s bytes) behind its own; lane 0 ends up with all of it (ops[k]: 2^k zero bytes, nibble tables in global memory)
+__device__ __forceinline__ uint32_t crc_fold32(const uint32_t *ops, uint32_t c)
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << k, 64);
+        c = crc_apply(reinterpret_cast<const uint32_t (*)[16]>(ops + (size_t)(5 + k) * 128), c) ^ right;
+    }
+    return c;
+}
+// bytes of a 16-byte piece that starts at position `at`: those in front of `from` count as zeros, those in [inv, inv + 4) are inverted
+// (the block's first four: the standard's all-ones start, in the linear form)
+__device__ __forceinline__ uint4 crc_masked(uint4 v, int32_t at, int32_t from, int32_t inv)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t keep = 0, flip = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int32_t p = at + 4 * k + b;
+            if (p >= from) keep |= 0xFFu << (8 * b);
+            if (p >= from && p >= inv && p < inv + 4) flip |= 0xFFu << (8 * b);
+        }
+        w[k] = (w[k] & keep) ^ flip;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // TEAMS: with the rounds of teams for batches of short tokens (files that compress less than ~12 : 1: the host picks the variant;
 // both are right for any input — the lean one is 4 % faster where no batch would use teams)
 // DIRECT: with the short far matches of a teams' batch finished in the batch's set-up (files that compress less than ~4 : 1: most of
 // their matches are 3 - 8 bytes long and come from anywhere in the 32 KB window; at 6 : 1 few do and the lean set-up is 3 % faster)
 template <bool TEAMS, bool DIRECT>
-__global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
+__global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
 {
-    __shared__ __attribute__((aligned(16))) struct { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; } s_lds;     // (the ring first: ring index = LDS address)
+    __shared__ __attribute__((aligned(16))) CopyShared S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform, and known to be: the block's fields go to scalar registers)
+    if (a.crc) {                                    // the tables of the workgroup's four wavefronts (CW * 64 = 256 lanes: an entry each)
+        static_assert(CW * 64 == 256, "one table entry per lane");
+        uint32_t c = threadIdx.x;                   // the reflected CRC-32 table (polynomial 0xEDB88320)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        S.t[0][threadIdx.x] = c;
+        if (threadIdx.x < 128) {
+            const uint32_t j = threadIdx.x >> 4, n = threadIdx.x & 15u;
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m ^= a.zeros_seg[4 * j + i] & (0u - ((n >> i) & 1u));
+            S.seg[j][n] = m;
+        }
+        __syncthreads();
+        for (int k = 1; k < 4; ++k) {               // one more zero byte behind it
+            c = S.t[0][c & 0xFFu] ^ (c >> 8);
+            S.t[k][threadIdx.x] = c;
+        }
+        __syncthreads();
+    }
+    CopyLds &s_lds = S.w[wave];
     uint8_t *const s_win = s_lds.win;
-    const int lane = threadIdx.x;
-    const int blk = a.first_block + (int)blockIdx.x;
+    const uint32_t B = (uint32_t)reinterpret_cast<uintptr_t>(s_win);    // the ring's LDS address (the copy loops take addresses, not ring indices)
+    const int blk = a.first_block + (int)blockIdx.x * CW + wave;
     if (blk >= a.n_blocks) return;
     const BlockDesc d = a.blocks[blk];
     const uint32_t ulen = d.ulen;
@@ -1143,7 +1267,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     const uint32_t lane0_31 = lane == 0 ? 31u : 0u;
     // (teams of eight lanes: lane l belongs to team l / 8 and takes that team's piece l % 8)
     const uint32_t team_of = (uint32_t)lane >> 3, team_sub = (uint32_t)lane & 7u, team_sub8 = team_sub * 8u;
-    const uint32_t team_base = (uint32_t)(CWIN + FAR_WORDS * 4), team_slot = team_base + team_of * 8u;     // s_lds.team, as LDS addresses
+    const uint32_t team_base = B + (uint32_t)(CWIN + FAR_WORDS * 4), team_slot = team_base + team_of * 8u;     // s_lds.team, as LDS addresses
 
     uint32_t op = a0, flushed = 0;
     uint32_t next_rec = d.entry >= 0 ? a0 + (uint32_t)d.entry : 0xFFFFFFF0u;
@@ -1181,6 +1305,9 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         return ok;
     };
 
+    const bool do_crc = a.crc != 0;
+    static_assert(CSEG == 2048, "the CRC's columns: 64 lanes x 32 bytes a segment");
+    uint32_t crc_acc = 0;               // this lane's column of the flushed segments (linear form)
     // List the record starts whose block_size field is complete, flush the segments that are complete.  The chain of records is
     // serial (a record's start is known when its predecessor's size is), but the records of a BAM block mostly have one size: 16
     // lanes look at where the next 16 records start if they all have the size of the last one, and the chain advances over all
@@ -1233,6 +1360,13 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             } else dst[lane] = src[lane];
 #pragma unroll
             for (int k = 1; k < CSEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+            if (do_crc) {
+                // the segment's CRC while it is in the ring: lane l takes the 32 bytes at 32 l (its column: the register of the column's
+                // bytes so far, CSEG zero bytes later, plus these)
+                uint4 p0 = src[2 * lane], p1 = src[2 * lane + 1];
+                if (flushed == 0) { p0 = crc_masked(p0, 32 * lane, (int32_t)a0, (int32_t)a0); p1 = crc_masked(p1, 32 * lane + 16, (int32_t)a0, (int32_t)a0); }
+                crc_acc = crc_apply(S.seg, crc_acc) ^ crc16(S.t, crc16(S.t, 0u, p0), p1);
+            }
             flushed += CSEG;
         }
         next_evt = flushed + (uint32_t)CSEG;
@@ -1338,7 +1472,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         const uint32_t dm = dst & CWMASK, sm = (dst - dist) & CWMASK;
         const bool plain = dist <= (uint32_t)CNEAR && dist + a0 <= dst && dist >= mylen && dm + mylen <= (uint32_t)CWIN && sm + mylen <= (uint32_t)CWIN && (mylen <= 64u || sm >= 4u);
         const bool far_ok = dist > (uint32_t)CNEAR && dist + a0 <= dst && dm + mylen <= (uint32_t)CWIN;      // (its source is flushed when its turn comes: CNEAR)
-        uint32_t vA = dm | (mylen << 16), vB = sm | (plain ? 0u : far_ok ? 1u << 16 : 2u << 16);
+        uint32_t vA = (B + dm) | (mylen << 16), vB = (B + sm) | (plain ? 0u : far_ok ? 1u << 16 : 2u << 16);     // (LDS addresses: B + ring index, below 64 K)
         const uint32_t vC = dst - dist;                         // a far match's source, as a position
         // A match that reaches back further than the ring holds reads what this wavefront flushed long ago — from HBM, a microsecond
         // away if it is fetched when the match comes up.  So the far matches of the batch whose sources are flushed already (all of
@@ -1391,7 +1525,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                     "ds_write_b8_d16_hi %[at], %[hi8] offset:7\n"
                     "s_mov_b64 exec, s[92:93]\n"
                     : [lo8] "=&v"(lo8), [hi8] "=&v"(hi8)
-                    : [dmask] "s"(dmask), [lo] "v"(lo), [hi] "v"(hi), [at] "v"(dm), [len] "v"(mylen)
+                    : [dmask] "s"(dmask), [lo] "v"(lo), [hi] "v"(hi), [at] "v"(B + dm), [len] "v"(mylen)
                     : "s92", "s93", "vcc", "memory");
             }
         }
@@ -1416,7 +1550,7 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
                         for (int i = 0; i < 8; ++i)
                             if (k + i < n) park[k + i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
                     }
-                    if (take) vB = (uint32_t)CWIN + 4u * (end_w - words);
+                    if (take) vB = B + (uint32_t)CWIN + 4u * (end_w - words);
                 }
             }
         }
@@ -1437,10 +1571,10 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
         // fifth of the rate): the first dword's address | 8 (destination & 3) << 16; the aligned address of the source dword that
         // holds the first dword's byte 0 | 8 (its place in it) << 16; and 32 - 8 (bytes from the first dword's start to the match's
         // end): + 32 lane = how far a lane's mask of bytes is to be shifted down (< 32: the lane has bytes at all).
-        const uint32_t vA2 = ((mylen - 1u) << 16) | ((dm - 7u) & 0xFFFFu), vB2 = vB - 7u;
+        const uint32_t vA2 = ((mylen - 1u) << 16) | ((B + dm - 7u) & 0xFFFFu), vB2 = vB - 7u;
         const uint32_t hoff = dm & 3u, s0 = sm - hoff;
-        const uint32_t vXl = (dm & ~3u) | (hoff * 8u) << 16, vYl = (s0 & 0xFFFCu) | ((s0 & 3u) * 8u) << 16, vKl = 32u - 8u * (hoff + mylen);
-        const uint32_t srcend = teamable ? (vB >= (uint32_t)CWIN ? 0u : dst - dist + mylen) : 0xFFFFFFFFu;
+        const uint32_t vXl = ((B + dm) & ~3u) | (hoff * 8u) << 16, vYl = ((B + s0) & 0xFFFCu) | ((s0 & 3u) * 8u) << 16, vKl = 32u - 8u * (hoff + mylen);
+        const uint32_t srcend = teamable ? (vB >= B + (uint32_t)CWIN ? 0u : dst - dist + mylen) : 0xFFFFFFFFu;
         const unsigned long long team_mask = plain_mask;
         uint32_t t_cur = 0;
         // (asked for HERE, behind the batch's set-up and its waits for earlier loads, in front of the copy loops: the load is under
@@ -1596,6 +1730,35 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
             else err = ST_BAD_RECORD;
         }
         for (uint32_t i = max(flushed, a0) + (uint32_t)lane; i < op; i += 64) out[i] = s_win[i & CWMASK];
+        if (do_crc) {
+            // ---- the block's CRC-32 against its trailer.  In the linear form crc(A || B) = later(crc(A), |B|) ^ crc(B) and zero bytes in
+            // front of a message leave the register at zero: the columns of the flushed segments are joined across the lanes, moved
+            // past the tail, and the tail — what lies in the ring behind the last whole segment, cut into 32-byte pieces from its END,
+            // lane l the piece that ends 32 (63 - l) bytes in front of the block's end — is joined the same way.
+            const uint8_t *e = a.file + d.cin + d.clen;         // the block's trailer: CRC32, ISIZE (little endian)
+            const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+            uint32_t got;
+            if (ulen < 128u) {                                  // (short blocks — the end-of-file marker's is empty — byte by byte)
+                uint32_t t = 0xFFFFFFFFu;
+                for (uint32_t i = 0; i < ulen; ++i) t = S.t[0][(t ^ s_win[(a0 + i) & CWMASK]) & 0xFFu] ^ (t >> 8);
+                got = ~t;
+            } else {
+                const int32_t from = (int32_t)max(flushed, a0);
+                const int32_t ps = (int32_t)vend - 32 * (64 - lane);                    // where this lane's piece of the tail starts
+                uint32_t tl = 0;
+                if (ps + 32 > from) {
+                    const uint4 q0 = make_uint4(ring_u32((uint32_t)ps), ring_u32((uint32_t)ps + 4u), ring_u32((uint32_t)ps + 8u), ring_u32((uint32_t)ps + 12u));
+                    const uint4 q1 = make_uint4(ring_u32((uint32_t)ps + 16u), ring_u32((uint32_t)ps + 20u), ring_u32((uint32_t)ps + 24u), ring_u32((uint32_t)ps + 28u));
+                    tl = crc16(S.t, crc16(S.t, 0u, crc_masked(q0, ps, from, (int32_t)a0)), crc_masked(q1, ps + 16, from, (int32_t)a0));
+                }
+                uint32_t full = uni(crc_fold32(a.crc_ops, crc_acc));
+                const uint32_t tail_len = vend - flushed;       // < CSEG
+                for (int k = 0; k < 11; ++k)
+                    if ((tail_len >> k) & 1u) full = crc_apply(reinterpret_cast<const uint32_t (*)[16]>(a.crc_ops + (size_t)k * 128), full);
+                got = ~(full ^ uni(crc_fold32(a.crc_ops, tl)));
+            }
+            if (got != want) err = ST_BAD_CRC;
+        }
     }
     if (lane == 0) {
         a.status[blk] = err;
@@ -1617,6 +1780,45 @@ __global__ __launch_bounds__(64) void bgzf_copy(CopyArgs a)
     }
 }
 
+// the CRC's operators: "append n zero bytes" is linear on the register — a 32 x 32 matrix over GF(2), built zlib's crc32_combine way
+// (one zero bit, squared up).  ops[k][j][n]: the register n << 4 j, 2^k zero bytes later; zeros_seg[i]: bit i, CSEG zero bytes later.
+struct CrcTables { uint32_t ops[CRC_NOPS][8][16]; uint32_t zeros_seg[32]; };
+static const CrcTables &crc_tables()
+{
+    static const CrcTables T = [] {
+        CrcTables t;
+        auto times = [](const uint32_t *mat, uint32_t vec) { uint32_t r = 0; for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1u) r ^= mat[i]; return r; };
+        uint32_t a[32], b[32];
+        a[0] = 0xEDB88320u;                                     // one zero BIT
+        for (int i = 1; i < 32; ++i) a[i] = 1u << (i - 1);
+        uint32_t *cur = a, *nxt = b;
+        for (int bits = 1; bits <= 8 * 2048; bits <<= 1) {      // `cur` appends `bits` zero bits
+            for (int k = 0; k < CRC_NOPS; ++k)
+                if (bits == 8 << k)
+                    for (int j = 0; j < 8; ++j)
+                        for (uint32_t n = 0; n < 16; ++n) t.ops[k][j][n] = times(cur, n << (4 * j));
+            if (bits == 8 * CSEG) std::memcpy(t.zeros_seg, cur, sizeof t.zeros_seg);
+            for (int i = 0; i < 32; ++i) nxt[i] = times(cur, cur[i]);
+            std::swap(cur, nxt);
+        }
+        return t;
+    }();
+    return T;
+}
+// ... in device memory, once per device
+static const uint32_t *crc_ops_on_device(tcmi_ctx *ctx)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, uint32_t *>> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : per_device) if (e.first == ctx->device) return e.second;
+    uint32_t *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(CrcTables::ops)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, crc_tables().ops, sizeof(CrcTables::ops), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    per_device.emplace_back(ctx->device, d);
+    return d;
+}
+
 } // namespace
 
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
@@ -1634,6 +1836,8 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.tokens = g.d_tok - g.tok_base; sa.n_tok = g.d_ntok; sa.status = g.d_stat; sa.n_blocks = (int32_t)b_end; sa.first_block = (int32_t)b_first;
     sa.pay_dwords = g.pay_dwords;
     sa.win_dwords = 0;
+    static const int gmax_env = std::getenv("TCMI_SYM_GATHER_MAX") ? std::atoi(std::getenv("TCMI_SYM_GATHER_MAX")) : -1;      // (A/B)
+    sa.gather_max = gmax_env >= 0 ? (uint32_t)gmax_env : 2048u;
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
     // (measured on one 4 187-block file, kernel alone: 4 blocks per workgroup 372 us, 2: 285 us, 1: 325 us; on the harder file —
     //  4 611 blocks of 10.7 KB — 1 634 / 1 036 / 698 us: with larger payloads more lanes per block pay)
@@ -1662,7 +1866,8 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
         if (per_wg == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<2, false>), 128, dyn);
         else if (windowed) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, true>), 64, dyn);
         else if (per_wg == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, reinterpret_cast<const void *>(bgzf_symbols<1, false>), 64, dyn);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false, false>), 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, reinterpret_cast<const void *>(bgzf_copy<false, false>), 64 * CW, 0);
+        occ_c *= CW;
         std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d%s>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
                      nb, pay, per_wg, windowed ? ", windowed" : "", dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
     }
@@ -1679,10 +1884,18 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     ca.stamps = d_stamps ? d_stamps + nb * 16 : nullptr;
     static const int team_env = std::getenv("TCMI_TEAM_BYTES") ? std::atoi(std::getenv("TCMI_TEAM_BYTES")) : -1;      // (A/B measurements)
     ca.team_bytes = team_env >= 0 ? (uint32_t)team_env : (uint32_t)TEAM_BATCH_BYTES;
+    ca.crc = g.verify_crc ? 1u : 0u;
+    ca.crc_ops = nullptr;
+    if (ca.crc) {
+        ca.crc_ops = crc_ops_on_device(ctx);
+        if (!ca.crc_ops) return tcmi_fail(ctx, TCMI_E_NOMEM, "device memory for the CRC operators");
+        std::memcpy(ca.zeros_seg, crc_tables().zeros_seg, sizeof ca.zeros_seg);
+    }
+    const unsigned copy_grid = (unsigned)((nb + CW - 1) / CW);
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
-    if (TCMI_COPY_TEAMS && g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
-    else if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
-    else hipLaunchKernelGGL((bgzf_copy<false, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, ca);
+    if (TCMI_COPY_TEAMS && g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
+    else if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
+    else hipLaunchKernelGGL((bgzf_copy<false, false>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
     tcmi_prof_end(ctx, TCMI_K_INFLATE_COPY);
     TCMI_HIP(ctx, hipGetLastError());
     if (d_stamps) {

@@ -198,6 +198,7 @@ struct tcmi_bgzf_decode_args {
     uint64_t tok_base = 0;          // d_tok holds the tokens from BlockDesc::tok = tok_base on (the batch's first block's)
     uint32_t pay_dwords;            // the largest block's payload in dwords + slack
     uint32_t n_ref;                 // reference sequences of the BAM header (a record's refID must be one of them)
+    int verify_crc = 1;             // bgzf_copy checks every block's CRC-32 against its trailer while it flushes the bytes (ST_BAD_CRC)
     int short_tokens;               // the file compresses less than ~12 : 1 (many short matches): bgzf_copy's variant with teams; 2: less than ~4 : 1: ... and short far matches finished in the set-up
 };
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &a);

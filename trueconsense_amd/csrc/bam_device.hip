@@ -6,7 +6,7 @@
 // enough to parse the BAM header; the compressed bytes (a few MB .. tens of MB) cross PCIe once.
 //
 //   (bgzf_decode.hip)  bgzf_symbols + bgzf_copy: the compressed blocks -> the inflated stream and every block's record starts
-//   bgzf_crc32     the CRC-32 of every block's output against its trailer (one wavefront per block, coalesced rows)
+//                  (bgzf_copy also takes every block's CRC-32 against its trailer while it flushes the bytes: no pass of its own)
 //   rec_compact    per-block record lists -> one dense array of record offsets (block scan + copy)
 //
 // Serial-latency-bound bit / byte work, not HBM-bound and not a contraction: no MFMA.
@@ -365,7 +365,7 @@ const char *tcmi_bamfile_text(const tcmi_bamfile *f) { return f ? f->text.c_str(
 
 } // extern "C"
 
-// ---- device decode: H2D of the compressed file, bgzf_symbols + bgzf_copy + bgzf_crc32 (all in the context's arena) -----------------
+// ---- device decode: H2D of the compressed file, bgzf_symbols + bgzf_copy (all in the context's arena) ---------------------------------
 namespace {
 struct DeviceBam { uint8_t *d_out = nullptr; uint64_t *d_rec = nullptr; BlockDesc *d_desc = nullptr; size_t n = 0; int64_t range_first = -1, range_next = -1; };
 

@@ -3,7 +3,8 @@
 //
 //   bgzf_symbols   Huffman symbols -> tokens.  A block's symbols are decoded by 32 lanes (two blocks per workgroup; 64 when a
 //                  payload exceeds 4 KB: one block per workgroup, staged a window at a time beyond 16 KB), speculatively in parallel.
-//   bgzf_copy      tokens -> bytes: the LZ77 copies through an LDS ring of the recent output, the chain of BAM records, the flush.
+//   bgzf_copy      tokens -> bytes: the LZ77 copies through an LDS ring of the recent output, the chain of BAM records, the flush —
+//                  and the block's CRC-32 against its trailer, taken from the ring while a segment is flushed.
 //
 // Why two kernels.  A deflate stream is serial twice over: the position of symbol k + 1 is known only when symbol k is decoded,
 // and a match may copy what the previous match produced.  Round 2's one-kernel decoder walked both chains in one wavefront, one
@@ -13,9 +14,10 @@
 // resynchronise: after a few dozen bits a decoder that started on a wrong bit starts a symbol on a right one, and from there on it
 // IS the serial decoder.  A lane stops when a symbol of its own starts on a position that the lane in front of it has noted: from
 // there the two would decode the same (pass A).  Starting from lane 0 the chain of these meeting points says which lane holds the
-// true symbols of which bit range, and how many they are; the tokens stay where the lanes parked them and bgzf_copy gets the list
-// of pieces (a lane that overflows its scratch sends the block through pass B: the true ranges once more, tokens straight to
-// their places).  Nothing in this depends on luck or timing: a lane that never meets anyone simply goes on to the block's end, and
+// true symbols of which bit range, and how many they are; the lanes then put the true tokens in order (gathered in output order, or —
+// blocks of thousands of tokens — moved row by row; a lane that overflows its scratch sends the block through pass B: the true
+// ranges once more, tokens straight to their places).  Nothing in this depends on luck or timing: a lane that never meets anyone
+// simply goes on to the block's end, and
 // lane 0 alone is the serial decoder.  (tools/spec_inflate_proto.py: the same scheme in Python.)
 //
 // Tokens (32 bits): literal 1<<31 | byte; match len (9 bits) | (dist - 1) << 9; raw 1<<30 | len << 17 | offset of the bytes from
@@ -127,6 +129,7 @@ struct SymArgs {
     uint32_t pay_dwords;        // dwords of dynamic LDS per block behind SymLds: the largest block's payload + slack
     uint32_t win_dwords;        // bgzf_symbols<1, true>: dwords of payload staged at a time (a window that moves along the block)
     uint32_t gather_max;        // a pass with more true tokens than this moves them row by row (else: gathered in output order)
+    uint32_t shift_bias;        // (A/B) pass A's stretches this many powers of two shorter than chunk / 4 .. chunk / 2
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
 };
 #define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             const uint32_t chunk = on ? (b_soft - min(b_soft, start) + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
             // stretches of >= 64 bits (a symbol takes <= 48: none is skipped), about chunk / 4: a lane trails its target by about
             // a chunk, RING stretches are kept
-            const uint32_t shift = max(6u, 30u - (uint32_t)__builtin_clz(chunk | 1u));
+            const uint32_t shift = (uint32_t)max(6, 30 - (int)__builtin_clz(chunk | 1u) - (int)a.shift_bias);
             const uint32_t s_c = start + (uint32_t)c * chunk;
             enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
             uint32_t state = on && s_c < b_soft ? RUN : DEAD;
@@ -1183,14 +1186,17 @@ __device__ __forceinline__ uint32_t crc_apply(const uint32_t (*tab)[16], uint32_
     return x3(x3(tab[0][c & 15u], tab[1][(c >> 4) & 15u], tab[2][(c >> 8) & 15u]), x3(tab[3][(c >> 12) & 15u], tab[4][(c >> 16) & 15u], tab[5][(c >> 20) & 15u]),
               tab[6][(c >> 24) & 15u] ^ tab[7][c >> 28]);
 }
-// XOR over the lanes of (x of lane l, 32 (63 - l) zero bytes later): a lane that starts a span of 2 s columns takes its right
-// neighbour's span (32 s bytes) behind its own; lane 0 ends up with all of it (ops[k]: 2^k zero bytes, nibble tables in global memory)
-__device__ __forceinline__ uint32_t crc_fold32(const uint32_t *ops, uint32_t c)
+// A lane's column of a segment: CCOL = CSEG / 64 bytes (32 of the 2 KiB segments, 16 of 1 KiB ones).
+constexpr int CCOL = CSEG / 64, CCOL_LOG = CCOL == 32 ? 5 : 4;
+static_assert(CCOL == 32 || CCOL == 16, "the CRC's columns: 64 lanes x 16 or 32 bytes a segment");
+// XOR over the lanes of (x of lane l, CCOL (63 - l) zero bytes later): a lane that starts a span of 2 s columns takes its right
+// neighbour's span (CCOL s bytes) behind its own; lane 0 ends up with all of it (ops[k]: 2^k zero bytes, nibble tables in global memory)
+__device__ __forceinline__ uint32_t crc_fold(const uint32_t *ops, uint32_t c)
 {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << k, 64);
-        c = crc_apply(reinterpret_cast<const uint32_t (*)[16]>(ops + (size_t)(5 + k) * 128), c) ^ right;
+        c = crc_apply(reinterpret_cast<const uint32_t (*)[16]>(ops + (size_t)(CCOL_LOG + k) * 128), c) ^ right;
     }
     return c;
 }
@@ -1306,7 +1312,6 @@ __global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
     };
 
     const bool do_crc = a.crc != 0;
-    static_assert(CSEG == 2048, "the CRC's columns: 64 lanes x 32 bytes a segment");
     uint32_t crc_acc = 0;               // this lane's column of the flushed segments (linear form)
     // List the record starts whose block_size field is complete, flush the segments that are complete.  The chain of records is
     // serial (a record's start is known when its predecessor's size is), but the records of a BAM block mostly have one size: 16
@@ -1361,11 +1366,13 @@ __global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
 #pragma unroll
             for (int k = 1; k < CSEG / 16 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
             if (do_crc) {
-                // the segment's CRC while it is in the ring: lane l takes the 32 bytes at 32 l (its column: the register of the column's
+                // the segment's CRC while it is in the ring: lane l takes the CCOL bytes at CCOL l (its column: the register of the column's
                 // bytes so far, CSEG zero bytes later, plus these)
-                uint4 p0 = src[2 * lane], p1 = src[2 * lane + 1];
-                if (flushed == 0) { p0 = crc_masked(p0, 32 * lane, (int32_t)a0, (int32_t)a0); p1 = crc_masked(p1, 32 * lane + 16, (int32_t)a0, (int32_t)a0); }
-                crc_acc = crc_apply(S.seg, crc_acc) ^ crc16(S.t, crc16(S.t, 0u, p0), p1);
+                uint4 p0 = src[(CCOL / 16) * lane], p1 = CCOL == 32 ? src[2 * lane + 1] : make_uint4(0u, 0u, 0u, 0u);
+                if (flushed == 0) { p0 = crc_masked(p0, CCOL * lane, (int32_t)a0, (int32_t)a0); if (CCOL == 32) p1 = crc_masked(p1, 32 * lane + 16, (int32_t)a0, (int32_t)a0); }
+                uint32_t cs = crc16(S.t, 0u, p0);
+                if (CCOL == 32) cs = crc16(S.t, cs, p1);
+                crc_acc = crc_apply(S.seg, crc_acc) ^ cs;
             }
             flushed += CSEG;
         }
@@ -1733,8 +1740,8 @@ __global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
         if (do_crc) {
             // ---- the block's CRC-32 against its trailer.  In the linear form crc(A || B) = later(crc(A), |B|) ^ crc(B) and zero bytes in
             // front of a message leave the register at zero: the columns of the flushed segments are joined across the lanes, moved
-            // past the tail, and the tail — what lies in the ring behind the last whole segment, cut into 32-byte pieces from its END,
-            // lane l the piece that ends 32 (63 - l) bytes in front of the block's end — is joined the same way.
+            // past the tail, and the tail — what lies in the ring behind the last whole segment, cut into CCOL-byte pieces from its END,
+            // lane l the piece that ends CCOL (63 - l) bytes in front of the block's end — is joined the same way.
             const uint8_t *e = a.file + d.cin + d.clen;         // the block's trailer: CRC32, ISIZE (little endian)
             const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
             uint32_t got;
@@ -1744,18 +1751,21 @@ __global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
                 got = ~t;
             } else {
                 const int32_t from = (int32_t)max(flushed, a0);
-                const int32_t ps = (int32_t)vend - 32 * (64 - lane);                    // where this lane's piece of the tail starts
+                const int32_t ps = (int32_t)vend - CCOL * (64 - lane);                  // where this lane's piece of the tail starts
                 uint32_t tl = 0;
-                if (ps + 32 > from) {
+                if (ps + CCOL > from) {
                     const uint4 q0 = make_uint4(ring_u32((uint32_t)ps), ring_u32((uint32_t)ps + 4u), ring_u32((uint32_t)ps + 8u), ring_u32((uint32_t)ps + 12u));
-                    const uint4 q1 = make_uint4(ring_u32((uint32_t)ps + 16u), ring_u32((uint32_t)ps + 20u), ring_u32((uint32_t)ps + 24u), ring_u32((uint32_t)ps + 28u));
-                    tl = crc16(S.t, crc16(S.t, 0u, crc_masked(q0, ps, from, (int32_t)a0)), crc_masked(q1, ps + 16, from, (int32_t)a0));
+                    tl = crc16(S.t, 0u, crc_masked(q0, ps, from, (int32_t)a0));
+                    if (CCOL == 32) {
+                        const uint4 q1 = make_uint4(ring_u32((uint32_t)ps + 16u), ring_u32((uint32_t)ps + 20u), ring_u32((uint32_t)ps + 24u), ring_u32((uint32_t)ps + 28u));
+                        tl = crc16(S.t, tl, crc_masked(q1, ps + 16, from, (int32_t)a0));
+                    }
                 }
-                uint32_t full = uni(crc_fold32(a.crc_ops, crc_acc));
+                uint32_t full = uni(crc_fold(a.crc_ops, crc_acc));
                 const uint32_t tail_len = vend - flushed;       // < CSEG
                 for (int k = 0; k < 11; ++k)
                     if ((tail_len >> k) & 1u) full = crc_apply(reinterpret_cast<const uint32_t (*)[16]>(a.crc_ops + (size_t)k * 128), full);
-                got = ~(full ^ uni(crc_fold32(a.crc_ops, tl)));
+                got = ~(full ^ uni(crc_fold(a.crc_ops, tl)));
             }
             if (got != want) err = ST_BAD_CRC;
         }
@@ -1838,6 +1848,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.win_dwords = 0;
     static const int gmax_env = std::getenv("TCMI_SYM_GATHER_MAX") ? std::atoi(std::getenv("TCMI_SYM_GATHER_MAX")) : -1;      // (A/B)
     sa.gather_max = gmax_env >= 0 ? (uint32_t)gmax_env : 2048u;
+    static const int sbias_env = std::getenv("TCMI_SYM_SHIFT_BIAS") ? std::atoi(std::getenv("TCMI_SYM_SHIFT_BIAS")) : -1;      // (A/B)
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
     // (measured on one 4 187-block file, kernel alone: 4 blocks per workgroup 372 us, 2: 285 us, 1: 325 us; on the harder file —
     //  4 611 blocks of 10.7 KB — 1 634 / 1 036 / 698 us: with larger payloads more lanes per block pay)
@@ -1852,6 +1863,9 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     const size_t win_bytes = per_wg == 1 ? (win_env >= 0 ? (size_t)win_env : pay > 16384 ? 5120u : 0u) : 0u;
     const bool windowed = win_bytes >= 2048 && win_bytes + 24 < pay;
     sa.win_dwords = windowed ? (uint32_t)((win_bytes / 4 + 6 + 1) & ~(size_t)1) : 0u;    // (even: the window loader stores 8 bytes a lane)
+    // a window's chunks are short (5 KB over 64 lanes: 640 bits): with stretches of chunk / 4 .. chunk / 2 bits a lane decodes a third of
+    // a chunk into its neighbour's before it can meet it; half as long there (2.5 : 1: 1 258 -> 1 200 us; the bench file, whole payloads: 142 -> 163)
+    sa.shift_bias = sbias_env >= 0 ? (uint32_t)sbias_env : windowed ? 1u : 0u;
     const size_t dyn = windowed ? (size_t)sa.win_dwords * 4 : (size_t)g.pay_dwords * 4 * per_wg;
     static const bool attr_once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_symbols<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(SymLds<4>)));

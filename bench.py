@@ -383,7 +383,7 @@ def run_split_bamfile(a, rank, local_rank, world, rehearse, dist, torch, ref, or
             "metric": "reference positions/sec (ONE BAM FILE of %d reads, %d GPU(s) each decoding its range of the file's BGZF blocks -> consensus FASTA)" % (a.reads * world, world),
             "value": L * a.steps / dt, "unit": "positions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_per_rank": [1e3 * x[0] / a.steps for x in per_rank],
-            "ms_per_step_in_tcmi_split_step": step_ms,
+            "ms_per_step_in_tcmi_split_step": step_ms, "ms_per_step_verdicts_entries_vote": 1e3 * float(np.mean([t_.get("entries", 0.0) for t_ in tms])),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: 29 903-bp reference, ONE BAM file of %d x %d synthetic 150-bp reads (%d bytes, %d BGZF blocks, "
                                    "zlib level %d); a step is distributed.consensus_split_bamfile — the product's function: tcmi_split_step in C (every rank "

@@ -110,13 +110,14 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "device_pack"    1 = tcmi_readset_upload copies the BAM-native arrays to the device and packs them there
  *                    (pack_device.hip; default; needs reads sorted by position and entries of <= 512 positions,
  *                    anything else takes the host packer); 0 = always pack on the host
- *   "verify_crc"     1 = the device decoder checks every BGZF block's CRC-32 (bgzf_crc32; default, as htslib does);
+ *   "verify_crc"     1 = the device decoder checks every BGZF block's CRC-32 (in bgzf_copy's flush; default, as htslib does);
  *                    0 = ISIZE, stream termination and the record chain only
  *   "one_sync"       1 = a file decoded on the device takes the one-sync path first (pk_index + pk_place + pk_pack: record index,
  *                    record chain, classification, places and planes without a host round trip; capacities instead of counts read back; default), 0 = only the
  *                    several-kernel path with its three waits (the path that words every refusal; the tests cross-check the two)
- *   "mid_wait"       1 = the one-sync path waits a second time, behind the decode kernels (default: two waits per file; measured
- *                    equal or faster than 0 with eight contexts), 0 = one wait per file
+ *   "mid_wait"       0 = ONE wait of the host per file (default since round 5: with the CRC taken in bgzf_copy's flush — a kernel less
+ *                    per file — eight contexts measured 69.3 - 70.0 M positions/s against 68.4 - 69.4 with the second wait, three turns
+ *                    each on one box), 1 = the one-sync path waits a second time, behind the decode kernels (round 4's default)
  *   "prefix_kernels" the one-sync path's kernels need, per BGZF block, the records / kept reads / plane words in front of it: 0 = every
  *                    workgroup adds them up for itself below 16 384 blocks and three one-workgroup scan launches do it from there on
  *                    (the sums are quadratic in the blocks; default), 1 = always the scan launches, -1 = never

@@ -612,9 +612,10 @@ int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int6
     int rc = decode_enqueue(ctx, f, D, first_block, n_blocks);
     if (rc) return rc;
     if (D.nb == 0) return TCMI_E_UNSUPPORTED;                       // (an empty range: the other path's few lines)
-    // A wait of the host behind the decode kernels (option "mid_wait", default 1: two waits per file).  With everything queued in
-    // one go (0) eight contexts measured 60 - 64 M positions/s on boxes where this gave 64 - 66: four hardware queues that always
-    // hold a ready kernel run four kernels at once, and these kernels (each sized to fill the chip alone) get in each other's way.
+    // A wait of the host behind the decode kernels (option "mid_wait" = 1; round 4's default: with everything queued in one go eight
+    // contexts measured 60 - 64 M positions/s on boxes where the wait gave 64 - 66 — four hardware queues that always hold a ready
+    // kernel run four kernels at once, and these kernels, each sized to fill the chip alone, get in each other's way).  Round 5: one
+    // kernel less per file (the CRC pass), and the single wait wins by 1 % (69.3 - 70.0 against 68.4 - 69.4 M, three turns each).
     static const int split_env = std::getenv("TCMI_ONE_SYNC_SPLIT") ? std::atoi(std::getenv("TCMI_ONE_SYNC_SPLIT")) : -1;    // (A/B: 0 none, 1 behind the decode, 2 behind the packer, 3 both)
     const int split = split_env >= 0 ? split_env : ctx->mid_wait;
     if (split == 1 || split == 3) TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));

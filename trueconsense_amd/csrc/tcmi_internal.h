@@ -160,7 +160,7 @@ struct tcmi_ctx {
     uint32_t rec_bytes_seen = 0;     // mean record size of the last file this context decoded (sizes the next file's arrays when the file's own first blocks say nothing)
     int64_t decode_token_mb = 4096;  // bam_device.hip decode_enqueue: the token scratch's size; files that need more are decoded in batches of blocks
     int prefix_kernels = 0;          // pk_index / pk_place take the sums in front of a block from scan launches: 0 = from 16 384 blocks on, 1 = always, -1 = never
-    int mid_wait = 1;                // the one-sync path waits once more, behind the decode kernels (bam_device.hip: fast_enqueue)
+    int mid_wait = 0;                // 1: the one-sync path waits once more, behind the decode kernels (bam_device.hip: fast_enqueue); default since round 5: ONE wait per file
     int one_sync = 1;                // device-decoded files take the one-sync path (pk_index + pk_place + pk_pack) first; 0: the several-kernel path only
     int device_pack = 1;             // tcmi_readset_upload packs on the device when the input allows it
     int n_cu = 256;                  // compute units of the device

@@ -176,7 +176,6 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "verify_crc")) c->verify_crc = value != 0;
     else if (!std::strcmp(key, "one_sync")) c->one_sync = value != 0;
     else if (!std::strcmp(key, "mid_wait")) c->mid_wait = value != 0;
-    else if (!std::strcmp(key, "chunks_per_slot")) c->chunks_per_slot = value < 1 ? 1 : value > 8 ? 8 : value;
     else if (!std::strcmp(key, "prefix_kernels")) c->prefix_kernels = value;
     else if (!std::strcmp(key, "decode_token_mb")) c->decode_token_mb = value > 0 ? value : 4096;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;

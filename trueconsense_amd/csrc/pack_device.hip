@@ -1474,9 +1474,7 @@ int tcmi_pack_fused_enqueue(tcmi_ctx *ctx, tcmi_fused_job *job, tcmi_readset *rs
     // capacities: what the arrays of the packed read set are sized for (a file beyond them takes the several-kernel path)
     const int n_stages = ctx->chunk_stages > 0 ? std::min(ctx->chunk_stages, TCMI_F_MAXSTAGE) : TCMI_F_MAXSTAGE;
     const bool balance = ctx->chunk_stages == 0 && ctx->balance_chunks;
-    // (chunks_per_slot: the tally kernel's workgroups take their chunks in turn and fetch the next one's first stage while they write the
-    //  current one's counters out — with two chunks per resident slot a 1M-read file's single round is no longer all exposed latency)
-    const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu * std::max(1, ctx->chunks_per_slot), longest = (int64_t)TCMI_F_MAXSTAGE * 400;
+    const int64_t slots = (int64_t)ctx->n_cu * ctx->wg_per_cu, longest = (int64_t)TCMI_F_MAXSTAGE * 400;
     const int64_t k_cap = std::max<int64_t>(1, (cap + slots * longest - 1) / (slots * longest));
     const int64_t n_wg = balance ? std::max<int64_t>(k_cap * slots, (cap + PK_CMAX - 1) / PK_CMAX) : (cap + PK_CMAX - 1) / PK_CMAX + (cap + 2047) / 2048;
     // words: a read of len positions takes <= len / 16 + 7 words, and a read without long deletions / skips has len <= l_seq,

@@ -145,17 +145,8 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     // grid is sized from the resident slots, not from the packer's CAPACITY — 5 700 blocks for the ~1 100 chunks of a 1M-read BAM, each
     // of the idle ones a trip to memory for the count while it held a slot (LDS and registers) that a chunk block was waiting for.
     const int n_real = a.dev_counts ? (int)min(a.dev_counts[0], (uint32_t)a.n_chunks) : a.n_chunks;
-    // prefetch registers: the next stage's headers (two slots per lane) and planes — of this chunk's next stage, or, while a chunk's last
-    // stage is counted and its counters are written out, of the workgroup's NEXT chunk's first stage
-    uint32_t h_lo0 = 0, h_lo1 = 0;              // packed headers: position - P0 | len << 10 | pair offset in the stage << 20
-    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};
-    bool prefetched = false;                    // the registers hold this chunk's first stage already
     for (int bid = b1 - a.n_tail; bid < n_real; bid += a.n_chunk_blocks) {
     const tcmi_fast_chunk *chp = a.chunks + bid;
-    const bool more = bid + a.n_chunk_blocks < n_real;
-    const tcmi_fast_chunk *nxp = a.chunks + (more ? bid + a.n_chunk_blocks : bid);   // (its fields: scalar loads, under way while this chunk is counted)
-    const int64_t nx_read0 = nxp->read0, nx_word0 = nxp->word0;
-    const int nx_reads = nxp->n_reads, nx_sub = nxp->sub_reads, nx_end0 = nxp->stage_end[0];
     const int64_t read0 = chp->read0, word0 = chp->word0;
     const int n_reads = chp->n_reads, P0 = chp->P0, Wn = chp->Wn, sub_reads = chp->sub_reads;
     const int npos = Wn * 8;
@@ -183,6 +174,9 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         for (int k = 0; k < NPL; ++k) cnt[v].p[k] = 0;
     }
 
+    // ---- prefetch registers: the next stage's headers (two slots per lane) and planes --------------
+    uint32_t h_lo0 = 0, h_lo1 = 0;              // packed headers: position - P0 | len << 10 | pair offset in the stage << 20
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {};
     int st_begin = 0, st_end = chp->stage_end[0];   // word range of the stage (from word0)
     int st_end_next = chp->stage_end[1];            // fetched one stage ahead (a scalar load: its round trip hides under a stage)
     // Uniform base pointers + 32-bit lane offsets: the loads take the scalar-base form (no 64-bit address math
@@ -190,14 +184,14 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     // flight across the inner loop.  (A macro, not a lambda: a closure kept the registers in scratch memory.)
     const uint32_t *lenoff_base = a.lenoff + read0;
     const uint32_t *seq_base = a.seq + word0;
-#define TCMI_ISSUE_STAGE_OF(lenoff_base_, seq_base_, sub_reads_, n_reads_, stage_, begin_, end_)      \
+#define TCMI_ISSUE_STAGE(stage_, begin_, end_)                                                        \
     do {                                                                                              \
-        const uint32_t r0_ = (uint32_t)min((stage_) * (sub_reads_) + tid, (n_reads_) - 1);            \
-        const uint32_t r1_ = (uint32_t)min((stage_) * (sub_reads_) + FB + tid, (n_reads_) - 1);       \
-        h_lo0 = (lenoff_base_)[r0_];                                                                  \
-        h_lo1 = (lenoff_base_)[r1_];                                                                  \
+        const uint32_t r0_ = (uint32_t)min((stage_) * sub_reads + tid, n_reads - 1);                  \
+        const uint32_t r1_ = (uint32_t)min((stage_) * sub_reads + FB + tid, n_reads - 1);             \
+        h_lo0 = lenoff_base[r0_];                                                                     \
+        h_lo1 = lenoff_base[r1_];                                                                     \
         const int mis_ = (begin_) & 3; /* keep the 16-byte loads aligned (word0 is a multiple of 4) */ \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>((seq_base_) + ((begin_) - mis_));         \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(seq_base + ((begin_) - mis_));            \
         const uint32_t last_ = (uint32_t)(((end_) - (begin_) + mis_ + 3) / 4 - 1);                    \
         pre0 = src_[min((uint32_t)(0 * FB + tid), last_)];                                            \
         pre1 = src_[min((uint32_t)(1 * FB + tid), last_)];                                            \
@@ -206,9 +200,8 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
         pre4 = src_[min((uint32_t)(4 * FB + tid), last_)];                                            \
         pre5 = src_[min((uint32_t)(5 * FB + tid), last_)];                                            \
     } while (0)
-#define TCMI_ISSUE_STAGE(stage_, begin_, end_) TCMI_ISSUE_STAGE_OF(lenoff_base, seq_base, sub_reads, n_reads, stage_, begin_, end_)
     static_assert(NLD == 6, "six 16-byte loads per lane cover a stage");
-    if (!prefetched) TCMI_ISSUE_STAGE(0, st_begin, st_end);
+    TCMI_ISSUE_STAGE(0, st_begin, st_end);
     // coverage: the packer lists the chunk's reads as runs of equal (position, length) — a few dozen words for a few
     // thousand reads of a sorted BAM; each becomes a (+n, -n) pair in the difference array (prefix-summed at the end)
     {
@@ -265,12 +258,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             st_end = st_end_next;
             st_end_next = chp->stage_end[min(stage + 2, TCMI_F_MAXSTAGE - 1)];
             TCMI_ISSUE_STAGE(stage + 1, st_begin, st_end);
-        } else if (more) {
-            // this chunk's last stage: the workgroup's next chunk's first stage is asked for now — its trip to memory runs under this
-            // stage's counting, the spread, the slice sums, the coverage scan and the adds to the matrix (with one chunk per resident
-            // slot — a file's only round — all of that was exposed latency: 20 us a launch of which the bytes take 11)
-            TCMI_ISSUE_STAGE_OF(a.lenoff + nx_read0, a.seq + nx_word0, nx_sub, nx_reads, 0, 0, nx_end0);
-            prefetched = true;
         }
         __syncthreads();
         // ---- C: this lane's slice of the staged reads: r = s, s + S, s + 2S, ...  Branch-free bodies of eight
@@ -413,7 +400,6 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
 }
 
 #undef TCMI_ISSUE_STAGE
-#undef TCMI_ISSUE_STAGE_OF
 #undef TCMI_XOR3
 #undef TCMI_MAJ
 
@@ -434,7 +420,7 @@ int tcmi_launch_tally_fast(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int
         a.dev_counts = rs->d_dev_counts;
         a.n_tail = (int32_t)std::min<int64_t>(a.n_tail, 128);
         // (one round of the chip's slots and a half: pk_pack cuts a file into about one chunk per slot; a file with more takes turns)
-        n_chunk_blocks = std::min<int64_t>(n_chunk_blocks, (int64_t)ctx->n_cu * ctx->wg_per_cu * (ctx->chunks_per_slot > 1 ? 2 : 3) / 2);
+        n_chunk_blocks = std::min<int64_t>(n_chunk_blocks, (int64_t)ctx->n_cu * ctx->wg_per_cu * 3 / 2);
     }
     a.n_chunk_blocks = (int32_t)std::max<int64_t>(1, n_chunk_blocks);
     int64_t grid = (rs->f_chunks ? n_chunk_blocks : 0) + a.n_tail;

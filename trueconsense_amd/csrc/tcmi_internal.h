@@ -166,7 +166,6 @@ struct tcmi_ctx {
     int n_cu = 256;                  // compute units of the device
     int wg_per_cu = TCMI_P_WAVES;    // resident workgroups per CU of the tally kernel (its register budget)
     int balance_chunks = 1;          // size the chunks so that their number is a multiple of the resident workgroups
-    int chunks_per_slot = 1;         // the one-sync packer cuts a file into this many chunks per resident tally workgroup (the kernel prefetches across chunks)
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin

@@ -442,12 +442,16 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
             cons, _ = consensus_from_records(plain, alt, flags, gff, inserts, True)
             text = ">%s mincov=%d\n%s\n" % (name, int(mincov), cons)
     finally:
+        t2 = time.perf_counter()
         if rs is not None:
             rs.free()
         if d is not None and own_d:
             d.close()
         if ctx is not None and own_ctx and step_fn is None:
             ctx.close()
+        if timings is not None:
+            timings["release"] = time.perf_counter() - t2
+            timings["total"] = time.perf_counter() - t0
     if return_parts:
         return (text, counts_root, toks) if root else None
     return text

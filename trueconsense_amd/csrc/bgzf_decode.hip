@@ -1158,7 +1158,10 @@ struct CopyArgs {
 // bgzf_copy: CW blocks per workgroup, a wavefront each (they share nothing but the CRC tables); every wavefront has its ring, the 512
 // bytes next to it where far matches are parked, and the teams' slots.  LDS addresses stay below 64 K: the copy loops do their
 // address arithmetic in 16 bits.
-constexpr int CW = 4;
+#ifndef TCMI_COPY_CW
+#define TCMI_COPY_CW 4                                // bgzf_copy: blocks (wavefronts) per workgroup: they share the CRC tables (A/B: 2, 3; 4 x 64 lanes build the tables)
+#endif
+constexpr int CW = TCMI_COPY_CW;
 constexpr int CRC_NOPS = 12;                        // crc_ops: 1, 2, 4, .. 2048 zero bytes
 struct CopyLds { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; };
 struct CopyShared {
@@ -1167,7 +1170,7 @@ struct CopyShared {
     uint32_t seg[8][16];        // seg[j][n]: the register n << 4 j, CSEG zero bytes later
 };
 static_assert(sizeof(CopyLds) % 16 == 0 && CW * sizeof(CopyLds) + CWIN < 65536, "16-bit LDS addresses in the copy loops");
-static_assert(4 * sizeof(CopyShared) <= 160 * 1024, "four workgroups (sixteen blocks) per compute unit");
+static_assert((160 * 1024 / sizeof(CopyShared)) * CW >= 14, "at least fourteen blocks per compute unit");
 
 // the CRC register (linear form: starts at 0, no final inversion) after the 16 bytes of v, from state c
 __device__ __forceinline__ uint32_t crc16(const uint32_t (*t)[256], uint32_t c, uint4 v)
@@ -1224,18 +1227,19 @@ __device__ __forceinline__ uint4 crc_masked(uint4 v, int32_t at, int32_t from, i
 // DIRECT: with the short far matches of a teams' batch finished in the batch's set-up (files that compress less than ~4 : 1: most of
 // their matches are 3 - 8 bytes long and come from anywhere in the 32 KB window; at 6 : 1 few do and the lean set-up is 3 % faster)
 template <bool TEAMS, bool DIRECT>
-__global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
+__global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_copy(CopyArgs a)
 {
     __shared__ __attribute__((aligned(16))) CopyShared S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform, and known to be: the block's fields go to scalar registers)
     if (a.crc) {                                    // the tables of the workgroup's four wavefronts (CW * 64 = 256 lanes: an entry each)
-        static_assert(CW * 64 == 256, "one table entry per lane");
-        uint32_t c = threadIdx.x;                   // the reflected CRC-32 table (polynomial 0xEDB88320)
+        for (uint32_t v = threadIdx.x; v < 256u; v += 64u * CW) {      // the reflected CRC-32 table (polynomial 0xEDB88320)
+            uint32_t c = v;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        S.t[0][threadIdx.x] = c;
-        if (threadIdx.x < 128) {
-            const uint32_t j = threadIdx.x >> 4, n = threadIdx.x & 15u;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            S.t[0][v] = c;
+        }
+        for (uint32_t v = threadIdx.x; v < 128u; v += 64u * CW) {
+            const uint32_t j = v >> 4, n = v & 15u;
             uint32_t m = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) m ^= a.zeros_seg[4 * j + i] & (0u - ((n >> i) & 1u));
@@ -1243,10 +1247,9 @@ __global__ __launch_bounds__(64 * CW, 4) void bgzf_copy(CopyArgs a)
         }
         __syncthreads();
         for (int k = 1; k < 4; ++k) {               // one more zero byte behind it
-            c = S.t[0][c & 0xFFu] ^ (c >> 8);
-            S.t[k][threadIdx.x] = c;
+            for (uint32_t v = threadIdx.x; v < 256u; v += 64u * CW) { const uint32_t c = S.t[k - 1][v]; S.t[k][v] = S.t[0][c & 0xFFu] ^ (c >> 8); }
+            __syncthreads();
         }
-        __syncthreads();
     }
     CopyLds &s_lds = S.w[wave];
     uint8_t *const s_win = s_lds.win;

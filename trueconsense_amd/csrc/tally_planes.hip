@@ -358,7 +358,11 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
     // ---- global atomics: coverage, C, G, T of TWO adjacent positions per 64-bit add (the columns never go
     //      negative and never carry out of 32 bits), A one position at a time (the tail blocks subtract from it, so
     //      it may be transiently negative and a carry would spill into the neighbour) ---------------------------
+#ifdef TCMI_TALLY_NO_ATOMICS                        // (diagnostic build: the kernel without its adds to the matrix — how much of its time they are)
+    if (a.L < 0) {
+#else
     if (a.pair_ok) {
+#endif
         for (int p = 2 * tid; p < npos; p += 2 * FB) {
             const int gp = P0 + p;                                  // even: P0 is a multiple of 8
             if (gp >= a.L) continue;
@@ -380,7 +384,11 @@ __global__ __launch_bounds__(FB, TCMI_P_WAVES) void tally_planes_kernel(FastArgs
             if (nA0) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp], nA0);
             if (nA1) atomicAdd(&a.counts[(int64_t)TCMI_A * a.ld + gp + 1], nA1);
         }
+#ifdef TCMI_TALLY_NO_ATOMICS
+    } else if (a.L < 0) {
+#else
     } else {
+#endif
         for (int p = tid; p < npos; p += FB) {
             const int gp = P0 + p;
             if (gp >= a.L) continue;

@@ -298,7 +298,7 @@ def test_a_damaged_stream_is_an_error(ctx, tmp_path):
 
 def test_crc32_of_every_block_is_checked_on_the_device(ctx, tmp_path):
     """A payload byte changed inside a STORED deflate block: the stream inflates, ISIZE holds, the record chain holds — only
-    the block's CRC-32 can tell (htslib checks it on every block; bgzf_crc32 does here)."""
+    the block's CRC-32 can tell (htslib checks it on every block; bgzf_copy does here, while it flushes the block's bytes)."""
     ref, _ = sy.make_reference(L=5000, cds=[(10, 600)])
     reads = sy.make_reads(ref, 6000, seed=2)
     p = str(tmp_path / "stored.bam")
@@ -338,6 +338,47 @@ def test_crc32_of_every_block_is_checked_on_the_device(ctx, tmp_path):
         ctx.upload_bamfile(d)
     assert e.value.code == _ffi.E_FORMAT and "CRC32" in str(e.value)
     d.close()
+
+
+def test_crc_in_the_flush_blocks_of_every_shape(ctx, tmp_path):
+    """The CRC-32 is taken from bgzf_copy's LDS ring while a block's 2 KiB segments are flushed: a block's first byte lies
+    at any offset of its first 16-byte row (the blocks' outputs follow each other without gaps), its length is anything — under a segment,
+    a whole number of them, one byte more or less — and its end is cut into 32-byte pieces from the END.  Stored blocks of random sizes
+    (level 0: what one flipped payload byte changes is the CRC alone), filled to the brim so that records straddle them: every intact
+    file decodes (all CRCs agree), and a flipped byte in a random block — first / middle / last bytes of it — is a CRC32 error of that block."""
+    rng = np.random.default_rng(11)
+    ref, _ = sy.make_reference(L=4000, cds=[(10, 600)])
+    reads = sy.make_reads(ref, 5000, seed=9)
+    n_flips = 0
+    for block in (700, 2047, 2048, 2049, 4096 + 17, 6000, 65280, int(rng.integers(800, 9000)), int(rng.integers(9000, 60000))):      # (blocks shorter than a record: the record search may not close — host reader — another test)
+        p = str(tmp_path / ("b%d.bam" % block))
+        bamwriter.write_bam(p, reads, "r", len(ref), level=0, block=block, split_records=True)
+        check_decode(ctx, p).close()
+        raw = bytearray(open(p, "rb").read())
+        offs, o = [], 0
+        while o < len(raw):
+            offs.append(o)
+            o += struct.unpack_from("<H", raw, o + 16)[0] + 1
+        body = [k for k in range(1, len(offs) - 1) if struct.unpack_from("<I", raw, offs[k + 1] - 4)[0] >= 128]      # (not the header's, not the end-of-file marker)
+        for k in (body[0], body[len(body) // 2], body[-1]):
+            ulen = struct.unpack_from("<I", raw, offs[k + 1] - 4)[0]
+            assert raw[offs[k] + 18] & 6 == 0                    # BTYPE 00: stored
+            for rel in (0, ulen // 2, ulen - 1):
+                at = offs[k] + 18 + 5 + rel
+                raw[at] ^= 0x40
+                p2 = str(tmp_path / "flip.bam")
+                open(p2, "wb").write(bytes(raw))
+                d = engine.DeviceBam(p2)
+                with pytest.raises(_ffi.TcmiError) as e:
+                    ctx.upload_bamfile(d)
+                # (a flipped length / name byte can also break the record chain or a record's fields: refused either way, and never silently)
+                assert e.value.code in (_ffi.E_FORMAT, _ffi.E_UNSUPPORTED), (block, k, rel, str(e.value))
+                if "CRC32" in str(e.value):
+                    assert ("block %d" % k) in str(e.value), (block, k, rel, str(e.value))
+                    n_flips += 1
+                d.close()
+                raw[at] ^= 0x40
+    assert n_flips >= 40
 
 
 def test_long_insertions_on_a_candidate_column_stay_on_the_device(ctx, tmp_path):

@@ -1068,7 +1068,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         n_cu, ghz = 256, 2.4
     issue = {"compute_units": n_cu, "clock_ghz": ghz, "source": r3.get("source"),
              "rates": "2 VALU + 1 SALU wave-instructions per CU and cycle (4 SIMD-32, a wave64 VALU instruction = 2 cycles of one SIMD)", "kernels": {}}
-    cold_key = {"bgzf_symbols": "inflate_symbols", "bgzf_copy": "inflate_copy", "bgzf_crc32": "crc32", "pk_index": "records", "tally_planes_kernel": "tally", "call_kernel": "call"}
+    cold_key = {"bgzf_symbols": "inflate_symbols", "bgzf_copy": "inflate_copy", "pk_index": "pack_classify", "tally_planes_kernel": "tally", "call_kernel": "call"}
     floor_sum = 0.0
     for name, c in r3k.items():
         wi = c.get("wave_insts")

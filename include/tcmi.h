@@ -145,7 +145,7 @@ enum { TCMI_K_TALLY = 0 /* bit-plane tally kernel */, TCMI_K_CALL = 1, TCMI_K_ZE
        TCMI_K_TALLY_GENERAL = 3 /* CIGAR-walk tally kernel */,
        TCMI_K_PACK_CLASSIFY = 4 /* device packer: classify + scan */, TCMI_K_PACK = 5 /* device packer: scatter + pack */,
        TCMI_K_INFLATE = 6 /* device BGZF inflate */, TCMI_K_RECORDS = 7 /* device BAM record walk */,
-       TCMI_K_CRC = 8 /* device CRC-32 of the inflated blocks */,
+       TCMI_K_CRC = 8 /* retired (always 0 since ABI 5): the blocks' CRC-32 is taken in bgzf_copy's flush, filed under TCMI_K_INFLATE_COPY */,
        TCMI_K_INFLATE_COPY = 9 /* device BGZF inflate, second kernel: tokens -> bytes (TCMI_K_INFLATE is the first: symbols -> tokens) */,
        TCMI_K_NKERNELS = 10 };
 int  tcmi_profile_enable(tcmi_ctx *ctx, int on);
@@ -365,7 +365,7 @@ int  tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, int32_t n_
 /* ---- ONE BAM file over several GPUs (BASELINE configs[4]; what the ranks jointly replace is the single-pass pile-up of
  * indexing.py:96-100 and, for the insert candidates, the region pile-ups of Events.py:47-82).
  * The library links no collective library: the one exchange of the path — a sum of the int32 count matrix to the rank that calls —
- * is a hook of the caller's (RCCL's ncclReduce on the given stream from C: tools/tcmi_rccl_hook.cpp; torch.distributed from Python:
+ * is a hook of the caller's (RCCL's ncclReduce on the given stream from C: include/tcmi_rccl.h, libtcmi_rccl.so; torch.distributed from Python:
  * trueconsense_amd/distributed.py).
  *   tcmi_split_step   this rank's part of one step, in C (rank 0 is the root): decode + pack + tally the alignment records that
  *                     start in BGZF blocks [first_block, first_block + n_blocks) into d_counts — device int32 [7][ld] +

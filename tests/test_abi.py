@@ -32,7 +32,10 @@ def test_every_header_under_include_is_covered():
 
 def test_rccl_hook_library_exports_what_its_header_declares():
     """include/tcmi_rccl.h -> trueconsense_amd/lib/libtcmi_rccl.so, built by build(): tcmi_split_step's reduce hook over RCCL
-    (no collective is called here: that needs a GPU, tests/test_rccl.py)."""
+    (no collective is called here: that needs a GPU, tests/test_rccl.py).  The hook is optional (csrc/Makefile builds it where RCCL's
+    header and library are installed): a box without RCCL has no libtcmi_rccl.so, and libtcmi.so does not need it."""
+    if not os.path.exists(_ffi.RCCL_LIB_PATH) and not os.path.exists(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include", "rccl", "rccl.h")):
+        pytest.skip("no RCCL on this box: the hook library is not built")
     lib = _ffi.rccl_lib()
     names = declared_symbols("tcmi_rccl.h")
     assert len(names) == 6 and "tcmi_rccl_reduce" in names, names

@@ -91,3 +91,17 @@ def test_spawn_ends_the_others_when_one_child_fails(monkeypatch):
     rc = cli._spawn([[sys.executable, "-c", "import sys; sys.exit(3)"], [sys.executable, "-c", "import time; time.sleep(120)"]], [None, None])
     assert rc >= 3 and time.monotonic() - t0 < 30
     assert cli._spawn([[sys.executable, "-c", "pass"]] * 2, [None, None]) == 0
+
+
+def test_console_scripts_of_the_reference_are_declared():
+    """pyproject.toml declares `trueconsense` and `TrueConsense` (the reference's pyproject.toml:38-40) and both resolve to a callable."""
+    import importlib
+    import os
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as fh:
+        scripts = tomli.load(fh)["project"]["scripts"]
+    assert set(scripts) == {"trueconsense", "TrueConsense"}
+    for target in scripts.values():
+        mod, fn = target.split(":")
+        assert callable(getattr(importlib.import_module(mod), fn))

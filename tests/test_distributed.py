@@ -228,14 +228,18 @@ def test_split_bam_allreduce_gpu_tally_gloo_world2():
     _run(2, use_gpu=True)
 
 
-def _bench_ranks(extra, env_extra=None, nproc=2):
+def _bench_ranks(extra, env_extra=None, nproc=2, launcher=True):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed with two ranks on
-    ONE GPU over gloo (TCMI_BENCH_REHEARSE=1: RCCL wants a GPU per rank); returns rank 0's JSON line."""
+    ONE GPU over gloo (TCMI_BENCH_REHEARSE=1: RCCL wants a GPU per rank); returns rank 0's JSON line.
+    launcher=False: plain `python bench.py --gpus N` — the script starts its own ranks (bench.spawn_ranks)."""
     import json
     import subprocess
     env = dict(os.environ, TCMI_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+           "--master-port", str(_free_port())] if launcher else [sys.executable]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
@@ -248,6 +252,38 @@ def test_bench_many_bam_shard_two_ranks_rehearsal():
     d = _bench_ranks(["--steps", "3", "--warmup", "1", "--reads", "40000", "--files", "2", "--no-cpu-baseline", "--no-resident"])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
     assert d["value"] > 0 and d["unit"] == "positions/s" and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (plain python, as the driver's N = 1 command is shaped): the flag alone must shard — two child ranks,
+    started before the parent touches a GPU, one JSON line with n_gpus 2."""
+    d = _bench_ranks(["--steps", "4", "--warmup", "1", "--reads", "40000", "--files", "2", "--no-cpu-baseline", "--no-resident", "--no-hard-bam",
+                      "--no-cli-batch", "--no-configs2", "--no-configs0", "--min-seconds", "0"], launcher=False)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
+    assert d["ms_per_step_per_rank"]["max"] >= d["ms_per_step_per_rank"]["min"] > 0
+
+
+def test_bench_spawn_ranks_ends_the_others_when_one_fails(tmp_path, monkeypatch):
+    """bench.spawn_ranks (CPU: the children are stand-ins): the worst exit code comes back, and a rank that sits in a 'collective' is
+    ended once another has failed."""
+    import bench
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "mode = sys.argv[1]\n"
+                      "if mode == 'ok': sys.exit(0)\n"
+                      "if r == 1: sys.exit(7)\n"
+                      "time.sleep(600)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setattr(bench.time, "monotonic", lambda base=__import__("time").monotonic: base() * 20.0)     # (the 20 s of grace in one)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "ok"])
+    assert bench.spawn_ranks(3) == 0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "hang"])
+    t0 = __import__("time").perf_counter()
+    assert bench.spawn_ranks(3) != 0
+    assert __import__("time").perf_counter() - t0 < 30
 
 
 @pytest.mark.gpu
@@ -273,6 +309,46 @@ def test_bench_many_bam_shard_four_ranks_rehearsal():
                       "--no-cli-batch", "--no-configs2", "--min-seconds", "0"], nproc=4)
     assert d["n_gpus"] == 4 and d["steps"] == 2 and d["scaling"] == "weak" and d["fasta_bit_exact"] is True
     assert d["fasta_all_timed"]["all_equal_the_oracle_chain"] is True
+
+
+@pytest.mark.gpu
+def test_configs4_eight_ranks_in_turn_on_one_gpu(tmp_path):
+    """BASELINE configs[4]'s shape — ONE file over EIGHT ranks — through the code every rank of the real job runs (tcmi_split_step: range +
+    the block behind it, range table, the root's pairwise check of the joins), the ranks played one after the other on the one GPU
+    (distributed.split_ranks_in_turn; tools/configs4_full.py runs it at 8 x 6.25 M reads).  (1) 8 x 1 M plain reads, htslib-style
+    blocks: counts = the scalar C tally, FASTA = the oracle chain.  (2) indel carriers, records across blocks, THREE ranks: the insert
+    candidates' entries gathered in rank order, FASTA = the oracle chain (Events.py:47-82)."""
+    from oracle import c_oracle
+    from oracle import tc_oracle as orc
+    from trueconsense_amd import distributed as td
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.io import bamwriter
+    ref, orfs = sy.make_reference()
+    L = len(ref)
+    tile = L - 150 + 1
+    path = str(tmp_path / "c4.bam")
+    want = np.zeros((L, 7), np.int64)
+    n, m = 1_000_000, 8
+    for k in range(m):
+        reads = sy.make_reads(ref, n, seed=9100 + k, start_range=(tile * k // m, tile * (k + 1) // m))
+        bamwriter.write_bam_fast(path, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", L, level=1, part=(k == 0, k == m - 1), first_id=k * n)
+        want += c_oracle.tally(reads, L)
+    rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
+    tm = {}
+    text, counts, _ = td.split_ranks_in_turn(path, L, rows, 30, 8, return_parts=True, timings=tm)
+    assert np.array_equal(counts.astype(np.int64), want) and int(counts[:, 0].sum()) == 150 * n * m
+    assert tm["one_sync_taken"] == 8 and len(tm["rank_seconds"]) == 8 and min(tm["blocks_per_rank"]) > 4000
+    has, ins = orc.list_inserts(want, 30, lambda pos1: [])
+    cons, _ = orc.build_consensus(30, want, [dict(o) for o in orfs], True, ins if has else None, True)
+    assert text == orc.fasta_text("S", 30, cons)
+    # (2)
+    ref2, orfs2, reads2 = _consensus_case()
+    want2, ins2 = _oracle_fasta(reads2, orfs2, len(ref2), 30)
+    assert len(ins2) >= 4
+    bamwriter.write_bam(path, reads2, "r", len(ref2), level=6, block=3000, split_records=True)
+    rows2 = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs2]
+    text2, counts2, toks2 = td.split_ranks_in_turn(path, len(ref2), rows2, 30, 3, return_parts=True)
+    assert text2 == want2 and np.array_equal(counts2, c_oracle.tally(reads2, len(ref2))) and sum(1 for v in toks2.values() if v) >= 4
 
 
 def test_check_range_anchors_joins_the_ranks_ranges_into_one_chain():

@@ -524,6 +524,15 @@ def test_cli_gpus_n_batch_shards_and_one_bam_split(ctx, tmp_path, monkeypatch):
         vcf = open(tag + ".vcf").read().split("\n")
         outs[tag] = (open(tag + ".fa").read(), open(tag + ".gff").read(), open(tag + ".tsv").read(), vcf[:1] + vcf[3:])
     assert outs["one"] == outs["two"]
+    # ... and the split worker itself with the exchange it uses on a node of GPUs: the C hook over an RCCL communicator (one rank here)
+    argv = [sys.executable, "-m", "trueconsense_amd.split_main", "-i", "one.bam", "-ref", "r2.fa", "-gff", "g2.gff", "-cov", "30", "-name", "S",
+            "-o", "hook.fa", "-vcf", "hook.vcf", "-ogff", "hook.gff", "-doc", "hook.tsv", "--gpus", "1"]
+    env1 = {k: v for k, v in env.items() if k not in ("TCMI_SPLIT_ONE_GPU", "TCMI_SPLIT_BACKEND")}
+    r = subprocess.run(argv, env=dict(env1, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TCMI_SPLIT_VERBOSE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "tcmi_rccl_reduce: ncclReduce" in r.stderr, r.stderr[-1500:]
+    vcf = open("hook.vcf").read().split("\n")
+    assert (open("hook.fa").read(), open("hook.gff").read(), open("hook.tsv").read(), vcf[:1] + vcf[3:]) == outs["one"]
     assert "ACGTACGTACGTAC" in outs["two"][0]                        # (the 14-base insertion, whose bases travelled as text, is in the consensus)
 
 

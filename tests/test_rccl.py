@@ -51,3 +51,37 @@ def test_split_step_reduces_through_rccl_on_a_one_rank_communicator(tmp_path):
         assert tm["step"] > 0 and sum(1 for v in toks.values() if v) >= 4
     finally:
         assert r.tcmi_rccl_comm_destroy(comm) == 0
+
+
+def test_cli_gpus_2_reduces_through_the_rccl_hook_on_two_gpus(tmp_path):
+    """The hook at world > 1 — `TrueConsense -i one.bam --gpus 2` on a node with two GPUs: the split workers make a two-rank RCCL
+    communicator (distributed.split_reduce_hook) and tcmi_split_step queues ncclReduce on each rank's stream; the four outputs equal
+    the single-GPU command line's.  Skips on the one-GPU boxes (RCCL wants a GPU per rank)."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    from trueconsense_amd import synthetic as sy
+    from trueconsense_amd.io import bamwriter
+    ref, orfs = sy.make_reference(L=4000, cds=[(100, 1900), (2100, 3900)])
+    sites = [(1900, "I", "A", 0.9), (1990, "I", "GT", 0.7), (2010, "D", 3, 0.6), (3000, "I", "TT", 0.95)]
+    reads = sy.make_reads(ref, 6000, seed=91, indel_sites=sites)
+    os.chdir(tmp_path)
+    bamwriter.write_bam("one.bam", reads, "MN", len(ref), block=3000, split_records=True)
+    open("r.fa", "w").write(">MN x\n" + ref + "\n")
+    head, body = sy.gff_text(orfs, seqid="MN")
+    open("g.gff", "w").write(head + body)
+    env = dict(os.environ, PYTHONPATH=ROOT, TCMI_SPLIT_VERBOSE="1")
+    for k in ("TCMI_SPLIT_ONE_GPU", "TCMI_SPLIT_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2"])):
+        argv = [sys.executable, "-m", "trueconsense_amd.TrueConsense", "-i", "one.bam", "-ref", "r.fa", "-gff", "g.gff", "-cov", "30", "-name", "S",
+                "-o", tag + ".fa", "-vcf", tag + ".vcf", "-ogff", tag + ".gff", "-doc", tag + ".tsv"] + extra
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        if extra:
+            assert "2-rank communicator" in r.stderr, r.stderr[-1500:]
+        vcf = open(tag + ".vcf").read().split("\n")
+        outs[tag] = (open(tag + ".fa").read(), open(tag + ".gff").read(), open(tag + ".tsv").read(), vcf[:1] + vcf[3:])
+    assert outs["one"] == outs["two"]

@@ -83,9 +83,39 @@ static int ctx_create(int device, bool own, void *stream, tcmi_ctx **out)
     tcmi_ctx *c = new tcmi_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // TCMI_STREAM_SPLIT (A/B): 1 = two streams by priority (inflate low, pack + tally + call high); 2 = by compute units
+    // (TCMI_CU_HI of them, default 48, for the high stream, the rest for the inflate); 3 = inflate on its share of the compute units,
+    // the rest at high priority on all of them
+    const char *sv = std::getenv("TCMI_STREAM_SPLIT");
+    const int split = sv ? std::atoi(sv) : 0;
     if (!own) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
+    } else if (split >= 1 && split <= 3) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char *hv = std::getenv("TCMI_CU_HI");
+        const int n_hi = std::max(1, std::min(c->n_cu - 1, hv ? std::atoi(hv) : 48));
+        uint32_t m_lo[16] = {0}, m_hi[16] = {0};
+        for (int i = 0; i < c->n_cu && i < 512; ++i) (i < c->n_cu - n_hi ? m_lo : m_hi)[i >> 5] |= 1u << (i & 31);
+        const uint32_t words = (uint32_t)((c->n_cu + 31) / 32);
+        hipError_t e1, e2;
+        if (split == 1) {
+            e1 = hipStreamCreateWithPriority(&c->stream_lo, hipStreamNonBlocking, least);
+            e2 = hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest);
+        } else if (split == 2) {
+            e1 = hipExtStreamCreateWithCUMask(&c->stream_lo, words, m_lo);
+            e2 = hipExtStreamCreateWithCUMask(&c->stream_hi, words, m_hi);
+        } else {
+            e1 = hipExtStreamCreateWithCUMask(&c->stream_lo, words, m_lo);
+            e2 = hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest);
+        }
+        if (e1 != hipSuccess || e2 != hipSuccess || hipEventCreateWithFlags(&c->ev_split, hipEventDisableTiming) != hipSuccess) {
+            const hipError_t e = e1 != hipSuccess ? e1 : e2;
+            delete c;
+            return tcmi_fail(nullptr, TCMI_E_HIP, "TCMI_STREAM_SPLIT=%d: the streams could not be made (%s)", split, hipGetErrorString(e));
+        }
+        c->stream = c->stream_lo;
     } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return tcmi_fail(nullptr, TCMI_E_HIP, "hipStreamCreate failed");
@@ -146,6 +176,12 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     if (c->tok_host) (void)hipHostFree(c->tok_host);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
+    if (c->stream_hi) {
+        (void)hipStreamSynchronize(c->stream_hi);
+        (void)hipStreamDestroy(c->stream_hi);
+        (void)hipEventDestroy(c->ev_split);
+        c->stream = c->stream_lo;
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TCMI_OK;
@@ -155,6 +191,7 @@ int tcmi_ctx_sync(tcmi_ctx *c)
 {
     if (!c) return tcmi_fail(nullptr, TCMI_E_ARG, "ctx is NULL");
     TCMI_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->stream_hi) TCMI_HIP(c, hipStreamSynchronize(c->stream_hi));
     return TCMI_OK;
 }
 

@@ -605,6 +605,29 @@ int tcmi_readset_from_bamfile(tcmi_ctx *ctx, const tcmi_bamfile *f, tcmi_readset
 namespace {
 std::atomic<uint64_t> g_next_uid{1ull << 40};
 
+// A context with two streams (TCMI_STREAM_SPLIT): the launches behind the inflate go to the high stream, which waits for the low
+// one's decode; the caller's scope ends with the host's wait for the step (or for the high stream), so the next file's launches on
+// the low stream find the arena free.
+int split_to_high(tcmi_ctx *c)
+{
+    if (!c->stream_hi || c->stream == c->stream_hi) return TCMI_OK;
+    TCMI_HIP(c, hipEventRecord(c->ev_split, c->stream_lo));
+    TCMI_HIP(c, hipStreamWaitEvent(c->stream_hi, c->ev_split, 0));
+    c->stream = c->stream_hi;
+    return TCMI_OK;
+}
+struct SplitScope {
+    tcmi_ctx *c;
+    explicit SplitScope(tcmi_ctx *ctx) : c(ctx) {}
+    ~SplitScope()
+    {
+        if (c->stream_hi && c->stream == c->stream_hi) {
+            (void)hipStreamSynchronize(c->stream_hi);               // (a no-op behind the step's wait; what an error path needs)
+            c->stream = c->stream_lo;
+        }
+    }
+};
+
 // queue everything of the one-sync path up to the packed read set; D and J must outlive the wait
 // (safe_caps: the arrays sized from the worst case the arena was reserved for, not from a hint of the records' mean size)
 int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int64_t n_blocks, Decoded &D, tcmi_fused_job &J, tcmi_readset *rs, bool safe_caps = false)
@@ -619,6 +642,8 @@ int fast_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, int6
     static const int split_env = std::getenv("TCMI_ONE_SYNC_SPLIT") ? std::atoi(std::getenv("TCMI_ONE_SYNC_SPLIT")) : -1;    // (A/B: 0 none, 1 behind the decode, 2 behind the packer, 3 both)
     const int split = split_env >= 0 ? split_env : ctx->mid_wait;
     if (split == 1 || split == 3) TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = split_to_high(ctx);                                        // (the caller's SplitScope brings the context back)
+    if (rc) return rc;
     J.d_stream = D.d_out; J.stream_len = D.f->inflated; J.d_desc = D.d_desc; J.d_slot = D.d_slot; J.d_nrec = D.d_nrec; J.d_first = D.d_first;
     J.d_over = D.d_over; J.d_stat = D.d_stat; J.n_blocks = (int64_t)D.nb; J.n_own = (int64_t)D.nb_own; J.ranged = D.ranged ? 1 : 0;
     // records: from the mean size of the file's first records (+ 25 %) where the host saw enough of them, else as the arena was reserved
@@ -657,6 +682,7 @@ static int readset_from_blocks(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t fir
     static const bool timing = std::getenv("TCMI_UPLOAD_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     for (int attempt = 0; ctx->one_sync && try_fused && attempt < 2; ++attempt) {
+        SplitScope back(ctx);
         Decoded D;
         tcmi_fused_job J;
         tcmi_readset *rs = new tcmi_readset();
@@ -758,6 +784,7 @@ int tcmi_bamfile_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t ref_len, int
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         const auto t0 = now();
+        SplitScope back(ctx);
         Decoded D;
         tcmi_fused_job J;
         tcmi_readset *rs = new tcmi_readset();

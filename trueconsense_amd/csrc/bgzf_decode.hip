@@ -990,9 +990,11 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
 #pragma unroll
                         for (int r = 0; r < R; ++r) t[r] = mine[(size_t)min(k0 + (uint32_t)r, last_row) * SYM_LANES];
                         if (k0 >= lo && k0 + R <= hi) {
-                            uint4 *q = reinterpret_cast<uint4 *>(dst + (k0 - lo));
+                            // (dst is word-aligned only: the 16-byte store goes through a type that says so)
+                            struct __attribute__((packed, aligned(4))) W4 { uint32_t w[4]; };
+                            W4 *q = reinterpret_cast<W4 *>(dst + (k0 - lo));
 #pragma unroll
-                            for (int r = 0; r < R; r += 4) __builtin_memcpy(q + r / 4, &t[r], 16);
+                            for (int r = 0; r < R; r += 4) q[r / 4] = W4{{t[r], t[r + 1], t[r + 2], t[r + 3]}};
                         } else {
 #pragma unroll
                             for (int r = 0; r < R; ++r) if (k0 + r >= lo && k0 + r < hi) dst[k0 + r - lo] = t[r];

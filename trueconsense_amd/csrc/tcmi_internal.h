@@ -168,6 +168,11 @@ struct tcmi_ctx {
     int balance_chunks = 1;          // size the chunks so that their number is a multiple of the resident workgroups
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    // Two streams per context (TCMI_STREAM_SPLIT, api.cpp ctx_create): the inflate kernels of a file stay on `stream_lo`, everything
+    // behind them (pk_index .. pk_report: short kernels that triple in duration next to a chip full of bgzf_copy workgroups) goes to
+    // `stream_hi` — a higher priority, or compute units of its own.  `stream` is the one the launches use at the moment.
+    hipStream_t stream_lo = nullptr, stream_hi = nullptr;
+    hipEvent_t ev_split = nullptr;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin
     std::string err;
     // profiling
@@ -256,13 +261,13 @@ extern "C" int tcmi_bamfile_read_threads(const char *path, int read_threads, tcm
 // input needs the host packer
 int tcmi_upload_and_pack_on_device(tcmi_ctx *ctx, const tcmi_reads *r, tcmi_readset *rs, uint32_t *why);
 int tcmi_pack_on_device(tcmi_ctx *ctx, const void *pack_src, tcmi_readset *rs, uint32_t *why);
-// The one-sync file path (bam_device.hip: tcmi_bamfile_step, tcmi_readset_from_bamfile): everything behind bgzf_copy / bgzf_crc32 —
+// The one-sync file path (bam_device.hip: tcmi_bamfile_step, tcmi_readset_from_bamfile): everything behind bgzf_copy —
 // record index, the chain of records across the blocks, classification, prefix sums, bit planes (pk_index, pk_place), chunk planning
 // (pk_pack) — queued on the context's stream from CAPACITIES instead of counts read back; _finish, once the stream has been
 // waited for, checks what was deferred (block verdicts, chain, capacities, packer flags) and fills the read set in, or says that
 // the file must take the several-kernel path (TCMI_E_UNSUPPORTED: nothing of the job may be used then).
 struct tcmi_fused_job {
-    // in: device pointers into the context's arena (bgzf_copy, bgzf_crc32)
+    // in: device pointers into the context's arena (bgzf_copy)
     const uint8_t *d_stream = nullptr;
     uint64_t stream_len = 0;
     const void *d_desc = nullptr;       // BlockDesc [n_blocks]

@@ -14,6 +14,7 @@ Two shard shapes (BASELINE.json configs[3] and [4]):
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -269,19 +270,63 @@ def rccl_communicator(rank, world, group=None):
     travel through the process group that is already up (any backend) — or nowhere at world 1.  -> (comm handle, _ffi.RcclUser);
     destroy with _ffi.rccl_lib().tcmi_rccl_comm_destroy(comm).  The current HIP device must be the rank's."""
     from . import _ffi
-    r = _ffi.rccl_lib()
+    # The ranks move in step: every rank enters the broadcast of the id and the gather of the verdicts whatever happened to it before
+    # (a hook library that does not load, an id that cannot be drawn, a communicator that cannot be made) — and then all raise, or none.
+    r, err = None, None
+    try:
+        r = _ffi.rccl_lib()
+    except (ImportError, OSError) as e:
+        err = str(e)
     ident = C.create_string_buffer(_ffi.RCCL_ID_BYTES)
-    if rank == 0 and r.tcmi_rccl_unique_id(ident):
-        raise RuntimeError((r.tcmi_rccl_last_error() or b"").decode())
-    if world > 1:
+    if rank == 0 and err is None and r.tcmi_rccl_unique_id(ident):
+        err = (r.tcmi_rccl_last_error() or b"").decode()
+    multi = world > 1
+    if multi:
         import torch.distributed as dist
-        box = [ident.raw if rank == 0 else None]
+        box = [(err, ident.raw) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        ident = C.create_string_buffer(box[0], _ffi.RCCL_ID_BYTES)
+        root_err, raw = box[0]
+        if root_err is not None:
+            raise RuntimeError("rccl_communicator: rank 0 could not draw the id: %s" % root_err)
+        ident = C.create_string_buffer(raw, _ffi.RCCL_ID_BYTES)
+    elif err is not None:
+        raise RuntimeError("rccl_communicator: %s" % err)
     comm = C.c_void_p()
-    if r.tcmi_rccl_comm_init(int(world), int(rank), ident, C.byref(comm)):
-        raise RuntimeError((r.tcmi_rccl_last_error() or b"").decode())
+    if err is None and r.tcmi_rccl_comm_init(int(world), int(rank), ident, C.byref(comm)):
+        err = (r.tcmi_rccl_last_error() or b"").decode()
+        comm = C.c_void_p()
+    if multi:
+        allv = [None] * world
+        dist.all_gather_object(allv, err, group=group)
+        bad = [(k, v) for k, v in enumerate(allv) if v is not None]
+        if bad:
+            if comm:
+                r.tcmi_rccl_comm_destroy(comm)
+            raise RuntimeError("rccl_communicator: rank %d: %s" % bad[0])
+    elif err is not None:
+        raise RuntimeError("rccl_communicator: %s" % err)
     return comm, _ffi.RcclUser(comm, 0)
+
+
+def split_reduce_hook(rank, world, group=None, rccl=True):
+    """The exchange tcmi_split_step's hook runs on for this job -> (comm or None, rccl_user or None, what it is, in words).
+    rccl: the C hook tcmi_rccl_reduce (libtcmi_rccl.so: ncclReduce queued on the context's stream) on a communicator of this job's own —
+    at ONE rank too, so that the collective itself runs wherever the step runs.  All ranks get the same answer (rccl_communicator's
+    ranks raise together): where the communicator cannot be made — no libtcmi_rccl.so, several ranks on one GPU — every rank falls
+    back to torch.distributed's reduce on the process group that is already up.  Destroy `comm` with split_reduce_hook_close."""
+    if rccl and os.environ.get("TCMI_SPLIT_HOOK", "rccl") == "rccl":
+        try:
+            comm, user = rccl_communicator(rank, world, group)
+            return comm, user, "tcmi_rccl_reduce: ncclReduce on the context's stream, %d-rank communicator" % world
+        except RuntimeError as e:
+            return None, None, "torch.distributed reduce (an RCCL communicator of its own could not be made: %s)" % e
+    return None, None, "torch.distributed reduce"
+
+
+def split_reduce_hook_close(comm):
+    if comm:
+        from . import _ffi
+        _ffi.rccl_lib().tcmi_rccl_comm_destroy(comm)
 
 
 def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True, name="S", rank=0, world=1, device=0, group=None,
@@ -341,9 +386,11 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
                 t[-1] = 1
                 if rccl_user is not None:                            # (the others are in ncclReduce on that communicator)
                     from . import _ffi
-                    _ffi.rccl_lib().tcmi_rccl_reduce(C.cast(C.pointer(rccl_user), C.c_void_p), C.c_void_p(t.data_ptr()), t.numel(),
-                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                    rrc = _ffi.rccl_lib().tcmi_rccl_reduce(C.cast(C.pointer(rccl_user), C.c_void_p), C.c_void_p(t.data_ptr()), t.numel(),
+                                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
                     torch.cuda.synchronize()
+                    if rrc:                                          # (the failure this rank reports gains the reduce's own)
+                        err = (err[0], "%s; and its share of the reduce failed too: %s" % (err[1], (_ffi.rccl_lib().tcmi_rccl_last_error() or b"").decode()))
                 else:
                     reduce_counts(t, 0, group)
             else:
@@ -455,3 +502,100 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
     if return_parts:
         return (text, counts_root, toks) if root else None
     return text
+
+
+def split_ranks_in_turn(path, ref_len, gff_rows, mincov, world, include_ambig=True, name="S", device=0, return_parts=False, timings=None):
+    """BASELINE configs[4] at ANY world size on the ONE GPU there is: the ranks' steps of a `world`-GPU job played one after the other
+    on one context — rank world-1 first, rank 0 (the root) last — each through tcmi_split_step exactly as a rank of the real job runs
+    it (its own contiguous range of the file's BGZF blocks + the block behind it, the range table and the failure word behind the
+    matrix, the root's pairwise check of the joins, the call kernel on the root).  The hook stands in for the collective: a non-root
+    rank's buffer is added to an accumulator on the device, the root's hook adds the accumulator to its own — the integer sum RCCL's
+    reduce delivers (indexing.py:96-100 is the pass the ranks share).  What it cannot show is the collective's time: `timings`
+    receives per rank the seconds of its step ("rank_seconds"), so that a node's step can be projected as max(rank) + reduce.
+    Insert candidates are voted on from every rank's entries, gathered in rank order as consensus_split_bamfile's step 4 does
+    (Events.py:47-82).  -> FASTA text (return_parts: + counts int32 [L,7] + {column: token})."""
+    import time
+    import torch
+    from ._ffi import TcmiError
+    from .engine import Context, DeviceBam, ReadSet
+    from .Events import inserts_from_flags
+    from .Sequences import consensus_from_records
+    L = int(ref_len)
+    ld = (L + 255) // 256 * 256
+    world = int(world)
+    torch.cuda.set_device(device)
+    ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
+    d = DeviceBam(path)
+    n_words = 7 * ld + 6 * world + 1                                 # TCMI_SPLIT_TAIL_WORDS(world)
+    acc = torch.zeros(n_words, dtype=torch.int32, device="cuda")
+    t = torch.zeros(n_words, dtype=torch.int32, device="cuda")
+    state = {"root": False}
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    def hook(user, ptr_, n, stream):                                 # (ptr_ IS t's buffer; the context runs on torch's current stream)
+        if int(n) != n_words or int(ptr_) != t.data_ptr():
+            return 1
+        if state["root"]:
+            t.add_(acc)
+        else:
+            acc.add_(t)
+        return 0
+
+    secs, sets = [0.0] * world, [None] * world
+    plain = alt = flags = None
+    try:
+        for rank in range(world - 1, -1, -1):
+            first, count = block_range(d.n_blocks, rank, world)
+            state["root"] = rank == 0
+            h, p_, a_, f_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = lib().tcmi_split_step(ctx.handle, d.handle, first, count, L, ld, C.c_void_p(t.data_ptr()), int(mincov), int(bool(include_ambig)), hook, None,
+                                       rank, world, C.byref(h), C.byref(p_), C.byref(a_), C.byref(f_))
+            torch.cuda.synchronize()
+            secs[rank] = time.perf_counter() - t0
+            if rc:
+                raise TcmiError(rc, "split_ranks_in_turn: rank %d of %d: %s" % (rank, world, (lib().tcmi_last_error(ctx.handle) or b"").decode("utf-8", "replace")))
+            sets[rank] = ReadSet(ctx, h, None)
+            if rank == 0:
+                grab = lambda vp: np.frombuffer(C.string_at(vp, L), np.uint8).copy()
+                plain, alt, flags = grab(p_), grab(a_), grab(f_)
+            elif rank > 0:                                           # (a context holds ONE resident stream: this rank's entries are collected below, from a decode of their own)
+                sets[rank].free()
+                sets[rank] = None
+        counts = np.ascontiguousarray(t[:7 * ld].view(7, ld)[:, :L].T.cpu().numpy()) if return_parts else None
+        cand = (np.nonzero(flags & 8)[0] + 1).tolist()
+        toks = {}
+        if cand:
+            pieces = []
+            for rank in range(world):                                # rank order = file order
+                rs = sets[rank]
+                if rs is None:
+                    rs = ctx.upload_bamfile(d, blocks=block_range(d.n_blocks, rank, world))
+                try:
+                    pieces.append(_entries_of_readset(ctx, rs, cand))
+                finally:
+                    rs.free()
+                    sets[rank] = None
+            toks, st = _vote(cand, pieces)
+            if st & 2:
+                from .engine import BamFile, modal_tokens
+                bam = BamFile(path)
+                try:
+                    toks = {p: tk for p, (tk, _) in modal_tokens(bam, cand).items()}
+                finally:
+                    bam.close()
+        _, inserts = inserts_from_flags(flags, _Tokens(toks))
+        cons, _ = consensus_from_records(plain, alt, flags, {i: dict(r) for i, r in enumerate(gff_rows)}, inserts, True)
+        text = ">%s mincov=%d\n%s\n" % (name, int(mincov), cons)
+        if timings is not None:
+            timings.update(rank_seconds=secs, blocks_per_rank=[block_range(d.n_blocks, r, world)[1] for r in range(world)],
+                           n_blocks=d.n_blocks, file_bytes=d.file_bytes, inflated_bytes=d.inflated_bytes,
+                           decode_batched=ctx.stat("decode_batched"), one_sync_taken=ctx.stat("one_sync_taken"))
+    finally:
+        for rs in sets:
+            if rs is not None:
+                rs.free()
+        d.close()
+        ctx.close()
+    return (text, counts, toks) if return_parts else text

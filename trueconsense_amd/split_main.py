@@ -38,7 +38,13 @@ def main(argv=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     rc = 0
+    comm = None
     try:
+        # the step's one exchange: the C hook over an RCCL communicator of this job's own (what tests/test_rccl.py and bench.py --split-bam
+        # --from-file run); a rehearsal of several ranks on one GPU (gloo) keeps the process group's reduce
+        comm, user, hook_kind = td.split_reduce_hook(rank, world, rccl=backend == "nccl" and (world == 1 or not one_gpu))
+        if os.environ.get("TCMI_SPLIT_VERBOSE") == "1" and rank == 0:
+            print("TrueConsense --gpus %d: the count matrices are summed by %s" % (world, hook_kind), file=sys.stderr)
         IndexGff = Gffindex(a.features)
         gffdf = IndexGff.df
         gffdf["seqid"] = a.samplename
@@ -46,7 +52,7 @@ def main(argv=None):
         rows = [{"start": int(r["start"]), "end": int(r["end"]), "strand": r.get("strand")} for r in gffdict.values()]
         _, refseq = fasta.read_first_record(a.reference)
         parts = td.consensus_split_bamfile(a.input, len(refseq), rows, a.coverage_level, a.noambiguity is False, a.samplename, rank, world,
-                                           device=device, return_parts=True)
+                                           device=device, return_parts=True, rccl_user=user)
         if rank == 0:
             _, counts, toks = parts
             index = _state.IndexDict(counts)
@@ -58,6 +64,10 @@ def main(argv=None):
         print("TrueConsense --gpus (rank %d): %s" % (rank, e), file=sys.stderr)
         rc = 1
     finally:
+        try:
+            td.split_reduce_hook_close(comm)
+        except Exception:                                            # noqa: BLE001
+            pass
         if world > 1 and dist.is_initialized():
             dist.destroy_process_group()
     return rc

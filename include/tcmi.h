@@ -124,6 +124,10 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "decode_token_mb" the device decoder's token scratch, MiB (default 4096): a file whose BGZF blocks need more (tokens take 3 - 10
  *                    times the inflated bytes while a block is decoded) is decoded in batches of blocks that share the scratch —
  *                    the inflated stream stays whole
+ *   "split_sub"      tcmi_split_step: a rank's block range is decoded, packed and tallied as this many SUB-RANGES side by side — the first on
+ *                    this context, the others on helper contexts it owns (a stream, an arena and a host thread each), so that the inflate of
+ *                    one sub-range runs under the pack of another; the sub-ranges must join like ranks' ranges, else the range is taken in
+ *                    one piece.  0 = auto (default: 3 from 6 144 blocks on, 2 from 4 096, else 1), 1 = never, up to 8
  *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
  *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)
@@ -137,7 +141,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
 int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 /* counters of a context: "one_sync_taken" / "one_sync_declined" — files (or block ranges) the one-sync path delivered / handed to the
  * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag);
- * "decode_batched" — files (or ranges) whose blocks the device decoder took in batches ("decode_token_mb") */
+ * "decode_batched" — files (or ranges) whose blocks the device decoder took in batches ("decode_token_mb");
+ * "split_sub_taken" — tcmi_split_step calls whose range went through sub-ranges ("split_sub") */
 int  tcmi_ctx_stat(tcmi_ctx *ctx, const char *key, int64_t *value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

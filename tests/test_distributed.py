@@ -337,7 +337,10 @@ def test_configs4_eight_ranks_in_turn_on_one_gpu(tmp_path):
     tm = {}
     text, counts, _ = td.split_ranks_in_turn(path, L, rows, 30, 8, return_parts=True, timings=tm)
     assert np.array_equal(counts.astype(np.int64), want) and int(counts[:, 0].sum()) == 150 * n * m
-    assert tm["one_sync_taken"] == 8 and len(tm["rank_seconds"]) == 8 and min(tm["blocks_per_rank"]) > 4000
+    assert tm["one_sync_taken"] >= 8 and len(tm["rank_seconds"]) == 8 and min(tm["blocks_per_rank"]) > 4000
+    assert tm["split_sub_taken"] == 8                               # (4 187 blocks a rank: two sub-ranges side by side, each rank)
+    text1, counts1, _ = td.split_ranks_in_turn(path, L, rows, 30, 8, return_parts=True, split_sub=1)       # ... and every range in one piece: the same
+    assert text1 == text and np.array_equal(counts1, counts)
     has, ins = orc.list_inserts(want, 30, lambda pos1: [])
     cons, _ = orc.build_consensus(30, want, [dict(o) for o in orfs], True, ins if has else None, True)
     assert text == orc.fasta_text("S", 30, cons)
@@ -347,8 +350,11 @@ def test_configs4_eight_ranks_in_turn_on_one_gpu(tmp_path):
     assert len(ins2) >= 4
     bamwriter.write_bam(path, reads2, "r", len(ref2), level=6, block=3000, split_records=True)
     rows2 = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs2]
-    text2, counts2, toks2 = td.split_ranks_in_turn(path, len(ref2), rows2, 30, 3, return_parts=True)
-    assert text2 == want2 and np.array_equal(counts2, c_oracle.tally(reads2, len(ref2))) and sum(1 for v in toks2.values() if v) >= 4
+    for sub_ranges in (1, 2, 3):                                     # the ranks' ranges in one piece / as sub-ranges side by side (their entries merged in file order)
+        tm2 = {}
+        text2, counts2, toks2 = td.split_ranks_in_turn(path, len(ref2), rows2, 30, 3, return_parts=True, split_sub=sub_ranges, timings=tm2)
+        assert text2 == want2 and np.array_equal(counts2, c_oracle.tally(reads2, len(ref2))) and sum(1 for v in toks2.values() if v) >= 4, sub_ranges
+        assert tm2["split_sub_taken"] == (3 if sub_ranges > 1 else 0), (sub_ranges, tm2)
 
 
 def test_check_range_anchors_joins_the_ranks_ranges_into_one_chain():

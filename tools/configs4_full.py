@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--mincov", type=int, default=30)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--split-sub", default=None, help="sub-ranges per rank in tcmi_split_step (default: the library's choice); a list \"1,3,0\": the passes once per value, turn about")
     a = ap.parse_args()
     from oracle import c_oracle
     from oracle import tc_oracle as orc
@@ -59,15 +60,16 @@ def main():
     rows = [{"start": o["start"], "end": o["end"], "strand": "+"} for o in orfs]
     out = {"reads": total, "world": a.world, "passes": []}
     text = counts = None
-    for rep in range(a.repeat):
+    subs = [None] if a.split_sub is None else [int(x) for x in str(a.split_sub).split(",")]
+    for rep, sub_ranges in [(r_, s_) for r_ in range(a.repeat) for s_ in subs]:
         tm = {}
         t1 = time.time()
-        text, counts, toks = td.split_ranks_in_turn(path, L, rows, a.mincov, a.world, True, "S", return_parts=True, timings=tm)
+        text, counts, toks = td.split_ranks_in_turn(path, L, rows, a.mincov, a.world, True, "S", return_parts=True, timings=tm, split_sub=sub_ranges)
         ms = [1e3 * s for s in tm["rank_seconds"]]
-        print("pass %d: per-rank tcmi_split_step ms %s | max %.2f sum %.2f | whole call %.2f s | blocks per rank %s | batches of blocks: %s, one-sync path: %d of %d"
-              % (rep, " ".join("%.2f" % m for m in ms), max(ms), sum(ms), time.time() - t1, tm["blocks_per_rank"], tm["decode_batched"] > 0, tm["one_sync_taken"], a.world), flush=True)
-        out["passes"].append({"rank_ms": ms, "max_ms": max(ms), "sum_ms": sum(ms), "blocks_per_rank": tm["blocks_per_rank"], "decode_batched": tm["decode_batched"],
-                              "one_sync_taken": tm["one_sync_taken"]})
+        print("pass %d (split_sub %s, taken %d): per-rank tcmi_split_step ms %s | max %.2f sum %.2f | whole call %.2f s | blocks per rank %s | batches of blocks: %s, one-sync path: %d of %d"
+              % (rep, sub_ranges, tm["split_sub_taken"], " ".join("%.2f" % m for m in ms), max(ms), sum(ms), time.time() - t1, tm["blocks_per_rank"], tm["decode_batched"] > 0, tm["one_sync_taken"], a.world), flush=True)
+        out["passes"].append({"split_sub": sub_ranges, "rank_ms": ms, "max_ms": max(ms), "sum_ms": sum(ms), "blocks_per_rank": tm["blocks_per_rank"], "decode_batched": tm["decode_batched"],
+                              "one_sync_taken": tm["one_sync_taken"], "split_sub_taken": tm["split_sub_taken"]})
         out.update(file_bytes=tm["file_bytes"], inflated_bytes=tm["inflated_bytes"], n_blocks=tm["n_blocks"])
     print("file %.1f MB, %.2f GiB inflated, %d BGZF blocks" % (out["file_bytes"] / 1e6, out["inflated_bytes"] / 2 ** 30, out["n_blocks"]))
     eq = bool(np.array_equal(counts.astype(np.int64), want))

@@ -163,6 +163,8 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     if (!c) return TCMI_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (tcmi_ctx *h : c->helpers) (void)tcmi_ctx_destroy(h);
+    c->helpers.clear();
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     free_ws(c);
@@ -216,6 +218,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "prefix_kernels")) c->prefix_kernels = value;
     else if (!std::strcmp(key, "decode_token_mb")) c->decode_token_mb = value > 0 ? value : 4096;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
+    else if (!std::strcmp(key, "split_sub")) c->split_sub = value < 0 ? 0 : value > 8 ? 8 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
     return TCMI_OK;
@@ -224,9 +227,10 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
 int tcmi_ctx_stat(tcmi_ctx *c, const char *key, int64_t *value)
 {
     if (!c || !key || !value) return tcmi_fail(c, TCMI_E_ARG, "null argument");
-    if (!std::strcmp(key, "one_sync_taken")) *value = c->stat_one_sync_taken;
+    if (!std::strcmp(key, "one_sync_taken")) { *value = c->stat_one_sync_taken; for (const tcmi_ctx *h : c->helpers) *value += h->stat_one_sync_taken; }
     else if (!std::strcmp(key, "one_sync_declined")) *value = c->stat_one_sync_declined;
-    else if (!std::strcmp(key, "decode_batched")) *value = c->stat_decode_batched;
+    else if (!std::strcmp(key, "decode_batched")) { *value = c->stat_decode_batched; for (const tcmi_ctx *h : c->helpers) *value += h->stat_decode_batched; }
+    else if (!std::strcmp(key, "split_sub_taken")) *value = c->stat_split_sub;
     else if (!std::strcmp(key, "one_sync_last_decline_flags")) *value = c->stat_last_decline;
     else return tcmi_fail(c, TCMI_E_ARG, "unknown statistic %s", key);
     return TCMI_OK;
@@ -332,6 +336,18 @@ int tcmi_tally_dev(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int64_t ld,
         return tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the read extent %lld (use tcmi_reads_extent)",
                          (long long)L, (long long)rs->max_end);
     TCMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!rs->parts.empty()) {                                   // a read set of sub-ranges: every part adds its counts from its own context
+        if (zero) {
+            TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
+            TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        for (const tcmi_readset::Part &p : rs->parts) {
+            const int rc = tcmi_tally_dev(p.cx, p.rs, L, ld, d_counts, 0);
+            if (rc) return tcmi_fail(ctx, rc, "%s", p.cx->err.c_str());
+            TCMI_HIP(ctx, hipStreamSynchronize(p.cx->stream));
+        }
+        return TCMI_OK;
+    }
     if (zero) {
         tcmi_prof_begin(ctx, TCMI_K_ZERO);
         TCMI_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
@@ -468,6 +484,7 @@ static int enqueue_step(tcmi_ctx *ctx, const tcmi_readset *rs, int64_t L, int32_
                         bool memset_first)
 {
     const int64_t ld = ctx->ws_ld;
+    if (!rs->parts.empty()) return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "a read set of sub-ranges (tcmi_split_step) takes no step of its own: tcmi_tally_dev + tcmi_call_dev");
     if (memset_first) TCMI_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ld * TCMI_NCOL * 4, ctx->stream));
     int rc = tcmi_tally_dev(ctx, rs, L, ld, ctx->d_counts, 0);
     if (rc) return rc;
@@ -615,8 +632,84 @@ static const char *ranges_join(const int64_t (*rg)[4], int world, int64_t inflat
         any_before = true;
         if (nxt >= 0) { expect = nxt; have = true; }
     }
-    if (have && expect != inflated) { *who = world - 1; *at = expect; *want = inflated; return "the last alignment record does not end with the file's stream"; }
+    if (have && inflated >= 0 && expect != inflated) { *who = world - 1; *at = expect; *want = inflated; return "the last alignment record does not end with the file's stream"; }
     return nullptr;
+}
+
+// A rank's block range [first, first + cnt) as K sub-ranges decoded, packed and tallied SIDE BY SIDE, each on a context of its own (sub-range 0
+// on the caller's, the others on helper contexts the caller's context owns: a stream and an arena each) with a host thread of its own
+// — the inflate of one sub-range runs under the pack of another, as the many-file runner's contexts overlap files; the tallies add
+// into the one matrix (the tally kernel's adds are atomic).  The sub-ranges join like ranks' ranges do: each starts where the one in
+// front ends its last record (ranges_join).  -> a read set that is the sum of its parts; TCMI_E_UNSUPPORTED: sub-ranges that cannot
+// vouch for each other (a sub-range without a record start, a chain that does not join) — the caller decodes the range in one piece.
+static int split_sub_ranges(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first, int64_t cnt, int K, int64_t L, int64_t ld, void *d_counts,
+                            size_t n_words, tcmi_readset **out)
+{
+    *out = nullptr;
+    while ((int)ctx->helpers.size() < K - 1) {
+        tcmi_ctx *h = nullptr;
+        const int rc = tcmi_ctx_create(ctx->device, &h);
+        if (rc) return tcmi_fail(ctx, rc, "a helper context for the sub-ranges could not be made");
+        ctx->helpers.push_back(h);
+    }
+    for (tcmi_ctx *h : ctx->helpers) {                          // (the caller's decoder options)
+        h->verify_crc = ctx->verify_crc; h->decode_token_mb = ctx->decode_token_mb; h->one_sync = ctx->one_sync; h->mid_wait = ctx->mid_wait;
+        h->prefix_kernels = ctx->prefix_kernels; h->prof = false;
+    }
+    TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (the matrix is zero before anybody adds to it)
+    std::vector<tcmi_readset *> rs((size_t)K, nullptr);
+    std::vector<int> rcs((size_t)K, TCMI_OK);
+    std::vector<int64_t> fb((size_t)K + 1);
+    for (int k = 0; k <= K; ++k) fb[(size_t)k] = first + cnt * k / K;
+    auto work = [&](int k) {
+        tcmi_ctx *cx = k == 0 ? ctx : ctx->helpers[(size_t)k - 1];
+        int rc = tcmi_readset_from_bamfile_blocks(cx, f, fb[(size_t)k], fb[(size_t)k + 1] - fb[(size_t)k], &rs[(size_t)k], nullptr);
+        if (rc == TCMI_OK && rs[(size_t)k]->max_end > L) rc = tcmi_fail(cx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs[(size_t)k]->max_end);
+        if (rc == TCMI_OK && rs[(size_t)k]->n_piled) rc = tcmi_tally_dev(cx, rs[(size_t)k], L, ld, d_counts, 0);
+        if (rc == TCMI_OK && hipStreamSynchronize(cx->stream) != hipSuccess) rc = tcmi_fail(cx, TCMI_E_HIP, "hipStreamSynchronize failed");
+        rcs[(size_t)k] = rc;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < K; ++k) th.emplace_back(work, k);
+        work(0);
+        for (std::thread &t : th) t.join();
+    }
+    auto drop = [&]() { for (int k = 0; k < K; ++k) if (rs[(size_t)k]) tcmi_readset_free(k == 0 ? ctx : ctx->helpers[(size_t)k - 1], rs[(size_t)k]); };
+    for (int k = 0; k < K; ++k)
+        if (rcs[(size_t)k]) {
+            const int rc = rcs[(size_t)k];
+            const std::string why = (k == 0 ? ctx : ctx->helpers[(size_t)k - 1])->err;
+            drop();
+            (void)n_words;
+            return tcmi_fail(ctx, rc == TCMI_E_UNSUPPORTED ? TCMI_E_UNSUPPORTED : rc, "sub-range %d of %d: %s", k, K, why.c_str());
+        }
+    // the joins: a sub-range behind the first vouches for nothing by itself
+    std::vector<int64_t> rg((size_t)K * 4);
+    bool plain = true;
+    for (int k = 0; k < K; ++k) {
+        rg[4 * (size_t)k] = fb[(size_t)k]; rg[4 * (size_t)k + 1] = fb[(size_t)k + 1] - fb[(size_t)k];
+        rg[4 * (size_t)k + 2] = rs[(size_t)k]->range_first; rg[4 * (size_t)k + 3] = rs[(size_t)k]->range_next;
+        if ((k > 0 && rs[(size_t)k]->range_first < 0) || rs[(size_t)k]->range_next < 0) plain = false;      // (a sub-range that found no record start, or lies inside one record)
+    }
+    int who = 0; int64_t at = 0, want = 0;
+    const char *why = plain ? ranges_join(reinterpret_cast<const int64_t (*)[4]>(rg.data()), K, -1, &who, &at, &want) : "a sub-range holds no record start";
+    if (why) {
+        drop();
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "the sub-ranges of blocks [%lld, %lld) do not join (%s): the range in one piece", (long long)first, (long long)(first + cnt), why);
+    }
+    tcmi_readset *sum = new tcmi_readset();
+    sum->device = ctx->device; sum->packed_on_device = 2;
+    sum->range_first = rs[0]->range_first; sum->range_next = rs[(size_t)K - 1]->range_next;
+    for (int k = 0; k < K; ++k) {
+        const tcmi_readset *r = rs[(size_t)k];
+        sum->n_reads += r->n_reads; sum->n_piled += r->n_piled; sum->alg_bytes += r->alg_bytes; sum->dev_bytes += r->dev_bytes;
+        sum->max_end = std::max(sum->max_end, r->max_end); sum->max_len = std::max(sum->max_len, r->max_len); sum->s_reads += r->s_reads;
+        sum->f_reads += r->f_reads;
+        sum->parts.push_back({k == 0 ? ctx : ctx->helpers[(size_t)k - 1], rs[(size_t)k]});
+    }
+    *out = sum;
+    return TCMI_OK;
 }
 
 // One rank's part of a step of ONE BAM file shared by several GPUs (include/tcmi.h): decode + pack + tally its block range, the
@@ -644,11 +737,25 @@ int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, i
     if (hipSetDevice(ctx->device) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipSetDevice(%d) failed", ctx->device));
     if (!own) { const int rc0 = ensure_ws(ctx, L); if (rc0) note(rc0); }
     if (!own && hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipMemsetAsync of the count matrix failed"));
-    if (!own) { const int rc0 = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr); if (rc0) note(rc0); }
-    if (!own && rs->max_end > L) note(tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs->max_end));
-    if (!own && rs->n_piled) { const int rc0 = tcmi_tally_dev(ctx, rs, L, ld, d_counts, 0); if (rc0) note(rc0); }
     int64_t all = 0, inflated = 0;
     (void)tcmi_bamfile_info(f, nullptr, &inflated, &all, nullptr, nullptr, nullptr);
+    bool tallied = false;
+    if (!own) {                                                 // sub-ranges side by side where the range is large enough (else, or if they do not work out: in one piece)
+        const int64_t cnt0 = std::max<int64_t>(0, n_blocks < 0 ? all - first_block : std::min<int64_t>(n_blocks, all - first_block));
+        static const int sub_env = std::getenv("TCMI_SPLIT_SUB") ? std::atoi(std::getenv("TCMI_SPLIT_SUB")) : 0;
+        int K = sub_env > 0 ? sub_env : ctx->split_sub;
+        if (K <= 0) K = cnt0 >= 6144 ? 3 : cnt0 >= 4096 ? 2 : 1;
+        K = (int)std::min<int64_t>(std::min(K, 8), std::max<int64_t>(1, cnt0 / 64));
+        if (K > 1 && !ctx->stream_hi) {
+            const int rc0 = split_sub_ranges(ctx, f, first_block, cnt0, K, L, ld, d_counts, n_words, &rs);
+            if (rc0 == TCMI_OK) { tallied = true; ++ctx->stat_split_sub; }
+            else if (rc0 != TCMI_E_UNSUPPORTED) note(rc0);
+            else if (hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipMemsetAsync of the count matrix failed"));
+        }
+    }
+    if (!own && !tallied) { const int rc0 = tcmi_readset_from_bamfile_blocks(ctx, f, first_block, n_blocks, &rs, nullptr); if (rc0) note(rc0); }
+    if (!own && rs->max_end > L) note(tcmi_fail(ctx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs->max_end));
+    if (!own && !tallied && rs->n_piled) { const int rc0 = tcmi_tally_dev(ctx, rs, L, ld, d_counts, 0); if (rc0) note(rc0); }
     if (own) {                                                  // this rank's share is zeros + one failure
         static const int32_t one = 1;
         (void)hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream);

@@ -1806,6 +1806,8 @@ extern "C" int tcmi_readset_modal_tokens(tcmi_ctx *ctx, const tcmi_readset *rs, 
 {
     if (!ctx || !rs || n_pos < 0 || (n_pos > 0 && (!positions || !tokens || !token_off || !n_tokens)))
         return tcmi_fail(ctx, TCMI_E_ARG, "null argument");
+    if (!rs->parts.empty())
+        return tcmi_fail(ctx, TCMI_E_UNSUPPORTED, "a read set of sub-ranges (tcmi_split_step): collect its entries (tcmi_readset_ins_entries) and vote on them (tcmi_modal_from_entries)");
     if (n_pos == 0) { if (status_flags) *status_flags = 0; return TCMI_OK; }
     std::vector<int64_t> off;
     std::vector<int32_t> cnt;
@@ -1865,6 +1867,49 @@ extern "C" int tcmi_readset_ins_entries(tcmi_ctx *ctx, const tcmi_readset *rs, i
     std::vector<int32_t> cnt;
     std::vector<uint8_t> text;
     const tcmi_dev_entry *ents = nullptr;
+    if (!rs->parts.empty()) {
+        // a read set of sub-ranges: the parts' entries per column one behind the other — file order —, the text offsets of a part's
+        // long insertions moved behind the texts of the parts in front of it (what rank 0 does with the ranks' pieces)
+        const size_t P = rs->parts.size();
+        std::vector<std::vector<int64_t>> p_off(P);
+        std::vector<std::vector<tcmi_dev_entry>> p_ent(P);
+        std::vector<int64_t> p_base(P, 0);
+        for (size_t p = 0; p < P; ++p) {
+            const tcmi_readset::Part &pt = rs->parts[p];
+            p_off[p].assign((size_t)n_pos + 1, 0);
+            p_base[p] = (int64_t)text.size();
+            if (pt.rs->n_piled == 0 || pt.rs->f_reads == 0) continue;
+            std::vector<uint8_t> t1;
+            const tcmi_dev_entry *e1 = nullptr;
+            const int rc = collect_ins_entries(pt.cx, pt.rs, n_pos, positions, flag_filter, ignore_orphans, p_off[p], cnt, &e1, t1);
+            if (rc) return tcmi_fail(ctx, rc, "%s", pt.cx->err.c_str());
+            const int64_t n1 = p_off[p][(size_t)n_pos];
+            if (n1) p_ent[p].assign(e1, e1 + n1);                // (the part's pinned scratch is its context's: copied out before the next call there)
+            if (n1 && p_base[p]) {
+                const int rc2 = tcmi_ins_entries_rebase(p_ent[p].data(), n1, p_base[p]);
+                if (rc2) return rc2;
+            }
+            text.insert(text.end(), t1.begin(), t1.end());
+        }
+        ent_off[0] = 0;
+        for (int32_t k = 0; k < n_pos; ++k) {
+            int64_t n = 0;
+            for (size_t p = 0; p < P; ++p) n += p_off[p][(size_t)k + 1] - p_off[p][(size_t)k];
+            ent_off[k + 1] = ent_off[k] + n;
+        }
+        if (long_used) *long_used = (int64_t)text.size();
+        if (ent_off[n_pos] > entries_cap || (int64_t)text.size() > long_cap)
+            return tcmi_fail(ctx, TCMI_E_ARG, "entry buffer too small: %lld entries, %zu bytes of long insertions (ent_off / long_used say what is needed)",
+                             (long long)ent_off[n_pos], text.size());
+        tcmi_dev_entry *dst = static_cast<tcmi_dev_entry *>(entries);
+        for (int32_t k = 0; k < n_pos; ++k)
+            for (size_t p = 0; p < P; ++p) {
+                const int64_t a = p_off[p][(size_t)k], b = p_off[p][(size_t)k + 1];
+                if (b > a) { std::memcpy(dst, p_ent[p].data() + a, (size_t)(b - a) * sizeof(tcmi_dev_entry)); dst += b - a; }
+            }
+        if (!text.empty()) std::memcpy(long_text, text.data(), text.size());
+        return TCMI_OK;
+    }
     if (rs->n_piled == 0 || rs->f_reads == 0) {                 // (no kept reads in this range: no entries)
         for (int32_t k = 0; k <= n_pos; ++k) ent_off[k] = 0;
         if (long_used) *long_used = 0;

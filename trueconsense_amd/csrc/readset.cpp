@@ -166,6 +166,8 @@ int tcmi_readset_free(tcmi_ctx *ctx, tcmi_readset *rs)
 {
     if (!rs) return TCMI_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
+    for (tcmi_readset::Part &p : rs->parts) (void)tcmi_readset_free(p.cx, p.rs);      // (a read set of sub-ranges: each part with its own context)
+    rs->parts.clear();
     if (rs->d_blob) {                                            // device-packed: one allocation holds the aligned set
         if (ctx && ctx->device == rs->device && ctx->blob_pool.size() < 4 && rs->blob_bytes)
             ctx->blob_pool.push_back({rs->d_blob, rs->blob_bytes});   // (stream order: the next user's kernels queue behind this one's)

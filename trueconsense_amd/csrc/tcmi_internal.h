@@ -126,6 +126,11 @@ struct tcmi_readset {
     uint32_t *d_seq = nullptr;  // [n_seqw] 8 bases per word, base i at bits [4(i%8), +4), raw BAM codes
     int64_t *d_round_cig = nullptr; // [n_rounds+1]
     int64_t *d_round_seq = nullptr; // [n_rounds+1]
+    // A rank's block range decoded as several SUB-RANGES side by side (tcmi_split_step, "split_sub"): this read set is then only the
+    // sum of its parts — each a read set of its own on a context of its own (its decoded stream lives in that context's arena) — in
+    // file order.  It answers tcmi_readset_info / _range_anchors / _ins_entries / tcmi_tally_dev / tcmi_readset_free.
+    struct Part { tcmi_ctx *cx; tcmi_readset *rs; };
+    std::vector<Part> parts;
 };
 
 struct tcmi_ride {                  // a finished matrix waiting for its call (see tally_common.h, call_other_tile)
@@ -155,6 +160,7 @@ struct tcmi_ctx {
     size_t h_pin_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
+    int64_t stat_split_sub = 0;      // tcmi_split_step calls whose range went through sub-ranges
     int64_t stat_decode_batched = 0; // files the device decoder took in batches of blocks (tcmi_ctx_stat "decode_batched")
     int32_t split_tail[6] = {0, 0, 0, 0, 0, 0};   // tcmi_split_step: this rank's slot of the range table on its way to the device (the copy is asynchronous)
     uint32_t rec_bytes_seen = 0;     // mean record size of the last file this context decoded (sizes the next file's arrays when the file's own first blocks say nothing)
@@ -171,6 +177,10 @@ struct tcmi_ctx {
     // Two streams per context (TCMI_STREAM_SPLIT, api.cpp ctx_create): the inflate kernels of a file stay on `stream_lo`, everything
     // behind them (pk_index .. pk_report: short kernels that triple in duration next to a chip full of bgzf_copy workgroups) goes to
     // `stream_hi` — a higher priority, or compute units of its own.  `stream` is the one the launches use at the moment.
+    // tcmi_split_step: a rank's block range is decoded as `split_sub` sub-ranges side by side (0 = auto: three from 6 144 blocks on, two
+    // from 4 096), the first on this context, the others on helper contexts this one owns (a stream and an arena each)
+    int split_sub = 0;
+    std::vector<tcmi_ctx *> helpers;
     hipStream_t stream_lo = nullptr, stream_hi = nullptr;
     hipEvent_t ev_split = nullptr;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin

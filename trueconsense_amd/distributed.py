@@ -504,7 +504,8 @@ def consensus_split_bamfile(path, ref_len, gff_rows, mincov, include_ambig=True,
     return text
 
 
-def split_ranks_in_turn(path, ref_len, gff_rows, mincov, world, include_ambig=True, name="S", device=0, return_parts=False, timings=None):
+def split_ranks_in_turn(path, ref_len, gff_rows, mincov, world, include_ambig=True, name="S", device=0, return_parts=False, timings=None,
+                        split_sub=None):
     """BASELINE configs[4] at ANY world size on the ONE GPU there is: the ranks' steps of a `world`-GPU job played one after the other
     on one context — rank world-1 first, rank 0 (the root) last — each through tcmi_split_step exactly as a rank of the real job runs
     it (its own contiguous range of the file's BGZF blocks + the block behind it, the range table and the failure word behind the
@@ -525,6 +526,8 @@ def split_ranks_in_turn(path, ref_len, gff_rows, mincov, world, include_ambig=Tr
     world = int(world)
     torch.cuda.set_device(device)
     ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
+    if split_sub is not None:                                        # (tcmi_split_step's sub-ranges per rank: 0 = auto, 1 = never)
+        ctx.set_option("split_sub", int(split_sub))
     d = DeviceBam(path)
     n_words = 7 * ld + 6 * world + 1                                 # TCMI_SPLIT_TAIL_WORDS(world)
     acc = torch.zeros(n_words, dtype=torch.int32, device="cuda")
@@ -591,7 +594,7 @@ def split_ranks_in_turn(path, ref_len, gff_rows, mincov, world, include_ambig=Tr
         if timings is not None:
             timings.update(rank_seconds=secs, blocks_per_rank=[block_range(d.n_blocks, r, world)[1] for r in range(world)],
                            n_blocks=d.n_blocks, file_bytes=d.file_bytes, inflated_bytes=d.inflated_bytes,
-                           decode_batched=ctx.stat("decode_batched"), one_sync_taken=ctx.stat("one_sync_taken"))
+                           decode_batched=ctx.stat("decode_batched"), one_sync_taken=ctx.stat("one_sync_taken"), split_sub_taken=ctx.stat("split_sub_taken"))
     finally:
         for rs in sets:
             if rs is not None:

@@ -124,6 +124,9 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "decode_token_mb" the device decoder's token scratch, MiB (default 4096): a file whose BGZF blocks need more (tokens take 3 - 10
  *                    times the inflated bytes while a block is decoded) is decoded in batches of blocks that share the scratch —
  *                    the inflated stream stays whole
+ *   "h2d_pieces"     compressed bytes that come from host memory cross PCIe in this many pieces of whole blocks on a copy stream of the
+ *                    context's, each piece's blocks inflated as soon as it has arrived (the copy runs ahead of the decoder): 0 = auto
+ *                    (default: from 12 MB on, a piece per 6 MB, at most 8 — a rank's range of a large file), -1 = always one copy, n = n pieces
  *   "split_sub"      tcmi_split_step: a rank's block range is decoded, packed and tallied as this many SUB-RANGES side by side — the first on
  *                    this context, the others on helper contexts it owns (a stream, an arena and a host thread each), so that the inflate of
  *                    one sub-range runs under the pack of another; the sub-ranges must join like ranks' ranges, else the range is taken in
@@ -142,7 +145,8 @@ int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
 /* counters of a context: "one_sync_taken" / "one_sync_declined" — files (or block ranges) the one-sync path delivered / handed to the
  * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag);
  * "decode_batched" — files (or ranges) whose blocks the device decoder took in batches ("decode_token_mb");
- * "split_sub_taken" — tcmi_split_step calls whose range went through sub-ranges ("split_sub") */
+ * "split_sub_taken" — tcmi_split_step calls whose range went through sub-ranges ("split_sub"); "h2d_piped" — decodes whose
+ * compressed bytes (12 MB and more, from host memory) crossed PCIe in pieces on a copy stream, ahead of the inflate kernels */
 int  tcmi_ctx_stat(tcmi_ctx *ctx, const char *key, int64_t *value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

@@ -103,6 +103,35 @@ def test_one_sync_path_on_block_ranges_and_straddling_records(ctx, tmp_path):
         assert np.array_equal(acc, want)
 
 
+def test_compressed_bytes_in_pieces_ahead_of_the_decoder(ctx, tmp_path):
+    """Option "h2d_pieces": the compressed bytes cross PCIe in pieces of whole blocks on a copy stream, each piece's blocks inflated as
+    soon as it has arrived (a rank's range of a large file does so by itself from 12 MB on).  Forced here on small files — blocks cut
+    on record boundaries, filled to the brim, tiny; the whole file and ranges; 2 .. 16 pieces: the same counts as in one copy."""
+    ref, orfs = sy.make_reference(L=6000, cds=[(100, 2500), (3000, 5800)])
+    L = len(ref)
+    reads = sy.make_reads(ref, 40_000, seed=43, indel_sites=sy.default_indel_sites(orfs))
+    want = c_oracle.tally(reads, L)
+    try:
+        for name, kw in (("hts.bam", {}), ("brim.bam", dict(split_records=True)), ("tiny.bam", dict(split_records=True, block=1021))):
+            p = write(tmp_path, name, reads, "ref", L, **kw)
+            d = engine.DeviceBam(p)
+            nb = d.n_blocks
+            d.close()
+            for pieces in (2, 3, 7, 16):
+                ctx.set_option("h2d_pieces", pieces)
+                before = ctx.stat("h2d_piped")
+                whole = both_paths(ctx, p, L)
+                assert np.array_equal(whole[8], want), (name, pieces)
+                assert ctx.stat("h2d_piped") - before == 2 if nb >= 64 else True        # (both paths decode: twice)
+                acc = np.zeros_like(want)
+                for a, b in ((0, nb // 2), (nb // 2, nb - nb // 2)):
+                    acc += both_paths(ctx, p, L, blocks=(a, b))[8]
+                assert np.array_equal(acc, want), (name, pieces)
+        assert ctx.stat("h2d_piped") > 0
+    finally:
+        ctx.set_option("h2d_pieces", 0)
+
+
 def test_bamfile_step_is_one_call_and_exact(ctx, tmp_path):
     ref, orfs = sy.make_reference()
     L = len(ref)

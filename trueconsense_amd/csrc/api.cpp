@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "tcmi_internal.h"
@@ -178,6 +180,9 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     if (c->tok_host) (void)hipHostFree(c->tok_host);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
+    if (c->ev_after_sym) (void)hipEventDestroy(c->ev_after_sym);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (hipEvent_t e : c->ev_piece) (void)hipEventDestroy(e);
     if (c->stream_hi) {
         (void)hipStreamSynchronize(c->stream_hi);
         (void)hipStreamDestroy(c->stream_hi);
@@ -218,6 +223,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "prefix_kernels")) c->prefix_kernels = value;
     else if (!std::strcmp(key, "decode_token_mb")) c->decode_token_mb = value > 0 ? value : 4096;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
+    else if (!std::strcmp(key, "h2d_pieces")) c->h2d_pieces = value < -1 ? -1 : value > 16 ? 16 : value;
     else if (!std::strcmp(key, "split_sub")) c->split_sub = value < 0 ? 0 : value > 8 ? 8 : value;
 
     else return tcmi_fail(c, TCMI_E_ARG, "unknown option %s", key);
@@ -231,6 +237,7 @@ int tcmi_ctx_stat(tcmi_ctx *c, const char *key, int64_t *value)
     else if (!std::strcmp(key, "one_sync_declined")) *value = c->stat_one_sync_declined;
     else if (!std::strcmp(key, "decode_batched")) { *value = c->stat_decode_batched; for (const tcmi_ctx *h : c->helpers) *value += h->stat_decode_batched; }
     else if (!std::strcmp(key, "split_sub_taken")) *value = c->stat_split_sub;
+    else if (!std::strcmp(key, "h2d_piped")) { *value = c->stat_h2d_piped; for (const tcmi_ctx *h : c->helpers) *value += h->stat_h2d_piped; }
     else if (!std::strcmp(key, "one_sync_last_decline_flags")) *value = c->stat_last_decline;
     else return tcmi_fail(c, TCMI_E_ARG, "unknown statistic %s", key);
     return TCMI_OK;
@@ -654,16 +661,37 @@ static int split_sub_ranges(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first,
     }
     for (tcmi_ctx *h : ctx->helpers) {                          // (the caller's decoder options)
         h->verify_crc = ctx->verify_crc; h->decode_token_mb = ctx->decode_token_mb; h->one_sync = ctx->one_sync; h->mid_wait = ctx->mid_wait;
-        h->prefix_kernels = ctx->prefix_kernels; h->prof = false;
+        h->prefix_kernels = ctx->prefix_kernels; h->h2d_pieces = ctx->h2d_pieces; h->prof = false;
     }
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (the matrix is zero before anybody adds to it)
     std::vector<tcmi_readset *> rs((size_t)K, nullptr);
     std::vector<int> rcs((size_t)K, TCMI_OK);
     std::vector<int64_t> fb((size_t)K + 1);
     for (int k = 0; k <= K; ++k) fb[(size_t)k] = first + cnt * k / K;
+    // skewed starts: sub-range k's inflate waits (on the device) for the bgzf_symbols of sub-range k - 1; its thread waits (on the host)
+    // until that launch and its event are queued.  A sub-range that fails before its launch lets the next one go all the same.
+    static const bool skew = !(std::getenv("TCMI_SPLIT_SKEW") && std::atoi(std::getenv("TCMI_SPLIT_SKEW")) == 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> queued((size_t)K, 0);
+    auto release = [&](int k) { { std::lock_guard<std::mutex> lk(mu); queued[(size_t)k] = 1; } cv.notify_all(); };
+    auto cx_of = [&](int k) { return k == 0 ? ctx : ctx->helpers[(size_t)k - 1]; };
+    if (skew)
+        for (int k = 0; k < K; ++k)
+            if (!cx_of(k)->ev_after_sym && hipEventCreateWithFlags(&cx_of(k)->ev_after_sym, hipEventDisableTiming) != hipSuccess)
+                return tcmi_fail(ctx, TCMI_E_HIP, "hipEventCreate failed");
     auto work = [&](int k) {
-        tcmi_ctx *cx = k == 0 ? ctx : ctx->helpers[(size_t)k - 1];
+        tcmi_ctx *cx = cx_of(k);
+        if (skew) {
+            if (k > 0) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queued[(size_t)k - 1] != 0; });
+                cx->ev_before_sym = cx_of(k - 1)->ev_after_sym;
+            }
+            cx->after_sym = [&release, k] { release(k); };
+        }
         int rc = tcmi_readset_from_bamfile_blocks(cx, f, fb[(size_t)k], fb[(size_t)k + 1] - fb[(size_t)k], &rs[(size_t)k], nullptr);
+        if (skew) { cx->after_sym = nullptr; cx->ev_before_sym = nullptr; release(k); }
         if (rc == TCMI_OK && rs[(size_t)k]->max_end > L) rc = tcmi_fail(cx, TCMI_E_ARG, "L=%lld is smaller than the reads' extent %lld", (long long)L, (long long)rs[(size_t)k]->max_end);
         if (rc == TCMI_OK && rs[(size_t)k]->n_piled) rc = tcmi_tally_dev(cx, rs[(size_t)k], L, ld, d_counts, 0);
         if (rc == TCMI_OK && hipStreamSynchronize(cx->stream) != hipSuccess) rc = tcmi_fail(cx, TCMI_E_HIP, "hipStreamSynchronize failed");

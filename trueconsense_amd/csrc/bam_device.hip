@@ -464,13 +464,33 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
     uint32_t *d_tok = (uint32_t *)tcmi_arena_take(ctx, b_tok);
 
+    // Many compressed bytes from the host (a rank's range of a large file: 48 MB for 6.25 M reads, a millisecond of PCIe): the copy goes
+    // out in pieces of whole blocks on a stream of its own, and the inflate kernels of a piece's blocks wait only for their piece —
+    // the copy engine runs ahead of the decoder instead of in front of it.  (Files of a few MB — the many-file runner's — go in one
+    // copy: their contexts overlap each other.)
+    static const int pipe_env = std::getenv("TCMI_H2D_PIECES") ? std::atoi(std::getenv("TCMI_H2D_PIECES")) : 0;      // (A/B: -1 = never, n = that many pieces)
+    const int pipe_opt = pipe_env ? pipe_env : ctx->h2d_pieces;
+    int pieces = 0;
+    if (!resident && batch_at.empty() && nb >= 64 && pipe_opt >= 0)
+        pieces = pipe_opt > 0 ? std::min(pipe_opt, 16) : f->n_bytes >= (12u << 20) ? (int)std::min<size_t>(8, f->n_bytes / (6u << 20)) : 0;
+    if (pieces >= 2 && !ctx->copy_stream) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; pieces = 0; }
+    }
+    while (pieces >= 2 && (int)ctx->ev_piece.size() < pieces + 1) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); pieces = 0; break; }
+        ctx->ev_piece.push_back(e);
+    }
+    const bool table_behind = !ranged && f->desc_at;
     if (resident) d_file = f->d_bytes;
-    else TCMI_HIP(ctx, hipMemcpyAsync(d_file, f->bytes, f->cap, hipMemcpyHostToDevice, ctx->stream));
+    else if (pieces < 2) TCMI_HIP(ctx, hipMemcpyAsync(d_file, f->bytes, f->cap, hipMemcpyHostToDevice, ctx->stream));
     D.d_file = d_file;
     // the block table: behind the file's bytes (one copy took both, or none: a resident file's table is resident too) — a range's
     // table, re-based, goes by a copy of its own
-    if (!ranged && f->desc_at) D.d_desc = reinterpret_cast<BlockDesc *>(d_file + f->desc_at);
-    else TCMI_HIP(ctx, hipMemcpyAsync(D.d_desc, f->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    if (table_behind) {
+        D.d_desc = reinterpret_cast<BlockDesc *>(d_file + f->desc_at);
+        if (pieces >= 2) TCMI_HIP(ctx, hipMemcpyAsync(d_file + f->desc_at, f->bytes + f->desc_at, f->cap - f->desc_at, hipMemcpyHostToDevice, ctx->stream));
+    } else TCMI_HIP(ctx, hipMemcpyAsync(D.d_desc, f->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
     (void)hipGetLastError();
     {
         tcmi_bgzf_decode_args g;
@@ -479,7 +499,25 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
         g.n_ref = (uint32_t)f->ref_name.size();
         g.verify_crc = ctx->verify_crc;
         g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;
-        if (batch_at.empty()) {
+        if (pieces >= 2) {
+            // (the copy stream starts behind whatever this context's stream still holds: the arena's last user)
+            TCMI_HIP(ctx, hipEventRecord(ctx->ev_piece[(size_t)pieces], ctx->stream));
+            TCMI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_piece[(size_t)pieces], 0));
+            const size_t top = table_behind ? f->desc_at : f->cap;
+            for (int k = 0; k < pieces; ++k) {
+                const size_t b0 = nb * (size_t)k / (size_t)pieces, b1 = nb * (size_t)(k + 1) / (size_t)pieces;
+                // bytes of blocks [b0, b1): from a little in front of the first payload (16-byte aligned) to a little behind the last trailer —
+                // bgzf_symbols stages up to 24 bytes past a payload, bgzf_copy reads the trailer; neighbouring pieces overlap by those bytes
+                const size_t lo = k == 0 ? 0 : (f->blocks[b0].cin > 64 ? (f->blocks[b0].cin - 64) & ~(size_t)15 : 0);
+                const size_t hi = k == pieces - 1 ? top : std::min(top, (f->blocks[b1 - 1].cin + f->blocks[b1 - 1].clen + 8 + 64 + 15) & ~(size_t)15);
+                if (hi > lo) TCMI_HIP(ctx, hipMemcpyAsync(d_file + lo, f->bytes + lo, hi - lo, hipMemcpyHostToDevice, ctx->copy_stream));
+                TCMI_HIP(ctx, hipEventRecord(ctx->ev_piece[(size_t)k], ctx->copy_stream));
+                TCMI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_piece[(size_t)k], 0));
+                g.first_block = b0; g.count = b1 - b0; g.tok_base = 0;
+                if (b1 > b0) { const int rc = tcmi_bgzf_decode_launch(ctx, g); if (rc) return rc; }
+            }
+            ++ctx->stat_h2d_piped;
+        } else if (batch_at.empty()) {
             const int rc = tcmi_bgzf_decode_launch(ctx, g);
             if (rc) return rc;
         } else {

@@ -1890,6 +1890,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
         std::fprintf(stderr, "[tcmi inflate] %zu blocks, payload %zu B + slack; bgzf_symbols<%d%s>: %zu B of LDS per workgroup, %d workgroups per CU; bgzf_copy: %d per CU\n",
                      nb, pay, per_wg, windowed ? ", windowed" : "", dyn + (per_wg == 2 ? sizeof(SymLds<2>) : per_wg == 1 ? sizeof(SymLds<1>) : sizeof(SymLds<4>)), occ_s, occ_c);
     }
+    if (ctx->ev_before_sym) { TCMI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_before_sym, 0)); ctx->ev_before_sym = nullptr; }      // (sub-ranges of a split step: skewed starts)
     tcmi_prof_begin(ctx, TCMI_K_INFLATE);
     if (per_wg == 4) hipLaunchKernelGGL((bgzf_symbols<4, false>), dim3((unsigned)((nb + 3) / 4)), dim3(256), dyn, ctx->stream, sa);
     else if (per_wg == 2) hipLaunchKernelGGL((bgzf_symbols<2, false>), dim3((unsigned)((nb + 1) / 2)), dim3(128), dyn, ctx->stream, sa);
@@ -1897,6 +1898,12 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     else hipLaunchKernelGGL((bgzf_symbols<1, false>), dim3((unsigned)nb), dim3(64), dyn, ctx->stream, sa);
     tcmi_prof_end(ctx, TCMI_K_INFLATE);
     TCMI_HIP(ctx, hipGetLastError());
+    if (ctx->after_sym) {
+        if (ctx->ev_after_sym) (void)hipEventRecord(ctx->ev_after_sym, ctx->stream);
+        auto fn = std::move(ctx->after_sym);
+        ctx->after_sym = nullptr;
+        fn();
+    }
     CopyArgs ca;
     ca.file = g.d_file; ca.blocks = sa.blocks; ca.tokens = sa.tokens; ca.n_tok = g.d_ntok; ca.out = g.d_out; ca.rec_slot = g.d_slot;
     ca.n_rec = g.d_nrec; ca.overshoot = g.d_over; ca.first_rec = g.d_first; ca.status = g.d_stat; ca.n_blocks = (int32_t)b_end; ca.first_block = (int32_t)b_first; ca.n_ref = g.n_ref;

@@ -160,6 +160,7 @@ struct tcmi_ctx {
     size_t h_pin_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
+    int64_t stat_h2d_piped = 0;      // decodes whose compressed bytes crossed PCIe in pieces, ahead of the inflate kernels (bam_device.hip: decode_enqueue)
     int64_t stat_split_sub = 0;      // tcmi_split_step calls whose range went through sub-ranges
     int64_t stat_decode_batched = 0; // files the device decoder took in batches of blocks (tcmi_ctx_stat "decode_batched")
     int32_t split_tail[6] = {0, 0, 0, 0, 0, 0};   // tcmi_split_step: this rank's slot of the range table on its way to the device (the copy is asynchronous)
@@ -181,6 +182,14 @@ struct tcmi_ctx {
     // from 4 096), the first on this context, the others on helper contexts this one owns (a stream and an arena each)
     int split_sub = 0;
     std::vector<tcmi_ctx *> helpers;
+    // ... started one behind the other: a sub-range's first inflate kernel waits for the bgzf_symbols of the sub-range in front (an event), so
+    // that the sub-ranges run skewed — symbols of k + 1 under copy of k under pack of k - 1 — instead of in step (bgzf_decode.hip:
+    // tcmi_bgzf_decode_launch records `ev_after_sym` and calls `after_sym` once per decode)
+    int h2d_pieces = 0;              // option "h2d_pieces": 0 = auto (from 12 MB of compressed bytes on: a piece per 6 MB, at most 8), -1 = one copy, n = n pieces
+    hipStream_t copy_stream = nullptr;           // H2D of a large file's / range's compressed bytes in pieces (decode_enqueue)
+    std::vector<hipEvent_t> ev_piece;
+    hipEvent_t ev_before_sym = nullptr, ev_after_sym = nullptr;
+    std::function<void()> after_sym;
     hipStream_t stream_lo = nullptr, stream_hi = nullptr;
     hipEvent_t ev_split = nullptr;
     hipEvent_t step_done = nullptr;  // recorded at the end of tcmi_step_begin

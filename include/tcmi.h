@@ -124,9 +124,11 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "decode_token_mb" the device decoder's token scratch, MiB (default 4096): a file whose BGZF blocks need more (tokens take 3 - 10
  *                    times the inflated bytes while a block is decoded) is decoded in batches of blocks that share the scratch —
  *                    the inflated stream stays whole
- *   "h2d_pieces"     compressed bytes that come from host memory cross PCIe in this many pieces of whole blocks on a copy stream of the
- *                    context's, each piece's blocks inflated as soon as it has arrived (the copy runs ahead of the decoder): 0 = auto
- *                    (default: from 12 MB on, a piece per 6 MB, at most 8 — a rank's range of a large file), -1 = always one copy, n = n pieces
+ *   "sym_scratch_div" (tests) bgzf_symbols' speculating lanes park 1 / n of their share of the token scratch: lanes overflow and their blocks
+ *                    are decoded once more in order (pass B), which must cut the stream into the same tokens; default 1
+ *   "h2d_pieces"     n >= 2: compressed bytes that come from host memory cross PCIe in n pieces of whole blocks on a copy stream of the
+ *                    context's, each piece's blocks inflated as soon as it has arrived; 0 (default): one copy in front of the decoder —
+ *                    on these boxes (46 GB/s) pieces lose: 4.5 ms against 3.97 ms for a 6.25 M-read range, DESIGN 7
  *   "split_sub"      tcmi_split_step: a rank's block range is decoded, packed and tallied as this many SUB-RANGES side by side — the first on
  *                    this context, the others on helper contexts it owns (a stream, an arena and a host thread each), so that the inflate of
  *                    one sub-range runs under the pack of another; the sub-ranges must join like ranks' ranges, else the range is taken in
@@ -146,7 +148,7 @@ int  tcmi_ctx_set_option(tcmi_ctx *ctx, const char *key, int value);
  * several-kernel path; "one_sync_last_decline_flags" — why the last one was handed over (packer flags; 0: it was not a packer flag);
  * "decode_batched" — files (or ranges) whose blocks the device decoder took in batches ("decode_token_mb");
  * "split_sub_taken" — tcmi_split_step calls whose range went through sub-ranges ("split_sub"); "h2d_piped" — decodes whose
- * compressed bytes (12 MB and more, from host memory) crossed PCIe in pieces on a copy stream, ahead of the inflate kernels */
+ * compressed bytes crossed PCIe in pieces on a copy stream ("h2d_pieces") */
 int  tcmi_ctx_stat(tcmi_ctx *ctx, const char *key, int64_t *value);
 
 /* per-kernel device timing (hipEvents on the context's stream); kernel ids below */

@@ -151,6 +151,45 @@ def test_device_inflate_on_other_deflate_flavours(ctx, tmp_path):
         bamwriter.DEFLATE.update(strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, flush_every=0)
 
 
+def test_two_literals_in_one_token_and_pass_b_cut_the_stream_alike(ctx, tmp_path):
+    """bgzf_symbols<1, *> (payloads beyond 4 KB) puts two literals into one token where the second code is a root-table literal in the same
+    stretch of bits — in the hand-scheduled rounds of pass A, and in the C++ decoder that pass B runs over a block whose lanes overflowed
+    their scratch: the two must cut the stream into the same tokens (a lane's `before` counts tokens).  Option "sym_scratch_div" makes lanes
+    overflow: Huffman-only streams (nothing but literals), files of short tokens at 6 : 1 and 2.5 : 1, fixed-Huffman blocks, whole payloads
+    and windows — byte for byte against zlib, counts against the oracle."""
+    import zlib
+    ref, _ = sy.make_reference()
+    rng = np.random.default_rng(17)
+    n = 30_000
+    reads = sy.make_reads(ref, n, seed=19)
+    q_real = rng.choice(np.arange(2, 42, dtype=np.uint8), size=(n, 150), p=(lambda w: w / w.sum())(np.exp(-0.5 * ((np.arange(2, 42) - 36) / 6.0) ** 2) + 0.004))
+    q_hard = rng.choice(np.array([2, 12, 23, 37], np.uint8), size=(n, 150), p=[0.02, 0.05, 0.13, 0.80])
+    names = rng.integers(48, 58, (n, 27)).astype(np.uint8)
+    files = []
+    for tag, q in (("real", q_real), ("hard", q_hard)):
+        p = str(tmp_path / (tag + ".bam"))
+        bamwriter.write_bam_fast(p, reads["pos"], reads["flag"], reads["seq"].reshape(n, -1), 150, "MN908947.3", len(ref), level=6, qual=q, names=names)
+        files.append(p)
+    r2 = dict(reads)
+    r2["qual"] = q_real.reshape(-1)
+    try:
+        for k, (strategy, level) in enumerate(((zlib.Z_HUFFMAN_ONLY, 6), (zlib.Z_FIXED, 6))):
+            bamwriter.DEFLATE.update(strategy=strategy, mem_level=8, flush_every=0)
+            p = str(tmp_path / ("lit%d.bam" % k))
+            bamwriter.write_bam(p, r2, "MN908947.3", len(ref), level=level)
+            files.append(p)
+    finally:
+        bamwriter.DEFLATE.update(strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, flush_every=0)
+    try:
+        for div in (1, 4, 16, 64):
+            ctx.set_option("sym_scratch_div", div)
+            for p in files:
+                check_decode(ctx, p).close()
+                check_counts(ctx, p, len(ref))
+    finally:
+        ctx.set_option("sym_scratch_div", 1)
+
+
 @pytest.mark.timeout(300)
 def test_damaged_files_end_in_an_error_or_the_right_answer(ctx, tmp_path):
     """Random damage to the compressed bytes (1 - 3 byte flips per trial, 60 trials, dynamic and fixed-Huffman streams): the

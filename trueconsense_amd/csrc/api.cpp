@@ -223,6 +223,7 @@ int tcmi_ctx_set_option(tcmi_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "prefix_kernels")) c->prefix_kernels = value;
     else if (!std::strcmp(key, "decode_token_mb")) c->decode_token_mb = value > 0 ? value : 4096;
     else if (!std::strcmp(key, "profile_every")) c->prof_every = value < 1 ? 1 : value;
+    else if (!std::strcmp(key, "sym_scratch_div")) c->sym_scratch_div = value < 1 ? 1 : value > 64 ? 64 : value;
     else if (!std::strcmp(key, "h2d_pieces")) c->h2d_pieces = value < -1 ? -1 : value > 16 ? 16 : value;
     else if (!std::strcmp(key, "split_sub")) c->split_sub = value < 0 ? 0 : value > 8 ? 8 : value;
 
@@ -661,7 +662,7 @@ static int split_sub_ranges(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first,
     }
     for (tcmi_ctx *h : ctx->helpers) {                          // (the caller's decoder options)
         h->verify_crc = ctx->verify_crc; h->decode_token_mb = ctx->decode_token_mb; h->one_sync = ctx->one_sync; h->mid_wait = ctx->mid_wait;
-        h->prefix_kernels = ctx->prefix_kernels; h->h2d_pieces = ctx->h2d_pieces; h->prof = false;
+        h->prefix_kernels = ctx->prefix_kernels; h->h2d_pieces = ctx->h2d_pieces; h->sym_scratch_div = ctx->sym_scratch_div; h->prof = false;
     }
     TCMI_HIP(ctx, hipStreamSynchronize(ctx->stream));            // (the matrix is zero before anybody adds to it)
     std::vector<tcmi_readset *> rs((size_t)K, nullptr);

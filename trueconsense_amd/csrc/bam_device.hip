@@ -464,15 +464,16 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
     uint32_t *d_ntok = (uint32_t *)tcmi_arena_take(ctx, al(nb * 4));
     uint32_t *d_tok = (uint32_t *)tcmi_arena_take(ctx, b_tok);
 
-    // Many compressed bytes from the host (a rank's range of a large file: 48 MB for 6.25 M reads, a millisecond of PCIe): the copy goes
-    // out in pieces of whole blocks on a stream of its own, and the inflate kernels of a piece's blocks wait only for their piece —
-    // the copy engine runs ahead of the decoder instead of in front of it.  (Files of a few MB — the many-file runner's — go in one
-    // copy: their contexts overlap each other.)
+    // Option "h2d_pieces" (off by default): many compressed bytes from the host (a rank's range of a large file: 48 MB for 6.25 M reads, a
+    // millisecond of PCIe) go out in pieces of whole blocks on a stream of its own, and the inflate kernels of a piece's blocks wait
+    // only for their piece.  Measured on a 6.25 M-read range (profiles/r06d_*): eight pieces 4.5 ms against 3.97 ms in one copy — every
+    // piece is a pair of launches with a tail of its own and a hand-over between the copy engine and the compute queue; the
+    // sub-ranges of tcmi_split_step ("split_sub") hide the copy better (3.5 ms).  Kept as an option for links slower than this one.
     static const int pipe_env = std::getenv("TCMI_H2D_PIECES") ? std::atoi(std::getenv("TCMI_H2D_PIECES")) : 0;      // (A/B: -1 = never, n = that many pieces)
     const int pipe_opt = pipe_env ? pipe_env : ctx->h2d_pieces;
     int pieces = 0;
     if (!resident && batch_at.empty() && nb >= 64 && pipe_opt >= 0)
-        pieces = pipe_opt > 0 ? std::min(pipe_opt, 16) : f->n_bytes >= (12u << 20) ? (int)std::min<size_t>(8, f->n_bytes / (6u << 20)) : 0;
+        pieces = pipe_opt > 0 ? std::min(pipe_opt, 16) : 0;
     if (pieces >= 2 && !ctx->copy_stream) {
         if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; pieces = 0; }
     }
@@ -498,6 +499,7 @@ int decode_enqueue(tcmi_ctx *ctx, const tcmi_bamfile *whole, Decoded &D, int64_t
         g.d_over = D.d_over; g.d_first = D.d_first; g.d_stat = D.d_stat; g.n_blocks = nb; g.pay_dwords = f->pay_dwords;
         g.n_ref = (uint32_t)f->ref_name.size();
         g.verify_crc = ctx->verify_crc;
+        g.scratch_div = ctx->sym_scratch_div;
         g.short_tokens = f->inflated < 4 * f->n_bytes ? 2 : f->inflated < 12 * f->n_bytes ? 1 : 0;
         if (pieces >= 2) {
             // (the copy stream starts behind whatever this context's stream still holds: the arena's last user)

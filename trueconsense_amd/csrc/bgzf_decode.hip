@@ -20,7 +20,9 @@
 // simply goes on to the block's end, and
 // lane 0 alone is the serial decoder.  (tools/spec_inflate_proto.py: the same scheme in Python.)
 //
-// Tokens (32 bits): literal 1<<31 | byte; match len (9 bits) | (dist - 1) << 9; raw 1<<30 | len << 17 | offset of the bytes from
+// Tokens (32 bits): literal 1<<31 | byte — or two literals in one token, 1<<31 | 1<<24 | byte | next byte << 8: a lane whose symbol is a
+// literal of at most nine bits takes the next code in the same round if that is such a literal too and starts in the same stretch
+// of bits (meeting points stay round starts; literal-heavy chunks are the ones whose lanes take longest) —; match len (9 bits) | (dist - 1) << 9; raw 1<<30 | len << 17 | offset of the bytes from
 // the block's payload start (a stored deflate block, in pieces of <= 8 191 bytes).  bgzf_copy takes 64 tokens at a time: an
 // inclusive scan of the lengths gives every token its output position, the literals of a stretch go to the ring at once, the
 // matches one after the other (TCMI_LM_ASM: a byte a lane up to 64 bytes, an aligned dword a lane beyond — the LDS takes unaligned
@@ -60,6 +62,7 @@ static_assert(CWIN >= 2 * CSEG + 528 && (CWIN & (CWIN - 1)) == 0 && CWIN % CSEG 
 constexpr int FAR_WORDS = 128;
 constexpr int TEAM_BATCH_BYTES = 1536;               // bgzf_copy: a batch of 64 tokens this short (<= 24 bytes a token) copies its matches in teams                      // bgzf_copy: words of LDS in which the sources of a batch's far matches are parked
 constexpr uint32_t TOK_LIT = 1u << 31, TOK_RAW = 1u << 30;
+constexpr uint32_t TOK_LIT2 = 1u << 24;              // a literal token that carries TWO bytes (the second in bits 8 - 15): bits 24 - 25 = literals - 1
 constexpr uint32_t RAW_PIECE = 8191;
 constexpr int CL_SLAB = 496;                        // bit positions of the code-length stream looked up at a time
 // bgzf_symbols<NB>: NB BGZF blocks per workgroup — one wavefront each for header and tables, then wavefront 0 decodes all of
@@ -130,6 +133,7 @@ struct SymArgs {
     uint32_t win_dwords;        // bgzf_symbols<1, true>: dwords of payload staged at a time (a window that moves along the block)
     uint32_t gather_max;        // a pass with more true tokens than this moves them row by row (else: gathered in output order)
     uint32_t shift_bias;        // (A/B) pass A's stretches this many powers of two shorter than chunk / 4 .. chunk / 2
+    uint32_t scratch_div;       // a lane's scratch is cut to 1 / scratch_div of its share (tests: lanes overflow and the block goes through pass B)
     uint64_t *stamps;           // diagnostic (TCMI_INFLATE_STAMPS): 16 words per block, s_memtime at the phase boundaries; or null
 };
 #define TCMI_STAMP(buf_, blk_, k_) do { if (buf_) { if ((threadIdx.x & 63) == 0) (buf_)[(size_t)(blk_) * 16 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -399,6 +403,314 @@ __device__ TCMI_HDR_INLINE void block_header(BlkTabs &T, HdrScratch &H, const ui
     if (lane == 0) { T.pos = pos; T.ntok = ntok; T.err = err; T.go = go && err == ST_OK ? 1u : 0u; T.last = last ? 1u : 0u; }
 }
 
+// The rounds of pass A, hand-scheduled (see the comment at their use).  Two insertion points for the kernels that put two literals into
+// one token (one block per workgroup: files whose blocks hold thousands of literals): the look-up of the code behind a literal, in
+// flight under the match lanes' distance look-up, and its resolution — this symbol a literal of <= 9 bits, the next code a root-table
+// literal that starts in the same stretch and ends within the soft end: then the token carries both bytes and the lane moves on
+// behind the second.  (For the bench file's blocks — two per workgroup, a thousand tokens each — the 22 instructions cost more than
+// the 19 % of rounds they save: 141 -> 150 us; at 2.6 : 1 the rounds fall by 38 %.)
+#define TCMI_PAIR_LOOK "v_lshrrev_b32 v44, v50, v47\n" "v_and_b32 v44, 0x1ff, v44\n" "v_lshl_add_u32 v44, v44, 2, %[tabs]\n" "ds_read_b32 v44, v44\n"
+#define TCMI_PAIR_RESOLVE "s_waitcnt lgkmcnt(0)\n" "v_and_b32 v40, v49, v44\n" "v_and_b32 v45, 15, v44\n" "v_add_u32 v46, v52, v45\n" "v_xor_b32 v42, %[p], v52\n" "v_lshrrev_b32 v42, %[shift], v42\n" "v_bfe_u32 v40, v40, 8, 1\n" "v_cmp_gt_u32 vcc, 10, v50\n" "v_cmp_eq_u32 s[86:87], 1, v40\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_cmp_eq_u32 s[86:87], 0, v42\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_cmp_le_u32 s[86:87], v46, %[wend]\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_bfe_u32 v40, v44, 16, 8\n" "v_lshl_or_b32 v40, v40, 8, v51\n" "v_or_b32 v40, 0x1000000, v40\n" "v_cndmask_b32 v51, v51, v40, vcc\n" "v_cndmask_b32 v52, v52, v46, vcc\n"
+#define TCMI_PASS_A_ASM(PAIR_LOOK_, PAIR_RESOLVE_) \
+                asm volatile( \
+                    "s_mov_b64 s[92:93], exec\n" \
+                    "LT%=:\n" \
+                    "s_mov_b64 exec, %[run]\n" \
+                    "s_cbranch_execz LX%=\n" \
+                    "v_lshrrev_b32 v40, %[shift], %[p]\n" \
+                    "v_cmp_ne_u32 vcc, v40, %[kprev]\n" \
+                    "s_and_saveexec_b64 s[80:81], vcc\n" \
+                    "s_cbranch_execz LA1%=\n" \
+                    "v_mov_b32 %[kprev], v40\n" \
+                    "v_and_b32 v41, 7, v40\n" \
+                    "v_lshl_add_u32 v41, v41, 3, %[ringb]\n" \
+                    "ds_write2_b32 v41, %[p], %[total] offset1:1\n" \
+                    "v_mov_b32 %[crossp], %[p]\n" \
+                    "v_mov_b32 %[crosst], %[total]\n" \
+                    "LA1%=:\n" \
+                    "s_mov_b64 exec, %[run]\n" \
+                    "s_and_b32 s90, %[rounds], 3\n" \
+                    "s_cmp_eq_u32 s90, 3\n" \
+                    "s_cbranch_scc0 LC%=\n" \
+                    "v_cmp_ne_u32 vcc, -1, %[crossp]\n" \
+                    "s_and_saveexec_b64 s[80:81], vcc\n" \
+                    "s_cbranch_execz LB9%=\n" \
+                    "v_add_u32 v41, -1, %[lim]\n" \
+                    "v_min_u32 v41, %[tgt], v41\n" \
+                    "v_lshl_add_u32 v42, v41, 3, %[recbase]\n" \
+                    "ds_read2_b32 v[44:45], v42 offset1:1\n" \
+                    "v_lshrrev_b32 v40, %[shift], %[crossp]\n" \
+                    "v_and_b32 v40, 7, v40\n" \
+                    "v_lshlrev_b32 v40, 3, v40\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v43, 3, v44\n" \
+                    "v_cmp_ne_u32 vcc, 0, v43\n" \
+                    "v_cmp_ge_u32 s[86:87], %[crossp], v45\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "v_cmp_lt_u32 s[86:87], %[tgt], %[lim]\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "s_and_saveexec_b64 s[82:83], vcc\n" \
+                    "v_cmp_eq_u32 vcc, 1, v43\n" \
+                    "v_add_u32 %[tgt], 1, %[tgt]\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "v_lshrrev_b32 %[tgt], 8, v44\n" \
+                    "s_mov_b64 exec, s[82:83]\n" \
+                    "v_cmp_lt_u32 vcc, %[tgt], %[lim]\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "s_cbranch_execz LB8%=\n" \
+                    "v_lshl_add_u32 v42, %[tgt], 6, v40\n" \
+                    "v_add_u32 v42, %[ringbase], v42\n" \
+                    "ds_read2_b32 v[44:45], v42 offset1:1\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_cmp_eq_u32 vcc, v44, %[crossp]\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "s_cbranch_execz LB8%=\n" \
+                    "v_mov_b32 %[midx], v45\n" \
+                    "v_mov_b32 %[state], 1\n" \
+                    "v_mov_b32 %[p], %[crossp]\n" \
+                    "v_mov_b32 %[total], %[crosst]\n" \
+                    "v_lshl_or_b32 v43, %[tgt], 8, 1\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "LB8%=:\n" \
+                    "s_mov_b64 exec, s[80:81]\n" \
+                    "v_mov_b32 %[crossp], -1\n" \
+                    "LB9%=:\n" \
+                    "s_mov_b64 exec, %[run]\n" \
+                    "s_cbranch_execz LX%=\n" \
+                    "LC%=:\n" \
+                    "v_cmp_lt_u32 vcc, %[p], %[wend]\n" \
+                    "s_xor_b64 s[86:87], vcc, exec\n" \
+                    "s_cmp_lg_u64 s[86:87], 0\n" \
+                    "s_cbranch_scc1 LDend%=\n" \
+                    "LC1%=:\n" \
+                    "v_lshrrev_b32 v40, 5, %[p]\n" \
+                    "v_lshl_add_u32 v40, v40, 2, %[pay]\n" \
+                    "ds_read2_b32 v[44:45], v40 offset1:1\n" \
+                    "ds_read_b32 v46, v40 offset:8\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_alignbit_b32 v47, v45, v44, %[p]\n" \
+                    "v_alignbit_b32 v48, v46, v45, %[p]\n" \
+                    "v_and_b32 v40, 0x1ff, v47\n" \
+                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n" \
+                    "ds_read_b32 v49, v40\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v50, 15, v49\n" \
+                    "v_cmp_eq_u32 vcc, 0, v50\n" \
+                    "s_cbranch_vccnz LLl%=\n" \
+                    "LC2%=:\n" \
+                    "v_bfe_u32 v41, v49, 8, 3\n" \
+                    "v_cmp_eq_u32 vcc, 4, v41\n" \
+                    "s_cbranch_vccnz LDeob%=\n" \
+                    "LC3%=:\n" \
+                    "v_bfe_u32 v51, v49, 16, 8\n" \
+                    "v_or_b32 v51, 0x80000000, v51\n" \
+                    "v_add_u32 v52, %[p], v50\n" \
+                    PAIR_LOOK_ \
+                    "s_mov_b64 s[88:89], exec\n" \
+                    "v_cmp_eq_u32 vcc, 2, v41\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "s_cbranch_execz LC5%=\n" \
+                    "v_bfe_u32 v53, v49, 11, 5\n" \
+                    "v_alignbit_b32 v54, v48, v47, v53\n" \
+                    "v_and_b32 v40, 0xff, v54\n" \
+                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n" \
+                    "ds_read_b32 v55, v40 offset:%[odt]\n" \
+                    "v_lshrrev_b32 v42, v50, v47\n" \
+                    "v_bfe_u32 v43, v49, 16, 4\n" \
+                    "v_bfe_u32 v42, v42, 0, v43\n" \
+                    "v_bfe_u32 v43, v49, 20, 9\n" \
+                    "v_add_u32 v56, v43, v42\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v57, 15, v55\n" \
+                    "v_cmp_eq_u32 vcc, 0, v57\n" \
+                    "s_cbranch_vccnz LLd%=\n" \
+                    "LC4%=:\n" \
+                    "v_bfe_u32 v43, v55, 4, 4\n" \
+                    "v_lshrrev_b32 v42, v57, v54\n" \
+                    "v_bfe_u32 v42, v42, 0, v43\n" \
+                    "v_lshrrev_b32 v40, 16, v55\n" \
+                    "v_add_u32 v42, v42, v40\n" \
+                    "v_add_u32 v42, -1, v42\n" \
+                    "v_lshl_or_b32 v51, v42, 9, v56\n" \
+                    "v_add3_u32 v52, %[p], v53, v57\n" \
+                    "v_add_u32 v52, v52, v43\n" \
+                    "LC5%=:\n" \
+                    "s_and_b64 exec, s[88:89], %[run]\n" \
+                    "s_cbranch_execz LT%=\n" \
+                    PAIR_RESOLVE_ \
+                    "v_mov_b32 %[p], v52\n" \
+                    "v_cmp_gt_u32 vcc, %[p], %[end]\n" \
+                    "s_cbranch_vccnz LDover%=\n" \
+                    "LC6%=:\n" \
+                    "s_mov_b64 s[80:81], exec\n" \
+                    "v_cmp_ne_u32 vcc, 0, %[room]\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "global_store_dword %[sptr], v51, off\n" \
+                    "v_add_u32 %[room], -1, %[room]\n" \
+                    "v_lshl_add_u64 %[sptr], %[sptr], 0, %[sstride]\n" \
+                    "s_mov_b64 exec, s[80:81]\n" \
+                    "v_add_u32 %[total], 1, %[total]\n" \
+                    "s_add_u32 %[rounds], %[rounds], 1\n" \
+                    "s_branch LT%=\n" \
+                    "LDend%=:\n" \
+                    "s_mov_b64 s[82:83], exec\n" \
+                    "s_mov_b64 exec, s[86:87]\n" \
+                    "v_mov_b32 %[state], 3\n" \
+                    "v_mov_b32 v43, 3\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "s_andn2_b64 exec, s[82:83], s[86:87]\n" \
+                    "s_cbranch_execz LT%=\n" \
+                    "s_branch LC1%=\n" \
+                    "LDeob%=:\n" \
+                    "s_mov_b64 s[82:83], exec\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "v_add_u32 %[p], %[p], v50\n" \
+                    "v_add_u32 %[total], 1, %[total]\n" \
+                    "v_mov_b32 %[state], 2\n" \
+                    "v_mov_b32 v43, 2\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "s_andn2_b64 exec, s[82:83], exec\n" \
+                    "s_cbranch_execz LT%=\n" \
+                    "s_branch LC3%=\n" \
+                    "LDover%=:\n" \
+                    "s_mov_b64 s[82:83], exec\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "v_mov_b32 %[state], 3\n" \
+                    "v_mov_b32 v43, 3\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "s_andn2_b64 exec, s[82:83], exec\n" \
+                    "s_cbranch_execz LT%=\n" \
+                    "s_branch LC6%=\n" \
+                    "LLl%=:\n" \
+                    "s_mov_b64 s[84:85], exec\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "v_bfrev_b32 v40, v47\n" \
+                    "v_lshrrev_b32 v40, 17, v40\n" \
+                    "v_add_u32 v41, %[oliml], %[tabs]\n" \
+                    "ds_read2_b32 v[58:59], v41 offset1:1\n" \
+                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n" \
+                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_sub_u32 v58, v40, v58\n" \
+                    "v_sub_u32 v59, v40, v59\n" \
+                    "v_sub_u32 v60, v40, v60\n" \
+                    "v_sub_u32 v61, v40, v61\n" \
+                    "v_sub_u32 v62, v40, v62\n" \
+                    "v_sub_u32 v63, v40, v63\n" \
+                    "v_ashrrev_i32 v58, 31, v58\n" \
+                    "v_ashrrev_i32 v59, 31, v59\n" \
+                    "v_ashrrev_i32 v60, 31, v60\n" \
+                    "v_ashrrev_i32 v61, 31, v61\n" \
+                    "v_ashrrev_i32 v62, 31, v62\n" \
+                    "v_ashrrev_i32 v63, 31, v63\n" \
+                    "v_add3_u32 v58, v58, v59, v60\n" \
+                    "v_add3_u32 v61, v61, v62, v63\n" \
+                    "v_add3_u32 v42, v58, v61, 6\n" \
+                    "v_min_u32 v41, 5, v42\n" \
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n" \
+                    "ds_read_b32 v43, v41 offset:%[ofbll]\n" \
+                    "v_sub_u32 v41, 5, v42\n" \
+                    "v_lshrrev_b32 v41, v41, v40\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v40, 0xffff, v43\n" \
+                    "v_cmp_ge_u32 vcc, v41, v40\n" \
+                    "v_cmp_gt_u32 s[86:87], 6, v42\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "v_sub_u32 v41, v41, v40\n" \
+                    "v_lshrrev_b32 v40, 16, v43\n" \
+                    "v_add_u32 v41, v41, v40\n" \
+                    "v_and_b32 v41, 0x1ff, v41\n" \
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n" \
+                    "ds_read_b32 v49, v41 offset:%[olongll]\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v50, 15, v49\n" \
+                    "v_cmp_ne_u32 s[86:87], 0, v50\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "s_andn2_b64 exec, exec, vcc\n" \
+                    "s_cbranch_execz LLl9%=\n" \
+                    "v_mov_b32 %[state], 3\n" \
+                    "v_mov_b32 v43, 3\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "LLl9%=:\n" \
+                    "s_and_b64 exec, s[84:85], %[run]\n" \
+                    "s_cbranch_execz LT%=\n" \
+                    "s_branch LC2%=\n" \
+                    "LLd%=:\n" \
+                    "s_mov_b64 s[84:85], exec\n" \
+                    "s_and_b64 exec, exec, vcc\n" \
+                    "v_bfrev_b32 v40, v54\n" \
+                    "v_lshrrev_b32 v40, 17, v40\n" \
+                    "v_add_u32 v41, %[olimd], %[tabs]\n" \
+                    "ds_read2_b32 v[58:59], v41 offset1:1\n" \
+                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n" \
+                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n" \
+                    "ds_read_b32 v42, v41 offset:24\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_sub_u32 v58, v40, v58\n" \
+                    "v_sub_u32 v59, v40, v59\n" \
+                    "v_sub_u32 v60, v40, v60\n" \
+                    "v_sub_u32 v61, v40, v61\n" \
+                    "v_sub_u32 v62, v40, v62\n" \
+                    "v_sub_u32 v63, v40, v63\n" \
+                    "v_sub_u32 v42, v40, v42\n" \
+                    "v_ashrrev_i32 v58, 31, v58\n" \
+                    "v_ashrrev_i32 v59, 31, v59\n" \
+                    "v_ashrrev_i32 v60, 31, v60\n" \
+                    "v_ashrrev_i32 v61, 31, v61\n" \
+                    "v_ashrrev_i32 v62, 31, v62\n" \
+                    "v_ashrrev_i32 v63, 31, v63\n" \
+                    "v_ashrrev_i32 v42, 31, v42\n" \
+                    "v_add3_u32 v58, v58, v59, v60\n" \
+                    "v_add3_u32 v61, v61, v62, v63\n" \
+                    "v_add3_u32 v42, v58, v61, v42\n" \
+                    "v_add_u32 v42, 7, v42\n" \
+                    "v_min_u32 v41, 6, v42\n" \
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n" \
+                    "ds_read_b32 v43, v41 offset:%[ofbd]\n" \
+                    "v_sub_u32 v41, 6, v42\n" \
+                    "v_lshrrev_b32 v41, v41, v40\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v40, 0xffff, v43\n" \
+                    "v_cmp_ge_u32 vcc, v41, v40\n" \
+                    "v_cmp_gt_u32 s[86:87], 7, v42\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "v_sub_u32 v41, v41, v40\n" \
+                    "v_lshrrev_b32 v40, 16, v43\n" \
+                    "v_add_u32 v41, v41, v40\n" \
+                    "v_and_b32 v41, 31, v41\n" \
+                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n" \
+                    "ds_read_b32 v55, v41 offset:%[olongd]\n" \
+                    "s_waitcnt lgkmcnt(0)\n" \
+                    "v_and_b32 v57, 15, v55\n" \
+                    "v_cmp_ne_u32 s[86:87], 0, v57\n" \
+                    "s_and_b64 vcc, vcc, s[86:87]\n" \
+                    "s_andn2_b64 exec, exec, vcc\n" \
+                    "s_cbranch_execz LLd9%=\n" \
+                    "v_mov_b32 %[state], 3\n" \
+                    "v_mov_b32 v43, 3\n" \
+                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n" \
+                    "s_andn2_b64 %[run], %[run], exec\n" \
+                    "LLd9%=:\n" \
+                    "s_and_b64 exec, s[84:85], %[run]\n" \
+                    "s_cbranch_execz LC5%=\n" \
+                    "s_branch LC4%=\n" \
+                    "LX%=:\n" \
+                    "s_mov_b64 exec, s[92:93]\n" \
+                    : [p] "+v"(p), [total] "+v"(total), [tgt] "+v"(tgt_abs), [midx] "+v"(midx), [kprev] "+v"(kprev), [state] "+v"(state), \
+                      [room] "+v"(room), [crossp] "+v"(crossp), [crosst] "+v"(crosst), [sptr] "+v"(sptr), [run] "+s"(run), [rounds] "+s"(rounds) \
+                    : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [wend] "v"(b_soft), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim), \
+                      [ringbase] "s"(ringbase), [recbase] "s"(recbase), [sstride] "s"(sstride), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)), \
+                      [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)), \
+                      [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d)) \
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+                      "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
+                      "s88", "s89", "s90", "s92", "s93", "vcc", "scc", "memory");
+
 // WIN (one block per workgroup): the payload is staged a window at a time.  A block of a file that compresses 2 - 4 : 1 has 16 - 26 KB of
 // payload; staged whole, four workgroups fit a CU and a BAM's blocks take four rounds and a half.  With a window of 6 KB pass A runs
 // over the symbols that START in the window, the chain's last lane says where the next window begins, and the tables stay.
@@ -407,6 +719,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
 {
     static_assert(!WIN || NB == 1, "a window per wavefront");
     constexpr int SYM_BLOCKS = NB, SYM_LANES = 64 / NB;
+    constexpr bool PAIRS = NB == 1;                 // two literals in one token: the kernels of one block per workgroup (payloads beyond 4 KB)
     static_assert(NB == 4 || NB == 2 || NB == 1, "a block's lanes: a row of 16, two rows, or the wavefront");
     __shared__ SymLds<NB> L;
     extern __shared__ __attribute__((aligned(8))) uint32_t pay_all[];   // per block: its compressed payload, from the dword that holds its first byte on
@@ -487,13 +800,19 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             const BlockDesc bd = blk0 + b < a.n_blocks ? a.blocks[blk0 + b] : BlockDesc{};
             uint32_t *const btok = a.tokens + bd.tok;
             const uint32_t bcap = bd.tok_cap;
-            const uint32_t lane_cap = bcap / (uint32_t)SYM_LANES;                    // tokens a lane may park in the scratch half
+            const uint32_t lane_cap = bcap / (uint32_t)SYM_LANES / max(a.scratch_div, 1u);     // tokens a lane may park in the scratch half (scratch_div: tests force pass B)
             // A lane's k-th parked token lies at scratch[k * SYM_LANES]: the lanes of a block decode one symbol a round each, so the
             // stores of a round fall into consecutive words (4-byte stores into a region of its own per lane cost a memory transaction
             // each: 115 MB of writes per BAM for 4.4 MB of tokens).
             uint32_t *const scratch = btok + bcap + (uint32_t)c;
 
-            // One literal / length / end-of-block code at bit p; a length is followed by its distance.
+            const uint32_t chunk = on ? (b_soft - min(b_soft, start) + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
+            // stretches of >= 64 bits (a symbol takes <= 48: none is skipped), about chunk / 4: a lane trails its target by about
+            // a chunk, RING stretches are kept
+            const uint32_t shift = (uint32_t)max(6, 30 - (int)__builtin_clz(chunk | 1u) - (int)a.shift_bias);
+            // One literal / length / end-of-block code at bit p; a length is followed by its distance.  A literal of at most nine bits
+            // takes the next code along if that is a root-table literal too, starts in the same stretch and ends within the soft end:
+            // a rule of the position alone, so that pass B and the hand-scheduled rounds below cut the stream into the same tokens.
             auto symbol = [&](uint32_t &p, uint32_t &tok) __attribute__((always_inline)) -> int {
                 uint32_t lo, hi;
                 peek64(bp, p, lo, hi);
@@ -503,7 +822,17 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                     if ((e & 15u) == 0) e = e2;
                 }
                 if ((e & 15u) == 0) return SY_BAD;
-                if (e & E_LIT) { p += e & 15u; tok = TOK_LIT | ((e >> 16) & 0xFFu); return SY_LIT; }
+                if (e & E_LIT) {
+                    const uint32_t p0 = p, nb1 = e & 15u;
+                    p += nb1;
+                    tok = TOK_LIT | ((e >> 16) & 0xFFu);
+                    if (PAIRS && nb1 < 10u) {
+                        const uint32_t e2 = B.ll[(lo >> nb1) & ((1u << LL_ROOT) - 1u)];
+                        const uint32_t p3 = p + (e2 & 15u);
+                        if ((e2 & E_LIT) && ((p ^ p0) >> shift) == 0u && p3 <= b_soft) { tok |= TOK_LIT2 | (((e2 >> 16) & 0xFFu) << 8); p = p3; }
+                    }
+                    return SY_LIT;
+                }
                 if (e & E_EOB) { p += e & 15u; return SY_EOB; }
                 const uint32_t k = (e >> 11) & 31u;                 // code + extra bits of the length
                 const uint32_t d32 = __builtin_amdgcn_alignbit(hi, lo, k);
@@ -527,10 +856,6 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             // first symbol start p in the stretch (and how many symbols it had decoded by then) in a ring of its own, and looks
             // p up in the ring of its target — the nearest lane in front that is still decoding, or the lane that one met.  Equal
             // positions are one trajectory from there on: the lane stops, its target's symbols from that one on are the true ones.
-            const uint32_t chunk = on ? (b_soft - min(b_soft, start) + (uint32_t)SYM_LANES - 1u) / (uint32_t)SYM_LANES : 1u;      // >= 1
-            // stretches of >= 64 bits (a symbol takes <= 48: none is skipped), about chunk / 4: a lane trails its target by about
-            // a chunk, RING stretches are kept
-            const uint32_t shift = (uint32_t)max(6, 30 - (int)__builtin_clz(chunk | 1u) - (int)a.shift_bias);
             const uint32_t s_c = start + (uint32_t)c * chunk;
             enum { RUN = 0, MERGED = 1, EOB = 2, DEAD = 3 };
             uint32_t state = on && s_c < b_soft ? RUN : DEAD;
@@ -558,308 +883,7 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 const uint32_t lim = (uint32_t)lane0 + (uint32_t)SYM_LANES;
                 unsigned long long run = __ballot(state == RUN);
                 static_assert(LL_ROOT == 9 && D_ROOT == 8 && RING == 8, "masks and counts below");
-                asm volatile(
-                    "s_mov_b64 s[92:93], exec\n"
-                    "LT%=:\n"
-                    "s_mov_b64 exec, %[run]\n"
-                    "s_cbranch_execz LX%=\n"
-                    // ---- a lane's symbols cross into a new stretch: note {p, total} in its ring
-                    "v_lshrrev_b32 v40, %[shift], %[p]\n"
-                    "v_cmp_ne_u32 vcc, v40, %[kprev]\n"
-                    "s_and_saveexec_b64 s[80:81], vcc\n"
-                    "s_cbranch_execz LA1%=\n"
-                    "v_mov_b32 %[kprev], v40\n"
-                    "v_and_b32 v41, 7, v40\n"
-                    "v_lshl_add_u32 v41, v41, 3, %[ringb]\n"
-                    "ds_write2_b32 v41, %[p], %[total] offset1:1\n"
-                    "v_mov_b32 %[crossp], %[p]\n"
-                    "v_mov_b32 %[crosst], %[total]\n"
-                    "LA1%=:\n"
-                    "s_mov_b64 exec, %[run]\n"
-                    // ---- every fourth round: the lanes that have crossed since look their position up in their target's ring
-                    "s_and_b32 s90, %[rounds], 3\n"
-                    "s_cmp_eq_u32 s90, 3\n"
-                    "s_cbranch_scc0 LC%=\n"
-                    "v_cmp_ne_u32 vcc, -1, %[crossp]\n"
-                    "s_and_saveexec_b64 s[80:81], vcc\n"
-                    "s_cbranch_execz LB9%=\n"
-                    "v_add_u32 v41, -1, %[lim]\n"
-                    "v_min_u32 v41, %[tgt], v41\n"
-                    "v_lshl_add_u32 v42, v41, 3, %[recbase]\n"
-                    "ds_read2_b32 v[44:45], v42 offset1:1\n"              // the target's {state | its target << 8, position}
-                    "v_lshrrev_b32 v40, %[shift], %[crossp]\n"
-                    "v_and_b32 v40, 7, v40\n"
-                    "v_lshlrev_b32 v40, 3, v40\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v43, 3, v44\n"
-                    "v_cmp_ne_u32 vcc, 0, v43\n"
-                    "v_cmp_ge_u32 s[86:87], %[crossp], v45\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "v_cmp_lt_u32 s[86:87], %[tgt], %[lim]\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "s_and_saveexec_b64 s[82:83], vcc\n"                    // a target that has stopped at or in front of the lane:
-                    "v_cmp_eq_u32 vcc, 1, v43\n"                            // on to the lane it met, or to the next one
-                    "v_add_u32 %[tgt], 1, %[tgt]\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "v_lshrrev_b32 %[tgt], 8, v44\n"
-                    "s_mov_b64 exec, s[82:83]\n"
-                    "v_cmp_lt_u32 vcc, %[tgt], %[lim]\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "s_cbranch_execz LB8%=\n"
-                    "v_lshl_add_u32 v42, %[tgt], 6, v40\n"
-                    "v_add_u32 v42, %[ringbase], v42\n"
-                    "ds_read2_b32 v[44:45], v42 offset1:1\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_cmp_eq_u32 vcc, v44, %[crossp]\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "s_cbranch_execz LB8%=\n"
-                    "v_mov_b32 %[midx], v45\n"                             // met: back to the meeting point, stop
-                    "v_mov_b32 %[state], 1\n"
-                    "v_mov_b32 %[p], %[crossp]\n"
-                    "v_mov_b32 %[total], %[crosst]\n"
-                    "v_lshl_or_b32 v43, %[tgt], 8, 1\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "LB8%=:\n"
-                    "s_mov_b64 exec, s[80:81]\n"
-                    "v_mov_b32 %[crossp], -1\n"
-                    "LB9%=:\n"
-                    "s_mov_b64 exec, %[run]\n"
-                    "s_cbranch_execz LX%=\n"
-                    "LC%=:\n"
-                    // ---- one symbol
-                    "v_cmp_lt_u32 vcc, %[p], %[wend]\n"
-                    "s_xor_b64 s[86:87], vcc, exec\n"
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 LDend%=\n"
-                    "LC1%=:\n"
-                    "v_lshrrev_b32 v40, 5, %[p]\n"
-                    "v_lshl_add_u32 v40, v40, 2, %[pay]\n"
-                    "ds_read2_b32 v[44:45], v40 offset1:1\n"
-                    "ds_read_b32 v46, v40 offset:8\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_alignbit_b32 v47, v45, v44, %[p]\n"
-                    "v_alignbit_b32 v48, v46, v45, %[p]\n"
-                    "v_and_b32 v40, 0x1ff, v47\n"
-                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n"
-                    "ds_read_b32 v49, v40\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v50, 15, v49\n"
-                    "v_cmp_eq_u32 vcc, 0, v50\n"
-                    "s_cbranch_vccnz LLl%=\n"
-                    "LC2%=:\n"
-                    "v_bfe_u32 v41, v49, 8, 3\n"                            // 1 literal, 2 length, 4 end of block
-                    "v_cmp_eq_u32 vcc, 4, v41\n"
-                    "s_cbranch_vccnz LDeob%=\n"
-                    "LC3%=:\n"
-                    "v_bfe_u32 v51, v49, 16, 8\n"
-                    "v_or_b32 v51, 0x80000000, v51\n"
-                    "v_add_u32 v52, %[p], v50\n"
-                    "s_mov_b64 s[88:89], exec\n"
-                    "v_cmp_eq_u32 vcc, 2, v41\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "s_cbranch_execz LC5%=\n"
-                    "v_bfe_u32 v53, v49, 11, 5\n"                          // code + extra bits of the length
-                    "v_alignbit_b32 v54, v48, v47, v53\n"
-                    "v_and_b32 v40, 0xff, v54\n"
-                    "v_lshl_add_u32 v40, v40, 2, %[tabs]\n"
-                    "ds_read_b32 v55, v40 offset:%[odt]\n"
-                    "v_lshrrev_b32 v42, v50, v47\n"
-                    "v_bfe_u32 v43, v49, 16, 4\n"
-                    "v_bfe_u32 v42, v42, 0, v43\n"
-                    "v_bfe_u32 v43, v49, 20, 9\n"
-                    "v_add_u32 v56, v43, v42\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v57, 15, v55\n"
-                    "v_cmp_eq_u32 vcc, 0, v57\n"
-                    "s_cbranch_vccnz LLd%=\n"
-                    "LC4%=:\n"
-                    "v_bfe_u32 v43, v55, 4, 4\n"
-                    "v_lshrrev_b32 v42, v57, v54\n"
-                    "v_bfe_u32 v42, v42, 0, v43\n"
-                    "v_lshrrev_b32 v40, 16, v55\n"
-                    "v_add_u32 v42, v42, v40\n"
-                    "v_add_u32 v42, -1, v42\n"
-                    "v_lshl_or_b32 v51, v42, 9, v56\n"
-                    "v_add3_u32 v52, %[p], v53, v57\n"
-                    "v_add_u32 v52, v52, v43\n"
-                    "LC5%=:\n"
-                    "s_and_b64 exec, s[88:89], %[run]\n"
-                    "s_cbranch_execz LT%=\n"
-                    "v_mov_b32 %[p], v52\n"
-                    "v_cmp_gt_u32 vcc, %[p], %[end]\n"
-                    "s_cbranch_vccnz LDover%=\n"
-                    "LC6%=:\n"
-                    "s_mov_b64 s[80:81], exec\n"
-                    "v_cmp_ne_u32 vcc, 0, %[room]\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "global_store_dword %[sptr], v51, off\n"
-                    "v_add_u32 %[room], -1, %[room]\n"
-                    "v_lshl_add_u64 %[sptr], %[sptr], 0, %[sstride]\n"
-                    "s_mov_b64 exec, s[80:81]\n"
-                    "v_add_u32 %[total], 1, %[total]\n"
-                    "s_add_u32 %[rounds], %[rounds], 1\n"
-                    "s_branch LT%=\n"
-                    // ---- the rare ways out of a round
-                    "LDend%=:\n"                                              // s[86:87]: lanes at the end of the payload without an end-of-block code
-                    "s_mov_b64 s[82:83], exec\n"
-                    "s_mov_b64 exec, s[86:87]\n"
-                    "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v43, 3\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "s_andn2_b64 exec, s[82:83], s[86:87]\n"
-                    "s_cbranch_execz LT%=\n"
-                    "s_branch LC1%=\n"
-                    "LDeob%=:\n"                                              // vcc: lanes at an end-of-block code
-                    "s_mov_b64 s[82:83], exec\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "v_add_u32 %[p], %[p], v50\n"
-                    "v_add_u32 %[total], 1, %[total]\n"
-                    "v_mov_b32 %[state], 2\n"
-                    "v_mov_b32 v43, 2\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "s_andn2_b64 exec, s[82:83], exec\n"
-                    "s_cbranch_execz LT%=\n"
-                    "s_branch LC3%=\n"
-                    "LDover%=:\n"                                             // vcc: lanes whose symbol runs over the end
-                    "s_mov_b64 s[82:83], exec\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v43, 3\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "s_andn2_b64 exec, s[82:83], exec\n"
-                    "s_cbranch_execz LT%=\n"
-                    "s_branch LC6%=\n"
-                    // ---- a literal / length code longer than nine bits (vcc: the lanes that have one): the code's first 15 bits against the ends of the six longer lengths
-                    "LLl%=:\n"
-                    "s_mov_b64 s[84:85], exec\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "v_bfrev_b32 v40, v47\n"
-                    "v_lshrrev_b32 v40, 17, v40\n"
-                    "v_add_u32 v41, %[oliml], %[tabs]\n"
-                    "ds_read2_b32 v[58:59], v41 offset1:1\n"
-                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n"
-                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_sub_u32 v58, v40, v58\n"
-                    "v_sub_u32 v59, v40, v59\n"
-                    "v_sub_u32 v60, v40, v60\n"
-                    "v_sub_u32 v61, v40, v61\n"
-                    "v_sub_u32 v62, v40, v62\n"
-                    "v_sub_u32 v63, v40, v63\n"
-                    "v_ashrrev_i32 v58, 31, v58\n"
-                    "v_ashrrev_i32 v59, 31, v59\n"
-                    "v_ashrrev_i32 v60, 31, v60\n"
-                    "v_ashrrev_i32 v61, 31, v61\n"
-                    "v_ashrrev_i32 v62, 31, v62\n"
-                    "v_ashrrev_i32 v63, 31, v63\n"
-                    "v_add3_u32 v58, v58, v59, v60\n"
-                    "v_add3_u32 v61, v61, v62, v63\n"
-                    "v_add3_u32 v42, v58, v61, 6\n"                        // lengths whose codes end at or below this one
-                    "v_min_u32 v41, 5, v42\n"
-                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
-                    "ds_read_b32 v43, v41 offset:%[ofbll]\n"                  // first code | index of its entry << 16
-                    "v_sub_u32 v41, 5, v42\n"
-                    "v_lshrrev_b32 v41, v41, v40\n"                           // the code, right-aligned
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v40, 0xffff, v43\n"
-                    "v_cmp_ge_u32 vcc, v41, v40\n"
-                    "v_cmp_gt_u32 s[86:87], 6, v42\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"                          // there is such a code
-                    "v_sub_u32 v41, v41, v40\n"
-                    "v_lshrrev_b32 v40, 16, v43\n"
-                    "v_add_u32 v41, v41, v40\n"
-                    "v_and_b32 v41, 0x1ff, v41\n"
-                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
-                    "ds_read_b32 v49, v41 offset:%[olongll]\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v50, 15, v49\n"
-                    "v_cmp_ne_u32 s[86:87], 0, v50\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "s_andn2_b64 exec, exec, vcc\n"                           // the lanes without: dead
-                    "s_cbranch_execz LLl9%=\n"
-                    "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v43, 3\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "LLl9%=:\n"
-                    "s_and_b64 exec, s[84:85], %[run]\n"
-                    "s_cbranch_execz LT%=\n"
-                    "s_branch LC2%=\n"
-                    // ---- ... a distance code longer than eight bits: seven lengths
-                    "LLd%=:\n"
-                    "s_mov_b64 s[84:85], exec\n"
-                    "s_and_b64 exec, exec, vcc\n"
-                    "v_bfrev_b32 v40, v54\n"
-                    "v_lshrrev_b32 v40, 17, v40\n"
-                    "v_add_u32 v41, %[olimd], %[tabs]\n"
-                    "ds_read2_b32 v[58:59], v41 offset1:1\n"
-                    "ds_read2_b32 v[60:61], v41 offset0:2 offset1:3\n"
-                    "ds_read2_b32 v[62:63], v41 offset0:4 offset1:5\n"
-                    "ds_read_b32 v42, v41 offset:24\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_sub_u32 v58, v40, v58\n"
-                    "v_sub_u32 v59, v40, v59\n"
-                    "v_sub_u32 v60, v40, v60\n"
-                    "v_sub_u32 v61, v40, v61\n"
-                    "v_sub_u32 v62, v40, v62\n"
-                    "v_sub_u32 v63, v40, v63\n"
-                    "v_sub_u32 v42, v40, v42\n"
-                    "v_ashrrev_i32 v58, 31, v58\n"
-                    "v_ashrrev_i32 v59, 31, v59\n"
-                    "v_ashrrev_i32 v60, 31, v60\n"
-                    "v_ashrrev_i32 v61, 31, v61\n"
-                    "v_ashrrev_i32 v62, 31, v62\n"
-                    "v_ashrrev_i32 v63, 31, v63\n"
-                    "v_ashrrev_i32 v42, 31, v42\n"
-                    "v_add3_u32 v58, v58, v59, v60\n"
-                    "v_add3_u32 v61, v61, v62, v63\n"
-                    "v_add3_u32 v42, v58, v61, v42\n"
-                    "v_add_u32 v42, 7, v42\n"
-                    "v_min_u32 v41, 6, v42\n"
-                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
-                    "ds_read_b32 v43, v41 offset:%[ofbd]\n"
-                    "v_sub_u32 v41, 6, v42\n"
-                    "v_lshrrev_b32 v41, v41, v40\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v40, 0xffff, v43\n"
-                    "v_cmp_ge_u32 vcc, v41, v40\n"
-                    "v_cmp_gt_u32 s[86:87], 7, v42\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "v_sub_u32 v41, v41, v40\n"
-                    "v_lshrrev_b32 v40, 16, v43\n"
-                    "v_add_u32 v41, v41, v40\n"
-                    "v_and_b32 v41, 31, v41\n"
-                    "v_lshl_add_u32 v41, v41, 2, %[tabs]\n"
-                    "ds_read_b32 v55, v41 offset:%[olongd]\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_and_b32 v57, 15, v55\n"
-                    "v_cmp_ne_u32 s[86:87], 0, v57\n"
-                    "s_and_b64 vcc, vcc, s[86:87]\n"
-                    "s_andn2_b64 exec, exec, vcc\n"
-                    "s_cbranch_execz LLd9%=\n"
-                    "v_mov_b32 %[state], 3\n"
-                    "v_mov_b32 v43, 3\n"
-                    "ds_write2_b32 %[recb], v43, %[p] offset1:1\n"
-                    "s_andn2_b64 %[run], %[run], exec\n"
-                    "LLd9%=:\n"
-                    "s_and_b64 exec, s[84:85], %[run]\n"
-                    "s_cbranch_execz LC5%=\n"
-                    "s_branch LC4%=\n"
-                    "LX%=:\n"
-                    "s_mov_b64 exec, s[92:93]\n"
-                    : [p] "+v"(p), [total] "+v"(total), [tgt] "+v"(tgt_abs), [midx] "+v"(midx), [kprev] "+v"(kprev), [state] "+v"(state),
-                      [room] "+v"(room), [crossp] "+v"(crossp), [crosst] "+v"(crosst), [sptr] "+v"(sptr), [run] "+s"(run), [rounds] "+s"(rounds)
-                    : [tabs] "v"(tabs), [pay] "v"(payb), [end] "v"(b_end), [wend] "v"(b_soft), [shift] "v"(shift), [ringb] "v"(ringb), [recb] "v"(recb), [lim] "v"(lim),
-                      [ringbase] "s"(ringbase), [recbase] "s"(recbase), [sstride] "s"(sstride), [odt] "n"(offsetof(BlkTabs, dt)), [olongll] "n"(offsetof(BlkTabs, long_ll)),
-                      [olongd] "n"(offsetof(BlkTabs, long_d)), [oliml] "n"(offsetof(BlkTabs, lim_ll)), [ofbll] "n"(offsetof(BlkTabs, fb_ll)),
-                      [olimd] "n"(offsetof(BlkTabs, lim_d)), [ofbd] "n"(offsetof(BlkTabs, fb_d))
-                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-                      "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-                      "s88", "s89", "s90", "s92", "s93", "vcc", "scc", "memory");
+                if constexpr (PAIRS) { TCMI_PASS_A_ASM(TCMI_PAIR_LOOK, TCMI_PAIR_RESOLVE) } else { TCMI_PASS_A_ASM(, ) }
                 tgt = tgt_abs - (uint32_t)lane0;
                 spilled = total > lane_cap;
             }
@@ -1438,9 +1462,11 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             for (uint32_t j = 0; j < nb && err == ST_OK && !bad; ++j) {
                 const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)j);
                 if (tj >> 31) {
-                    if (op + 1 > vend) { err = ST_BAD_LENGTH; break; }
+                    const uint32_t nl = TEAMS ? 1u + ((tj >> 24) & 3u) : 1u;         // (one literal, or — files of short tokens — two in one token)
+                    if (op + nl > vend) { err = ST_BAD_LENGTH; break; }
                     s_win[op & CWMASK] = (uint8_t)tj;
-                    ++op;
+                    if (nl > 1u) s_win[(op + 1u) & CWMASK] = (uint8_t)(tj >> 8);
+                    op += nl;
                 } else if (tj & TOK_RAW) {
                     uint32_t len = (tj >> 17) & 0x1FFFu;
                     const uint8_t *src = payload + (tj & 0x1FFFFu);
@@ -1466,7 +1492,7 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #if TCMI_COPY_PHASES >= 2
         PH(5);
 #endif
-        const uint32_t mylen = is_lit ? 1u : (t & 511u);
+        const uint32_t mylen = is_lit ? (TEAMS ? 1u + ((t >> 24) & 3u) : 1u) : (t & 511u);       // (a literal token carries one byte, or — bgzf_symbols<1, *>, whose files get this kernel's TEAMS variants — two)
         const uint32_t dist = ((t >> 9) & 0x7FFFu) + 1u;
         const uint32_t incl = wave_scan_add(mylen);
         const uint32_t dst = op + incl - mylen;                 // where this lane's token starts
@@ -1605,7 +1631,10 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const uint32_t t_stop = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
             const unsigned long long rng = t_stop < 64u ? from & ~(~0ull << t_stop) : from;
             const bool mine = (rng >> lane) & 1ull;
-            if (mine && is_lit) s_win[dm] = (uint8_t)t;
+            if (mine && is_lit) {
+                s_win[dm] = (uint8_t)t;
+                if (TEAMS && (t & TOK_LIT2)) s_win[(dm + 1u) & CWMASK] = (uint8_t)(t >> 8);
+            }
             unsigned long long mm = __ballot(mine && is_match && !done);
             n_match += (uint32_t)__popcll(mm);
             while (mm) {
@@ -1853,6 +1882,7 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     sa.win_dwords = 0;
     static const int gmax_env = std::getenv("TCMI_SYM_GATHER_MAX") ? std::atoi(std::getenv("TCMI_SYM_GATHER_MAX")) : -1;      // (A/B)
     sa.gather_max = gmax_env >= 0 ? (uint32_t)gmax_env : 2048u;
+    sa.scratch_div = (uint32_t)std::max(g.scratch_div, 1);
     static const int sbias_env = std::getenv("TCMI_SYM_SHIFT_BIAS") ? std::atoi(std::getenv("TCMI_SYM_SHIFT_BIAS")) : -1;      // (A/B)
     static const int forced = std::getenv("TCMI_SYM_BLOCKS") ? std::atoi(std::getenv("TCMI_SYM_BLOCKS")) : 0;      // (A/B measurements)
     // (measured on one 4 187-block file, kernel alone: 4 blocks per workgroup 372 us, 2: 285 us, 1: 325 us; on the harder file —
@@ -1919,8 +1949,10 @@ int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &g)
     }
     const unsigned copy_grid = (unsigned)((nb + CW - 1) / CW);
     tcmi_prof_begin(ctx, TCMI_K_INFLATE_COPY);
-    if (TCMI_COPY_TEAMS && g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
-    else if (TCMI_COPY_TEAMS && g.short_tokens) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
+    // (bgzf_symbols<1, *> — payloads beyond 4 KB — puts two literals into one token: only the TEAMS variants read those)
+    static_assert(TCMI_COPY_TEAMS, "bgzf_symbols<1, *> writes tokens of two literals: the copy kernel's TEAMS variants read them");
+    if (g.short_tokens >= 2) hipLaunchKernelGGL((bgzf_copy<true, true>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
+    else if (g.short_tokens || per_wg == 1) hipLaunchKernelGGL((bgzf_copy<true, false>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
     else hipLaunchKernelGGL((bgzf_copy<false, false>), dim3(copy_grid), dim3(64 * CW), 0, ctx->stream, ca);
     tcmi_prof_end(ctx, TCMI_K_INFLATE_COPY);
     TCMI_HIP(ctx, hipGetLastError());

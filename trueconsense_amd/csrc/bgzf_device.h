@@ -199,6 +199,7 @@ struct tcmi_bgzf_decode_args {
     uint32_t pay_dwords;            // the largest block's payload in dwords + slack
     uint32_t n_ref;                 // reference sequences of the BAM header (a record's refID must be one of them)
     int verify_crc = 1;             // bgzf_copy checks every block's CRC-32 against its trailer while it flushes the bytes (ST_BAD_CRC)
+    int scratch_div = 1;            // (tests) a lane of bgzf_symbols may park 1 / scratch_div of its share of the token scratch: overflowing lanes send their block through pass B
     int short_tokens;               // the file compresses less than ~12 : 1 (many short matches): bgzf_copy's variant with teams; 2: less than ~4 : 1: ... and short far matches finished in the set-up
 };
 int tcmi_bgzf_decode_launch(tcmi_ctx *ctx, const tcmi_bgzf_decode_args &a);

@@ -185,7 +185,8 @@ struct tcmi_ctx {
     // ... started one behind the other: a sub-range's first inflate kernel waits for the bgzf_symbols of the sub-range in front (an event), so
     // that the sub-ranges run skewed — symbols of k + 1 under copy of k under pack of k - 1 — instead of in step (bgzf_decode.hip:
     // tcmi_bgzf_decode_launch records `ev_after_sym` and calls `after_sym` once per decode)
-    int h2d_pieces = 0;              // option "h2d_pieces": 0 = auto (from 12 MB of compressed bytes on: a piece per 6 MB, at most 8), -1 = one copy, n = n pieces
+    int sym_scratch_div = 1;         // option "sym_scratch_div" (tests): bgzf_symbols' lanes park 1 / n of their share before they overflow (pass B)
+    int h2d_pieces = 0;              // option "h2d_pieces": 0 / -1 = one copy (default), n = n pieces
     hipStream_t copy_stream = nullptr;           // H2D of a large file's / range's compressed bytes in pieces (decode_enqueue)
     std::vector<hipEvent_t> ev_piece;
     hipEvent_t ev_before_sym = nullptr, ev_after_sym = nullptr;

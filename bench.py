@@ -1085,7 +1085,7 @@ def cold_rooflines(a, timed, cold, file_bytes, inflated_bytes, reads0):
         except Exception:
             traffic = {}
 
-    r3_key = next((k for k in ("round5", "round4", "round3") if k in traffic), None)
+    r3_key = next((k for k in ("round6", "round5", "round4", "round3") if k in traffic), None)
     r3 = traffic.get(r3_key, {})
     r3k = r3.get("kernels", {})
 
@@ -1268,7 +1268,7 @@ def resident_leg(a, ctx0, Pipeline, local_rank, np, _ffi, sy, ref, orfs, L, rank
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            rk = next((k for k in ("round5", "round4") if k in tj), None)
+            rk = next((k for k in ("round6", "round5", "round4") if k in tj), None)
             per = ((tj.get(rk) or {}).get("kernels", {}).get("tally_planes_kernel") or {}).get("hbm_bytes")
             traffic = per * B if per else None                      # (a round-1 figure stood here until round 3: dropped rather than quoted stale)
             traffic_src = ("profiles/traffic.json %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tally_planes_kernel per 1M-read BAM (one BAM per launch) x batch" % rk) if per else None

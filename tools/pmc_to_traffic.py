@@ -1,9 +1,9 @@
-"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round5" block (or the key given as third argument: round5_hard, round5_real) of profiles/traffic.json that
+"""tools/pmc_e2e.sh's summary (per-kernel PMC averages, one 1M-read BAM per launch) -> the "round6" block (or the key given as third argument: round6_hard, round6_real) of profiles/traffic.json that
 bench.py's roofline blocks quote.   python3 tools/pmc_to_traffic.py gpurun_out/TAG/pmc_e2e_summary.txt profiles/TAG_pmc_e2e.txt"""
 import ast, json, os, re, sys
 
 src, committed_as = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else "round5"
+key = sys.argv[3] if len(sys.argv) > 3 else "round6"
 k, seen = {}, {}
 for line in open(src):
     m = re.match(r"^([\w<>, ]+?) (\{.*\}) n= (\d+)$", line.strip())

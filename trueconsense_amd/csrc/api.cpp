@@ -777,8 +777,9 @@ int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, i
         K = (int)std::min<int64_t>(std::min(K, 8), std::max<int64_t>(1, cnt0 / 64));
         if (K > 1 && !ctx->stream_hi) {
             const int rc0 = split_sub_ranges(ctx, f, first_block, cnt0, K, L, ld, d_counts, n_words, &rs);
+            // (whatever kept the sub-ranges from working out — they do not join, a helper context could not be made, a sub-range was
+            //  refused — the range in one piece has the last word: it words the refusal, or simply works)
             if (rc0 == TCMI_OK) { tallied = true; ++ctx->stat_split_sub; }
-            else if (rc0 != TCMI_E_UNSUPPORTED) note(rc0);
             else if (hipMemsetAsync(d_counts, 0, n_words * 4, ctx->stream) != hipSuccess) note(tcmi_fail(ctx, TCMI_E_HIP, "hipMemsetAsync of the count matrix failed"));
         }
     }

@@ -1184,20 +1184,87 @@ struct CopyArgs {
 // bgzf_copy: CW blocks per workgroup, a wavefront each (they share nothing but the CRC tables); every wavefront has its ring, the 512
 // bytes next to it where far matches are parked, and the teams' slots.  LDS addresses stay below 64 K: the copy loops do their
 // address arithmetic in 16 bits.
+// TCMI_CRC_REG (A/B): the CRC's tables not in LDS but across the lanes of four registers — sixteen 16-entry nibble tables
+// (t[k][v] = lo_k[v & 15] ^ hi_k[v >> 4]: the tables are linear in v), looked up with ds_bpermute_b32: twice the look-ups, no LDS,
+// and with no tables to share a workgroup is ONE wavefront again (18 a CU instead of 16: a 1M-read BAM's 4 187 blocks in one round).
+#ifndef TCMI_CRC_REG
+#define TCMI_CRC_REG 0
+#endif
 #ifndef TCMI_COPY_CW
-#define TCMI_COPY_CW 4                                // bgzf_copy: blocks (wavefronts) per workgroup: they share the CRC tables (A/B: 2, 3; 4 x 64 lanes build the tables)
+#define TCMI_COPY_CW (TCMI_CRC_REG ? 1 : 4)           // bgzf_copy: blocks (wavefronts) per workgroup: they share the CRC tables (A/B: 2, 3; 4 x 64 lanes build the tables)
 #endif
 constexpr int CW = TCMI_COPY_CW;
 constexpr int CRC_NOPS = 12;                        // crc_ops: 1, 2, 4, .. 2048 zero bytes
 struct CopyLds { uint8_t win[CWIN]; uint32_t far[FAR_WORDS]; uint2 team[8]; };
 struct CopyShared {
     CopyLds w[CW];
+#if !TCMI_CRC_REG
     uint32_t t[4][256];         // t[k][v]: the CRC register after byte v and k zero bytes ("slicing by 4")
     uint32_t seg[8][16];        // seg[j][n]: the register n << 4 j, CSEG zero bytes later
+#endif
 };
+#if TCMI_CRC_REG
+// ---- TCMI_CRC_REG: the same tables as 16-entry nibble tables across the lanes of registers ----------------------------------------
+// Four tables a register (lane 16 q + n: table q, entry n).  R.t[0]: tables 0 - 3, R.t[1]: 4 - 7 — table 2 k + h is t[k] of the nibble
+// value n << 4 h; R.s[0], R.s[1]: the operator "CSEG zero bytes later" by nibble j = 0 .. 7 of the register.
+struct CrcRegs { uint32_t t[2], s[2]; };
+__device__ __forceinline__ uint32_t crc_lane(uint32_t reg, uint32_t table_in_reg, uint32_t nib)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((table_in_reg * 16u + nib) << 2), (int)reg);
+}
+__device__ __forceinline__ CrcRegs crc_regs_make(const uint32_t *zeros_seg)
+{
+    const uint32_t lane = threadIdx.x & 63u, q = lane >> 4, n = lane & 15u;
+    CrcRegs R;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t id = 4u * r + q, k = id >> 1, h = id & 1u;       // t[k] of n << 4 h
+        uint32_t c = n << (4u * h);
+        for (uint32_t step = 0; step < 8u * (k + 1u); ++step) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));     // the byte, then k zero bytes
+        R.t[r] = c;
+        const uint32_t j = 4u * r + q;                                  // nibble j of the register, CSEG zero bytes later
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 32u; ++e)                              // (uniform indices: the array is a kernel argument)
+            m ^= zeros_seg[e] & (0u - (uint32_t)((e >> 2) == j && ((n >> (e & 3u)) & 1u)));
+        R.s[r] = m;
+    }
+    return R;
+}
+// t[k][v] for a byte v
+__device__ __forceinline__ uint32_t crc_tk(const CrcRegs &R, uint32_t k, uint32_t v)
+{
+    const uint32_t lo = 2u * k, hi = 2u * k + 1u;
+    return crc_lane(R.t[lo >> 2], lo & 3u, v & 15u) ^ crc_lane(R.t[hi >> 2], hi & 3u, (v >> 4) & 15u);
+}
+__device__ __forceinline__ uint32_t crc16_reg(const CrcRegs &R, uint32_t c, uint4 v)
+{
+    auto x3 = [](uint32_t x, uint32_t y, uint32_t z) { return (uint32_t)__builtin_amdgcn_bitop3_b32(x, y, z, 0x96); };
+    auto step = [&](uint32_t x) {
+        // byte b of x goes through t[3 - b]: nibble 2 b is table 2 (3 - b), nibble 2 b + 1 table 2 (3 - b) + 1
+        const uint32_t a0 = crc_lane(R.t[1], 2u, x & 15u), a1 = crc_lane(R.t[1], 3u, (x >> 4) & 15u);            // t[3]
+        const uint32_t b0 = crc_lane(R.t[1], 0u, (x >> 8) & 15u), b1 = crc_lane(R.t[1], 1u, (x >> 12) & 15u);    // t[2]
+        const uint32_t c0 = crc_lane(R.t[0], 2u, (x >> 16) & 15u), c1 = crc_lane(R.t[0], 3u, (x >> 20) & 15u);   // t[1]
+        const uint32_t d0 = crc_lane(R.t[0], 0u, (x >> 24) & 15u), d1 = crc_lane(R.t[0], 1u, x >> 28);            // t[0]
+        return x3(x3(a0, a1, b0), x3(b1, c0, c1), d0 ^ d1);
+    };
+    c = step(c ^ v.x);
+    c = step(c ^ v.y);
+    c = step(c ^ v.z);
+    return step(c ^ v.w);
+}
+__device__ __forceinline__ uint32_t crc_seg_reg(const CrcRegs &R, uint32_t c)
+{
+    auto x3 = [](uint32_t x, uint32_t y, uint32_t z) { return (uint32_t)__builtin_amdgcn_bitop3_b32(x, y, z, 0x96); };
+    return x3(x3(crc_lane(R.s[0], 0u, c & 15u), crc_lane(R.s[0], 1u, (c >> 4) & 15u), crc_lane(R.s[0], 2u, (c >> 8) & 15u)),
+              x3(crc_lane(R.s[0], 3u, (c >> 12) & 15u), crc_lane(R.s[1], 0u, (c >> 16) & 15u), crc_lane(R.s[1], 1u, (c >> 20) & 15u)),
+              crc_lane(R.s[1], 2u, (c >> 24) & 15u) ^ crc_lane(R.s[1], 3u, c >> 28));
+}
+#endif
 static_assert(sizeof(CopyLds) % 16 == 0 && CW * sizeof(CopyLds) + CWIN < 65536, "16-bit LDS addresses in the copy loops");
 static_assert((160 * 1024 / sizeof(CopyShared)) * CW >= 14, "at least fourteen blocks per compute unit");
 
+#if !TCMI_CRC_REG
 // the CRC register (linear form: starts at 0, no final inversion) after the 16 bytes of v, from state c
 __device__ __forceinline__ uint32_t crc16(const uint32_t (*t)[256], uint32_t c, uint4 v)
 {
@@ -1208,6 +1275,7 @@ __device__ __forceinline__ uint32_t crc16(const uint32_t (*t)[256], uint32_t c, 
     c = step(c ^ v.z);
     return step(c ^ v.w);
 }
+#endif
 // a linear operator on the register given by nibble tables (tab[j][n] = op(n << 4 j)): LDS or global memory
 __device__ __forceinline__ uint32_t crc_apply(const uint32_t (*tab)[16], uint32_t c)
 {
@@ -1253,10 +1321,13 @@ __device__ __forceinline__ uint4 crc_masked(uint4 v, int32_t at, int32_t from, i
 // DIRECT: with the short far matches of a teams' batch finished in the batch's set-up (files that compress less than ~4 : 1: most of
 // their matches are 3 - 8 bytes long and come from anywhere in the 32 KB window; at 6 : 1 few do and the lean set-up is 3 % faster)
 template <bool TEAMS, bool DIRECT>
-__global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_copy(CopyArgs a)
+__global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, TCMI_CRC_REG ? 5 : 4))) void bgzf_copy(CopyArgs a)
 {
     __shared__ __attribute__((aligned(16))) CopyShared S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform, and known to be: the block's fields go to scalar registers)
+#if TCMI_CRC_REG
+    const CrcRegs CR = crc_regs_make(a.zeros_seg);
+#else
     if (a.crc) {                                    // the tables of the workgroup's four wavefronts (CW * 64 = 256 lanes: an entry each)
         for (uint32_t v = threadIdx.x; v < 256u; v += 64u * CW) {      // the reflected CRC-32 table (polynomial 0xEDB88320)
             uint32_t c = v;
@@ -1277,6 +1348,7 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             __syncthreads();
         }
     }
+#endif
     CopyLds &s_lds = S.w[wave];
     uint8_t *const s_win = s_lds.win;
     const uint32_t B = (uint32_t)reinterpret_cast<uintptr_t>(s_win);    // the ring's LDS address (the copy loops take addresses, not ring indices)
@@ -1399,9 +1471,15 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 // bytes so far, CSEG zero bytes later, plus these)
                 uint4 p0 = src[(CCOL / 16) * lane], p1 = CCOL == 32 ? src[2 * lane + 1] : make_uint4(0u, 0u, 0u, 0u);
                 if (flushed == 0) { p0 = crc_masked(p0, CCOL * lane, (int32_t)a0, (int32_t)a0); if (CCOL == 32) p1 = crc_masked(p1, 32 * lane + 16, (int32_t)a0, (int32_t)a0); }
+#if TCMI_CRC_REG
+                uint32_t cs = crc16_reg(CR, 0u, p0);
+                if (CCOL == 32) cs = crc16_reg(CR, cs, p1);
+                crc_acc = crc_seg_reg(CR, crc_acc) ^ cs;
+#else
                 uint32_t cs = crc16(S.t, 0u, p0);
                 if (CCOL == 32) cs = crc16(S.t, cs, p1);
                 crc_acc = crc_apply(S.seg, crc_acc) ^ cs;
+#endif
             }
             flushed += CSEG;
         }
@@ -1781,12 +1859,26 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             uint32_t got;
             if (ulen < 128u) {                                  // (short blocks — the end-of-file marker's is empty — byte by byte)
                 uint32_t t = 0xFFFFFFFFu;
+#if TCMI_CRC_REG
+                for (uint32_t i = 0; i < ulen; ++i) t = crc_tk(CR, 0u, (t ^ s_win[(a0 + i) & CWMASK]) & 0xFFu) ^ (t >> 8);
+#else
                 for (uint32_t i = 0; i < ulen; ++i) t = S.t[0][(t ^ s_win[(a0 + i) & CWMASK]) & 0xFFu] ^ (t >> 8);
+#endif
                 got = ~t;
             } else {
                 const int32_t from = (int32_t)max(flushed, a0);
                 const int32_t ps = (int32_t)vend - CCOL * (64 - lane);                  // where this lane's piece of the tail starts
                 uint32_t tl = 0;
+#if TCMI_CRC_REG
+                {   // (every lane goes through the look-ups — they read the tables from each other's registers; a piece wholly in front of `from` is zeros)
+                    const uint4 q0 = make_uint4(ring_u32((uint32_t)ps), ring_u32((uint32_t)ps + 4u), ring_u32((uint32_t)ps + 8u), ring_u32((uint32_t)ps + 12u));
+                    tl = crc16_reg(CR, 0u, crc_masked(q0, ps, from, (int32_t)a0));
+                    if (CCOL == 32) {
+                        const uint4 q1 = make_uint4(ring_u32((uint32_t)ps + 16u), ring_u32((uint32_t)ps + 20u), ring_u32((uint32_t)ps + 24u), ring_u32((uint32_t)ps + 28u));
+                        tl = crc16_reg(CR, tl, crc_masked(q1, ps + 16, from, (int32_t)a0));
+                    }
+                }
+#else
                 if (ps + CCOL > from) {
                     const uint4 q0 = make_uint4(ring_u32((uint32_t)ps), ring_u32((uint32_t)ps + 4u), ring_u32((uint32_t)ps + 8u), ring_u32((uint32_t)ps + 12u));
                     tl = crc16(S.t, 0u, crc_masked(q0, ps, from, (int32_t)a0));
@@ -1795,6 +1887,7 @@ __global__ __launch_bounds__(64 * CW) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         tl = crc16(S.t, tl, crc_masked(q1, ps + 16, from, (int32_t)a0));
                     }
                 }
+#endif
                 uint32_t full = uni(crc_fold(a.crc_ops, crc_acc));
                 const uint32_t tail_len = vend - flushed;       // < CSEG
                 for (int k = 0; k < 11; ++k)

@@ -132,7 +132,8 @@ void *tcmi_ctx_stream(tcmi_ctx *ctx);              /* the hipStream_t all launch
  *   "split_sub"      tcmi_split_step: a rank's block range is decoded, packed and tallied as this many SUB-RANGES side by side — the first on
  *                    this context, the others on helper contexts it owns (a stream, an arena and a host thread each), so that the inflate of
  *                    one sub-range runs under the pack of another; the sub-ranges must join like ranks' ranges, else the range is taken in
- *                    one piece.  0 = auto (default: 3 from 6 144 blocks on, 2 from 4 096, else 1), 1 = never, up to 8
+ *                    one piece.  0 = auto (default: for a true range of a larger file 3 from 6 144 blocks on, 2 from 4 096, else 1 — the whole file as
+ *                    one range is taken in one piece: measured), 1 = never, up to 8
  *   "chunk_stages"   stages per chunk of the bit-plane kernel: 0 = default (up to 8, capped by "balance_chunks"), or 1..8
  *   "balance_chunks" chunk_stages = 0: size the chunks so that a launch has a multiple of
  *                    (compute units x "wg_per_cu", default 4) of them (default 1)

@@ -773,7 +773,11 @@ int tcmi_split_step(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first_block, i
         const int64_t cnt0 = std::max<int64_t>(0, n_blocks < 0 ? all - first_block : std::min<int64_t>(n_blocks, all - first_block));
         static const int sub_env = std::getenv("TCMI_SPLIT_SUB") ? std::atoi(std::getenv("TCMI_SPLIT_SUB")) : 0;
         int K = sub_env > 0 ? sub_env : ctx->split_sub;
-        if (K <= 0) K = cnt0 >= 6144 ? 3 : cnt0 >= 4096 ? 2 : 1;
+        // (auto: a true RANGE of a larger file gains ~ 10 % from three sub-ranges — 2.65 - 2.83 -> 2.42 - 2.54 ms at 4 M reads, 3.9 -> 3.5 - 3.6 ms
+        //  at 6.25 M; the WHOLE file as one rank's range — world 1 — is decoded without the range's re-based block table and loses 3 - 8 % to them:
+        //  profiles/r06i_split_ab.log, r06j_*)
+        const bool whole = first_block == 0 && cnt0 == all;
+        if (K <= 0) K = whole ? 1 : cnt0 >= 6144 ? 3 : cnt0 >= 4096 ? 2 : 1;
         K = (int)std::min<int64_t>(std::min(K, 8), std::max<int64_t>(1, cnt0 / 64));
         if (K > 1 && !ctx->stream_hi) {
             const int rc0 = split_sub_ranges(ctx, f, first_block, cnt0, K, L, ld, d_counts, n_words, &rs);

@@ -178,8 +178,8 @@ struct tcmi_ctx {
     // Two streams per context (TCMI_STREAM_SPLIT, api.cpp ctx_create): the inflate kernels of a file stay on `stream_lo`, everything
     // behind them (pk_index .. pk_report: short kernels that triple in duration next to a chip full of bgzf_copy workgroups) goes to
     // `stream_hi` — a higher priority, or compute units of its own.  `stream` is the one the launches use at the moment.
-    // tcmi_split_step: a rank's block range is decoded as `split_sub` sub-ranges side by side (0 = auto: three from 6 144 blocks on, two
-    // from 4 096), the first on this context, the others on helper contexts this one owns (a stream and an arena each)
+    // tcmi_split_step: a rank's block range is decoded as `split_sub` sub-ranges side by side (0 = auto: a true range of a larger file: three from 6 144 blocks on, two
+    // from 4 096; the whole file: one), the first on this context, the others on helper contexts this one owns (a stream and an arena each)
     int split_sub = 0;
     std::vector<tcmi_ctx *> helpers;
     // ... started one behind the other: a sub-range's first inflate kernel waits for the bgzf_symbols of the sub-range in front (an event), so

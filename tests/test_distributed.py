@@ -415,3 +415,22 @@ def test_check_range_anchors_on_random_chains_and_cuts():
         bad[last] = ranges[last][:3] + (ranges[last][3] + 5,) if ranges[last][3] == total else bad[last]
         if bad[last] != ranges[last]:
             assert chk(bad, total) is not None
+
+
+def test_split_reduce_hook_falls_back_to_the_process_groups_reduce(monkeypatch):
+    """distributed.split_reduce_hook (what the command line's split worker and bench.py both call): where the RCCL hook library cannot be
+    loaded — or a communicator cannot be made — the answer is torch.distributed's reduce, with the reason in words; `rccl=False`
+    (a rehearsal of several ranks on one GPU) never tries.  No GPU: the hook library's loader is made to fail."""
+    from trueconsense_amd import _ffi
+    from trueconsense_amd import distributed as td
+
+    def no_lib():
+        raise ImportError("libtcmi_rccl.so is missing (test)")
+    monkeypatch.setattr(_ffi, "rccl_lib", no_lib)
+    comm, user, what = td.split_reduce_hook(0, 1)
+    assert comm is None and user is None and "torch.distributed reduce" in what and "missing (test)" in what
+    comm, user, what = td.split_reduce_hook(0, 1, rccl=False)
+    assert comm is None and user is None and what == "torch.distributed reduce"
+    monkeypatch.setenv("TCMI_SPLIT_HOOK", "torch")
+    assert td.split_reduce_hook(0, 1)[2] == "torch.distributed reduce"
+    td.split_reduce_hook_close(None)                                 # (nothing to destroy)

@@ -30,7 +30,7 @@ inflate|stamps)
   for kind in $kinds; do for r in 1 2; do for v in "$@"; do
     echo "== $kind $v: $(TCMI_LIB=$(lib_of $v) timeout -k 10 300 python3 tools/$tool $kind 1000000 2>&1 | grep -v amdgpu.ids | grep -E "$pat" | tr '\n' ' ')"
     [ $mode = stamps ] && break
-  done; [ $mode = stamps ] && break; done; done ;;
+  done; [ $mode = stamps ] && break; done; done; true ;;
 inflate-env)
   var=$1; kinds=${2//,/ }; shift 2
   for kind in $kinds; do for v in "$@"; do

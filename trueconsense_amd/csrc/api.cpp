@@ -699,9 +699,16 @@ static int split_sub_ranges(tcmi_ctx *ctx, const tcmi_bamfile *f, int64_t first,
         rcs[(size_t)k] = rc;
     };
     {
+        // (a thread that cannot be started — std::system_error must not cross the C ABI — has its sub-range done by this one, after its own;
+        //  in order: a sub-range waits for the one in front to be queued)
         std::vector<std::thread> th;
-        for (int k = 1; k < K; ++k) th.emplace_back(work, k);
+        std::vector<int> inline_k;
+        for (int k = 1; k < K; ++k) {
+            try { th.emplace_back(work, k); }
+            catch (const std::exception &) { inline_k.push_back(k); }
+        }
         work(0);
+        for (int k : inline_k) work(k);                             // (ascending: each waits only for the one in front of it to be queued)
         for (std::thread &t : th) t.join();
     }
     auto drop = [&]() { for (int k = 0; k < K; ++k) if (rs[(size_t)k]) tcmi_readset_free(k == 0 ? ctx : ctx->helpers[(size_t)k - 1], rs[(size_t)k]); };

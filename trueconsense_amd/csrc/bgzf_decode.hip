@@ -409,6 +409,13 @@ __device__ TCMI_HDR_INLINE void block_header(BlkTabs &T, HdrScratch &H, const ui
 // literal that starts in the same stretch and ends within the soft end: then the token carries both bytes and the lane moves on
 // behind the second.  (For the bench file's blocks — two per workgroup, a thousand tokens each — the 22 instructions cost more than
 // the 19 % of rounds they save: 141 -> 150 us; at 2.6 : 1 the rounds fall by 38 %.)
+// The round's sections, in order (labels in the text below): LT the loop's head — a lane whose symbols cross into a new stretch of 2^shift
+// bits notes {p, total} in its ring (LA1); every fourth round the lanes that have crossed since look their position up in their target's
+// ring (LB*: a target that has stopped at or in front of the lane is replaced by the lane it met, or by the next one; equal positions:
+// met — back to the meeting point, stop); LC1 one symbol: 64 bits of payload, the 9-bit root look-up (LLl: a longer literal / length
+// code by range compare), LDeob an end-of-block code, LC3 the literal's token / the length's base and extra bits, PAIR_LOOK_, the
+// 8-bit distance root look-up (LLd: a longer one), LC5 PAIR_RESOLVE_, the new position (LDover: past the end), LC6 the token's store
+// into the lane's row of the scratch; LDend lanes at the payload's end without an end-of-block code; LX out.
 #define TCMI_PAIR_LOOK "v_lshrrev_b32 v44, v50, v47\n" "v_and_b32 v44, 0x1ff, v44\n" "v_lshl_add_u32 v44, v44, 2, %[tabs]\n" "ds_read_b32 v44, v44\n"
 #define TCMI_PAIR_RESOLVE "s_waitcnt lgkmcnt(0)\n" "v_and_b32 v40, v49, v44\n" "v_and_b32 v45, 15, v44\n" "v_add_u32 v46, v52, v45\n" "v_xor_b32 v42, %[p], v52\n" "v_lshrrev_b32 v42, %[shift], v42\n" "v_bfe_u32 v40, v40, 8, 1\n" "v_cmp_gt_u32 vcc, 10, v50\n" "v_cmp_eq_u32 s[86:87], 1, v40\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_cmp_eq_u32 s[86:87], 0, v42\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_cmp_le_u32 s[86:87], v46, %[wend]\n" "s_and_b64 vcc, vcc, s[86:87]\n" "v_bfe_u32 v40, v44, 16, 8\n" "v_lshl_or_b32 v40, v40, 8, v51\n" "v_or_b32 v40, 0x1000000, v40\n" "v_cndmask_b32 v51, v51, v40, vcc\n" "v_cndmask_b32 v52, v52, v46, vcc\n"
 #define TCMI_PASS_A_ASM(PAIR_LOOK_, PAIR_RESOLVE_) \

@@ -536,6 +536,34 @@ def test_cli_gpus_n_batch_shards_and_one_bam_split(ctx, tmp_path, monkeypatch):
     assert "ACGTACGTACGTAC" in outs["two"][0]                        # (the 14-base insertion, whose bases travelled as text, is in the consensus)
 
 
+def test_two_streams_per_context_give_the_same_outputs(tmp_path, monkeypatch):
+    """TCMI_STREAM_SPLIT (the scheduling experiment of round 6: everything behind the inflate on a second stream per context — by
+    priority, on compute units of its own, or both; all three lose to one stream and stay behind the variable): the code
+    path must stay right.  `--batch` through the native runner in a process of its own per mode: four outputs per sample = the golden text."""
+    import subprocess
+    case = next(c for c in load("outputs") if "raises" not in c["runs"]["amb1"] and c["runs"]["amb1"]["fa"].count("\n") == 2)
+    spec, run = case["spec"], case["runs"]["amb1"]
+    monkeypatch.chdir(tmp_path)
+    bamwriter.write_bam("in.bam", ss.reads_from_spec(spec), "refid", len(spec["ref"]))
+    with open("ref.fa", "w") as fh:
+        fh.write(">refid some description\n" + spec["ref"] + "\n")
+    with open("f.gff", "w") as fh:
+        fh.write("##gff-version 3\n")
+        for k, o in enumerate(spec["orfs"]):
+            fh.write("S\tx\tCDS\t%d\t%d\t.\t%s\t0\tID=o%d;Name=orf%d\n" % (o["start"], o["end"], o["strand"], k, k))
+    for mode in ("1", "2", "3"):
+        with open("m.tsv", "w") as fh:
+            for k in range(6):
+                fh.write("in.bam\tSAMPLE\tm%s_%d.fa\tm%s_%d.vcf\tm%s_%d.gff\tm%s_%d.tsv\n" % ((mode, k) * 4))
+        env = dict(os.environ, TCMI_STREAM_SPLIT=mode, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-m", "trueconsense_amd.TrueConsense", "--batch", "m.tsv", "-ref", "ref.fa", "-gff", "f.gff", "-cov", str(spec["mincov"])],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (mode, r.stderr[-1500:])
+        for k in range(6):
+            assert open("m%s_%d.fa" % (mode, k)).read() == run["fa"] and open("m%s_%d.tsv" % (mode, k)).read() == run["tsv"], mode
+            assert open("m%s_%d.gff" % (mode, k)).read() == run["gff_cli"], mode
+
+
 def test_configs1_full_size_from_bam_files_through_eight_contexts(ctx, tmp_path):
     """BASELINE configs[1] at full size FROM BAM FILES through the runner the bench's headline uses (FileRunner.run_resident, eight
     GPU contexts, the files' compressed bytes resident in HBM): every FASTA text against the Python oracle chain on its file

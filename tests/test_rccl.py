@@ -53,7 +53,7 @@ def test_split_step_reduces_through_rccl_on_a_one_rank_communicator(tmp_path):
         assert r.tcmi_rccl_comm_destroy(comm) == 0
 
 
-def test_cli_gpus_2_reduces_through_the_rccl_hook_on_two_gpus(tmp_path):
+def test_cli_gpus_2_reduces_through_the_rccl_hook_on_two_gpus(tmp_path, monkeypatch):
     """The hook at world > 1 — `TrueConsense -i one.bam --gpus 2` on a node with two GPUs: the split workers make a two-rank RCCL
     communicator (distributed.split_reduce_hook) and tcmi_split_step queues ncclReduce on each rank's stream; the four outputs equal
     the single-GPU command line's.  Skips on the one-GPU boxes (RCCL wants a GPU per rank)."""
@@ -66,7 +66,7 @@ def test_cli_gpus_2_reduces_through_the_rccl_hook_on_two_gpus(tmp_path):
     ref, orfs = sy.make_reference(L=4000, cds=[(100, 1900), (2100, 3900)])
     sites = [(1900, "I", "A", 0.9), (1990, "I", "GT", 0.7), (2010, "D", 3, 0.6), (3000, "I", "TT", 0.95)]
     reads = sy.make_reads(ref, 6000, seed=91, indel_sites=sites)
-    os.chdir(tmp_path)
+    monkeypatch.chdir(tmp_path)
     bamwriter.write_bam("one.bam", reads, "MN", len(ref), block=3000, split_records=True)
     open("r.fa", "w").write(">MN x\n" + ref + "\n")
     head, body = sy.gff_text(orfs, seqid="MN")

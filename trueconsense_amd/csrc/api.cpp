@@ -179,6 +179,7 @@ int tcmi_ctx_destroy(tcmi_ctx *c)
     if (c->tok_dev) (void)hipFree(c->tok_dev);
     if (c->tok_host) (void)hipHostFree(c->tok_host);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     if (c->ev_after_sym) (void)hipEventDestroy(c->ev_after_sym);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }

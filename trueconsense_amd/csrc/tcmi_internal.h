@@ -158,6 +158,8 @@ struct tcmi_ctx {
     // memory makes the runtime pin and unpin the destination's pages on every call
     char *h_pin = nullptr;
     size_t h_pin_cap = 0;
+    char *h_desc = nullptr;          // pinned: the re-based block table of a block range on its way to the device (bam_device.hip: decode_enqueue)
+    size_t h_desc_cap = 0;
     int verify_crc = 1;              // the device decoder checks the BGZF CRC-32 of every block
     int64_t stat_one_sync_taken = 0, stat_one_sync_declined = 0, stat_last_decline = 0;     // tcmi_ctx_stat
     int64_t stat_h2d_piped = 0;      // decodes whose compressed bytes crossed PCIe in pieces, ahead of the inflate kernels (bam_device.hip: decode_enqueue)

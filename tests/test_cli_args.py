@@ -105,3 +105,37 @@ def test_console_scripts_of_the_reference_are_declared():
     for target in scripts.values():
         mod, fn = target.split(":")
         assert callable(getattr(importlib.import_module(mod), fn))
+
+
+def test_gff_index_dict_without_pandas_is_what_the_dataframe_gives(tmp_path):
+    """The command line takes its GFF rows from `Gffindex(...).index_dict(seqid)` — what upstream gets from `df["seqid"] = name;
+    df.to_dict("index")` (TrueConsense.py:238-241) — without importing pandas (0.6 s of the single-sample process).  Same keys in the
+    same order, same values, a missing attribute NaN either way, and the same GFF text line from the writer."""
+    import math
+    import subprocess
+    import sys
+    from trueconsense_amd import Outputs
+    from trueconsense_amd.indexing import Gffindex
+    texts = ["##gff-version 3\n#!x y\nS\tsrc\tCDS\t10\t90\t.\t+\t0\tID=a;Name=orfA\nS\tsrc\tCDS\t100\t190\t0.5\t-\t2\tID=b;product=p q;Note=n\n"
+             "S\tsrc\tgene\t5\t300\t.\t+\t.\tName=g\n",
+             "##gff-version 3\n",
+             "S\tx\tCDS\t1\t9\t.\t+\t0\tID=o0\n"]
+    for k, text in enumerate(texts):
+        p = tmp_path / ("g%d.gff" % k)
+        p.write_text(text)
+        lean = Gffindex(str(p)).index_dict(seqid="NAME")
+        g = Gffindex(str(p))
+        df = g.df
+        df["seqid"] = "NAME"
+        want = df.to_dict("index")
+        assert list(lean) == list(want)
+        for i in want:
+            assert list(lean[i]) == list(want[i])
+            for c in want[i]:
+                a, b = lean[i][c], want[i][c]
+                assert (isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b)) or (a == b and type(a) is type(b)), (i, c, a, b)
+            assert Outputs._gff_line(lean[i]) == Outputs._gff_line(want[i])
+        assert g.index_dict(seqid="OTHER")[0]["seqid"] == "OTHER" if want else True      # (a DataFrame that was asked for has the last word)
+    r = subprocess.run([sys.executable, "-c", "import sys, trueconsense_amd.TrueConsense, trueconsense_amd.split_main; print('pandas' in sys.modules)"],
+                       capture_output=True, text=True, cwd=str(tmp_path.parent), env=dict(__import__("os").environ, PYTHONPATH=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
+    assert r.stdout.strip() == "False", r.stdout + r.stderr

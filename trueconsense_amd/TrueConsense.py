@@ -216,9 +216,7 @@ def run_batch(a):
                 sys.exit(-1)
             rows.append([f[0], f[1], f[2]] + [None if x in ("", "-") else x for x in f[3:6]])
     IndexGff = Gffindex(a.features)
-    gffdf = IndexGff.df
-    gffdf["seqid"] = "S"                                         # (the runner puts each sample's name there: TrueConsense.py:240)
-    gffrows = list(gffdf.to_dict("index").values())
+    gffrows = list(IndexGff.index_dict(seqid="S").values())       # (the runner puts each sample's name there: TrueConsense.py:240)
     refID, refseq = fasta.read_first_record(a.reference)
     t0 = time.perf_counter()
     cores = max(1, min(int(a.threads), os.cpu_count() or 1))
@@ -280,9 +278,7 @@ def main(args=None):
         counts = df.values
     indexDict = _state.IndexDict(counts)
     GffHeader = IndexGff.header
-    GffDF = IndexGff.df
-    GffDF["seqid"] = a.samplename
-    GffDict = GffDF.to_dict("index")
+    GffDict = IndexGff.index_dict(seqid=a.samplename)           # (TrueConsense.py:238-241: df["seqid"] = samplename; df.to_dict("index") — without importing pandas)
 
     if a.depth_of_coverage is not None:
         BuildCoverage(indexDict, a.depth_of_coverage)

@@ -6,8 +6,6 @@ BuildIndex (indexing.py:75-154) keeps its signature and its return value (a Data
 """
 from __future__ import annotations
 
-import pandas as pd
-
 from . import _state
 from ._ffi import COLS
 from . import _ffi
@@ -28,6 +26,7 @@ def Gffindex(file):
 
 def read_override_index(f):
     """indexing.py:39-52."""
+    import pandas as pd                                 # (where a DataFrame is the interface: imported when it is asked for)
     return pd.read_csv(f, sep=",", compression="gzip", index_col=0)
 
 
@@ -71,6 +70,7 @@ build_counts.last_reads = 0         # alignment records of the file the last cal
 def BuildIndex(bamfile, ref):
     """indexing.py:75-154."""
     counts = build_counts(bamfile, ref)
+    import pandas as pd
     df = pd.DataFrame(counts.astype("int64"), columns=list(COLS), index=range(1, len(counts) + 1))
     df.index.name = None
     return df

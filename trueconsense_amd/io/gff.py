@@ -6,8 +6,6 @@ column set is not pinned here — SURVEY §8-c — but stage B only reads start 
 the writer folds every extra column back into `attributes`, Outputs.py:32-58)."""
 from __future__ import annotations
 
-import pandas as pd
-
 GFF3_COLUMNS = ["seqid", "source", "type", "start", "end", "score", "strand", "phase", "attributes"]
 
 
@@ -17,8 +15,40 @@ class GFFHeader:
 
 
 class GFFDataFrame:
-    def __init__(self, header, df):
-        self.header, self.df = header, df
+    """`.header`, and `.df` — the DataFrame, made when somebody asks for it: importing pandas costs the single-sample command line
+    more than its GPU work (0.6 s of a 0.85-s process), and the command line itself only needs `index_dict`."""
+
+    def __init__(self, header, rows, cols):
+        self.header, self.rows, self.columns = header, rows, cols
+        self._df = None
+
+    @property
+    def df(self):
+        if self._df is None:
+            import pandas as pd
+            self._df = pd.DataFrame(self.rows, columns=self.columns)
+        return self._df
+
+    @df.setter
+    def df(self, value):
+        self._df = value
+
+    def index_dict(self, seqid=None):
+        """What `df["seqid"] = seqid; df.to_dict("index")` gives (TrueConsense.py:238-241) — {row number: {column: value}} with every
+        column in every row, a missing attribute as NaN (pandas' fill: it prints as "nan", as upstream's writer prints it) — without
+        the DataFrame.  (A DataFrame somebody has asked for, and possibly edited, has the last word.)"""
+        if self._df is not None:
+            d = self._df.copy()
+            if seqid is not None:
+                d["seqid"] = seqid
+            return d.to_dict("index")
+        out = {}
+        for i, r in enumerate(self.rows):
+            row = {c: r.get(c, float("nan")) for c in self.columns}
+            if seqid is not None:
+                row["seqid"] = seqid
+            out[i] = row
+        return out
 
 
 def read_gff(path):
@@ -48,5 +78,4 @@ def read_gff(path):
         for k in r:
             if k not in cols:
                 cols.append(k)
-    df = pd.DataFrame(rows, columns=cols)
-    return GFFDataFrame(GFFHeader("".join(head)), df)
+    return GFFDataFrame(GFFHeader("".join(head)), rows, cols)

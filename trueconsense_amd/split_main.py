@@ -46,9 +46,7 @@ def main(argv=None):
         if os.environ.get("TCMI_SPLIT_VERBOSE") == "1" and rank == 0:
             print("TrueConsense --gpus %d: the count matrices are summed by %s" % (world, hook_kind), file=sys.stderr)
         IndexGff = Gffindex(a.features)
-        gffdf = IndexGff.df
-        gffdf["seqid"] = a.samplename
-        gffdict = gffdf.to_dict("index")
+        gffdict = IndexGff.index_dict(seqid=a.samplename)
         rows = [{"start": int(r["start"]), "end": int(r["end"]), "strand": r.get("strand")} for r in gffdict.values()]
         _, refseq = fasta.read_first_record(a.reference)
         parts = td.consensus_split_bamfile(a.input, len(refseq), rows, a.coverage_level, a.noambiguity is False, a.samplename, rank, world,

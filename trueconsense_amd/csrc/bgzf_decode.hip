@@ -91,9 +91,6 @@ struct HdrScratch {                                 // per block, while its head
     uint16_t cnt_ll[16], cnt_d[16], cnt_cl[16];
     uint32_t rs[6];
 };
-#ifndef TCMI_SYM_ASM
-#define TCMI_SYM_ASM 1
-#endif
 #ifndef TCMI_SYM_MOVE
 #define TCMI_SYM_MOVE 8                             // bgzf_symbols: tokens a lane has in flight when the tokens are gathered to their places
 #endif
@@ -875,11 +872,11 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
             for (int k = 0; k < RING; ++k) L.a.ring[lane][k] = make_uint2(0xFFFFFFFFu, 0u);
             L.a.rec[lane] = make_uint2(state, p);
             wave_sync();
-#if TCMI_SYM_ASM
-            // The rounds, hand-scheduled (the compiler's version of the loop below takes ~180 instructions a round, half of them
-            // bookkeeping of which lanes are in which branch; this one ~85).  Differences to the C++ loop: a lane's look at its
-            // target's ring waits for the next round that is a multiple of four (the lane goes on decoding meanwhile; if it
-            // has met its target, it steps back to the meeting point), and a lane's target is kept as a lane of the wavefront.
+            // The rounds, hand-scheduled (TCMI_PASS_A_ASM: ~85 instructions a round; the compiler's version of the same loop took ~180,
+            // half of them bookkeeping of which lanes are in which branch — tools/spec_inflate_proto.py and tools/sym_balance_sim.py
+            // are the scheme in Python).  A lane's look at its target's ring waits for the next round that is a multiple of four (the
+            // lane goes on decoding meanwhile; if it has met its target, it steps back to the meeting point), and a lane's target is
+            // kept as a lane of the wavefront.
             {
                 uint32_t tgt_abs = (uint32_t)lane0 + tgt, room = lane_cap, crossp = 0xFFFFFFFFu, crosst = 0;
                 uint64_t sptr = reinterpret_cast<uint64_t>(scratch);
@@ -894,39 +891,6 @@ __global__ __launch_bounds__(64 * NB) __attribute__((amdgpu_waves_per_eu(TCMI_SY
                 tgt = tgt_abs - (uint32_t)lane0;
                 spilled = total > lane_cap;
             }
-#else
-            while (__ballot(state == RUN)) {
-                const uint32_t kk = p >> shift;
-                const bool cross = state == RUN && kk != kprev;
-                if (cross) L.a.ring[lane][kk & (RING - 1)] = make_uint2(p, total);
-                wave_sync();                        // (orders the notes before the looks)
-                if (cross) {
-                    kprev = kk;
-                    // a target that has stopped at or in front of p: on to the lane it met, or to the next one
-                    {
-                        const uint2 r = L.a.rec[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)];
-                        const uint32_t st = r.x & 3u;
-                        const uint32_t nxt = st == MERGED ? r.x >> 8 : tgt + 1u;
-                        tgt = st != RUN && p >= r.y && tgt < (uint32_t)SYM_LANES ? nxt : tgt;      // (one step per stretch)
-                        const uint2 e = L.a.ring[lane0 + (int)min(tgt, (uint32_t)SYM_LANES - 1u)][kk & (RING - 1)];
-                        if (tgt < (uint32_t)SYM_LANES && e.x == p) { state = MERGED; midx = e.y; }
-                    }
-                }
-                if (state == RUN) {
-                    uint32_t tok = 0;
-                    const int k = p >= b_end ? SY_BAD : symbol(p, tok);
-                    if (k == SY_BAD || p > b_end) state = DEAD;
-                    else {
-                        if (k == SY_EOB) state = EOB;
-                        else if (total < lane_cap) scratch[(size_t)total * SYM_LANES] = tok;
-                        else spilled = true;
-                        ++total;
-                    }
-                }
-                if (cross || state != RUN) L.a.rec[lane] = make_uint2(state | (tgt << 8), p);
-                ++rounds;
-            }
-#endif
             TCMI_STAMP(a.stamps, blk0, 4);
             TCMI_STAMP_ADD(a.stamps, blk0, 8, rounds);
             // ---- per block the chain of lanes that hold the true symbols: lane 0 from `start`, then whoever it met, ... ----------

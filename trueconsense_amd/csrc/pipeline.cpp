@@ -541,7 +541,10 @@ int filerunner_core(tcmi_filerunner *r, int64_t n, const char *const *paths, con
             FileItem &it = items[(size_t)i];
             if (resident) it.file = resident[i];
             else if (device_decode) {
-                it.rc = tcmi_bamfile_read_threads(paths[i], r->n_readers > 1 ? 1 : 0, &it.file);
+                // (several readers: two copy threads a file — with one, a reader needs 1.0 - 1.4 ms for a 7.7 MB file and three readers run
+                //  close to the GPU's 0.42 ms per file: on a slower host the file leg fell to 55 - 66 M positions/s where two threads gave
+                //  63 - 69 M, three turns each, profiles/r06l_read_threads_ab.log)
+                it.rc = tcmi_bamfile_read_threads(paths[i], r->n_readers > 1 ? 2 : 0, &it.file);
                 if (it.rc) it.err = tcmi_last_error(nullptr);
             }
             const double dt = seconds_since(t0);
